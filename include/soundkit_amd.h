@@ -1,0 +1,235 @@
+/*
+ * soundkit_amd.h -- C ABI of the MI355X (gfx950) batched decode-DSP engine.
+ *
+ * This is the drop-in boundary for soundkit's per-frame decode DSP hot path
+ * (SURVEY.md section 8).  The reference has no C FFI on this path: the three Rust
+ * surfaces it would bind behind are cited per entry point below
+ * (paths relative to the upstream soundkit tree).  INTEGRATION.md shows the Rust
+ * `extern "C"` block and the `impl Decoder` / access-unit shims a maintainer adds.
+ *
+ * Conventions (mirrored from the reference):
+ *  - the caller owns every buffer it passes; the engine owns per-stream carried
+ *    state (overlap delay + previous window shape: dsp.rs:143-152; resampler
+ *    history: soundkit-decoder lib.rs:1917-1927) in device memory;
+ *  - no allocation per call once buffers have grown to the working size
+ *    (soundkit-aac-lc/tests/no_alloc_decode.rs);
+ *  - a bad frame fails that frame only (per-frame status word), never the batch
+ *    (soundkit-decoder lib.rs:3131-3134 ends only that stream's worker);
+ *  - frames of one stream inside one call are applied in array order; calls for
+ *    one stream must not race (one worker per stream, lib.rs:2764); calls for
+ *    different streams may come from different threads (the engine serialises
+ *    submission internally).
+ *  - every function returns SK_OK (0) or a negative sk_status; sk_strerror() names it.
+ *
+ * Pointers named d_* are DEVICE addresses on the engine's GPU; the *_dev entry
+ * points enqueue on the engine's HIP stream (sk_engine_hip_stream) and return
+ * without synchronising.  All other pointers are host memory and those entry
+ * points return with results complete.
+ */
+#ifndef SOUNDKIT_AMD_H
+#define SOUNDKIT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SK_AAC_FRAME_LEN 1024u /* dsp.rs:9 LONG_SPECTRUM_LEN */
+#define SK_MAX_CHANNELS 2u     /* AAC-LC SCE / CPE only: decoder.rs:116-133 */
+
+typedef enum sk_status {
+    SK_OK = 0,
+    SK_ERR_INVALID_ARG = -1,
+    SK_ERR_NO_DEVICE = -2,   /* no usable gfx950 device / HIP runtime error at create */
+    SK_ERR_HIP = -3,         /* a HIP call failed (sk_engine_last_hip_error) */
+    SK_ERR_OOM = -4,
+    SK_ERR_BAD_STREAM = -5,  /* stream id not open */
+    SK_ERR_UNSUPPORTED = -6, /* e.g. resample ratio other than 48k->16k on the MFMA path */
+    SK_ERR_CAPACITY = -7     /* max_streams exhausted */
+} sk_status;
+
+/* per-frame status words written by the AAC entry points */
+typedef enum sk_frame_status {
+    SK_FRAME_OK = 0,
+    SK_FRAME_BAD_STREAM = 1,   /* stream not open */
+    SK_FRAME_BAD_CHANNELS = 2, /* desc.channels != the stream's channel count */
+    SK_FRAME_BAD_WINDOW = 3    /* window_sequence > 3 or window_shape > 1 */
+} sk_frame_status;
+
+/* ics.rs:7-12 WindowSequence (bitstream coding) / ics.rs:32-35 WindowShape */
+enum { SK_ONLY_LONG = 0, SK_LONG_START = 1, SK_EIGHT_SHORT = 2, SK_LONG_STOP = 3 };
+enum { SK_SHAPE_SINE = 0, SK_SHAPE_KBD = 1 };
+
+typedef struct sk_engine sk_engine; /* one per GPU */
+
+/* One decoded-but-not-yet-synthesised AAC-LC frame: what decoder.rs:336-374
+ * synthesize_channel reads from IcsInfo per channel. */
+typedef struct sk_aac_frame_desc {
+    uint32_t stream;
+    uint8_t channels;           /* 1 or 2; must equal the stream's */
+    uint8_t window_sequence[2]; /* per channel */
+    uint8_t window_shape[2];    /* per channel */
+    uint8_t reserved[3];
+} sk_aac_frame_desc;
+
+/* ---- engine / stream lifetime ------------------------------------------- */
+
+int sk_engine_create(int device, uint32_t max_streams, sk_engine **out);
+void sk_engine_destroy(sk_engine *);
+int sk_engine_device(const sk_engine *);
+void *sk_engine_hip_stream(sk_engine *); /* hipStream_t */
+int sk_engine_synchronize(sk_engine *);
+const char *sk_engine_last_hip_error(const sk_engine *);
+const char *sk_strerror(int status);
+const char *sk_version(void);
+
+/* AacLcDecoder::new (decoder.rs:56-78): allocates the per-channel DspChannel state
+ * (delay zeroed, previous shape = Sine, dsp.rs:162-163). */
+int sk_stream_open(sk_engine *, uint32_t sample_rate, uint8_t channels, uint32_t *stream_out);
+int sk_stream_close(sk_engine *, uint32_t stream);
+int sk_stream_reset(sk_engine *, uint32_t stream);
+/* checkpoint / inspection of the carried state: delay [channels][1024] f32, prev_shape [channels] */
+int sk_stream_get_state(sk_engine *, uint32_t stream, float *delay_out, uint8_t *prev_shape_out);
+int sk_stream_set_state(sk_engine *, uint32_t stream, const float *delay, const uint8_t *prev_shape);
+
+/* ---- AAC-LC synthesis: IMDCT + window + overlap-add ---------------------- */
+/* Replaces AacLcDecoder::synthesize_channel (decoder.rs:336-374) =
+ * DspChannel::synthesize_long_sequence / synthesize_eight_short (dsp.rs:230-338) over
+ * imdct_fast (dsp.rs:476-535), for n frames at once.
+ * coeffs: frame i holds desc[i].channels x 1024 f32, planar, frames packed back to back
+ *         (the dequantised, stereo- and TNS-processed spectra: decoder.rs:341, 358).
+ * pcm_out (f32): same packing, planar f32 = PlanarF32 (decoder.rs:22-36, 385-390).
+ * pcm_out (s16): frame i holds 1024 x channels interleaved i16 = decode_aac_access_unit
+ *         (soundkit-decoder lib.rs:1793-1813) with float_sample_to_i16 (lib.rs:1815-1827).
+ * status_per_frame may be NULL.  Output of a frame whose status != 0 is not written. */
+int sk_aac_synthesize_f32(sk_engine *, const sk_aac_frame_desc *descs, const float *coeffs, float *pcm_out,
+                          uint32_t n, int32_t *status_per_frame);
+int sk_aac_synthesize_s16(sk_engine *, const sk_aac_frame_desc *descs, const float *coeffs, int16_t *pcm_out,
+                          uint32_t n, int32_t *status_per_frame);
+
+/* The same, split so that a schedule can be validated/uploaded once and run on
+ * device-resident spectra (the throughput path: no PCIe inside the run). */
+typedef struct sk_aac_plan sk_aac_plan;
+int sk_aac_plan_create(sk_engine *, const sk_aac_frame_desc *descs, uint32_t n, int32_t *status_per_frame,
+                       sk_aac_plan **out);
+void sk_aac_plan_destroy(sk_aac_plan *);
+uint64_t sk_aac_plan_elements(const sk_aac_plan *); /* total f32 elements of coeffs / pcm */
+uint32_t sk_aac_plan_frames_ok(const sk_aac_plan *);
+int sk_aac_plan_run_f32_dev(sk_engine *, const sk_aac_plan *, const float *d_coeffs, float *d_pcm);
+int sk_aac_plan_run_s16_dev(sk_engine *, const sk_aac_plan *, const float *d_coeffs, int16_t *d_pcm);
+
+/* dsp.rs:389-450 dequantize_signed_scaled over a batch: out[i] = sign(q)*|q|^(4/3)*2^((sf-100)/4).
+ * quant: n i16 quantised values; sf_per_band_of[i]: i16 scale factor applying to value i. */
+int sk_aac_dequantize_dev(sk_engine *, const int16_t *d_quant, const int16_t *d_scalefactor, float *d_out, size_t n);
+int sk_aac_dequantize(sk_engine *, const int16_t *quant, const int16_t *scalefactor, float *out, size_t n);
+
+/* ---- sample-width / interleave conversion: soundkit::audio_bytes -------- */
+/* Elementwise ops; n = number of OUTPUT samples.  Citations: soundkit/src/audio_bytes.rs
+ * unless noted. */
+typedef enum sk_pcm_op {
+    SK_PCM_I16LE_TO_F32 = 0,      /* :3   i16le_to_f32 */
+    SK_PCM_I16_TO_I16LE = 1,      /* :17  i16_to_i16le */
+    SK_PCM_I16LE_TO_I16 = 2,      /* :25  i16le_to_i16 */
+    SK_PCM_S24LE_TO_I32 = 3,      /* :36  s24le_to_i32 */
+    SK_PCM_S24LE_TO_I16 = 4,      /* :51  s24le_to_i16 */
+    SK_PCM_S24BE_TO_I16 = 5,      /* :66  s24be_to_i16 */
+    SK_PCM_S32LE_TO_I32 = 6,      /* :81  s32le_to_i32 */
+    SK_PCM_S32BE_TO_I32 = 7,      /* :91  s32be_to_i32 */
+    SK_PCM_S32LE_TO_S24 = 8,      /* :101 s32le_to_s24 */
+    SK_PCM_S32BE_TO_S24 = 9,      /* :112 s32be_to_s24 */
+    SK_PCM_S32LE_TO_F32 = 10,     /* :123 s32le_to_f32 */
+    SK_PCM_S32BE_TO_F32 = 11,     /* :134 s32be_to_f32 */
+    SK_PCM_S32LE_TO_I16 = 12,     /* :145 s32le_to_i16 */
+    SK_PCM_S32BE_TO_I16 = 13,     /* :156 s32be_to_i16 */
+    SK_PCM_F32LE_TO_I16 = 14,     /* :167 f32le_to_i16 */
+    SK_PCM_F32BE_TO_I16 = 15,     /* :178 f32be_to_i16 */
+    SK_PCM_F32LE_TO_I32 = 16,     /* :189 f32le_to_i32 */
+    SK_PCM_F32LE_TO_S24 = 17,     /* :205 f32le_to_s24 */
+    SK_PCM_S16BE_TO_I16 = 18,     /* :222 s16be_to_i16 */
+    SK_PCM_S16LE_TO_I16 = 19,     /* :231 s16le_to_i16 */
+    SK_PCM_S16LE_TO_I32 = 20,     /* :240 s16le_to_i32 */
+    SK_PCM_STEREO_TO_MONO_TAKE_LEFT = 21, /* :317 / :331 */
+    SK_PCM_STEREO_TO_MONO_AVG = 22,       /* :344 / :360 */
+    SK_PCM_VEC_F32_TO_I16 = 23,   /* soundkit/src/audio_pipeline.rs:17 */
+    SK_PCM_VEC_I16_TO_F32 = 24,   /* soundkit/src/audio_pipeline.rs:29 */
+    SK_PCM_VEC_I32_TO_F32 = 25,   /* soundkit/src/audio_pipeline.rs:40 */
+    SK_PCM_FLOAT_TO_I16_ROUND = 26, /* soundkit-decoder/src/lib.rs:1815 float_sample_to_i16 */
+    SK_PCM_MP3_F32_TO_I16 = 27,   /* soundkit-mp3/src/lib.rs:376 f32_to_i16 */
+    SK_PCM_MP3_F32_TO_I32 = 28,   /* soundkit-mp3/src/lib.rs:387 f32_to_i32 */
+    SK_PCM_OP_COUNT = 29
+} sk_pcm_op;
+int sk_pcm_op_in_bytes(int op);  /* bytes consumed per output sample */
+int sk_pcm_op_out_bytes(int op); /* bytes produced per output sample */
+int sk_pcm_convert(sk_engine *, int op, const void *in, void *out, size_t n);
+int sk_pcm_convert_dev(sk_engine *, int op, const void *d_in, void *d_out, size_t n);
+
+typedef enum sk_pcm_fmt {
+    SK_FMT_S16LE = 0, SK_FMT_S16BE = 1, SK_FMT_S24LE = 2, SK_FMT_S24BE = 3,
+    SK_FMT_S32LE = 4, SK_FMT_S32BE = 5, SK_FMT_F32LE = 6, SK_FMT_F32BE = 7
+} sk_pcm_fmt;
+int sk_pcm_fmt_bytes(int fmt);
+
+/* Layout-only ops: interleave_vecs_i16 :250, deinterleave_vecs_i16 :264,
+ * deinterleave_vecs_s24 :280 (widens to i32), deinterleave_vecs_f32 :296,
+ * interleave_vecs_f32 (soundkit-decoder lib.rs:3685).  planar = [ch][frames]. */
+int sk_pcm_interleave_i16(sk_engine *, const int16_t *planar, size_t frames, uint32_t ch, uint8_t *out);
+int sk_pcm_deinterleave_i16(sk_engine *, const uint8_t *in, size_t frames, uint32_t ch, int16_t *planar);
+int sk_pcm_deinterleave_s24(sk_engine *, const uint8_t *in, size_t frames, uint32_t ch, int32_t *planar);
+int sk_pcm_deinterleave_f32(sk_engine *, const uint8_t *in, size_t frames, uint32_t ch, float *planar);
+int sk_pcm_interleave_f32(sk_engine *, const float *planar, size_t frames, uint32_t ch, uint8_t *out);
+int sk_pcm_interleave_i16_dev(sk_engine *, const int16_t *d_planar, size_t frames, uint32_t ch, uint8_t *d_out);
+int sk_pcm_deinterleave_i16_dev(sk_engine *, const uint8_t *d_in, size_t frames, uint32_t ch, int16_t *d_planar);
+int sk_pcm_deinterleave_s24_dev(sk_engine *, const uint8_t *d_in, size_t frames, uint32_t ch, int32_t *d_planar);
+int sk_pcm_deinterleave_f32_dev(sk_engine *, const uint8_t *d_in, size_t frames, uint32_t ch, float *d_planar);
+int sk_pcm_interleave_f32_dev(sk_engine *, const float *d_planar, size_t frames, uint32_t ch, uint8_t *d_out);
+
+/* interleaved bytes -> planar f32.  variant 0 = soundkit-decoder audio_data_to_f32_channels
+ * (lib.rs:3563-3617; any fmt; non-finite -> 0); variant 1 = soundkit::audio_to_f32_channels
+ * (audio_pipeline.rs:74-98; LE only; s24 is divided by 2^31 as the reference does). */
+int sk_pcm_bytes_to_f32_planar(sk_engine *, int variant, int fmt, const uint8_t *in, size_t frames, uint32_t ch,
+                               float *planar);
+int sk_pcm_bytes_to_f32_planar_dev(sk_engine *, int variant, int fmt, const uint8_t *d_in, size_t frames,
+                                   uint32_t ch, float *d_planar);
+/* planar f32 -> interleaved bytes: f32_channels_to_bytes (soundkit-decoder lib.rs:3619-3683);
+ * fmt in {S16LE, S24LE, S32LE, F32LE} */
+int sk_pcm_f32_planar_to_bytes(sk_engine *, int fmt, const float *planar, size_t frames, uint32_t ch, uint8_t *out);
+int sk_pcm_f32_planar_to_bytes_dev(sk_engine *, int fmt, const float *d_planar, size_t frames, uint32_t ch,
+                                   uint8_t *d_out);
+/* downmix_channels target 1 (soundkit-decoder lib.rs:3500-3509) */
+int sk_pcm_downmix_mono(sk_engine *, const float *planar, size_t frames, uint32_t ch, float *mono);
+int sk_pcm_downmix_mono_dev(sk_engine *, const float *d_planar, size_t frames, uint32_t ch, float *d_mono);
+/* exact_signed_pcm_to_i16 (soundkit-decoder lib.rs:3458-3489); fmt in {S24LE,S24BE,S32LE,S32BE} */
+int sk_pcm_exact_to_i16(sk_engine *, int fmt, const uint8_t *in, size_t samples, uint8_t *out_s16le);
+int sk_pcm_exact_to_i16_dev(sk_engine *, int fmt, const uint8_t *d_in, size_t samples, uint8_t *d_out_s16le);
+
+/* ---- 48 kHz -> 16 kHz sinc FIR ------------------------------------------ */
+/* Replaces soundkit::audio_pipeline::downsample_audio (audio_pipeline.rs:438-493) for the
+ * 48000 -> 16000 case, where rubato's SincFixedIn<f32> (sinc_len 256, f_cutoff 0.95,
+ * Linear, oversampling 256, BlackmanHarris2) has step exactly 3 and zero fractional phase:
+ *   out[r][m] = sum_{p<256} h[p] * in[r][3m - 125 + p],  in[<0] = 0,
+ *   m < sk_downsample_48k_16k_out_frames(frames) = ceil((frames - 132) / 3).
+ * rows = independent channel signals (streams x channels), each `frames` long. */
+uint32_t sk_downsample_48k_16k_out_frames(uint32_t frames);
+int sk_downsample_48k_16k_taps(sk_engine *, float *taps256); /* the h[] the engine uses */
+int sk_downsample_48k_16k_f32(sk_engine *, const float *in, uint32_t rows, uint32_t frames, float *out,
+                              uint32_t *out_frames);
+int sk_downsample_48k_16k_f32_dev(sk_engine *, const float *d_in, size_t in_stride, uint32_t rows, uint32_t frames,
+                                  float *d_out, size_t out_stride, uint32_t *out_frames);
+
+/* StreamingResampler (soundkit-decoder lib.rs:1917-2060), 48k->16k, fixed 4096-frame
+ * chunks, history kept per stream on the device.  in: n_streams x channels x frames planar
+ * (stream-major); out: capacity out_cap frames per channel row; out_frames[s] receives the
+ * frames produced for stream s by this call (0 until 4096 input frames have accumulated). */
+int sk_resampler_open(sk_engine *, uint32_t stream, uint32_t in_hz, uint32_t out_hz);
+int sk_resampler_close(sk_engine *, uint32_t stream);
+int sk_resampler_process_f32(sk_engine *, const uint32_t *streams, uint32_t n_streams, const float *in,
+                             uint32_t frames, float *out, uint32_t out_cap, uint32_t *out_frames);
+int sk_resampler_flush_f32(sk_engine *, const uint32_t *streams, uint32_t n_streams, float *out, uint32_t out_cap,
+                           uint32_t *out_frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOUNDKIT_AMD_H */

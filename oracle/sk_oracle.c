@@ -76,10 +76,17 @@ void sko_imdct_direct_f64(const float *in, double *out, int n) {
     }
 }
 
-/* forward complex FFT, unnormalised, e^{-2 pi i nk/N}; in-place radix-2, f32.
+/* forward complex FFT, unnormalised, e^{-2 pi i nk/N}; in-place radix-2, f32 (below).
  * Stands in for rustfft 6.4.1 (dsp.rs:107-109, 505): the reference pins only the
  * mathematical result (dsp.rs:694-723), not rustfft's rounding. */
-static void fft_forward_f32(float *re, float *im, int n) {
+/* per-length tables, built once (the reference builds its ImdctTransform once per decoder) */
+typedef struct {
+    int n;                 /* IMDCT input length */
+    float twr[512], twi[512];   /* dsp.rs:99-106 */
+    float fwr[256], fwi[256];   /* FFT roots e^{-2 pi i k / (n/2)}, k < n/4 */
+} imdct_tables;
+
+static void fft_forward_f32(float *re, float *im, int n, const float *fwr, const float *fwi) {
     for (int i = 1, j = 0; i < n; ++i) {
         int bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
@@ -90,41 +97,60 @@ static void fft_forward_f32(float *re, float *im, int n) {
         }
     }
     for (int len = 2; len <= n; len <<= 1) {
-        int half = len >> 1;
-        for (int k = 0; k < half; ++k) {
-            double a = -2.0 * PI_D * (double)k / (double)len;
-            float wr = (float)cos(a), wi = (float)sin(a);
-            for (int i = k; i < n; i += len) {
-                int j = i + half;
-                float xr = re[j] * wr - im[j] * wi;
-                float xi = re[j] * wi + im[j] * wr;
-                re[j] = re[i] - xr; im[j] = im[i] - xi;
-                re[i] = re[i] + xr; im[i] = im[i] + xi;
+        int half = len >> 1, step = n / len;
+        for (int i = 0; i < n; i += len) {
+            for (int k = 0; k < half; ++k) {
+                float wr = fwr[k * step], wi = fwi[k * step];
+                int a = i + k, b = a + half;
+                float xr = re[b] * wr - im[b] * wi;
+                float xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr; im[b] = im[a] - xi;
+                re[a] = re[a] + xr; im[a] = im[a] + xi;
             }
         }
     }
 }
 
-/* dsp.rs:94-119 (twiddles) + 476-535 */
-int sko_imdct_fast(const float *in, float *out, int n) {
-    if (n < 4 || n > 1024 || (n & (n - 1))) return -1;
-    float twr[512], twi[512], fr[512], fi[512];
+static const imdct_tables *get_tables(int n) {
+    static imdct_tables cache[8];
+    static int used = 0;
+    for (int i = 0; i < used; ++i)
+        if (cache[i].n == n) return &cache[i];
+    if (used == 8) used = 0;
+    imdct_tables *t = &cache[used];
     float nf = (float)n;
     float output_scale = (1.0f / 32768.0f) / nf;
     float twiddle_scale = sqrtf(output_scale);
-    int half = n / 2, quarter = n / 4;
+    int half = n / 2;
     for (int b = 0; b < half; ++b) {
         float angle = PI_F / nf * ((float)b + 0.125f);
-        twr[b] = cosf(angle) * twiddle_scale;
-        twi[b] = sinf(angle) * twiddle_scale;
+        t->twr[b] = cosf(angle) * twiddle_scale;
+        t->twi[b] = sinf(angle) * twiddle_scale;
     }
+    for (int k = 0; k < half / 2; ++k) {
+        double a = -2.0 * PI_D * (double)k / (double)half;
+        t->fwr[k] = (float)cos(a);
+        t->fwi[k] = (float)sin(a);
+    }
+    t->n = n;
+    ++used;
+    return t;
+}
+
+/* dsp.rs:94-119 (twiddles) + 476-535 */
+int sko_imdct_fast(const float *in, float *out, int n) {
+    if (n < 4 || n > 1024 || (n & (n - 1))) return -1;
+    float fr[512], fi[512];
+    const imdct_tables *tb = get_tables(n);
+    const float *twr = tb->twr, *twi = tb->twi;
+    int half = n / 2, quarter = n / 4;
     for (int i = 0; i < half; ++i) {
         float even = in[i * 2];
         float odd = -in[n - 1 - i * 2];
         fr[i] = odd * twi[i] - even * twr[i];
         fi[i] = odd * twr[i] + even * twi[i];
     }
-    fft_forward_f32(fr, fi, half);
+    fft_forward_f32(fr, fi, half, tb->fwr, tb->fwi);
     float *out0 = out, *out1 = out + half, *out2 = out + 2 * half, *out3 = out + 3 * half;
     for (int i = 0; i < quarter; ++i) {
         /* value = twiddle * conj(fft) */

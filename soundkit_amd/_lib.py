@@ -1,0 +1,119 @@
+"""Loader for libsoundkit_amd.so (the C ABI of include/soundkit_amd.h).
+
+The HIP library is the product; there is no Python or CPU compute fallback.  If the
+shared object is missing or cannot be loaded this module raises ImportError loudly.
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsoundkit_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "soundkit_amd.h")
+
+SK_OK = 0
+ERR_NAMES = {0: "SK_OK", -1: "SK_ERR_INVALID_ARG", -2: "SK_ERR_NO_DEVICE", -3: "SK_ERR_HIP", -4: "SK_ERR_OOM",
+             -5: "SK_ERR_BAD_STREAM", -6: "SK_ERR_UNSUPPORTED", -7: "SK_ERR_CAPACITY"}
+
+
+class FrameDesc(C.Structure):
+    """sk_aac_frame_desc"""
+    _fields_ = [("stream", C.c_uint32), ("channels", C.c_uint8), ("window_sequence", C.c_uint8 * 2),
+                ("window_shape", C.c_uint8 * 2), ("reserved", C.c_uint8 * 3)]
+
+
+def declared_symbols():
+    """Every function name include/soundkit_amd.h declares."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sk_[a-z0-9_]+)\s*\(", text)))
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "soundkit_amd: %s is missing -- build it with `make -C soundkit_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
+    try:
+        return C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the host
+        raise ImportError("soundkit_amd: cannot load %s: %s (no CPU fallback exists)" % (LIB_PATH, exc))
+
+
+lib = _load()
+
+_vp, _u32, _sz, _i = C.c_void_p, C.c_uint32, C.c_size_t, C.c_int
+_sig = {
+    "sk_engine_create": (_i, [_i, _u32, C.POINTER(_vp)]),
+    "sk_engine_destroy": (None, [_vp]),
+    "sk_engine_device": (_i, [_vp]),
+    "sk_engine_hip_stream": (_vp, [_vp]),
+    "sk_engine_synchronize": (_i, [_vp]),
+    "sk_engine_last_hip_error": (C.c_char_p, [_vp]),
+    "sk_strerror": (C.c_char_p, [_i]),
+    "sk_version": (C.c_char_p, []),
+    "sk_stream_open": (_i, [_vp, _u32, C.c_uint8, C.POINTER(_u32)]),
+    "sk_stream_close": (_i, [_vp, _u32]),
+    "sk_stream_reset": (_i, [_vp, _u32]),
+    "sk_stream_get_state": (_i, [_vp, _u32, _vp, _vp]),
+    "sk_stream_set_state": (_i, [_vp, _u32, _vp, _vp]),
+    "sk_aac_synthesize_f32": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    "sk_aac_synthesize_s16": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    "sk_aac_plan_create": (_i, [_vp, _vp, _u32, _vp, C.POINTER(_vp)]),
+    "sk_aac_plan_destroy": (None, [_vp]),
+    "sk_aac_plan_elements": (C.c_uint64, [_vp]),
+    "sk_aac_plan_frames_ok": (_u32, [_vp]),
+    "sk_aac_plan_run_f32_dev": (_i, [_vp, _vp, _vp, _vp]),
+    "sk_aac_plan_run_s16_dev": (_i, [_vp, _vp, _vp, _vp]),
+    "sk_aac_dequantize_dev": (_i, [_vp, _vp, _vp, _vp, _sz]),
+    "sk_aac_dequantize": (_i, [_vp, _vp, _vp, _vp, _sz]),
+    "sk_pcm_op_in_bytes": (_i, [_i]),
+    "sk_pcm_op_out_bytes": (_i, [_i]),
+    "sk_pcm_convert": (_i, [_vp, _i, _vp, _vp, _sz]),
+    "sk_pcm_convert_dev": (_i, [_vp, _i, _vp, _vp, _sz]),
+    "sk_pcm_fmt_bytes": (_i, [_i]),
+    "sk_pcm_bytes_to_f32_planar": (_i, [_vp, _i, _i, _vp, _sz, _u32, _vp]),
+    "sk_pcm_bytes_to_f32_planar_dev": (_i, [_vp, _i, _i, _vp, _sz, _u32, _vp]),
+    "sk_pcm_f32_planar_to_bytes": (_i, [_vp, _i, _vp, _sz, _u32, _vp]),
+    "sk_pcm_f32_planar_to_bytes_dev": (_i, [_vp, _i, _vp, _sz, _u32, _vp]),
+    "sk_pcm_downmix_mono": (_i, [_vp, _vp, _sz, _u32, _vp]),
+    "sk_pcm_downmix_mono_dev": (_i, [_vp, _vp, _sz, _u32, _vp]),
+    "sk_pcm_exact_to_i16": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "sk_pcm_exact_to_i16_dev": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "sk_downsample_48k_16k_out_frames": (_u32, [_u32]),
+    "sk_downsample_48k_16k_taps": (_i, [_vp, _vp]),
+    "sk_downsample_48k_16k_f32": (_i, [_vp, _vp, _u32, _u32, _vp, C.POINTER(_u32)]),
+    "sk_downsample_48k_16k_f32_dev": (_i, [_vp, _vp, _sz, _u32, _u32, _vp, _sz, C.POINTER(_u32)]),
+    "sk_resampler_open": (_i, [_vp, _u32, _u32, _u32]),
+    "sk_resampler_close": (_i, [_vp, _u32]),
+    "sk_resampler_process_f32": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp]),
+    "sk_resampler_flush_f32": (_i, [_vp, _vp, _u32, _vp, _u32, _vp]),
+}
+for _name in ("sk_pcm_interleave_i16", "sk_pcm_deinterleave_i16", "sk_pcm_deinterleave_s24", "sk_pcm_deinterleave_f32",
+              "sk_pcm_interleave_f32"):
+    _sig[_name] = (_i, [_vp, _vp, _sz, _u32, _vp])
+    _sig[_name + "_dev"] = (_i, [_vp, _vp, _sz, _u32, _vp])
+
+for _name, (_res, _args) in _sig.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library lacks a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class SoundkitError(RuntimeError):
+    """A negative sk_status; the reference's errors on this path are Strings / DecodeError
+    (soundkit-decoder/src/lib.rs:108-118), so the message is what callers see."""
+
+    def __init__(self, status, what="", detail=""):
+        self.status = status
+        name = ERR_NAMES.get(status, str(status))
+        msg = lib.sk_strerror(status).decode()
+        super().__init__("%s failed: %s (%s)%s" % (what, name, msg, (": " + detail) if detail else ""))
+
+
+def check(status, what, engine_handle=None):
+    if status != SK_OK:
+        detail = ""
+        if engine_handle is not None and status in (-3, -4):
+            detail = lib.sk_engine_last_hip_error(engine_handle).decode()
+        raise SoundkitError(status, what, detail)

@@ -1,0 +1,1033 @@
+// engine.cpp -- host side of libsoundkit_amd.so: the C ABI of include/soundkit_amd.h.
+//
+// One sk_engine per GPU.  It owns the per-stream carried state in HBM (overlap delay and
+// previous window shape: soundkit-aac-lc/src/dsp.rs:143-152; resampler history:
+// soundkit-decoder/src/lib.rs:1917-1927), the constant tables, and grow-only staging
+// buffers, and turns batches of frames into per-(stream, channel) wave tasks.
+// There is no CPU compute path here: without a GPU sk_engine_create fails.
+#include "../../include/soundkit_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sk_device.h"
+
+namespace {
+
+constexpr float kPiF = 3.14159274101257324219f;  // f32 PI, as the reference uses
+constexpr double kPi = 3.14159265358979323846;
+constexpr uint32_t kRsChunk = 4096;  // RESAMPLE_CHUNK_SIZE, soundkit-decoder lib.rs:79
+constexpr uint32_t kRsHist = 512;    // 2 * sinc_len kept in front of each chunk (rubato SincFixedIn buffer)
+constexpr uint32_t kRsRow = kRsChunk + kRsHist;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        size_t want = bytes + bytes / 4 + 4096;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct StreamInfo {
+    bool open = false;
+    uint32_t sample_rate = 0;
+    uint8_t channels = 0;
+    // streaming resampler (soundkit-decoder lib.rs:1917-2060)
+    bool rs_open = false;
+    uint32_t rs_fill = 0;     // frames waiting in the chunk area
+    uint64_t rs_chunks = 0;   // chunks already processed (q)
+    uint64_t rs_next_m = 0;   // next output index to produce
+};
+
+// ---- constant tables --------------------------------------------------------------------------
+
+void make_twiddle(int input_len, std::vector<float> &out) {  // dsp.rs:94-106
+    const float nf = (float)input_len;
+    const float output_scale = (1.0f / 32768.0f) / nf;
+    const float twiddle_scale = std::sqrt(output_scale);
+    const int fft_len = input_len / 2;
+    out.resize(2 * (size_t)fft_len);
+    for (int b = 0; b < fft_len; ++b) {
+        const float angle = kPiF / nf * ((float)b + 0.125f);
+        out[2 * b] = std::cos(angle) * twiddle_scale;
+        out[2 * b + 1] = std::sin(angle) * twiddle_scale;
+    }
+}
+
+void make_roots(int n, std::vector<float> &out) {  // e^{-2 pi i m / n}
+    out.resize(2 * (size_t)n);
+    for (int m = 0; m < n; ++m) {
+        const double a = -2.0 * kPi * (double)m / (double)n;
+        out[2 * m] = (float)std::cos(a);
+        out[2 * m + 1] = (float)std::sin(a);
+    }
+}
+
+void sine_window(int len, float *out) {  // dsp.rs:542-547
+    const float scale = kPiF / (float)len;
+    for (int i = 0; i < len; ++i) out[i] = std::sin(((float)i + 0.5f) * scale);
+}
+
+double bessel_i0(double x) {  // dsp.rs:572-587
+    const double half = x * 0.5;
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k <= 64; ++k) {
+        const double ratio = half / (double)k;
+        term *= ratio * ratio;
+        sum += term;
+        if (std::fabs(term) < 1.0e-14 * sum) break;
+    }
+    return sum;
+}
+
+void kbd_window(int len, float alpha, float *out) {  // dsp.rs:549-570
+    const int half = len / 2;
+    std::vector<double> kernel((size_t)half + 1);
+    const double denom_arg = kPi * (double)alpha;
+    for (int i = 0; i <= half; ++i) {
+        const double ratio = 2.0 * (double)i / (double)half - 1.0;
+        double inner = 1.0 - ratio * ratio;
+        if (inner < 0.0) inner = 0.0;
+        kernel[i] = bessel_i0(denom_arg * std::sqrt(inner));
+    }
+    double total = 0.0;
+    for (double v : kernel) total += v;
+    double cumulative = 0.0;
+    for (int i = 0; i < len; ++i) out[i] = 0.0f;
+    for (int i = 0; i < half; ++i) {
+        cumulative += kernel[i];
+        out[i] = (float)std::sqrt(cumulative / total);
+        out[len - 1 - i] = out[i];
+    }
+}
+
+// rubato 0.14.1 make_sincs, T = f32, sinc_len 256, oversampling 256, BlackmanHarris2,
+// cutoff 0.95 * ratio (ratio < 1): sub-filter 0 only (the one a zero fractional phase selects).
+void make_taps_48k_16k(float *taps) {
+    const size_t npoints = 256, factor = 256, tot = npoints * factor;
+    const float f_cutoff = 0.95f * (float)(16000.0 / 48000.0);
+    std::vector<float> y(tot);
+    const float pi2 = 2.0f * kPiF, pi4 = 4.0f * kPiF, pi6 = 6.0f * kPiF, np_f = (float)tot;
+    float sum = 0.0f;
+    for (size_t x = 0; x < tot; ++x) {
+        const float xf = (float)x;
+        float w = 0.35875f - 0.48829f * std::cos(pi2 * xf / np_f) + 0.14128f * std::cos(pi4 * xf / np_f) -
+                  0.01168f * std::cos(pi6 * xf / np_f);
+        w = w * w;
+        const float v = (xf - (float)(tot / 2)) * f_cutoff / (float)factor;
+        const float sinc = v == 0.0f ? 1.0f : std::sin(v * kPiF) / (v * kPiF);
+        const float val = w * sinc;
+        sum += val;
+        y[x] = val;
+    }
+    sum /= (float)factor;
+    for (size_t p = 0; p < npoints; ++p) taps[p] = y[factor * p + (factor - 1)] / sum;  // sincs[0][p]
+}
+
+}  // namespace
+
+struct sk_engine {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint32_t max_streams = 0;
+    std::mutex mu;
+    std::string last_hip_error;
+
+    std::vector<StreamInfo> streams;
+    std::vector<uint32_t> free_ids;
+
+    float *d_delay = nullptr;
+    uint8_t *d_prev_shape = nullptr;
+    float *d_rs = nullptr;  // [max_streams * 2][kRsRow], allocated on first sk_resampler_open
+
+    // tables
+    float *d_tables = nullptr;
+    sk::SynthTables synth_tables{};
+    float *d_pow43 = nullptr, *d_sftab = nullptr, *d_taps = nullptr, *d_afrag = nullptr, *d_zeros = nullptr;
+    std::vector<float> h_taps;
+
+    // grow-only scratch
+    DevBuf in_buf, out_buf, aux_buf, aux2_buf;
+    std::vector<uint32_t> state_count, state_task;  // plan construction scratch
+
+    int hip_fail(hipError_t e, const char *what) {
+        last_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? SK_ERR_OOM : SK_ERR_HIP;
+    }
+};
+
+struct sk_aac_plan {
+    sk_engine *eng = nullptr;
+    uint32_t n_tasks = 0, n_entries = 0, n_frames_ok = 0;
+    uint64_t elements = 0;
+    sk::SynthTask *d_tasks = nullptr;
+    sk::SynthEntry *d_entries = nullptr;
+    sk::FrameSpan *d_spans = nullptr;
+};
+
+#define SK_HIP(expr, what)                               \
+    do {                                                  \
+        hipError_t _e = (expr);                           \
+        if (_e != hipSuccess) return e->hip_fail(_e, what); \
+    } while (0)
+
+namespace {
+
+struct DeviceGuard {
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); want = dev; }
+    ~DeviceGuard() { if (prev != want && prev >= 0) (void)hipSetDevice(prev); }
+    int prev = -1, want = -1;
+};
+
+template <typename T>
+hipError_t upload(T **dst, const std::vector<T> &src) {
+    hipError_t e = hipMalloc((void **)dst, src.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+int build_tables(sk_engine *e) {
+    std::vector<float> tw_long, tw_short, w64, w512;
+    make_twiddle(1024, tw_long);
+    make_twiddle(128, tw_short);
+    make_roots(64, w64);
+    make_roots(512, w512);
+    std::vector<float> win(2048 * 2 + 256 * 2);
+    sine_window(2048, win.data());
+    kbd_window(2048, 4.0f, win.data() + 2048);
+    sine_window(256, win.data() + 4096);
+    kbd_window(256, 6.0f, win.data() + 4096 + 256);
+
+    std::vector<float> all;
+    const size_t o_twl = 0, o_tws = o_twl + tw_long.size(), o_w64 = o_tws + tw_short.size(),
+                 o_w512 = o_w64 + w64.size(), o_win = o_w512 + w512.size();
+    all.insert(all.end(), tw_long.begin(), tw_long.end());
+    all.insert(all.end(), tw_short.begin(), tw_short.end());
+    all.insert(all.end(), w64.begin(), w64.end());
+    all.insert(all.end(), w512.begin(), w512.end());
+    all.insert(all.end(), win.begin(), win.end());
+    SK_HIP(upload(&e->d_tables, all), "upload synthesis tables");
+    e->synth_tables.tw_long = reinterpret_cast<const float2 *>(e->d_tables + o_twl);
+    e->synth_tables.tw_short = reinterpret_cast<const float2 *>(e->d_tables + o_tws);
+    e->synth_tables.w64 = reinterpret_cast<const float2 *>(e->d_tables + o_w64);
+    e->synth_tables.w512 = reinterpret_cast<const float2 *>(e->d_tables + o_w512);
+    e->synth_tables.win = e->d_tables + o_win;
+
+    std::vector<float> pow43(8192), sftab(768);  // dsp.rs:420-450
+    for (int v = 0; v < 8192; ++v) pow43[v] = std::pow((float)v, 4.0f / 3.0f);
+    for (int sf = -256; sf <= 511; ++sf) sftab[sf + 256] = std::pow(2.0f, ((float)sf - 100.0f) * 0.25f);
+    SK_HIP(upload(&e->d_pow43, pow43), "upload pow43");
+    SK_HIP(upload(&e->d_sftab, sftab), "upload scalefactor table");
+
+    e->h_taps.resize(256);
+    make_taps_48k_16k(e->h_taps.data());
+    SK_HIP(upload(&e->d_taps, e->h_taps), "upload taps");
+    // MFMA A-operand fragments: step s, lane l (i = l & 15, q = l >> 4):
+    //   tap p = 16 (s >> 2) + 4 q + (s & 3) - 3 i - 3, zero outside [0, 255]
+    std::vector<float> afrag(76 * 64, 0.0f);
+    for (int s = 0; s < 76; ++s)
+        for (int l = 0; l < 64; ++l) {
+            const int p = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3) - 3 * (l & 15) - 3;
+            if (p >= 0 && p < 256) afrag[s * 64 + l] = e->h_taps[p];
+        }
+    SK_HIP(upload(&e->d_afrag, afrag), "upload tap fragments");
+    std::vector<float> zeros(1024, 0.0f);
+    SK_HIP(upload(&e->d_zeros, zeros), "upload zeros");
+    return SK_OK;
+}
+
+// shared shape of every host-buffer PCM entry point: H2D, one launch, D2H, sync
+template <typename Launch>
+int host_roundtrip(sk_engine *e, const void *in, size_t in_bytes, void *out, size_t out_bytes, Launch launch) {
+    if (!e || (in_bytes && !in) || (out_bytes && !out)) return SK_ERR_INVALID_ARG;
+    if (out_bytes == 0) return SK_OK;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    SK_HIP(e->in_buf.reserve(in_bytes), "alloc staging");
+    SK_HIP(e->out_buf.reserve(out_bytes), "alloc staging");
+    SK_HIP(hipMemcpyAsync(e->in_buf.p, in, in_bytes, hipMemcpyHostToDevice, e->stream), "H2D pcm");
+    SK_HIP(launch(e->in_buf.p, e->out_buf.p), "launch pcm kernel");
+    SK_HIP(hipMemcpyAsync(out, e->out_buf.p, out_bytes, hipMemcpyDeviceToHost, e->stream), "D2H pcm");
+    SK_HIP(hipStreamSynchronize(e->stream), "pcm sync");
+    return SK_OK;
+}
+
+bool stream_ok(const sk_engine *e, uint32_t id) { return id < e->streams.size() && e->streams[id].open; }
+
+}  // namespace
+
+extern "C" {
+
+const char *sk_version(void) { return "soundkit_amd 0.1.0 (gfx950)"; }
+
+const char *sk_strerror(int status) {
+    switch (status) {
+    case SK_OK: return "ok";
+    case SK_ERR_INVALID_ARG: return "invalid argument";
+    case SK_ERR_NO_DEVICE: return "no usable HIP device";
+    case SK_ERR_HIP: return "HIP runtime error";
+    case SK_ERR_OOM: return "out of device memory";
+    case SK_ERR_BAD_STREAM: return "stream is not open";
+    case SK_ERR_UNSUPPORTED: return "unsupported configuration";
+    case SK_ERR_CAPACITY: return "max_streams exhausted";
+    default: return "unknown status";
+    }
+}
+
+int sk_engine_create(int device, uint32_t max_streams, sk_engine **out) {
+    if (!out || max_streams == 0) return SK_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return SK_ERR_NO_DEVICE;
+    sk_engine *e = new (std::nothrow) sk_engine();
+    if (!e) return SK_ERR_OOM;
+    e->device = device;
+    e->max_streams = max_streams;
+    DeviceGuard guard(device);
+    int rc = SK_OK;
+    do {
+        hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        if (he != hipSuccess) { rc = e->hip_fail(he, "hipStreamCreate"); break; }
+        const size_t states = (size_t)max_streams * 2;
+        he = hipMalloc((void **)&e->d_delay, states * 1024 * sizeof(float));
+        if (he != hipSuccess) { rc = e->hip_fail(he, "alloc delay"); break; }
+        he = hipMalloc((void **)&e->d_prev_shape, states);
+        if (he != hipSuccess) { rc = e->hip_fail(he, "alloc prev_shape"); break; }
+        (void)hipMemset(e->d_delay, 0, states * 1024 * sizeof(float));
+        (void)hipMemset(e->d_prev_shape, 0, states);
+        rc = build_tables(e);
+        if (rc != SK_OK) break;
+        e->streams.resize(max_streams);
+        e->free_ids.reserve(max_streams);
+        for (uint32_t i = max_streams; i-- > 0;) e->free_ids.push_back(i);
+        e->state_count.assign(states, 0);
+        e->state_task.assign(states, 0);
+    } while (0);
+    if (rc != SK_OK) {
+        sk_engine_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return SK_OK;
+}
+
+void sk_engine_destroy(sk_engine *e) {
+    if (!e) return;
+    {
+        DeviceGuard guard(e->device);
+        if (e->stream) (void)hipStreamSynchronize(e->stream);
+        for (void *p : {(void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
+                        (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag,
+                        (void *)e->d_zeros})
+            if (p) (void)hipFree(p);
+        e->in_buf.release();
+        e->out_buf.release();
+        e->aux_buf.release();
+        e->aux2_buf.release();
+        if (e->stream) (void)hipStreamDestroy(e->stream);
+    }
+    delete e;
+}
+
+int sk_engine_device(const sk_engine *e) { return e ? e->device : -1; }
+void *sk_engine_hip_stream(sk_engine *e) { return e ? (void *)e->stream : nullptr; }
+const char *sk_engine_last_hip_error(const sk_engine *e) { return e ? e->last_hip_error.c_str() : ""; }
+
+int sk_engine_synchronize(sk_engine *e) {
+    if (!e) return SK_ERR_INVALID_ARG;
+    DeviceGuard guard(e->device);
+    SK_HIP(hipStreamSynchronize(e->stream), "stream synchronize");
+    return SK_OK;
+}
+
+// ---- streams --------------------------------------------------------------------------------
+
+static int reset_stream_state(sk_engine *e, uint32_t id) {
+    SK_HIP(hipMemsetAsync(e->d_delay + (size_t)id * 2048, 0, 2048 * sizeof(float), e->stream), "reset delay");
+    SK_HIP(hipMemsetAsync(e->d_prev_shape + (size_t)id * 2, 0, 2, e->stream), "reset shape");
+    return SK_OK;
+}
+
+int sk_stream_open(sk_engine *e, uint32_t sample_rate, uint8_t channels, uint32_t *stream_out) {
+    if (!e || !stream_out || channels < 1 || channels > SK_MAX_CHANNELS || sample_rate == 0) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (e->free_ids.empty()) return SK_ERR_CAPACITY;
+    DeviceGuard guard(e->device);
+    const uint32_t id = e->free_ids.back();
+    int rc = reset_stream_state(e, id);
+    if (rc != SK_OK) return rc;
+    e->free_ids.pop_back();
+    StreamInfo &s = e->streams[id];
+    s = StreamInfo();
+    s.open = true;
+    s.sample_rate = sample_rate;
+    s.channels = channels;
+    *stream_out = id;
+    return SK_OK;
+}
+
+int sk_stream_close(sk_engine *e, uint32_t id) {
+    if (!e) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
+    e->streams[id] = StreamInfo();
+    e->free_ids.push_back(id);
+    return SK_OK;
+}
+
+int sk_stream_reset(sk_engine *e, uint32_t id) {
+    if (!e) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
+    DeviceGuard guard(e->device);
+    StreamInfo &s = e->streams[id];
+    s.rs_fill = 0;
+    s.rs_chunks = 0;
+    s.rs_next_m = 0;
+    if (s.rs_open && e->d_rs)
+        SK_HIP(hipMemsetAsync(e->d_rs + (size_t)id * 2 * kRsRow, 0, 2 * kRsRow * sizeof(float), e->stream), "reset rs");
+    return reset_stream_state(e, id);
+}
+
+int sk_stream_get_state(sk_engine *e, uint32_t id, float *delay_out, uint8_t *prev_shape_out) {
+    if (!e || !delay_out || !prev_shape_out) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
+    DeviceGuard guard(e->device);
+    const uint32_t ch = e->streams[id].channels;
+    SK_HIP(hipMemcpyAsync(delay_out, e->d_delay + (size_t)id * 2048, ch * 1024 * sizeof(float), hipMemcpyDeviceToHost,
+                          e->stream), "get delay");
+    SK_HIP(hipMemcpyAsync(prev_shape_out, e->d_prev_shape + (size_t)id * 2, ch, hipMemcpyDeviceToHost, e->stream),
+           "get shape");
+    SK_HIP(hipStreamSynchronize(e->stream), "get state sync");
+    return SK_OK;
+}
+
+int sk_stream_set_state(sk_engine *e, uint32_t id, const float *delay, const uint8_t *prev_shape) {
+    if (!e || !delay || !prev_shape) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
+    const uint32_t ch = e->streams[id].channels;
+    for (uint32_t c = 0; c < ch; ++c)
+        if (prev_shape[c] > 1) return SK_ERR_INVALID_ARG;
+    DeviceGuard guard(e->device);
+    SK_HIP(hipMemcpyAsync(e->d_delay + (size_t)id * 2048, delay, ch * 1024 * sizeof(float), hipMemcpyHostToDevice,
+                          e->stream), "set delay");
+    SK_HIP(hipMemcpyAsync(e->d_prev_shape + (size_t)id * 2, prev_shape, ch, hipMemcpyHostToDevice, e->stream),
+           "set shape");
+    SK_HIP(hipStreamSynchronize(e->stream), "set state sync");
+    return SK_OK;
+}
+
+// ---- AAC synthesis ----------------------------------------------------------------------------
+
+void sk_aac_plan_destroy(sk_aac_plan *p) {
+    if (!p) return;
+    if (p->eng) {
+        DeviceGuard guard(p->eng->device);
+        if (p->d_tasks) (void)hipFree(p->d_tasks);
+        if (p->d_entries) (void)hipFree(p->d_entries);
+        if (p->d_spans) (void)hipFree(p->d_spans);
+    }
+    delete p;
+}
+
+uint64_t sk_aac_plan_elements(const sk_aac_plan *p) { return p ? p->elements : 0; }
+uint32_t sk_aac_plan_frames_ok(const sk_aac_plan *p) { return p ? p->n_frames_ok : 0; }
+
+int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, int32_t *status, sk_aac_plan **out) {
+    if (!e || !out || (n && !descs)) return SK_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+
+    // pass 1: validate, count entries per (stream, channel) state, in first-touch order
+    std::vector<uint32_t> touched;
+    std::vector<uint8_t> ok(n, 0);
+    uint32_t frames_ok = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const sk_aac_frame_desc &d = descs[i];
+        int32_t st = SK_FRAME_OK;
+        if (!stream_ok(e, d.stream)) st = SK_FRAME_BAD_STREAM;
+        else if (d.channels != e->streams[d.stream].channels) st = SK_FRAME_BAD_CHANNELS;
+        else {
+            for (uint32_t c = 0; c < d.channels; ++c)
+                if (d.window_sequence[c] > 3 || d.window_shape[c] > 1) st = SK_FRAME_BAD_WINDOW;
+        }
+        if (status) status[i] = st;
+        if (st != SK_FRAME_OK) continue;
+        ok[i] = 1;
+        ++frames_ok;
+        for (uint32_t c = 0; c < d.channels; ++c) {
+            const uint32_t state = d.stream * 2 + c;
+            if (e->state_count[state]++ == 0) touched.push_back(state);
+        }
+    }
+    // tasks in first-touch order; entries grouped per task, array order kept inside a task
+    std::vector<sk::SynthTask> tasks(touched.size());
+    uint32_t n_entries = 0;
+    for (size_t t = 0; t < touched.size(); ++t) {
+        const uint32_t state = touched[t];
+        tasks[t].state = state;
+        tasks[t].begin = n_entries;
+        tasks[t].count = 0;
+        tasks[t].pad = 0;
+        n_entries += e->state_count[state];
+        e->state_task[state] = (uint32_t)t;
+    }
+    std::vector<sk::SynthEntry> entries(n_entries);
+    std::vector<sk::FrameSpan> spans;
+    spans.reserve(frames_ok);
+    uint64_t off = 0;  // in units of 1024 f32; advances for failed frames too (packing follows the descs)
+    bool bad_desc_channels = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const sk_aac_frame_desc &d = descs[i];
+        if (ok[i]) {
+            for (uint32_t c = 0; c < d.channels; ++c) {
+                sk::SynthTask &t = tasks[e->state_task[d.stream * 2 + c]];
+                sk::SynthEntry &en = entries[t.begin + t.count++];
+                en.off1024 = (uint32_t)(off + c);
+                en.win = (uint32_t)d.window_sequence[c] | ((uint32_t)d.window_shape[c] << 2);
+            }
+            spans.push_back(sk::FrameSpan{(uint32_t)off, d.channels});
+        }
+        if (d.channels < 1 || d.channels > SK_MAX_CHANNELS) bad_desc_channels = true;
+        off += d.channels;
+    }
+    for (uint32_t state : touched) e->state_count[state] = 0;
+    if (bad_desc_channels || off > 0xffffffffull) return SK_ERR_INVALID_ARG;
+
+    sk_aac_plan *p = new (std::nothrow) sk_aac_plan();
+    if (!p) return SK_ERR_OOM;
+    p->eng = e;
+    p->n_tasks = (uint32_t)tasks.size();
+    p->n_entries = n_entries;
+    p->n_frames_ok = frames_ok;
+    p->elements = off * 1024;
+    if (!tasks.empty()) {
+        hipError_t he = upload(&p->d_tasks, tasks);
+        if (he == hipSuccess) he = upload(&p->d_entries, entries);
+        if (he == hipSuccess) he = upload(&p->d_spans, spans);
+        if (he != hipSuccess) {
+            sk_aac_plan_destroy(p);
+            return e->hip_fail(he, "upload plan");
+        }
+    }
+    *out = p;
+    return SK_OK;
+}
+
+static int run_plan(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, float *d_pcm) {
+    sk::SynthArgs a{};
+    a.coeffs = d_coeffs;
+    a.pcm = d_pcm;
+    a.delay = e->d_delay;
+    a.prev_shape = e->d_prev_shape;
+    a.tasks = p->d_tasks;
+    a.entries = p->d_entries;
+    a.n_tasks = p->n_tasks;
+    a.t = e->synth_tables;
+    SK_HIP(sk::launch_aac_synth(a, e->stream), "launch aac synth");
+    return SK_OK;
+}
+
+int sk_aac_plan_run_f32_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, float *d_pcm) {
+    if (!e || !p || p->eng != e) return SK_ERR_INVALID_ARG;
+    if (p->n_tasks == 0) return SK_OK;
+    if (!d_coeffs || !d_pcm) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    return run_plan(e, p, d_coeffs, d_pcm);
+}
+
+int sk_aac_plan_run_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, int16_t *d_pcm) {
+    if (!e || !p || p->eng != e) return SK_ERR_INVALID_ARG;
+    if (p->n_tasks == 0) return SK_OK;
+    if (!d_coeffs || !d_pcm) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    SK_HIP(e->aux_buf.reserve(p->elements * sizeof(float)), "alloc planar scratch");
+    int rc = run_plan(e, p, d_coeffs, (float *)e->aux_buf.p);
+    if (rc != SK_OK) return rc;
+    SK_HIP(sk::launch_frames_to_s16((const float *)e->aux_buf.p, d_pcm, p->d_spans, p->n_frames_ok, e->stream),
+           "launch s16 interleave");
+    return SK_OK;
+}
+
+static int synthesize_host(sk_engine *e, const sk_aac_frame_desc *descs, const float *coeffs, void *pcm_out, uint32_t n,
+                           int32_t *status, bool s16) {
+    if (!e || (n && (!descs || !coeffs || !pcm_out))) return SK_ERR_INVALID_ARG;
+    if (n == 0) return SK_OK;
+    sk_aac_plan *p = nullptr;
+    int rc = sk_aac_plan_create(e, descs, n, status, &p);
+    if (rc != SK_OK) return rc;
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        DeviceGuard guard(e->device);
+        const size_t elems = (size_t)p->elements;
+        do {
+            hipError_t he = e->in_buf.reserve(elems * sizeof(float));
+            if (he == hipSuccess) he = e->out_buf.reserve(elems * sizeof(float));
+            if (he != hipSuccess) { rc = e->hip_fail(he, "alloc staging"); break; }
+            if (p->n_tasks == 0) break;
+            he = hipMemcpyAsync(e->in_buf.p, coeffs, elems * sizeof(float), hipMemcpyHostToDevice, e->stream);
+            if (he != hipSuccess) { rc = e->hip_fail(he, "H2D coeffs"); break; }
+            // frames that failed validation keep the caller's bytes: bring the current contents over first
+            const size_t out_bytes = elems * (s16 ? sizeof(int16_t) : sizeof(float));
+            if (p->n_frames_ok != n) {
+                he = hipMemcpyAsync(e->out_buf.p, pcm_out, out_bytes, hipMemcpyHostToDevice, e->stream);
+                if (he != hipSuccess) { rc = e->hip_fail(he, "H2D pcm"); break; }
+            }
+            if (s16) {
+                he = e->aux_buf.reserve(elems * sizeof(float));
+                if (he != hipSuccess) { rc = e->hip_fail(he, "alloc planar scratch"); break; }
+                rc = run_plan(e, p, (const float *)e->in_buf.p, (float *)e->aux_buf.p);
+                if (rc != SK_OK) break;
+                he = sk::launch_frames_to_s16((const float *)e->aux_buf.p, (int16_t *)e->out_buf.p, p->d_spans,
+                                              p->n_frames_ok, e->stream);
+                if (he != hipSuccess) { rc = e->hip_fail(he, "launch s16 interleave"); break; }
+            } else {
+                rc = run_plan(e, p, (const float *)e->in_buf.p, (float *)e->out_buf.p);
+                if (rc != SK_OK) break;
+            }
+            he = hipMemcpyAsync(pcm_out, e->out_buf.p, out_bytes, hipMemcpyDeviceToHost, e->stream);
+            if (he != hipSuccess) { rc = e->hip_fail(he, "D2H pcm"); break; }
+            he = hipStreamSynchronize(e->stream);
+            if (he != hipSuccess) { rc = e->hip_fail(he, "synthesize sync"); break; }
+        } while (0);
+    }
+    sk_aac_plan_destroy(p);
+    return rc;
+}
+
+int sk_aac_synthesize_f32(sk_engine *e, const sk_aac_frame_desc *descs, const float *coeffs, float *pcm_out, uint32_t n,
+                          int32_t *status) {
+    return synthesize_host(e, descs, coeffs, pcm_out, n, status, false);
+}
+
+int sk_aac_synthesize_s16(sk_engine *e, const sk_aac_frame_desc *descs, const float *coeffs, int16_t *pcm_out,
+                          uint32_t n, int32_t *status) {
+    return synthesize_host(e, descs, coeffs, pcm_out, n, status, true);
+}
+
+int sk_aac_dequantize_dev(sk_engine *e, const int16_t *d_quant, const int16_t *d_sf, float *d_out, size_t n) {
+    if (!e || (n && (!d_quant || !d_sf || !d_out))) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    SK_HIP(sk::launch_dequantize(d_quant, d_sf, d_out, n, e->d_pow43, e->d_sftab, e->stream), "launch dequantize");
+    return SK_OK;
+}
+
+int sk_aac_dequantize(sk_engine *e, const int16_t *quant, const int16_t *sf, float *out, size_t n) {
+    if (!e || (n && (!quant || !sf || !out))) return SK_ERR_INVALID_ARG;
+    if (n == 0) return SK_OK;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    SK_HIP(e->in_buf.reserve(n * 4), "alloc staging");
+    SK_HIP(e->out_buf.reserve(n * 4), "alloc staging");
+    int16_t *dq = (int16_t *)e->in_buf.p, *dsf = dq + n;
+    SK_HIP(hipMemcpyAsync(dq, quant, n * 2, hipMemcpyHostToDevice, e->stream), "H2D quant");
+    SK_HIP(hipMemcpyAsync(dsf, sf, n * 2, hipMemcpyHostToDevice, e->stream), "H2D sf");
+    SK_HIP(sk::launch_dequantize(dq, dsf, (float *)e->out_buf.p, n, e->d_pow43, e->d_sftab, e->stream), "launch dequantize");
+    SK_HIP(hipMemcpyAsync(out, e->out_buf.p, n * 4, hipMemcpyDeviceToHost, e->stream), "D2H dequant");
+    SK_HIP(hipStreamSynchronize(e->stream), "dequant sync");
+    return SK_OK;
+}
+
+// ---- PCM conversion ----------------------------------------------------------------------------
+
+static const int8_t kOpIn[SK_PCM_OP_COUNT] = {2, 2, 2, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 2, 2, 4, 4, 4, 2, 4, 4, 4, 4};
+static const int8_t kOpOut[SK_PCM_OP_COUNT] = {4, 2, 2, 4, 2, 2, 4, 4, 4, 4, 4, 4, 2, 2, 2, 2, 4, 4, 2, 2, 4, 2, 2, 2, 4, 4, 2, 2, 4};
+
+int sk_pcm_op_in_bytes(int op) { return (op < 0 || op >= SK_PCM_OP_COUNT) ? -1 : kOpIn[op]; }
+int sk_pcm_op_out_bytes(int op) { return (op < 0 || op >= SK_PCM_OP_COUNT) ? -1 : kOpOut[op]; }
+
+int sk_pcm_fmt_bytes(int fmt) {
+    switch (fmt) {
+    case SK_FMT_S16LE: case SK_FMT_S16BE: return 2;
+    case SK_FMT_S24LE: case SK_FMT_S24BE: return 3;
+    case SK_FMT_S32LE: case SK_FMT_S32BE: case SK_FMT_F32LE: case SK_FMT_F32BE: return 4;
+    default: return -1;
+    }
+}
+
+int sk_pcm_convert_dev(sk_engine *e, int op, const void *d_in, void *d_out, size_t n) {
+    if (!e || op < 0 || op >= SK_PCM_OP_COUNT || (n && (!d_in || !d_out))) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    SK_HIP(sk::launch_pcm_convert(op, d_in, d_out, n, e->stream), "launch pcm convert");
+    return SK_OK;
+}
+
+int sk_pcm_convert(sk_engine *e, int op, const void *in, void *out, size_t n) {
+    if (op < 0 || op >= SK_PCM_OP_COUNT) return SK_ERR_INVALID_ARG;
+    return host_roundtrip(e, in, n * kOpIn[op], out, n * kOpOut[op], [&](void *di, void *dout) {
+        return sk::launch_pcm_convert(op, di, dout, n, e->stream);
+    });
+}
+
+#define SK_DEV_ENTRY(call)                              \
+    do {                                                \
+        std::lock_guard<std::mutex> lock(e->mu);        \
+        DeviceGuard guard(e->device);                   \
+        SK_HIP(call, "launch pcm kernel");              \
+        return SK_OK;                                   \
+    } while (0)
+
+int sk_pcm_interleave_i16_dev(sk_engine *e, const int16_t *d_planar, size_t frames, uint32_t ch, uint8_t *d_out) {
+    if (!e || ch == 0 || (frames && (!d_planar || !d_out))) return SK_ERR_INVALID_ARG;
+    SK_DEV_ENTRY(sk::launch_interleave(d_planar, d_out, frames, ch, 2, e->stream));
+}
+int sk_pcm_deinterleave_i16_dev(sk_engine *e, const uint8_t *d_in, size_t frames, uint32_t ch, int16_t *d_planar) {
+    if (!e || ch == 0 || (frames && (!d_in || !d_planar))) return SK_ERR_INVALID_ARG;
+    SK_DEV_ENTRY(sk::launch_deinterleave(d_in, d_planar, frames, ch, 2, e->stream));
+}
+int sk_pcm_deinterleave_s24_dev(sk_engine *e, const uint8_t *d_in, size_t frames, uint32_t ch, int32_t *d_planar) {
+    if (!e || ch == 0 || (frames && (!d_in || !d_planar))) return SK_ERR_INVALID_ARG;
+    SK_DEV_ENTRY(sk::launch_deinterleave_s24(d_in, d_planar, frames, ch, e->stream));
+}
+int sk_pcm_deinterleave_f32_dev(sk_engine *e, const uint8_t *d_in, size_t frames, uint32_t ch, float *d_planar) {
+    if (!e || ch == 0 || (frames && (!d_in || !d_planar))) return SK_ERR_INVALID_ARG;
+    SK_DEV_ENTRY(sk::launch_deinterleave(d_in, d_planar, frames, ch, 4, e->stream));
+}
+int sk_pcm_interleave_f32_dev(sk_engine *e, const float *d_planar, size_t frames, uint32_t ch, uint8_t *d_out) {
+    if (!e || ch == 0 || (frames && (!d_planar || !d_out))) return SK_ERR_INVALID_ARG;
+    SK_DEV_ENTRY(sk::launch_interleave(d_planar, d_out, frames, ch, 4, e->stream));
+}
+
+int sk_pcm_interleave_i16(sk_engine *e, const int16_t *planar, size_t frames, uint32_t ch, uint8_t *out) {
+    if (ch == 0) return SK_ERR_INVALID_ARG;
+    const size_t bytes = frames * ch * 2;
+    return host_roundtrip(e, planar, bytes, out, bytes, [&](void *di, void *dout) {
+        return sk::launch_interleave(di, dout, frames, ch, 2, e->stream);
+    });
+}
+int sk_pcm_deinterleave_i16(sk_engine *e, const uint8_t *in, size_t frames, uint32_t ch, int16_t *planar) {
+    if (ch == 0) return SK_ERR_INVALID_ARG;
+    const size_t bytes = frames * ch * 2;
+    return host_roundtrip(e, in, bytes, planar, bytes, [&](void *di, void *dout) {
+        return sk::launch_deinterleave(di, dout, frames, ch, 2, e->stream);
+    });
+}
+int sk_pcm_deinterleave_s24(sk_engine *e, const uint8_t *in, size_t frames, uint32_t ch, int32_t *planar) {
+    if (ch == 0) return SK_ERR_INVALID_ARG;
+    return host_roundtrip(e, in, frames * ch * 3, planar, frames * ch * 4, [&](void *di, void *dout) {
+        return sk::launch_deinterleave_s24((const uint8_t *)di, (int32_t *)dout, frames, ch, e->stream);
+    });
+}
+int sk_pcm_deinterleave_f32(sk_engine *e, const uint8_t *in, size_t frames, uint32_t ch, float *planar) {
+    if (ch == 0) return SK_ERR_INVALID_ARG;
+    const size_t bytes = frames * ch * 4;
+    return host_roundtrip(e, in, bytes, planar, bytes, [&](void *di, void *dout) {
+        return sk::launch_deinterleave(di, dout, frames, ch, 4, e->stream);
+    });
+}
+int sk_pcm_interleave_f32(sk_engine *e, const float *planar, size_t frames, uint32_t ch, uint8_t *out) {
+    if (ch == 0) return SK_ERR_INVALID_ARG;
+    const size_t bytes = frames * ch * 4;
+    return host_roundtrip(e, planar, bytes, out, bytes, [&](void *di, void *dout) {
+        return sk::launch_interleave(di, dout, frames, ch, 4, e->stream);
+    });
+}
+
+static bool to_f32_args_ok(int variant, int fmt) {
+    if (variant == 0) return fmt >= SK_FMT_S16LE && fmt <= SK_FMT_F32BE;
+    return variant == 1 && (fmt == SK_FMT_S16LE || fmt == SK_FMT_S24LE || fmt == SK_FMT_S32LE || fmt == SK_FMT_F32LE);
+}
+static bool from_f32_fmt_ok(int fmt) {
+    return fmt == SK_FMT_S16LE || fmt == SK_FMT_S24LE || fmt == SK_FMT_S32LE || fmt == SK_FMT_F32LE;
+}
+
+int sk_pcm_bytes_to_f32_planar_dev(sk_engine *e, int variant, int fmt, const uint8_t *d_in, size_t frames, uint32_t ch,
+                                   float *d_planar) {
+    if (!e || ch == 0 || !to_f32_args_ok(variant, fmt) || (frames && (!d_in || !d_planar))) return SK_ERR_INVALID_ARG;
+    SK_DEV_ENTRY(sk::launch_bytes_to_f32_planar(variant, fmt, d_in, frames, ch, d_planar, e->stream));
+}
+int sk_pcm_bytes_to_f32_planar(sk_engine *e, int variant, int fmt, const uint8_t *in, size_t frames, uint32_t ch,
+                               float *planar) {
+    if (ch == 0 || !to_f32_args_ok(variant, fmt)) return SK_ERR_INVALID_ARG;
+    return host_roundtrip(e, in, frames * ch * sk_pcm_fmt_bytes(fmt), planar, frames * ch * 4, [&](void *di, void *dout) {
+        return sk::launch_bytes_to_f32_planar(variant, fmt, (const uint8_t *)di, frames, ch, (float *)dout, e->stream);
+    });
+}
+int sk_pcm_f32_planar_to_bytes_dev(sk_engine *e, int fmt, const float *d_planar, size_t frames, uint32_t ch,
+                                   uint8_t *d_out) {
+    if (!e || ch == 0 || !from_f32_fmt_ok(fmt) || (frames && (!d_planar || !d_out))) return SK_ERR_INVALID_ARG;
+    SK_DEV_ENTRY(sk::launch_f32_planar_to_bytes(fmt, d_planar, frames, ch, d_out, e->stream));
+}
+int sk_pcm_f32_planar_to_bytes(sk_engine *e, int fmt, const float *planar, size_t frames, uint32_t ch, uint8_t *out) {
+    if (ch == 0 || !from_f32_fmt_ok(fmt)) return SK_ERR_INVALID_ARG;
+    return host_roundtrip(e, planar, frames * ch * 4, out, frames * ch * sk_pcm_fmt_bytes(fmt), [&](void *di, void *dout) {
+        return sk::launch_f32_planar_to_bytes(fmt, (const float *)di, frames, ch, (uint8_t *)dout, e->stream);
+    });
+}
+int sk_pcm_downmix_mono_dev(sk_engine *e, const float *d_planar, size_t frames, uint32_t ch, float *d_mono) {
+    if (!e || ch == 0 || (frames && (!d_planar || !d_mono))) return SK_ERR_INVALID_ARG;
+    SK_DEV_ENTRY(sk::launch_downmix_mono(d_planar, frames, ch, d_mono, e->stream));
+}
+int sk_pcm_downmix_mono(sk_engine *e, const float *planar, size_t frames, uint32_t ch, float *mono) {
+    if (ch == 0) return SK_ERR_INVALID_ARG;
+    return host_roundtrip(e, planar, frames * ch * 4, mono, frames * 4, [&](void *di, void *dout) {
+        return sk::launch_downmix_mono((const float *)di, frames, ch, (float *)dout, e->stream);
+    });
+}
+static bool exact_fmt_ok(int fmt) { return fmt >= SK_FMT_S24LE && fmt <= SK_FMT_S32BE; }
+int sk_pcm_exact_to_i16_dev(sk_engine *e, int fmt, const uint8_t *d_in, size_t samples, uint8_t *d_out) {
+    if (!e || !exact_fmt_ok(fmt) || (samples && (!d_in || !d_out))) return SK_ERR_INVALID_ARG;
+    SK_DEV_ENTRY(sk::launch_exact_to_i16(fmt, d_in, samples, d_out, e->stream));
+}
+int sk_pcm_exact_to_i16(sk_engine *e, int fmt, const uint8_t *in, size_t samples, uint8_t *out) {
+    if (!exact_fmt_ok(fmt)) return SK_ERR_INVALID_ARG;
+    return host_roundtrip(e, in, samples * sk_pcm_fmt_bytes(fmt), out, samples * 2, [&](void *di, void *dout) {
+        return sk::launch_exact_to_i16(fmt, (const uint8_t *)di, samples, (uint8_t *)dout, e->stream);
+    });
+}
+
+// ---- 48 kHz -> 16 kHz FIR ----------------------------------------------------------------------
+
+uint32_t sk_downsample_48k_16k_out_frames(uint32_t frames) {
+    // rubato SincFixedIn: idx starts at -128, advances by 3 before each output, loop runs while
+    // idx < frames - 257 - 3
+    if (frames <= 132) return 0;
+    return (frames - 132 + 2) / 3;
+}
+
+int sk_downsample_48k_16k_taps(sk_engine *e, float *taps256) {
+    if (!e || !taps256) return SK_ERR_INVALID_ARG;
+    std::memcpy(taps256, e->h_taps.data(), 256 * sizeof(float));
+    return SK_OK;
+}
+
+static sk::FirArgs fir_base(sk_engine *e) {
+    sk::FirArgs a{};
+    a.zeros = e->d_zeros;
+    a.afrag = e->d_afrag;
+    a.taps = e->d_taps;
+    return a;
+}
+
+int sk_downsample_48k_16k_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uint32_t rows, uint32_t frames,
+                                  float *d_out, size_t out_stride, uint32_t *out_frames) {
+    if (!e) return SK_ERR_INVALID_ARG;
+    const uint32_t n_out = sk_downsample_48k_16k_out_frames(frames);
+    if (out_frames) *out_frames = n_out;
+    if (rows == 0 || n_out == 0) return SK_OK;
+    if (!d_in || !d_out || in_stride < frames || out_stride < n_out) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    sk::FirArgs a = fir_base(e);
+    a.in = d_in;
+    a.out = d_out;
+    a.in_stride = in_stride;
+    a.out_stride = out_stride;
+    a.rows = rows;
+    a.in_frames = frames;
+    a.in_origin = 0;
+    a.out_first = 0;
+    a.out_count = n_out;
+    SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch fir");
+    return SK_OK;
+}
+
+int sk_downsample_48k_16k_f32(sk_engine *e, const float *in, uint32_t rows, uint32_t frames, float *out,
+                              uint32_t *out_frames) {
+    if (!e) return SK_ERR_INVALID_ARG;
+    const uint32_t n_out = sk_downsample_48k_16k_out_frames(frames);
+    if (out_frames) *out_frames = n_out;
+    if (rows == 0 || n_out == 0) return SK_OK;
+    if (!in || !out) return SK_ERR_INVALID_ARG;
+    const size_t in_stride = ((size_t)frames + 3) & ~(size_t)3, out_stride = ((size_t)n_out + 3) & ~(size_t)3;
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        DeviceGuard guard(e->device);
+        SK_HIP(e->in_buf.reserve(rows * in_stride * 4), "alloc staging");
+        SK_HIP(e->out_buf.reserve(rows * out_stride * 4), "alloc staging");
+        SK_HIP(hipMemcpy2DAsync(e->in_buf.p, in_stride * 4, in, (size_t)frames * 4, (size_t)frames * 4, rows,
+                                hipMemcpyHostToDevice, e->stream), "H2D fir input");
+    }
+    int rc = sk_downsample_48k_16k_f32_dev(e, (const float *)e->in_buf.p, in_stride, rows, frames, (float *)e->out_buf.p,
+                                           out_stride, nullptr);
+    if (rc != SK_OK) return rc;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    SK_HIP(hipMemcpy2DAsync(out, (size_t)n_out * 4, e->out_buf.p, out_stride * 4, (size_t)n_out * 4, rows,
+                            hipMemcpyDeviceToHost, e->stream), "D2H fir output");
+    SK_HIP(hipStreamSynchronize(e->stream), "fir sync");
+    return SK_OK;
+}
+
+// ---- StreamingResampler (soundkit-decoder lib.rs:1917-2060) ------------------------------------
+
+int sk_resampler_open(sk_engine *e, uint32_t id, uint32_t in_hz, uint32_t out_hz) {
+    if (!e) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
+    if (in_hz != 48000 || out_hz != 16000) return SK_ERR_UNSUPPORTED;
+    DeviceGuard guard(e->device);
+    if (!e->d_rs) {
+        const size_t bytes = (size_t)e->max_streams * 2 * kRsRow * sizeof(float);
+        SK_HIP(hipMalloc((void **)&e->d_rs, bytes), "alloc resampler history");
+        SK_HIP(hipMemsetAsync(e->d_rs, 0, bytes, e->stream), "clear resampler history");
+    }
+    StreamInfo &s = e->streams[id];
+    s.rs_open = true;
+    s.rs_fill = 0;
+    s.rs_chunks = 0;
+    s.rs_next_m = 0;
+    SK_HIP(hipMemsetAsync(e->d_rs + (size_t)id * 2 * kRsRow, 0, 2 * kRsRow * sizeof(float), e->stream), "clear rs rows");
+    return SK_OK;
+}
+
+int sk_resampler_close(sk_engine *e, uint32_t id) {
+    if (!e) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
+    e->streams[id].rs_open = false;
+    return SK_OK;
+}
+
+// outputs of chunk q: m in [next_m, last], last = ceil((3961 + 4096 q) / 3)
+static uint64_t rs_chunk_last_m(uint64_t q) { return (3961 + 4096 * q + 2) / 3; }
+
+// One chunk for one stream: FIR over its history rows into d_dst (row stride dst_stride, column dst_off).
+static int rs_run_chunk(sk_engine *e, uint32_t id, float *d_dst, size_t dst_stride, uint32_t dst_off, uint32_t *produced) {
+    StreamInfo &s = e->streams[id];
+    const uint64_t last = rs_chunk_last_m(s.rs_chunks);
+    const uint32_t count = (uint32_t)(last + 1 - s.rs_next_m);
+    sk::FirArgs a = fir_base(e);
+    a.in = e->d_rs + (size_t)id * 2 * kRsRow;
+    a.in_stride = kRsRow;
+    a.rows = s.channels;
+    a.in_frames = kRsRow;
+    a.in_origin = (int32_t)((int64_t)4096 * (int64_t)s.rs_chunks - (int64_t)kRsHist);
+    a.out = d_dst + dst_off;
+    a.out_stride = dst_stride;
+    a.out_first = (uint32_t)s.rs_next_m;
+    a.out_count = count;
+    SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch streaming fir");
+    // slide: the last 512 samples of this chunk become the history of the next (rubato copy_within)
+    for (uint32_t c = 0; c < s.channels; ++c) {
+        float *row = e->d_rs + ((size_t)id * 2 + c) * kRsRow;
+        SK_HIP(hipMemcpyAsync(row, row + kRsChunk, kRsHist * sizeof(float), hipMemcpyDeviceToDevice, e->stream),
+               "slide resampler history");
+    }
+    s.rs_next_m = last + 1;
+    s.rs_chunks += 1;
+    s.rs_fill = 0;
+    *produced = count;
+    return SK_OK;
+}
+
+int sk_resampler_process_f32(sk_engine *e, const uint32_t *streams, uint32_t n_streams, const float *in, uint32_t frames,
+                             float *out, uint32_t out_cap, uint32_t *out_frames) {
+    if (!e || (n_streams && (!streams || !out_frames)) || (frames && n_streams && !in)) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    size_t total_rows = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (!stream_ok(e, streams[i]) || !e->streams[streams[i]].rs_open) return SK_ERR_BAD_STREAM;
+        total_rows += e->streams[streams[i]].channels;
+    }
+    if (total_rows == 0) return SK_OK;
+    const size_t out_stride = ((size_t)out_cap + 3) & ~(size_t)3;
+    SK_HIP(e->in_buf.reserve(total_rows * (size_t)frames * 4 + 16), "alloc staging");
+    SK_HIP(e->out_buf.reserve(total_rows * out_stride * 4 + 16), "alloc staging");
+    if (frames)
+        SK_HIP(hipMemcpyAsync(e->in_buf.p, in, total_rows * (size_t)frames * 4, hipMemcpyHostToDevice, e->stream),
+               "H2D resampler input");
+    size_t row0 = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        const uint32_t id = streams[i];
+        StreamInfo &s = e->streams[id];
+        uint32_t consumed = 0, produced_total = 0;
+        while (consumed < frames || s.rs_fill == kRsChunk) {
+            const uint32_t take = std::min(frames - consumed, kRsChunk - s.rs_fill);
+            for (uint32_t c = 0; c < s.channels && take; ++c) {
+                float *row = e->d_rs + ((size_t)id * 2 + c) * kRsRow + kRsHist + s.rs_fill;
+                const float *src = (const float *)e->in_buf.p + (row0 + c) * frames + consumed;
+                SK_HIP(hipMemcpyAsync(row, src, (size_t)take * 4, hipMemcpyDeviceToDevice, e->stream), "append chunk");
+            }
+            s.rs_fill += take;
+            consumed += take;
+            if (s.rs_fill < kRsChunk) break;
+            const uint64_t need = rs_chunk_last_m(s.rs_chunks) + 1 - s.rs_next_m;
+            if (produced_total + need > out_cap) return SK_ERR_INVALID_ARG;
+            uint32_t got = 0;
+            int rc = rs_run_chunk(e, id, (float *)e->out_buf.p + row0 * out_stride, out_stride, produced_total, &got);
+            if (rc != SK_OK) return rc;
+            produced_total += got;
+        }
+        out_frames[i] = produced_total;
+        for (uint32_t c = 0; c < s.channels && produced_total; ++c)
+            SK_HIP(hipMemcpyAsync(out + (row0 + c) * out_cap, (float *)e->out_buf.p + (row0 + c) * out_stride,
+                                  (size_t)produced_total * 4, hipMemcpyDeviceToHost, e->stream), "D2H resampler output");
+        row0 += s.channels;
+    }
+    SK_HIP(hipStreamSynchronize(e->stream), "resampler sync");
+    return SK_OK;
+}
+
+int sk_resampler_flush_f32(sk_engine *e, const uint32_t *streams, uint32_t n_streams, float *out, uint32_t out_cap,
+                           uint32_t *out_frames) {
+    if (!e || (n_streams && (!streams || !out_frames || !out))) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    size_t total_rows = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (!stream_ok(e, streams[i]) || !e->streams[streams[i]].rs_open) return SK_ERR_BAD_STREAM;
+        total_rows += e->streams[streams[i]].channels;
+    }
+    if (total_rows == 0) return SK_OK;
+    const size_t out_stride = ((size_t)out_cap + 3) & ~(size_t)3;
+    SK_HIP(e->out_buf.reserve(total_rows * out_stride * 4 + 16), "alloc staging");
+    size_t row0 = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        const uint32_t id = streams[i];
+        StreamInfo &s = e->streams[id];
+        const uint32_t remaining = s.rs_fill;
+        const uint32_t padded = kRsChunk - remaining;
+        // process_partial: the chunk is zero-padded to 4096 (lib.rs:2020-2031, 2048-2052)
+        for (uint32_t c = 0; c < s.channels && padded; ++c) {
+            float *row = e->d_rs + ((size_t)id * 2 + c) * kRsRow + kRsHist + remaining;
+            SK_HIP(hipMemsetAsync(row, 0, (size_t)padded * 4, e->stream), "pad chunk");
+        }
+        const uint64_t need = rs_chunk_last_m(s.rs_chunks) + 1 - s.rs_next_m;
+        if (need > out_cap) return SK_ERR_INVALID_ARG;
+        uint32_t got = 0;
+        int rc = rs_run_chunk(e, id, (float *)e->out_buf.p + row0 * out_stride, out_stride, 0, &got);
+        if (rc != SK_OK) return rc;
+        if (remaining > 0 && padded > 0) {  // lib.rs:2032-2039
+            const uint32_t trim = (uint32_t)std::llround(((double)padded * 16000.0) / 48000.0);
+            got = got > trim ? got - trim : 0;
+        }
+        out_frames[i] = got;
+        for (uint32_t c = 0; c < s.channels && got; ++c)
+            SK_HIP(hipMemcpyAsync(out + (row0 + c) * out_cap, (float *)e->out_buf.p + (row0 + c) * out_stride,
+                                  (size_t)got * 4, hipMemcpyDeviceToHost, e->stream), "D2H flush output");
+        row0 += s.channels;
+    }
+    SK_HIP(hipStreamSynchronize(e->stream), "flush sync");
+    return SK_OK;
+}
+
+}  // extern "C"

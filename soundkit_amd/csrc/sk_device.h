@@ -1,0 +1,82 @@
+// sk_device.h -- structures shared between the host engine and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sk {
+
+// One schedule entry = one channel-frame.  off1024: index (in units of 1024 f32) of this
+// channel's spectrum inside the packed coeffs buffer and of its PCM inside the planar output.
+// win: window_sequence | (window_shape << 2).
+struct SynthEntry {
+    uint32_t off1024;
+    uint32_t win;
+};
+
+// One task = one wavefront = one (stream, channel); its entries are applied in order.
+struct SynthTask {
+    uint32_t state;  // stream * 2 + channel: index into delay / prev_shape
+    uint32_t begin;  // first entry
+    uint32_t count;  // entries
+    uint32_t pad;
+};
+
+struct SynthTables {
+    const float2 *tw_long;   // [512]  dsp.rs:99-106 twiddle, input_len 1024
+    const float2 *tw_short;  // [64]   same, input_len 128
+    const float2 *w64;       // [64]   e^{-2 pi i m/64}
+    const float2 *w512;      // [512]  e^{-2 pi i m/512}
+    const float *win;        // long_sine[2048] long_kbd[2048] short_sine[256] short_kbd[256]
+};
+
+struct SynthArgs {
+    const float *coeffs;
+    float *pcm;
+    float *delay;         // [states][1024]
+    uint8_t *prev_shape;  // [states]
+    const SynthTask *tasks;
+    const SynthEntry *entries;
+    uint32_t n_tasks;
+    SynthTables t;
+};
+
+// one frame of the planar-f32 -> interleaved-s16 pass that follows synthesis on the s16 path
+struct FrameSpan {
+    uint32_t off1024;  // planar f32 offset (units of 1024 f32) = s16 offset (units of 1024 i16)
+    uint32_t channels;
+};
+
+hipError_t launch_aac_synth(const SynthArgs &a, hipStream_t s);
+hipError_t launch_frames_to_s16(const float *planar, int16_t *out, const FrameSpan *frames, uint32_t n, hipStream_t s);
+hipError_t launch_dequantize(const int16_t *q, const int16_t *sf, float *out, size_t n, const float *pow43,
+                             const float *sftab, hipStream_t s);
+
+// pcm.hip
+hipError_t launch_pcm_convert(int op, const void *in, void *out, size_t n, hipStream_t s);
+hipError_t launch_interleave(const void *planar, void *out, size_t frames, uint32_t ch, int elem_bytes, hipStream_t s);
+hipError_t launch_deinterleave(const void *in, void *planar, size_t frames, uint32_t ch, int elem_bytes, hipStream_t s);
+hipError_t launch_deinterleave_s24(const uint8_t *in, int32_t *planar, size_t frames, uint32_t ch, hipStream_t s);
+hipError_t launch_bytes_to_f32_planar(int variant, int fmt, const uint8_t *in, size_t frames, uint32_t ch, float *planar,
+                                      hipStream_t s);
+hipError_t launch_f32_planar_to_bytes(int fmt, const float *planar, size_t frames, uint32_t ch, uint8_t *out,
+                                      hipStream_t s);
+hipError_t launch_downmix_mono(const float *planar, size_t frames, uint32_t ch, float *mono, hipStream_t s);
+hipError_t launch_exact_to_i16(int fmt, const uint8_t *in, size_t samples, uint8_t *out, hipStream_t s);
+
+// fir.hip
+struct FirArgs {
+    const float *in;      // [rows][in_stride]
+    float *out;           // [rows][out_stride]
+    const float *zeros;   // >= 1 KiB of zeros (source for out-of-range input)
+    const float *afrag;   // [76][64] MFMA A-operand fragments of the Toeplitz tap matrix
+    const float *taps;    // [256]
+    size_t in_stride, out_stride;
+    uint32_t rows;
+    uint32_t in_frames;   // valid input samples per row (n >= in_frames reads as 0)
+    int32_t in_origin;    // sample index of in[r][0] relative to the stream's time 0 (history rows: negative)
+    uint32_t out_first;   // first output index m to produce
+    uint32_t out_count;   // outputs per row
+};
+hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s);
+
+}  // namespace sk

@@ -1,0 +1,335 @@
+"""Engine: thin object wrapper over the C ABI (include/soundkit_amd.h).
+
+Host entry points take/return numpy arrays; the *_dev entry points take device addresses
+(ints, or anything with .data_ptr() such as a torch tensor) and enqueue on the engine's
+HIP stream.  All compute happens in libsoundkit_amd.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FrameDesc, check, lib
+
+ONLY_LONG, LONG_START, EIGHT_SHORT, LONG_STOP = 0, 1, 2, 3
+SINE, KBD = 0, 1
+
+FMT_S16LE, FMT_S16BE, FMT_S24LE, FMT_S24BE, FMT_S32LE, FMT_S32BE, FMT_F32LE, FMT_F32BE = range(8)
+
+PCM_OPS = [
+    "I16LE_TO_F32", "I16_TO_I16LE", "I16LE_TO_I16", "S24LE_TO_I32", "S24LE_TO_I16", "S24BE_TO_I16",
+    "S32LE_TO_I32", "S32BE_TO_I32", "S32LE_TO_S24", "S32BE_TO_S24", "S32LE_TO_F32", "S32BE_TO_F32",
+    "S32LE_TO_I16", "S32BE_TO_I16", "F32LE_TO_I16", "F32BE_TO_I16", "F32LE_TO_I32", "F32LE_TO_S24",
+    "S16BE_TO_I16", "S16LE_TO_I16", "S16LE_TO_I32", "STEREO_TO_MONO_TAKE_LEFT", "STEREO_TO_MONO_AVG",
+    "VEC_F32_TO_I16", "VEC_I16_TO_F32", "VEC_I32_TO_F32", "FLOAT_TO_I16_ROUND", "MP3_F32_TO_I16",
+    "MP3_F32_TO_I32",
+]
+PCM_OP = {name: i for i, name in enumerate(PCM_OPS)}
+
+
+def _ptr(x):
+    """Device or host address of x (torch tensor, numpy array, int or None)."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if isinstance(x, np.ndarray):
+        return C.c_void_p(x.ctypes.data)
+    raise TypeError("cannot take the address of %r" % type(x))
+
+
+def make_descs(frames):
+    """frames: iterable of (stream, channels, (seq...), (shape...)) -> ctypes array of sk_aac_frame_desc."""
+    frames = list(frames)
+    arr = (FrameDesc * max(len(frames), 1))()
+    for i, (stream, ch, seqs, shapes) in enumerate(frames):
+        d = arr[i]
+        d.stream = stream
+        d.channels = ch
+        for c in range(min(ch, 2)):
+            d.window_sequence[c] = seqs[c]
+            d.window_shape[c] = shapes[c]
+    return arr, len(frames)
+
+
+def descs_from_arrays(streams, channels, seqs, shapes):
+    """Vectorised builder: streams [n], channels scalar or [n], seqs/shapes [n][2] -> (ctypes array, n)."""
+    streams = np.asarray(streams, np.uint32)
+    n = streams.size
+    raw = np.zeros(n, dtype=np.dtype([("stream", "<u4"), ("channels", "u1"), ("seq", "u1", (2,)),
+                                      ("shape", "u1", (2,)), ("reserved", "u1", (3,))]))
+    assert raw.dtype.itemsize == C.sizeof(FrameDesc)
+    raw["stream"] = streams
+    raw["channels"] = channels
+    raw["seq"] = np.asarray(seqs, np.uint8).reshape(n, 2)
+    raw["shape"] = np.asarray(shapes, np.uint8).reshape(n, 2)
+    arr = (FrameDesc * max(n, 1)).from_buffer_copy(raw.tobytes() if n else bytes(C.sizeof(FrameDesc)))
+    return arr, n
+
+
+class Plan:
+    """A validated, device-resident schedule of AAC frames (sk_aac_plan)."""
+
+    def __init__(self, engine, descs, n):
+        self.engine = engine
+        self.n = n
+        self.status = np.zeros(max(n, 1), np.int32)
+        h = C.c_void_p()
+        check(lib.sk_aac_plan_create(engine._h, descs, n, _ptr(self.status), C.byref(h)), "sk_aac_plan_create", engine._h)
+        self._h = h
+        self.status = self.status[:n]
+        self.elements = int(lib.sk_aac_plan_elements(h))
+        self.frames_ok = int(lib.sk_aac_plan_frames_ok(h))
+
+    def run_f32(self, d_coeffs, d_pcm):
+        check(lib.sk_aac_plan_run_f32_dev(self.engine._h, self._h, _ptr(d_coeffs), _ptr(d_pcm)),
+              "sk_aac_plan_run_f32_dev", self.engine._h)
+
+    def run_s16(self, d_coeffs, d_pcm):
+        check(lib.sk_aac_plan_run_s16_dev(self.engine._h, self._h, _ptr(d_coeffs), _ptr(d_pcm)),
+              "sk_aac_plan_run_s16_dev", self.engine._h)
+
+    def destroy(self):
+        if self._h:
+            lib.sk_aac_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, device=0, max_streams=4096):
+        h = C.c_void_p()
+        check(lib.sk_engine_create(device, max_streams, C.byref(h)), "sk_engine_create")
+        self._h = h
+        self.device = device
+        self.max_streams = max_streams
+
+    # ---- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sk_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def hip_stream(self):
+        return lib.sk_engine_hip_stream(self._h)
+
+    def synchronize(self):
+        check(lib.sk_engine_synchronize(self._h), "sk_engine_synchronize", self._h)
+
+    # ---- streams ----------------------------------------------------------------------
+    def open_stream(self, sample_rate=48000, channels=2):
+        sid = C.c_uint32()
+        check(lib.sk_stream_open(self._h, sample_rate, channels, C.byref(sid)), "sk_stream_open", self._h)
+        return sid.value
+
+    def close_stream(self, sid):
+        check(lib.sk_stream_close(self._h, sid), "sk_stream_close", self._h)
+
+    def reset_stream(self, sid):
+        check(lib.sk_stream_reset(self._h, sid), "sk_stream_reset", self._h)
+
+    def get_state(self, sid, channels):
+        delay = np.zeros((channels, 1024), np.float32)
+        shape = np.zeros(channels, np.uint8)
+        check(lib.sk_stream_get_state(self._h, sid, _ptr(delay), _ptr(shape)), "sk_stream_get_state", self._h)
+        return delay, shape
+
+    def set_state(self, sid, delay, shape):
+        delay = np.ascontiguousarray(delay, np.float32)
+        shape = np.ascontiguousarray(shape, np.uint8)
+        check(lib.sk_stream_set_state(self._h, sid, _ptr(delay), _ptr(shape)), "sk_stream_set_state", self._h)
+
+    # ---- AAC synthesis ----------------------------------------------------------------
+    def plan(self, descs, n):
+        return Plan(self, descs, n)
+
+    def aac_synthesize(self, descs, n, coeffs, out="f32", pcm=None):
+        """Host-buffer batch synthesis.  coeffs: packed f32 (sum(ch) * 1024).  Returns (pcm, status)."""
+        coeffs = np.ascontiguousarray(coeffs, np.float32).ravel()
+        status = np.zeros(max(n, 1), np.int32)
+        if out == "f32":
+            if pcm is None:
+                pcm = np.zeros(coeffs.size, np.float32)
+            rc = lib.sk_aac_synthesize_f32(self._h, descs, _ptr(coeffs), _ptr(pcm), n, _ptr(status))
+        else:
+            if pcm is None:
+                pcm = np.zeros(coeffs.size, np.int16)
+            rc = lib.sk_aac_synthesize_s16(self._h, descs, _ptr(coeffs), _ptr(pcm), n, _ptr(status))
+        check(rc, "sk_aac_synthesize_" + out, self._h)
+        return pcm, status[:n]
+
+    def dequantize(self, quant, scalefactor):
+        quant = np.ascontiguousarray(quant, np.int16).ravel()
+        scalefactor = np.ascontiguousarray(scalefactor, np.int16).ravel()
+        assert quant.size == scalefactor.size
+        out = np.zeros(quant.size, np.float32)
+        check(lib.sk_aac_dequantize(self._h, _ptr(quant), _ptr(scalefactor), _ptr(out), quant.size),
+              "sk_aac_dequantize", self._h)
+        return out
+
+    # ---- PCM ---------------------------------------------------------------------------
+    @staticmethod
+    def _op_out_dtype(op):
+        name = PCM_OPS[op]
+        ob = lib.sk_pcm_op_out_bytes(op)
+        if ob == 2:
+            return np.int16
+        return np.float32 if name.endswith("_F32") else np.int32
+
+    def pcm_convert(self, op, data, n=None):
+        if isinstance(op, str):
+            op = PCM_OP[op]
+        raw = np.ascontiguousarray(data).view(np.uint8).ravel()
+        if n is None:
+            n = raw.size // lib.sk_pcm_op_in_bytes(op)
+        out = np.zeros(n, self._op_out_dtype(op))
+        check(lib.sk_pcm_convert(self._h, op, _ptr(raw), _ptr(out), n), "sk_pcm_convert", self._h)
+        return out
+
+    def pcm_convert_dev(self, op, d_in, d_out, n):
+        if isinstance(op, str):
+            op = PCM_OP[op]
+        check(lib.sk_pcm_convert_dev(self._h, op, _ptr(d_in), _ptr(d_out), n), "sk_pcm_convert_dev", self._h)
+
+    def interleave_i16(self, planar):
+        planar = np.ascontiguousarray(planar, np.int16)
+        ch, frames = planar.shape
+        out = np.zeros(ch * frames * 2, np.uint8)
+        check(lib.sk_pcm_interleave_i16(self._h, _ptr(planar), frames, ch, _ptr(out)), "sk_pcm_interleave_i16", self._h)
+        return out
+
+    def deinterleave(self, kind, data, ch):
+        raw = np.ascontiguousarray(data).view(np.uint8).ravel()
+        bps = {"i16": 2, "s24": 3, "f32": 4}[kind]
+        dt = {"i16": np.int16, "s24": np.int32, "f32": np.float32}[kind]
+        frames = raw.size // (bps * ch)
+        out = np.zeros((ch, frames), dt)
+        fn = getattr(lib, "sk_pcm_deinterleave_" + kind)
+        check(fn(self._h, _ptr(raw), frames, ch, _ptr(out)), "sk_pcm_deinterleave_" + kind, self._h)
+        return out
+
+    def interleave_f32(self, planar):
+        planar = np.ascontiguousarray(planar, np.float32)
+        ch, frames = planar.shape
+        out = np.zeros(ch * frames * 4, np.uint8)
+        check(lib.sk_pcm_interleave_f32(self._h, _ptr(planar), frames, ch, _ptr(out)), "sk_pcm_interleave_f32", self._h)
+        return out
+
+    def bytes_to_f32_planar(self, variant, fmt, data, ch):
+        raw = np.ascontiguousarray(data).view(np.uint8).ravel()
+        frames = raw.size // (lib.sk_pcm_fmt_bytes(fmt) * ch)
+        out = np.zeros((ch, frames), np.float32)
+        check(lib.sk_pcm_bytes_to_f32_planar(self._h, variant, fmt, _ptr(raw), frames, ch, _ptr(out)),
+              "sk_pcm_bytes_to_f32_planar", self._h)
+        return out
+
+    def f32_planar_to_bytes(self, fmt, planar):
+        planar = np.ascontiguousarray(planar, np.float32)
+        ch, frames = planar.shape
+        out = np.zeros(ch * frames * lib.sk_pcm_fmt_bytes(fmt), np.uint8)
+        check(lib.sk_pcm_f32_planar_to_bytes(self._h, fmt, _ptr(planar), frames, ch, _ptr(out)),
+              "sk_pcm_f32_planar_to_bytes", self._h)
+        return out
+
+    def downmix_mono(self, planar):
+        planar = np.ascontiguousarray(planar, np.float32)
+        ch, frames = planar.shape
+        out = np.zeros(frames, np.float32)
+        check(lib.sk_pcm_downmix_mono(self._h, _ptr(planar), frames, ch, _ptr(out)), "sk_pcm_downmix_mono", self._h)
+        return out
+
+    def exact_to_i16(self, fmt, data):
+        raw = np.ascontiguousarray(data).view(np.uint8).ravel()
+        n = raw.size // lib.sk_pcm_fmt_bytes(fmt)
+        out = np.zeros(n * 2, np.uint8)
+        check(lib.sk_pcm_exact_to_i16(self._h, fmt, _ptr(raw), n, _ptr(out)), "sk_pcm_exact_to_i16", self._h)
+        return out
+
+    # ---- resampling ---------------------------------------------------------------------
+    @staticmethod
+    def downsample_out_frames(frames):
+        return int(lib.sk_downsample_48k_16k_out_frames(frames))
+
+    def taps(self):
+        t = np.zeros(256, np.float32)
+        check(lib.sk_downsample_48k_16k_taps(self._h, _ptr(t)), "sk_downsample_48k_16k_taps", self._h)
+        return t
+
+    def downsample_48k_16k(self, rows):
+        """rows: [n_rows][frames] f32 -> [n_rows][out_frames]"""
+        rows = np.ascontiguousarray(rows, np.float32)
+        n_rows, frames = rows.shape
+        n_out = self.downsample_out_frames(frames)
+        out = np.zeros((n_rows, n_out), np.float32)
+        got = C.c_uint32()
+        check(lib.sk_downsample_48k_16k_f32(self._h, _ptr(rows), n_rows, frames, _ptr(out), C.byref(got)),
+              "sk_downsample_48k_16k_f32", self._h)
+        assert got.value == n_out
+        return out
+
+    def downsample_48k_16k_dev(self, d_in, in_stride, rows, frames, d_out, out_stride):
+        got = C.c_uint32()
+        check(lib.sk_downsample_48k_16k_f32_dev(self._h, _ptr(d_in), in_stride, rows, frames, _ptr(d_out), out_stride,
+                                                C.byref(got)), "sk_downsample_48k_16k_f32_dev", self._h)
+        return got.value
+
+    def resampler_open(self, sid, in_hz=48000, out_hz=16000):
+        check(lib.sk_resampler_open(self._h, sid, in_hz, out_hz), "sk_resampler_open", self._h)
+
+    def resampler_close(self, sid):
+        check(lib.sk_resampler_close(self._h, sid), "sk_resampler_close", self._h)
+
+    def resampler_process(self, sids, data, channels):
+        """data: [n_streams][channels][frames] f32 -> list of [channels][out_frames] arrays."""
+        sids = np.ascontiguousarray(sids, np.uint32)
+        data = np.ascontiguousarray(data, np.float32)
+        n, ch, frames = data.shape
+        assert ch == channels
+        cap = (frames + 4096) // 3 + 16
+        out = np.zeros((n, ch, cap), np.float32)
+        got = np.zeros(n, np.uint32)
+        check(lib.sk_resampler_process_f32(self._h, _ptr(sids), n, _ptr(data), frames, _ptr(out), cap, _ptr(got)),
+              "sk_resampler_process_f32", self._h)
+        return [out[i, :, :got[i]].copy() for i in range(n)]
+
+    def resampler_flush(self, sids, channels):
+        sids = np.ascontiguousarray(sids, np.uint32)
+        n = sids.size
+        cap = 4096 // 3 + 16
+        out = np.zeros((n, channels, cap), np.float32)
+        got = np.zeros(n, np.uint32)
+        check(lib.sk_resampler_flush_f32(self._h, _ptr(sids), n, _ptr(out), cap, _ptr(got)),
+              "sk_resampler_flush_f32", self._h)
+        return [out[i, :, :got[i]].copy() for i in range(n)]
+
+
+_default = None
+
+
+def default_engine():
+    """Process-wide engine on HIP device 0 (LOCAL_RANK if set), created on first use."""
+    global _default
+    if _default is None:
+        import os
+        _default = Engine(int(os.environ.get("LOCAL_RANK", "0")), 8192)
+    return _default

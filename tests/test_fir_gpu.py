@@ -1,0 +1,150 @@
+"""HIP 48k->16k MFMA FIR vs the oracle.  Tolerance: 1e-6 RMS relative (north_star), max-abs 2e-6."""
+import numpy as np
+import pytest
+
+import soundkit_amd
+from soundkit_amd import audio_pipeline, decoder
+from soundkit_amd.audio_types import AudioData, EncodingFlag
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_rms(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b * b)) or 1.0)
+
+
+def test_taps_match_oracle(engine, oracle):
+    assert np.array_equal(engine.taps(), oracle.resampler_taps(16000 / 48000))
+
+
+@pytest.mark.parametrize("rows,frames", [(1, 133), (1, 4096), (2, 4800), (5, 1000), (16, 2048), (17, 3001), (33, 999),
+                                         (64, 48000), (3, 131), (2, 0)])
+def test_downsample_matches_oracle(engine, oracle, rows, frames):
+    rng = np.random.default_rng(rows * 100000 + frames)
+    x = rng.uniform(-1, 1, (rows, frames)).astype(np.float32)
+    got = engine.downsample_48k_16k(x)
+    if frames == 0:
+        assert got.shape == (rows, 0)
+        return
+    want = oracle.downsample_planar(x, 48000, 16000)
+    assert got.shape == want.shape
+    if want.size:
+        assert rel_rms(got, want) < 1e-6
+        assert np.abs(got - want).max() < 2e-6
+
+
+def test_downsample_sine_440(engine, oracle):  # the reference's test signal, soundkit-decoder lib.rs:5192-5197
+    n = 48000
+    x = (0.5 * np.sin(2 * np.pi * 440.0 * np.arange(n) / 48000.0)).astype(np.float32)
+    got = engine.downsample_48k_16k(np.stack([x, -x]))
+    want = oracle.downsample_planar(np.stack([x, -x]), 48000, 16000)
+    assert got.shape == want.shape == (2, 15956)
+    assert rel_rms(got, want) < 1e-6
+    ref = 0.5 * np.sin(2 * np.pi * 440.0 * (3 * np.arange(got.shape[1]) + 2) / 48000.0)
+    assert np.abs(got[0, 200:-200] - ref[200:-200]).max() < 2e-4  # it is a resampler, not just a match
+
+
+def test_downsample_audio_mirror(engine, oracle):
+    rng = np.random.default_rng(0)
+    pcm = rng.integers(-20000, 20000, (4800, 2)).astype("<i2")
+    audio = AudioData(16, 2, 48000, pcm.view(np.uint8).ravel())
+    got = audio_pipeline.downsample_audio(audio, 16000)
+    planar = oracle.core_bytes_to_f32_planar(oracle.FMT_S16LE, pcm.view(np.uint8).ravel(), 2)
+    want = oracle.downsample_planar(planar, 48000, 16000)
+    assert got.shape == want.shape and rel_rms(got, want) < 1e-6
+    with pytest.raises(ValueError):
+        audio_pipeline.downsample_audio(AudioData(16, 2, 12345, pcm.view(np.uint8).ravel()), 16000)
+    with pytest.raises(ValueError):
+        audio_pipeline.downsample_audio(AudioData(8, 2, 48000, pcm.view(np.uint8).ravel()), 16000)
+    with pytest.raises(soundkit_amd.SoundkitError):
+        audio_pipeline.downsample_audio(AudioData(16, 2, 44100, pcm.view(np.uint8).ravel()), 16000)
+
+
+def test_device_entry_strided_rows(engine, oracle):
+    import torch
+    rows, frames, stride = 40, 9000, 9216
+    g = torch.Generator(device="cuda").manual_seed(3)
+    buf = torch.rand((rows, stride), generator=g, device="cuda") * 2 - 1
+    n_out = engine.downsample_out_frames(frames)
+    out_stride = (n_out + 3) // 4 * 4 + 4
+    out = torch.full((rows, out_stride), 9.0, device="cuda")
+    got_n = engine.downsample_48k_16k_dev(buf, stride, rows, frames, out, out_stride)
+    engine.synchronize()
+    assert got_n == n_out
+    want = oracle.downsample_planar(buf[:, :frames].cpu().numpy(), 48000, 16000)
+    res = out.cpu().numpy()
+    assert rel_rms(res[:, :n_out], want) < 1e-6
+    assert np.all(res[:, n_out:] == 9.0)  # nothing written past out_frames
+
+
+def test_streaming_resampler_matches_oracle(engine, oracle):
+    """StreamingResampler (lib.rs:1917-2060): same chunking, same lengths, same samples as the restated one."""
+    rng = np.random.default_rng(12)
+    total = 48000 + 777
+    x = rng.uniform(-1, 1, (2, total)).astype(np.float32)
+    ours = decoder.StreamingResampler(48000, 16000, 2, engine)
+    ref = oracle.StreamingResampler(48000, 16000, 2)
+    pos = 0
+    got_chunks, want_chunks = [], []
+    for size in [1024, 1024, 1024, 1024, 5000, 997, 1, 4095, 9000, 20000]:
+        blk = x[:, pos:pos + size]
+        pos += blk.shape[1]
+        a, b = ours.process(blk), ref.process(blk)
+        assert a.shape == b.shape, (size, a.shape, b.shape)
+        got_chunks.append(a), want_chunks.append(b)
+    blk = x[:, pos:]
+    a, b = ours.process(blk), ref.process(blk)
+    assert a.shape == b.shape
+    got_chunks.append(a), want_chunks.append(b)
+    a, b = ours.flush(), ref.flush()
+    assert a.shape == b.shape and a.shape[1] > 0
+    got_chunks.append(a), want_chunks.append(b)
+    got, want = np.concatenate(got_chunks, 1), np.concatenate(want_chunks, 1)
+    assert rel_rms(got, want) < 1e-6 and np.abs(got - want).max() < 2e-6
+    ours.close()
+
+
+def test_streaming_equals_single_pass_length(engine, oracle):  # lib.rs:5188-5238 at the supported ratio
+    n = 48000
+    x = (0.5 * np.sin(2 * np.pi * 440.0 * np.arange(n) / 48000.0)).astype(np.float32)[None]
+    s = decoder.StreamingResampler(48000, 16000, 1, engine)
+    chunks = [s.process(x[:, i:i + 997]) for i in range(0, n, 997)] + [s.flush()]
+    s.close()
+    one = decoder.StreamingResampler(48000, 16000, 1, engine)
+    single = [one.process(x), one.flush()]
+    one.close()
+    a, b = np.concatenate(chunks, 1), np.concatenate(single, 1)
+    assert a.shape == b.shape and a.shape[1] > 0
+    assert np.array_equal(a, b)
+
+
+def test_unsupported_ratio_is_loud(engine):
+    with pytest.raises(soundkit_amd.SoundkitError) as exc:
+        decoder.StreamingResampler(44100, 16000, 2, engine)
+    assert exc.value.status == -6
+
+
+def test_full_size_dc_gain_and_linearity(engine, oracle):
+    """Config-3 scale on the device (4096 streams x 2 ch x 1 s): DC gain = sum(taps), linear, and a
+    spot-checked row equals the oracle."""
+    import torch
+    rows, frames = 8192, 48000
+    n_out = engine.downsample_out_frames(frames)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.rand((rows, frames), generator=g, device="cuda") * 2 - 1
+    ya = torch.empty((rows, n_out), device="cuda")
+    engine.downsample_48k_16k_dev(a, frames, rows, frames, ya, n_out)
+    ones = torch.ones((16, frames), device="cuda")
+    y1 = torch.empty((16, n_out), device="cuda")
+    engine.downsample_48k_16k_dev(ones, frames, 16, frames, y1, n_out)
+    engine.synchronize()
+    taps = engine.taps().astype(np.float64)
+    assert abs(y1[:, 100:].mean().item() - taps.sum()) < 1e-5
+    row = 4099
+    want = oracle.downsample_planar(a[row:row + 1].cpu().numpy(), 48000, 16000)
+    assert rel_rms(ya[row].cpu().numpy(), want[0]) < 1e-6
+    yb = torch.empty((rows, n_out), device="cuda")
+    engine.downsample_48k_16k_dev(a * 0.5, frames, rows, frames, yb, n_out)
+    engine.synchronize()
+    assert (ya * 0.5 - yb).abs().max().item() < 1e-6

@@ -1,0 +1,214 @@
+"""Pins the CPU oracle against the reference's own in-file known answers.
+
+Every case cites the reference test it restates.  No GPU.
+"""
+import numpy as np
+import pytest
+
+
+def test_imdct_zero_input(oracle):  # dsp.rs:616-624
+    out = oracle.imdct_direct_f32(np.zeros(8, np.float32))
+    assert np.all(out == 0.0)
+
+
+def test_imdct_fast_small_block(oracle):  # dsp.rs:626-651, tol 1e-10
+    x = np.array([0.0, 1.0, -2.0, 0.5, 3.0, -4.0, 0.25, -0.75], np.float32)
+    assert np.abs(oracle.imdct_fast(x) - oracle.imdct_direct_f32(x)).max() < 1.0e-10
+
+
+@pytest.mark.parametrize("n", [128, 1024])
+def test_imdct_fast_aac_blocks(oracle, n):  # dsp.rs:653-692, tol 2e-8
+    pat = [0.0, 1.0, -2.0, 0.5, -0.25, 4.0, -8.0, 0.125, -0.75]
+    x = np.array([pat[i % 9] for i in range(n)], np.float32)
+    assert np.abs(oracle.imdct_fast(x) - oracle.imdct_direct_f32(x)).max() < 2.0e-8
+
+
+@pytest.mark.parametrize("n", [8, 16, 128, 1024])
+@pytest.mark.parametrize("seed", [0x12345678, 0xA5A50101, 0xDEADBEEF])
+def test_imdct_fast_seeded_spectra(oracle, n, seed):  # dsp.rs:694-738, tol 4e-8
+    x = oracle.seeded_spectrum(n, seed)
+    fast = oracle.imdct_fast(x)
+    assert np.abs(fast - oracle.imdct_direct_f32(x)).max() < 4.0e-8
+    # and against the mathematical definition in f64
+    assert np.abs(fast - oracle.imdct_direct_f64(x)).max() < 4.0e-8
+
+
+def test_seeded_spectrum_shape(oracle):  # dsp.rs:725-738
+    x = oracle.seeded_spectrum(1024, 0x12345678)
+    assert np.all(x[::7] == 0.0)
+    assert np.abs(x).max() <= 12.0
+    state = (0x12345678 * 1664525 + 1013904223) & 0xFFFFFFFF
+    state = (state * 1664525 + 1013904223) & 0xFFFFFFFF  # index 1
+    assert x[1] == np.float32((np.float32((state >> 8) & 0xFFFF) / np.float32(32768.0) - np.float32(1.0)) * np.float32(12.0))
+
+
+def test_sine_window_princen_bradley(oracle):  # dsp.rs:593-602
+    w = oracle.sine_window(2048).astype(np.float32)
+    s = w[:1024] * w[:1024] + w[1024:] * w[1024:]
+    assert np.abs(s - 1.0).max() < 2.0e-6
+
+
+def test_kbd_window_symmetric_complementary(oracle):  # dsp.rs:604-614
+    w = oracle.kbd_window(2048, 4.0)
+    assert np.abs(w - w[::-1]).max() < 1.0e-6
+    s = w[:1024] * w[:1024] + w[1024:] * w[1024:]
+    assert np.abs(s - 1.0).max() < 2.0e-6
+
+
+def test_long_synthesis_zero_coefficients(oracle):  # dsp.rs:751-769
+    ch = oracle.Channel()
+    out = ch.synthesize(np.zeros(1024, np.float32), oracle.ONLY_LONG, oracle.SINE)
+    assert np.abs(out).max() < 1.0e-6 and np.abs(ch.delay).max() < 1.0e-6
+
+
+def test_sequence_windows_use_previous_shape(oracle):  # dsp.rs:771-795 through the synthesis itself
+    # an impulse-free check: with unit "imdct" we cannot poke the window directly, so check the
+    # documented selections via two syntheses that differ only in the previous shape
+    x = oracle.seeded_spectrum(1024, 0xA5A50101)
+    a, b = oracle.Channel(), oracle.Channel()
+    b.set_state(np.zeros(1024, np.float32), oracle.KBD)
+    ya = a.synthesize(x, oracle.ONLY_LONG, oracle.KBD)
+    yb = b.synthesize(x, oracle.ONLY_LONG, oracle.KBD)
+    imd = oracle.imdct_fast(x)
+    ls, lk = oracle.sine_window(2048), oracle.kbd_window(2048, 4.0)
+    assert np.array_equal(ya, imd[:1024] * ls[:1024])       # previous shape (Sine) on the left half
+    assert np.array_equal(yb, imd[:1024] * lk[:1024])       # previous shape (KBD)
+    assert np.array_equal(a.delay, imd[1024:] * lk[1024:])  # current shape on the right half
+    # LongStop: 0 | prev short[0..128] | 1 at 448/576 ; LongStart: 1 | cur short[128..256] | 0
+    c = oracle.Channel()
+    y = c.synthesize(x, oracle.LONG_STOP, oracle.KBD)
+    ss = oracle.sine_window(256)
+    assert np.all(y[:448] == 0.0)
+    assert np.array_equal(y[448:576], imd[448:576] * ss[:128])
+    assert np.array_equal(y[576:], imd[576:1024])
+    d = oracle.Channel()
+    d.synthesize(x, oracle.LONG_START, oracle.KBD)
+    sk = oracle.kbd_window(256, 6.0)
+    assert np.array_equal(d.delay[:448], imd[1024:1472])
+    assert np.array_equal(d.delay[448:576], imd[1472:1600] * sk[128:])
+    assert np.all(d.delay[576:] == 0.0)
+
+
+def test_channel_tracks_previous_shape(oracle):  # dsp.rs:797-807, decoder.rs:371
+    ch = oracle.Channel()
+    assert ch.prev_shape == oracle.SINE
+    ch.synthesize(np.zeros(1024, np.float32), oracle.ONLY_LONG, oracle.KBD)
+    assert ch.prev_shape == oracle.KBD
+
+
+def test_dequantize_known_answers(oracle):  # dsp.rs:809-822
+    L = oracle.lib()
+    assert L.sko_dequantize_signed(0, 100) == 0.0
+    assert abs(L.sko_dequantize_signed(1, 100) - 1.0) < 1e-6
+    assert abs(L.sko_dequantize_signed(-1, 100) + 1.0) < 1e-6
+    assert abs(L.sko_dequantize_signed(8, 100) - 16.0) < 1e-5
+    assert abs(L.sko_scalefactor_multiplier(100) - 1.0) < 1e-6
+    assert abs(L.sko_scalefactor_multiplier(104) - 2.0) < 1e-6
+    assert abs(L.sko_scalefactor_multiplier(96) - 0.5) < 1e-6
+
+
+# ---- audio_bytes.rs:380-468 -------------------------------------------------------------------
+
+def test_deinterleave_vecs_i16(oracle):
+    out = oracle.deinterleave("i16", np.array([1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 0], np.uint8), 2)
+    assert out.tolist() == [[1, 3, 5], [2, 4, 6]]
+
+
+def test_interleave_vecs_i16(oracle):
+    out = oracle.interleave_i16(np.array([[1, 3, 5], [2, 4, 6]], np.int16))
+    assert out.tolist() == [1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 0]
+
+
+def test_deinterleave_vecs_s24(oracle):
+    data = np.array([1, 0, 0, 2, 0, 0, 3, 0, 0, 4, 0, 0, 5, 0, 0, 6, 0, 0], np.uint8)
+    assert oracle.deinterleave("s24", data, 2).tolist() == [[1, 3, 5], [2, 4, 6]]
+
+
+def test_deinterleave_vecs_f32(oracle):
+    data = np.array([0, 0, 128, 63, 0, 0, 0, 64, 0, 0, 64, 64, 0, 0, 128, 64, 0, 0, 160, 64, 0, 0, 192, 64], np.uint8)
+    assert oracle.deinterleave("f32", data, 2).tolist() == [[1.0, 3.0, 5.0], [2.0, 4.0, 6.0]]
+
+
+def test_i16le_to_f32(oracle):
+    data = np.array([0, 0, 0, 64, 255, 127, 0, 192, 0, 128], np.uint8)
+    got = oracle.pcm_convert("I16LE_TO_F32", data)
+    assert np.abs(got - np.array([0.0, 0.5, 0.9999694, -0.5, -1.0])).max() < 1e-4
+
+
+def test_stereo_to_mono(oracle):
+    assert oracle.pcm_convert("STEREO_TO_MONO_TAKE_LEFT", np.array([10, 20, -30, -40, 50, 60], np.int16)).tolist() == [10, -30, 50]
+    assert oracle.pcm_convert("STEREO_TO_MONO_AVG", np.array([100, -100, 50, 150, -200, 200], np.int16)).tolist() == [0, 100, 0]
+
+
+# ---- audio_pipeline.rs:698-763 ----------------------------------------------------------------
+
+def test_audio_to_mono_f32_averages_channels(oracle):  # :698-713
+    data = oracle.interleave_i16(np.array([[32767, -32768], [-32768, 32767]], np.int16))
+    ch = oracle.core_bytes_to_f32_planar(oracle.FMT_S16LE, data, 2)
+    mono = (ch[0] + ch[1]) * np.float32(0.5)
+    assert np.abs(mono).max() < 0.01
+
+
+def test_decoder_side_scales(oracle):  # audio_pipeline.rs:715-755 values, decoder lib.rs:3563-3617 scales
+    be = np.array([0x7F, 0xFF, 0x80, 0x00], np.uint8)  # i16::MAX, i16::MIN big-endian
+    ch = oracle.decoder_bytes_to_f32_planar(oracle.FMT_S16BE, be, 2)
+    assert abs(ch[0, 0] - 32767.0 / 32768.0) < np.finfo(np.float32).eps and ch[1, 0] == -1.0
+    s24 = np.array([0xFF, 0xFF, 0x7F, 0x00, 0x00, 0x80], np.uint8)
+    ch = oracle.decoder_bytes_to_f32_planar(oracle.FMT_S24LE, s24, 2)
+    assert abs(ch[0, 0] - 8388607.0 / 8388608.0) < np.finfo(np.float32).eps and ch[1, 0] == -1.0
+    nan = np.array([np.nan], np.float32).view(np.uint8)
+    assert oracle.decoder_bytes_to_f32_planar(oracle.FMT_F32LE, nan, 1)[0, 0] == 0.0
+
+
+def test_float_sample_to_i16_semantics(oracle):  # soundkit-decoder lib.rs:1815-1827
+    f = oracle.float_sample_to_i16
+    assert f(1.0) == 32767 and f(-1.0) == -32768 and f(2.0) == 32767 and f(-2.0) == -32768
+    assert f(float("nan")) == 0 and f(float("inf")) == 0
+    assert f(0.5) == 16384   # 16383.5 rounds half away from zero
+    assert f(-0.5) == -16384
+    assert f(0.25) == 8192 and f(-0.25) == -8192 and f(1.0e-6) == 0
+
+
+def test_rust_cast_semantics(oracle):  # audio_bytes.rs:167-220 (`as` casts saturate, NaN -> 0, truncate)
+    x = np.array([np.nan, np.inf, -np.inf, 0.99999, -0.99999, 1.0, -1.0, 3.0e-5], np.float32)
+    assert oracle.pcm_convert("F32LE_TO_I16", x).tolist() == [0, 32767, -32767, 32766, -32766, 32767, -32767, 0]
+    got = oracle.pcm_convert("F32LE_TO_I32", x).tolist()
+    assert got[0] == 0 and got[1] == 2147483647 and got[2] == -2147483648 and got[5] == 2147483647 and got[6] == -2147483648
+    got = oracle.pcm_convert("F32LE_TO_S24", x).tolist()
+    assert got[5] == 8388607 and got[6] == -8388608 and got[0] == 0
+
+
+# ---- resampler: the reference pins lengths only (soundkit-decoder lib.rs:5188-5238) -------------
+
+def test_streaming_resampler_matches_single_pass_length(oracle):
+    n = 44100
+    x = (0.5 * np.sin(2 * np.pi * 440.0 * np.arange(n) / 44100.0)).astype(np.float32)[None]
+    s = oracle.StreamingResampler(44100, 16000, 1)
+    chunks = [s.process(x[:, i:i + 997]) for i in range(0, n, 997)]
+    chunks.append(s.flush())
+    one = oracle.StreamingResampler(44100, 16000, 1)
+    single = [one.process(x), one.flush()]
+    a, b = np.concatenate(chunks, 1), np.concatenate(single, 1)
+    assert a.shape == b.shape and a.shape[1] > 0
+    assert np.array_equal(a, b)
+
+
+def test_downsample_48k_16k_is_phase0_fir(oracle):
+    """At ratio 1/3 rubato's time step is exactly 3 and the fractional phase 0."""
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, (2, 3000)).astype(np.float32)
+    y = oracle.downsample_planar(x, 48000, 16000)
+    assert y.shape[1] == (3000 - 132 + 2) // 3
+    taps = oracle.resampler_taps(16000 / 48000).astype(np.float64)
+    m = 400
+    ref = sum(taps[p] * x[0, 3 * m - 125 + p] for p in range(256))
+    assert abs(y[0, m] - ref) < 1e-6
+    assert abs(taps.sum() - 1.0) < 1e-4
+
+
+def test_pcm_stats_fnv(oracle):  # aac-wasm-bench lib.rs:73-100
+    st = oracle.pcm_stats(np.zeros(0, np.float32))
+    assert st["checksum"] == 0xCBF29CE484222325 and st["rms"] == 0.0
+    st = oracle.pcm_stats(np.array([1.0], np.float32))
+    assert st["checksum"] == ((0xCBF29CE484222325 ^ 0x3F800000) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    assert st["rms"] == 1.0 and st["peak_abs"] == 1.0
