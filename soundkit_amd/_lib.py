@@ -29,12 +29,34 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(sk_[a-z0-9_]+)\s*\(", text)))
 
 
+def _preload_hip_runtime():
+    """One process must use ONE HIP/HSA runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (same SONAME libamdhip64.so.7 as /opt/rocm's): if libsoundkit_amd.so pulled in
+    the system copy first, a later `import torch` would start a second runtime that finds no device.
+    So when torch is installed, bind to its copy (set SOUNDKIT_AMD_HIP_RUNTIME=system to opt out;
+    a non-Python host simply links the system ROCm)."""
+    if os.environ.get("SOUNDKIT_AMD_HIP_RUNTIME", "torch") != "torch":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "soundkit_amd: %s is missing -- build it with `make -C soundkit_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
     try:
+        _preload_hip_runtime()
         return C.CDLL(LIB_PATH)
     except OSError as exc:  # pragma: no cover - depends on the host
         raise ImportError("soundkit_amd: cannot load %s: %s (no CPU fallback exists)" % (LIB_PATH, exc))

@@ -222,16 +222,19 @@ def test_full_size_linearity_property(engine, oracle):
     shape = (n_streams * n_frames, ch, 1024)
     a = (torch.rand(shape, generator=g, device="cuda") - 0.5) * 2000
     b = (torch.rand(shape, generator=g, device="cuda") - 0.5) * 2000
+    ab = a + b
+    torch.cuda.synchronize()  # inputs are produced on torch's stream, the engine runs on its own
     seqs = np.zeros((n_streams * n_frames, 2), np.uint8)
     shapes = np.tile(np.array([[0, 1]], np.uint8), (n_streams * n_frames, 1))
     outs = []
-    for x in (a, b, a + b):
+    for x in (a, b, ab):
         sids = [engine.open_stream(48000, ch) for _ in range(n_streams)]
         ids = np.repeat(np.array(sids, np.uint32), n_frames)
         descs, n = soundkit_amd.descs_from_arrays(ids, ch, seqs, shapes)
         plan = engine.plan(descs, n)
         assert plan.frames_ok == n
         y = torch.empty_like(x)
+        torch.cuda.synchronize()
         plan.run_f32(x, y)
         engine.synchronize()
         outs.append(y)

@@ -66,9 +66,11 @@ def test_device_entry_strided_rows(engine, oracle):
     rows, frames, stride = 40, 9000, 9216
     g = torch.Generator(device="cuda").manual_seed(3)
     buf = torch.rand((rows, stride), generator=g, device="cuda") * 2 - 1
+    torch.cuda.synchronize()  # inputs are produced on torch's stream, the engine runs on its own
     n_out = engine.downsample_out_frames(frames)
     out_stride = (n_out + 3) // 4 * 4 + 4
     out = torch.full((rows, out_stride), 9.0, device="cuda")
+    torch.cuda.synchronize()
     got_n = engine.downsample_48k_16k_dev(buf, stride, rows, frames, out, out_stride)
     engine.synchronize()
     assert got_n == n_out
@@ -134,8 +136,10 @@ def test_full_size_dc_gain_and_linearity(engine, oracle):
     g = torch.Generator(device="cuda").manual_seed(5)
     a = torch.rand((rows, frames), generator=g, device="cuda") * 2 - 1
     ya = torch.empty((rows, n_out), device="cuda")
-    engine.downsample_48k_16k_dev(a, frames, rows, frames, ya, n_out)
     ones = torch.ones((16, frames), device="cuda")
+    half = a * 0.5
+    torch.cuda.synchronize()  # inputs are produced on torch's stream, the engine runs on its own
+    engine.downsample_48k_16k_dev(a, frames, rows, frames, ya, n_out)
     y1 = torch.empty((16, n_out), device="cuda")
     engine.downsample_48k_16k_dev(ones, frames, 16, frames, y1, n_out)
     engine.synchronize()
@@ -145,6 +149,6 @@ def test_full_size_dc_gain_and_linearity(engine, oracle):
     want = oracle.downsample_planar(a[row:row + 1].cpu().numpy(), 48000, 16000)
     assert rel_rms(ya[row].cpu().numpy(), want[0]) < 1e-6
     yb = torch.empty((rows, n_out), device="cuda")
-    engine.downsample_48k_16k_dev(a * 0.5, frames, rows, frames, yb, n_out)
+    engine.downsample_48k_16k_dev(half, frames, rows, frames, yb, n_out)
     engine.synchronize()
     assert (ya * 0.5 - yb).abs().max().item() < 1e-6

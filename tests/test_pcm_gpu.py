@@ -20,7 +20,8 @@ def raw_input_for(op_name, n, rng):
     if op_name.startswith(("F32", "VEC_F32", "FLOAT_", "MP3_")):
         x = rng.uniform(-1.3, 1.3, n).astype(np.float32)
         x[:EDGE_F32.size] = EDGE_F32[:min(n, EDGE_F32.size)]
-        x[EDGE_F32.size:EDGE_F32.size + 64] = (rng.integers(-32768, 32768, 64) + 0.5).astype(np.float32) / 32767.0  # ties
+        ties = x[EDGE_F32.size:EDGE_F32.size + 64]
+        ties[:] = ((rng.integers(-32768, 32768, ties.size) + 0.5).astype(np.float32) / 32767.0)  # rounding ties
         if "BE" in op_name:
             x = x.byteswap()
         return x.view(np.uint8)
@@ -35,7 +36,7 @@ def raw_input_for(op_name, n, rng):
 @pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 1023, 4099])
 def test_elementwise_op_bit_exact(engine, oracle, op, n):
     rng = np.random.default_rng(hash(op) % 2**32 + n)
-    raw = raw_input_for(op, max(n, 32), rng)
+    raw = raw_input_for(op, max(n, 128), rng)
     ib = soundkit_amd._lib.lib.sk_pcm_op_in_bytes(soundkit_amd.engine.PCM_OP[op])
     raw = raw[:n * ib]
     got = engine.pcm_convert(op, raw, n)
@@ -56,6 +57,7 @@ def test_elementwise_op_large_and_unaligned(engine, oracle, op):
     # device path, 16-byte aligned
     d_in = torch.from_numpy(raw[:n * ib].copy()).cuda()
     d_out = torch.zeros(n * ob, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # inputs are produced on torch's stream, the engine runs on its own
     engine.pcm_convert_dev(op, d_in, d_out, n)
     engine.synchronize()
     assert np.array_equal(d_out.cpu().numpy(), want.view(np.uint8))
@@ -63,6 +65,7 @@ def test_elementwise_op_large_and_unaligned(engine, oracle, op):
     d_in2 = torch.zeros(n * ib + 64, dtype=torch.uint8, device="cuda")
     d_in2[ib:ib + n * ib] = d_in
     d_out2 = torch.zeros(n * ob + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     engine.pcm_convert_dev(op, d_in2.data_ptr() + ib, d_out2.data_ptr() + ob, n)
     engine.synchronize()
     assert np.array_equal(d_out2[ob:ob + n * ob].cpu().numpy(), want.view(np.uint8))
