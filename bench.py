@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--workload", default="aac_synth", choices=["aac_synth", "fir", "pipeline"])
     ap.add_argument("--streams", type=int, default=4096)
     ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--layout", default="frame", choices=["frame", "stream"],
+                    help="packing of the batch: frame-major [frame][stream] (one tick of every stream after another) or stream-major")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -134,11 +136,17 @@ def main():
         kernel_ms.setdefault(name, []).append((a, b))
 
     if args.workload in ("aac_synth", "pipeline"):
-        coeffs = seeded_spectra(torch, device, streams, frames, ch, stream0=rank * streams)
+        coeffs = seeded_spectra(torch, device, streams, frames, ch, stream0=rank * streams)  # [stream][frame]
         sids = np.array([eng.open_stream(48000, ch) for _ in range(streams)], np.uint32)
-        ids = np.repeat(sids, frames)
-        seqs = np.zeros((streams * frames, 2), np.uint8)                       # OnlyLong
-        shapes = np.tile((np.arange(frames) & 1).astype(np.uint8).repeat(2).reshape(frames, 2), (streams, 1))  # Sine/KBD alternate
+        shape_of_frame = (np.arange(frames) & 1).astype(np.uint8)  # Sine / KBD alternate
+        if args.layout == "frame":
+            coeffs = coeffs.view(streams, frames, ch, 1024).transpose(0, 1).contiguous().view(-1, ch, 1024)
+            ids = np.tile(sids, frames)
+            shapes = np.repeat(shape_of_frame, streams)[:, None].repeat(2, 1)
+        else:
+            ids = np.repeat(sids, frames)
+            shapes = np.tile(shape_of_frame, streams)[:, None].repeat(2, 1)
+        seqs = np.zeros((streams * frames, 2), np.uint8)  # OnlyLong
         descs, n = soundkit_amd.descs_from_arrays(ids, ch, seqs, shapes)
         plan = eng.plan(descs, n)
         assert plan.frames_ok == n
@@ -148,7 +156,7 @@ def main():
 
         def step():
             timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
-        workload = "aac_lc_synth: %d streams x %d frames, 48 kHz stereo, IMDCT+window+OLA, f32 planar out" % (streams, frames)
+        workload = "aac_lc_synth: %d streams x %d frames, 48 kHz stereo, IMDCT+window+OLA, f32 planar out, %s-major batch" % (streams, frames, args.layout)
     else:
         frames_in = 48000
         rows = streams * ch

@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsoundkit_amd.so")
+LIB_PATH = os.environ.get("SOUNDKIT_AMD_LIB") or os.path.join(_HERE, "libsoundkit_amd.so")  # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "soundkit_amd.h")
 
 SK_OK = 0

@@ -23,33 +23,47 @@ namespace sk {
 
 namespace {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
 constexpr int kWavesPerBlock = 4;
-constexpr int kExchange = 576;  // float2 per wave: max(8*68, 8*72)
+#ifndef SK_WAVES_PER_SIMD
+#define SK_WAVES_PER_SIMD 3
+#endif
+#ifndef SK_WIN_EARLY
+#define SK_WIN_EARLY 1
+#endif
+#ifndef SK_PREFETCH_DEPTH
+#define SK_PREFETCH_DEPTH 1
+#endif
+constexpr int kDepth = SK_PREFETCH_DEPTH;  // spectra in flight per wave
+constexpr int kWavesPerSimd = SK_WAVES_PER_SIMD;  // occupancy the register budget is held to
+constexpr int kExchange = 576;  // f2 per wave: max(8*68, 8*72)
 constexpr int kStage = 1024;    // floats per wave: rare-path staging (transition windows, eight-short output)
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+__device__ __forceinline__ f2 cmul(f2 a, f2 b) {
+    return (f2){fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)};
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ f2 cadd(f2 a, f2 b) { return (f2){a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f2 csub(f2 a, f2 b) { return (f2){a.x - b.x, a.y - b.y}; }
 // multiply by -i
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+__device__ __forceinline__ f2 mul_mi(f2 a) { return (f2){a.y, -a.x}; }
 
 // forward 8-point DFT (e^{-2 pi i nk/8}), natural order in and out, all in registers
-__device__ __forceinline__ void dft8(float2 (&x)[8]) {
+__device__ __forceinline__ void dft8(f2 (&x)[8]) {
     const float h = 0.70710678118654752440f;
     // even half: DFT4(x0,x2,x4,x6)
-    float2 t0 = cadd(x[0], x[4]), t1 = csub(x[0], x[4]);
-    float2 t2 = cadd(x[2], x[6]), t3 = mul_mi(csub(x[2], x[6]));
-    float2 e0 = cadd(t0, t2), e2 = csub(t0, t2), e1 = cadd(t1, t3), e3 = csub(t1, t3);
+    f2 t0 = cadd(x[0], x[4]), t1 = csub(x[0], x[4]);
+    f2 t2 = cadd(x[2], x[6]), t3 = mul_mi(csub(x[2], x[6]));
+    f2 e0 = cadd(t0, t2), e2 = csub(t0, t2), e1 = cadd(t1, t3), e3 = csub(t1, t3);
     // odd half: DFT4(x1,x3,x5,x7)
-    float2 u0 = cadd(x[1], x[5]), u1 = csub(x[1], x[5]);
-    float2 u2 = cadd(x[3], x[7]), u3 = mul_mi(csub(x[3], x[7]));
-    float2 o0 = cadd(u0, u2), o2 = csub(u0, u2), o1 = cadd(u1, u3), o3 = csub(u1, u3);
+    f2 u0 = cadd(x[1], x[5]), u1 = csub(x[1], x[5]);
+    f2 u2 = cadd(x[3], x[7]), u3 = mul_mi(csub(x[3], x[7]));
+    f2 o0 = cadd(u0, u2), o2 = csub(u0, u2), o1 = cadd(u1, u3), o3 = csub(u1, u3);
     // twiddles W8^k
-    float2 w1 = make_float2((o1.x + o1.y) * h, (o1.y - o1.x) * h);   // o1 * (1-i)/sqrt2
-    float2 w2 = mul_mi(o2);                                          // o2 * (-i)
-    float2 w3 = make_float2((o3.y - o3.x) * h, -(o3.x + o3.y) * h);  // o3 * (-1-i)/sqrt2
+    f2 w1 = (f2){(o1.x + o1.y) * h, (o1.y - o1.x) * h};   // o1 * (1-i)/sqrt2
+    f2 w2 = mul_mi(o2);                                          // o2 * (-i)
+    f2 w3 = (f2){(o3.y - o3.x) * h, -(o3.x + o3.y) * h};  // o3 * (-1-i)/sqrt2
     x[0] = cadd(e0, o0); x[4] = csub(e0, o0);
     x[1] = cadd(e1, w1); x[5] = csub(e1, w1);
     x[2] = cadd(e2, w2); x[6] = csub(e2, w2);
@@ -63,15 +77,28 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+typedef __attribute__((address_space(3))) f2 lds_f2;
+typedef __attribute__((address_space(3))) f4 lds_f4;
+typedef __attribute__((address_space(3))) float lds_f;
+
 // this lane's 16 positions (4l+256r+e, 1020-4l-256r+e) of a 1024-float LDS array
-__device__ __forceinline__ void read_positions(const float *buf, int lane, float (&v)[16]) {
+__device__ __forceinline__ void read_positions(const lds_f *buf, int lane, float (&v)[16]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int j = 4 * lane + 256 * r;
-        const float4 f = *reinterpret_cast<const float4 *>(buf + j);
-        const float4 m = *reinterpret_cast<const float4 *>(buf + 1020 - j);
+        const f4 f = *reinterpret_cast<const lds_f4 *>(buf + j);
+        const f4 m = *reinterpret_cast<const lds_f4 *>(buf + 1020 - j);
         v[8 * r + 0] = f.x; v[8 * r + 1] = f.y; v[8 * r + 2] = f.z; v[8 * r + 3] = f.w;
         v[8 * r + 4] = m.x; v[8 * r + 5] = m.y; v[8 * r + 6] = m.z; v[8 * r + 7] = m.w;
+    }
+}
+
+__device__ __forceinline__ void write_positions(lds_f *buf, int lane, const float (&v)[16]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 4 * lane + 256 * r;
+        *reinterpret_cast<lds_f4 *>(buf + j) = (f4){v[8 * r + 0], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3]};
+        *reinterpret_cast<lds_f4 *>(buf + 1020 - j) = (f4){v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]};
     }
 }
 
@@ -94,7 +121,7 @@ __device__ __forceinline__ float second_window(int seq, const float *cur_long, c
 }
 
 // sample t (0..255) of a 128-input IMDCT from its post-twiddled spectrum v[0..63] (dsp.rs:511-532)
-__device__ __forceinline__ float short_sample(const float2 *v, int t) {
+__device__ __forceinline__ float short_sample(const lds_f2 *v, int t) {
     const int seg = t >> 6, u = t & 63;
     const bool odd = u & 1;
     const int lo = odd ? (63 - u) >> 1 : u >> 1;
@@ -107,7 +134,7 @@ __device__ __forceinline__ float short_sample(const float2 *v, int t) {
 }
 
 // value at position p (0..2047) of the eight-short overlap buffer (dsp.rs:303-330)
-__device__ __forceinline__ float short_buffer_value(const float2 *v, int p, const float *prev_short,
+__device__ __forceinline__ float short_buffer_value(const lds_f2 *v, int p, const float *prev_short,
                                                     const float *cur_short) {
     const int q = p - 448;
     if (q < 0 || q >= 1152) return 0.0f;
@@ -124,248 +151,334 @@ __device__ __forceinline__ float short_buffer_value(const float2 *v, int p, cons
     return acc;
 }
 
-__global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth(SynthArgs a) {
-    __shared__ float2 lds[kWavesPerBlock][kExchange];
+// 512-point forward FFT of z (z[r] = element 64 r + lane) through two LDS exchanges:
+// n = 64 n1 + 8 n2 + n3, k = k1 + 8 k2 + 64 k3; on return z[j] = Z[lane + 64 j].
+// Stage 1 (lane = 8 n2 + n3) needs W64^{n2 k1}; stage 2 (lane = 8 n3 + k1) needs
+// W512^{n3 (k1 + 8 k2)} = W512^{n3 k1} * W64^{n3 k2}: both W64 factors are W64^{(lane>>3) k}, so one
+// 8 x 8 table (t64[k][lane>>3], in LDS) serves both stages and stage 2 adds one per-lane constant.
+__device__ __forceinline__ void fft512(f2 (&z)[8], lds_f2 *ex, const lds_f2 *t64, f2 base2, int lane) {
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    dft8(z);  // over n1 -> k1
+#pragma unroll
+    for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], t64[8 * k + hi3]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ex[k * 68 + lane] = z[k];
+    wave_sync();
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) z[n2] = cmul(ex[lo3 * 68 + 8 * n2 + hi3], base2);
+    wave_sync();
+    dft8(z);  // over n2 -> k2
+#pragma unroll
+    for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], t64[8 * k + hi3]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ex[hi3 * 72 + k * 8 + lo3] = z[k];
+    wave_sync();
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) z[n3] = ex[n3 * 72 + lane];
+    wave_sync();
+    dft8(z);  // over n3 -> k3
+}
+
+// Everything after the pre-twiddle for a frame that is NOT OnlyLong (LongStart, LongStop,
+// EightShort: a few percent of real frames).  Kept out of line on purpose: inlined, its
+// registers and hoisted table loads are charged to the OnlyLong loop and halve the occupancy.
+// Its vector inputs and outputs travel through the wave's LDS, so that nothing but scalars and
+// pointers is live across the call:
+//   in : ex[64 r + lane] = pre-twiddled FFT input z[r] (long: element 64 r + lane; short: element
+//        `lane` of block r); stage = overlap delay at this lane's 16 positions (write_positions)
+//   out: PCM written to out_ptr; stage = new delay at this lane's 16 positions
+__device__ __attribute__((noinline)) void synth_rare_frame(lds_f2 *ex, lds_f *stage, const lds_f2 *tw_lds,
+                                                            const lds_f2 *t64, float base2_re, float base2_im,
+                                                            const float *win, const f2 *w64, const f2 *tw_short,
+                                                            float *out_ptr, int seq, int prev_shape, int shape,
+                                                            int lane) {
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const f2 base2 = (f2){base2_re, base2_im};
+    const float *prev_long = win + 2048 * prev_shape;
+    const float *cur_long = win + 2048 * shape;
+    const float *prev_short = win + 4096 + 256 * prev_shape;
+    const float *cur_short = win + 4096 + 256 * shape;
+    f2 z[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) z[r] = ex[64 * r + lane];
+    float dly[16];
+    read_positions(stage, lane, dly);
+    wave_sync();
+    float o[16], d[16];  // windowed first half / second half at this lane's 16 positions
+
+    if (seq != 2) {
+        fft512(z, ex, t64, base2, lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ex[lane + 64 * j] = cmul(tw_lds[lane + 64 * j], (f2){z[j].x, -z[j].y});
+        wave_sync();
+        // piecewise windows of LongStart / LongStop: built in LDS by a rolled loop, read back per position
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) {
+            const int i = 64 * k + lane;
+            stage[i] = first_window(seq, prev_long, prev_short, i);
+        }
+        wave_sync();
+        read_positions(stage, lane, o);
+        wave_sync();
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) {
+            const int i = 64 * k + lane;
+            stage[i] = second_window(seq, cur_long, cur_short, i);
+        }
+        wave_sync();
+        read_positions(stage, lane, d);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int q = 2 * lane + 128 * r;
+            const f4 F = *reinterpret_cast<const lds_f4 *>(&ex[256 + q]);
+            const f4 M = *reinterpret_cast<const lds_f4 *>(&ex[254 - q]);
+            o[8 * r + 0] *= -F.x; o[8 * r + 1] *= -M.w; o[8 * r + 2] *= -F.z; o[8 * r + 3] *= -M.y;
+            o[8 * r + 4] *= M.y; o[8 * r + 5] *= F.z; o[8 * r + 6] *= M.w; o[8 * r + 7] *= F.x;
+            d[8 * r + 0] *= F.y; d[8 * r + 1] *= M.z; d[8 * r + 2] *= F.w; d[8 * r + 3] *= M.x;
+            d[8 * r + 4] *= M.x; d[8 * r + 5] *= F.w; d[8 * r + 6] *= M.z; d[8 * r + 7] *= F.y;
+        }
+        wave_sync();
+    } else {
+        // eight short windows (dsp.rs:284-338): 8 independent 64-point FFTs, lane = 8 w + a,
+        // n = a + 8 b, k = kb + 8 ka
+#pragma unroll
+        for (int w = 0; w < 8; ++w) ex[64 * w + lane] = z[w];
+        wave_sync();
+#pragma unroll
+        for (int b2 = 0; b2 < 8; ++b2) z[b2] = ex[64 * hi3 + lo3 + 8 * b2];
+        wave_sync();
+        dft8(z);  // over b -> kb
+#pragma unroll
+        for (int kb = 1; kb < 8; ++kb) z[kb] = cmul(z[kb], w64[lo3 * kb]);
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) ex[64 * hi3 + 8 * kb + lo3] = z[kb];
+        wave_sync();
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) z[aa] = ex[64 * hi3 + 8 * lo3 + aa];  // lane = 8 w + kb
+        wave_sync();
+        dft8(z);  // over a -> ka: z[ka] = Z_w[kb + 8 ka]
+#pragma unroll
+        for (int ka = 0; ka < 8; ++ka) {
+            const int k = lo3 + 8 * ka;
+            ex[64 * hi3 + k] = cmul(tw_short[k], (f2){z[ka].x, -z[ka].y});
+        }
+        wave_sync();
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) {
+            const int i = 64 * k + lane;
+            stage[i] = short_buffer_value(ex, i, prev_short, cur_short);
+        }
+        wave_sync();
+        read_positions(stage, lane, o);
+        wave_sync();
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) {
+            const int i = 64 * k + lane;
+            stage[i] = short_buffer_value(ex, 1024 + i, prev_short, cur_short);
+        }
+        wave_sync();
+        read_positions(stage, lane, d);
+        wave_sync();
+    }
+
+    // overlap-add (dsp.rs:277-278, 333-334)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 4 * lane + 256 * r;
+        f4 f, m;
+        f.x = o[8 * r + 0] + dly[8 * r + 0]; f.y = o[8 * r + 1] + dly[8 * r + 1];
+        f.z = o[8 * r + 2] + dly[8 * r + 2]; f.w = o[8 * r + 3] + dly[8 * r + 3];
+        m.x = o[8 * r + 4] + dly[8 * r + 4]; m.y = o[8 * r + 5] + dly[8 * r + 5];
+        m.z = o[8 * r + 6] + dly[8 * r + 6]; m.w = o[8 * r + 7] + dly[8 * r + 7];
+        *reinterpret_cast<f4 *>(out_ptr + j) = f;
+        *reinterpret_cast<f4 *>(out_ptr + 1020 - j) = m;
+    }
+    write_positions(stage, lane, d);
+    wave_sync();
+}
+
+__global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synth(SynthArgs a) {
+    __shared__ f2 lds[kWavesPerBlock][kExchange];
     __shared__ float stage_lds[kWavesPerBlock][kStage];
+    __shared__ f2 tw_tab[512];  // pre/post twiddle (dsp.rs:99-106), shared by the block's waves
+    __shared__ f2 t64_tab[64];  // t64[k][n] = W64^{n k}
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 512; i += kWavesPerBlock * 64) tw_tab[i] = reinterpret_cast<const f2 *>(a.t.tw_long)[i];
+    if (threadIdx.x < 64) t64_tab[threadIdx.x] = reinterpret_cast<const f2 *>(a.t.w64)[((threadIdx.x >> 3) * (threadIdx.x & 7)) & 63];
+    __syncthreads();
+
     const uint32_t task_id = blockIdx.x * kWavesPerBlock + wave;
     if (task_id >= a.n_tasks) return;
-    float2 *ex = lds[wave];
-    float *stage = stage_lds[wave];
+    lds_f2 *ex = (lds_f2 *)lds[wave];
+    lds_f *stage = (lds_f *)stage_lds[wave];
+    const lds_f2 *tw_lds = (const lds_f2 *)tw_tab;
+    const lds_f2 *t64 = (const lds_f2 *)t64_tab;
 
-    const SynthTask task = a.tasks[task_id];
-    const uint32_t count = task.count;
+    // everything read from the schedule is wave-uniform: say so, so that addresses keep an SGPR base
+    // and the per-frame branches are scalar
+    const SynthTask task_v = a.tasks[task_id];
+    const uint32_t count = __builtin_amdgcn_readfirstlane(task_v.count);
+    const uint32_t state = __builtin_amdgcn_readfirstlane(task_v.state);
     if (count == 0) return;
-    const SynthEntry *entries = a.entries + task.begin;
+    const SynthEntry *entries = a.entries + __builtin_amdgcn_readfirstlane(task_v.begin);
 
-    // per-lane constants --------------------------------------------------------
     const int hi3 = lane >> 3, lo3 = lane & 7;
-    float2 tw[8];   // pre/post twiddle[lane + 64 j]
-    float2 tw1[8];  // W64^{(lane>>3) k}
-    float2 tw2[8];  // W512^{n3 (k1 + 8 k2)}, stage-2 lane = 8 n3 + k1
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        tw[j] = a.t.tw_long[lane + 64 * j];
-        tw1[j] = a.t.w64[(hi3 * j) & 63];
-        tw2[j] = a.t.w512[(hi3 * (lo3 + 8 * j)) & 511];
-    }
+    const f2 base2 = reinterpret_cast<const f2 *>(a.t.w512)[hi3 * lo3];
 
     // carried state ---------------------------------------------------------------
-    float *delay_ptr = a.delay + (size_t)task.state * 1024;
-    int prev_shape = a.prev_shape[task.state];
+    float *delay_ptr = a.delay + (size_t)state * 1024;
+    int prev_shape = __builtin_amdgcn_readfirstlane((int)a.prev_shape[state]);
     float dly[16];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int j = 4 * lane + 256 * r;
-        const float4 f = *reinterpret_cast<const float4 *>(delay_ptr + j);
-        const float4 m = *reinterpret_cast<const float4 *>(delay_ptr + 1020 - j);
-        dly[8 * r + 0] = f.x; dly[8 * r + 1] = f.y; dly[8 * r + 2] = f.z; dly[8 * r + 3] = f.w;
-        dly[8 * r + 4] = m.x; dly[8 * r + 5] = m.y; dly[8 * r + 6] = m.z; dly[8 * r + 7] = m.w;
-    }
-
-    // prefetch the first spectrum ---------------------------------------------------
-    float2 xin[8];
     {
-        const float *src = a.coeffs + (size_t)entries[0].off1024 * 1024 + 2 * lane;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) xin[r] = *reinterpret_cast<const float2 *>(src + 128 * r);
-    }
-
-    for (uint32_t e = 0; e < count; ++e) {
-        const SynthEntry ent = entries[e];
-        const int seq = ent.win & 3;
-        const int shape = (ent.win >> 2) & 1;
-        float *out_ptr = a.pcm + (size_t)ent.off1024 * 1024;
-
-        const float *prev_long = a.t.win + 2048 * prev_shape;
-        const float *cur_long = a.t.win + 2048 * shape;
-        const float *prev_short = a.t.win + 4096 + 256 * prev_shape;
-        const float *cur_short = a.t.win + 4096 + 256 * shape;
-
-        float2 x[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = xin[r];
-        if (e + 1 < count) {  // next spectrum in flight while this one is transformed
-            const float *src = a.coeffs + (size_t)entries[e + 1].off1024 * 1024 + 2 * lane;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) xin[r] = *reinterpret_cast<const float2 *>(src + 128 * r);
-        }
-
-        float o[16], d[16];  // windowed first half / second half at this lane's 16 positions
-
-        if (seq != 2) {
-            // ---- 1024-input IMDCT: pre-twiddle (dsp.rs:495-503) ------------------
-            float2 z[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {  // z[64 r + lane]
-                const float even = x[r].x;
-                const float odd = -__shfl(x[7 - r].y, 63 - lane);  // X[1023 - 2 i]
-                z[r] = make_float2(odd * tw[r].y - even * tw[r].x, odd * tw[r].x + even * tw[r].y);
-            }
-            // ---- 512-point FFT, n = 64 n1 + 8 n2 + n3, k = k1 + 8 k2 + 64 k3 --------
-            dft8(z);  // over n1 -> k1; lane = 8 n2 + n3
-#pragma unroll
-            for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], tw1[k]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) ex[k * 68 + lane] = z[k];
-            wave_sync();
-#pragma unroll
-            for (int n2 = 0; n2 < 8; ++n2) z[n2] = ex[lo3 * 68 + 8 * n2 + hi3];  // lane = 8 n3 + k1
-            wave_sync();
-            dft8(z);  // over n2 -> k2
-#pragma unroll
-            for (int k = 0; k < 8; ++k) z[k] = cmul(z[k], tw2[k]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) ex[hi3 * 72 + k * 8 + lo3] = z[k];
-            wave_sync();
-#pragma unroll
-            for (int n3 = 0; n3 < 8; ++n3) z[n3] = ex[n3 * 72 + lane];  // lane = k1 + 8 k2
-            wave_sync();
-            dft8(z);  // over n3 -> k3: z[j] = Z[lane + 64 j]
-            // ---- post-twiddle: value = twiddle * conj(fft) (dsp.rs:512, 523) --------
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float2 c = make_float2(z[j].x, -z[j].y);
-                ex[lane + 64 * j] = cmul(tw[j], c);
-            }
-            wave_sync();
-            float im1[16], im2[16];  // imdct[i] and imdct[1024 + i] at this lane's positions
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int q = 2 * lane + 128 * r;
-                const float4 F = *reinterpret_cast<const float4 *>(&ex[256 + q]);  // v[256+q], v[257+q]
-                const float4 M = *reinterpret_cast<const float4 *>(&ex[254 - q]);  // v[254-q], v[255-q]
-                // out0[j..j+3], j = 2q  (dsp.rs:516, 528)
-                im1[8 * r + 0] = -F.x; im1[8 * r + 1] = -M.w; im1[8 * r + 2] = -F.z; im1[8 * r + 3] = -M.y;
-                // out1[508-j .. 511-j]  (dsp.rs:517, 529)
-                im1[8 * r + 4] = M.y; im1[8 * r + 5] = F.z; im1[8 * r + 6] = M.w; im1[8 * r + 7] = F.x;
-                // out2[j..j+3]  (dsp.rs:518, 530)
-                im2[8 * r + 0] = F.y; im2[8 * r + 1] = M.z; im2[8 * r + 2] = F.w; im2[8 * r + 3] = M.x;
-                // out3[508-j .. 511-j]  (dsp.rs:519, 531)
-                im2[8 * r + 4] = M.x; im2[8 * r + 5] = F.w; im2[8 * r + 6] = M.z; im2[8 * r + 7] = F.y;
-            }
-            wave_sync();
-            // ---- window (dsp.rs:267-279) ---------------------------------------------
-            if (seq == 0) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int j = 4 * lane + 256 * r;
-                    const float4 w1f = *reinterpret_cast<const float4 *>(prev_long + j);
-                    const float4 w1m = *reinterpret_cast<const float4 *>(prev_long + 1020 - j);
-                    const float4 w2f = *reinterpret_cast<const float4 *>(cur_long + 1024 + j);
-                    const float4 w2m = *reinterpret_cast<const float4 *>(cur_long + 2044 - j);
-                    o[8 * r + 0] = im1[8 * r + 0] * w1f.x; o[8 * r + 1] = im1[8 * r + 1] * w1f.y;
-                    o[8 * r + 2] = im1[8 * r + 2] * w1f.z; o[8 * r + 3] = im1[8 * r + 3] * w1f.w;
-                    o[8 * r + 4] = im1[8 * r + 4] * w1m.x; o[8 * r + 5] = im1[8 * r + 5] * w1m.y;
-                    o[8 * r + 6] = im1[8 * r + 6] * w1m.z; o[8 * r + 7] = im1[8 * r + 7] * w1m.w;
-                    d[8 * r + 0] = im2[8 * r + 0] * w2f.x; d[8 * r + 1] = im2[8 * r + 1] * w2f.y;
-                    d[8 * r + 2] = im2[8 * r + 2] * w2f.z; d[8 * r + 3] = im2[8 * r + 3] * w2f.w;
-                    d[8 * r + 4] = im2[8 * r + 4] * w2m.x; d[8 * r + 5] = im2[8 * r + 5] * w2m.y;
-                    d[8 * r + 6] = im2[8 * r + 6] * w2m.z; d[8 * r + 7] = im2[8 * r + 7] * w2m.w;
-                }
-            } else {
-                // LongStart / LongStop (rare): build the piecewise window in LDS with a rolled loop,
-                // then apply it from this lane's positions
-#pragma unroll 1
-                for (int k = 0; k < 16; ++k) {
-                    const int i = 64 * k + lane;
-                    stage[i] = first_window(seq, prev_long, prev_short, i);
-                }
-                wave_sync();
-                read_positions(stage, lane, o);
-                wave_sync();
-#pragma unroll 1
-                for (int k = 0; k < 16; ++k) {
-                    const int i = 64 * k + lane;
-                    stage[i] = second_window(seq, cur_long, cur_short, i);
-                }
-                wave_sync();
-                read_positions(stage, lane, d);
-                wave_sync();
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    o[t] *= im1[t];
-                    d[t] *= im2[t];
-                }
-            }
-        } else {
-            // ---- eight short windows (dsp.rs:284-338): 8 independent 64-point FFTs ---------
-            const float2 tws = a.t.tw_short[lane];
-#pragma unroll
-            for (int w = 0; w < 8; ++w) {  // z_w[lane]
-                const float even = x[w].x;
-                const float odd = -__shfl(x[w].y, 63 - lane);  // X_w[127 - 2 lane]
-                ex[64 * w + lane] = make_float2(odd * tws.y - even * tws.x, odd * tws.x + even * tws.y);
-            }
-            wave_sync();
-            float2 g[8];
-            // lane = 8 w + a: n = a + 8 b, k = kb + 8 ka
-#pragma unroll
-            for (int b = 0; b < 8; ++b) g[b] = ex[64 * hi3 + lo3 + 8 * b];
-            wave_sync();
-            dft8(g);  // over b -> kb
-#pragma unroll
-            for (int kb = 1; kb < 8; ++kb) g[kb] = cmul(g[kb], a.t.w64[lo3 * kb]);
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) ex[64 * hi3 + 8 * kb + lo3] = g[kb];
-            wave_sync();
-#pragma unroll
-            for (int aa = 0; aa < 8; ++aa) g[aa] = ex[64 * hi3 + 8 * lo3 + aa];  // lane = 8 w + kb
-            wave_sync();
-            dft8(g);  // over a -> ka: g[ka] = Z_w[kb + 8 ka]
-#pragma unroll
-            for (int ka = 0; ka < 8; ++ka) {
-                const int k = lo3 + 8 * ka;
-                const float2 c = make_float2(g[ka].x, -g[ka].y);
-                ex[64 * hi3 + k] = cmul(a.t.tw_short[k], c);
-            }
-            wave_sync();
-#pragma unroll 1
-            for (int k = 0; k < 16; ++k) {
-                const int i = 64 * k + lane;
-                stage[i] = short_buffer_value(ex, i, prev_short, cur_short);
-            }
-            wave_sync();
-            read_positions(stage, lane, o);
-            wave_sync();
-#pragma unroll 1
-            for (int k = 0; k < 16; ++k) {
-                const int i = 64 * k + lane;
-                stage[i] = short_buffer_value(ex, 1024 + i, prev_short, cur_short);
-            }
-            wave_sync();
-            read_positions(stage, lane, d);
-            wave_sync();
-        }
-
-        // ---- overlap-add, state update (dsp.rs:277-278, 333-334; decoder.rs:371) -------
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int j = 4 * lane + 256 * r;
-            float4 f, m;
-            f.x = o[8 * r + 0] + dly[8 * r + 0]; f.y = o[8 * r + 1] + dly[8 * r + 1];
-            f.z = o[8 * r + 2] + dly[8 * r + 2]; f.w = o[8 * r + 3] + dly[8 * r + 3];
-            m.x = o[8 * r + 4] + dly[8 * r + 4]; m.y = o[8 * r + 5] + dly[8 * r + 5];
-            m.z = o[8 * r + 6] + dly[8 * r + 6]; m.w = o[8 * r + 7] + dly[8 * r + 7];
-            *reinterpret_cast<float4 *>(out_ptr + j) = f;
-            *reinterpret_cast<float4 *>(out_ptr + 1020 - j) = m;
+            const f4 f = *reinterpret_cast<const f4 *>(delay_ptr + j);
+            const f4 m = *reinterpret_cast<const f4 *>(delay_ptr + 1020 - j);
+            dly[8 * r + 0] = f.x; dly[8 * r + 1] = f.y; dly[8 * r + 2] = f.z; dly[8 * r + 3] = f.w;
+            dly[8 * r + 4] = m.x; dly[8 * r + 5] = m.y; dly[8 * r + 6] = m.z; dly[8 * r + 7] = m.w;
         }
+    }
+
+    // ---- frame loop with a register ring of kDepth prefetched spectra -------------------------------
+    // One wave has (kDepth x 4 KiB) of HBM reads in flight while it transforms a frame; with two
+    // waves per SIMD that is what keeps enough bytes in flight to cover HBM latency (one spectrum
+    // per wave measured ~2 TB/s of reads = Little's law at ~4 us).  The ring is named statically
+    // (loop unrolled by kDepth), so it stays in VGPRs.
+    auto load_spectrum = [&](f2 (&xin)[8], uint32_t e) {
+        const float *src = a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e].off1024) * 1024 + 2 * lane;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) dly[s] = d[s];
-        prev_shape = shape;
+        for (int r = 0; r < 8; ++r) xin[r] = *reinterpret_cast<const f2 *>(src + 128 * r);
+    };
+    auto frame = [&](f2 (&xin)[8], uint32_t e) __attribute__((always_inline)) {
+        const SynthEntry ent = entries[e];
+        const uint32_t win = __builtin_amdgcn_readfirstlane(ent.win);
+        const int seq = win & 3;
+        const int shape = (win >> 2) & 1;
+        float *out_ptr = a.pcm + (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024;
+
+        // ---- pre-twiddle (dsp.rs:495-503): consumes xin so the next spectrum can land in it ----
+        f2 z[8];
+        if (seq != 2) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {  // z[64 r + lane]
+                const float even = xin[r].x;
+                const float odd = -__shfl(xin[7 - r].y, 63 - lane);  // X[1023 - 2 i]
+                const f2 t = tw_lds[lane + 64 * r];
+                z[r] = (f2){odd * t.y - even * t.x, odd * t.x + even * t.y};
+            }
+        } else {
+            int opq = 0;  // keeps this rare-path table load inside the branch (no hoisting out of the frame loop)
+            asm volatile("" : "+v"(opq));
+            const f2 tws = reinterpret_cast<const f2 *>(a.t.tw_short)[lane + opq];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {  // z_w[lane] of short block w
+                const float even = xin[w].x;
+                const float odd = -__shfl(xin[w].y, 63 - lane);  // X_w[127 - 2 lane]
+                z[w] = (f2){odd * tws.y - even * tws.x, odd * tws.x + even * tws.y};
+            }
+        }
+        if (seq == 0) {
+            const float *prev_long = a.t.win + 2048 * prev_shape;
+            const float *cur_long = a.t.win + 2048 * shape;
+#if SK_WIN_EARLY
+            // Window loads go out BEFORE the prefetch: vector-memory results return in issue order, so
+            // windows queued behind the next spectrum would make the epilogue wait for that HBM fetch.
+            f4 w1f[2], w1m[2], w2f[2], w2m[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int j = 4 * lane + 256 * r;
+                w1f[r] = *reinterpret_cast<const f4 *>(prev_long + j);
+                w1m[r] = *reinterpret_cast<const f4 *>(prev_long + 1020 - j);
+                w2f[r] = *reinterpret_cast<const f4 *>(cur_long + 1024 + j);
+                w2m[r] = *reinterpret_cast<const f4 *>(cur_long + 2044 - j);
+            }
+#endif
+            if (e + kDepth < count) {  // next spectrum in flight while this one is transformed
+                const float *src =
+                    a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e + kDepth].off1024) * 1024 + 2 * lane;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) xin[r] = *reinterpret_cast<const f2 *>(src + 128 * r);
+            }
+#if !defined(SK_ABLATE_FFT)
+            fft512(z, ex, t64, base2, lane);
+#endif
+            // ---- post-twiddle: value = twiddle * conj(fft) (dsp.rs:512, 523) --------
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ex[lane + 64 * j] = cmul(tw_lds[lane + 64 * j], (f2){z[j].x, -z[j].y});
+            wave_sync();
+            // ---- OnlyLong: window (dsp.rs:267-279) + overlap-add, one 512-sample half at a time ----
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int q = 2 * lane + 128 * r, j = 2 * q;
+                const f4 F = *reinterpret_cast<const lds_f4 *>(&ex[256 + q]);
+                const f4 M = *reinterpret_cast<const lds_f4 *>(&ex[254 - q]);
+#if SK_WIN_EARLY
+                const f4 W1f = w1f[r], W1m = w1m[r], W2f = w2f[r], W2m = w2m[r];
+#else
+                const f4 W1f = *reinterpret_cast<const f4 *>(prev_long + j);
+                const f4 W1m = *reinterpret_cast<const f4 *>(prev_long + 1020 - j);
+                const f4 W2f = *reinterpret_cast<const f4 *>(cur_long + 1024 + j);
+                const f4 W2m = *reinterpret_cast<const f4 *>(cur_long + 2044 - j);
+#endif
+                f4 f, m;
+                // out0[j..j+3] = -F0.re, -M1.im, -F1.re, -M0.im   (dsp.rs:516, 528)
+                f.x = -F.x * W1f.x + dly[8 * r + 0]; f.y = -M.w * W1f.y + dly[8 * r + 1];
+                f.z = -F.z * W1f.z + dly[8 * r + 2]; f.w = -M.y * W1f.w + dly[8 * r + 3];
+                // out1[508-j..511-j] = M0.im, F1.re, M1.im, F0.re (dsp.rs:517, 529)
+                m.x = M.y * W1m.x + dly[8 * r + 4]; m.y = F.z * W1m.y + dly[8 * r + 5];
+                m.z = M.w * W1m.z + dly[8 * r + 6]; m.w = F.x * W1m.w + dly[8 * r + 7];
+                *reinterpret_cast<f4 *>(out_ptr + j) = f;
+                *reinterpret_cast<f4 *>(out_ptr + 1020 - j) = m;
+                // out2[j..j+3] = F0.im, M1.re, F1.im, M0.re       (dsp.rs:518, 530)
+                dly[8 * r + 0] = F.y * W2f.x; dly[8 * r + 1] = M.z * W2f.y;
+                dly[8 * r + 2] = F.w * W2f.z; dly[8 * r + 3] = M.x * W2f.w;
+                // out3[508-j..511-j] = M0.re, F1.im, M1.re, F0.im (dsp.rs:519, 531)
+                dly[8 * r + 4] = M.x * W2m.x; dly[8 * r + 5] = F.w * W2m.y;
+                dly[8 * r + 6] = M.z * W2m.z; dly[8 * r + 7] = F.y * W2m.w;
+            }
+            wave_sync();
+        } else {
+            // hand the frame over through LDS (see synth_rare_frame), then restart the prefetch
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ex[64 * r + lane] = z[r];
+            write_positions(stage, lane, dly);
+            wave_sync();
+            synth_rare_frame(ex, stage, tw_lds, t64, base2.x, base2.y, a.t.win, reinterpret_cast<const f2 *>(a.t.w64),
+                             reinterpret_cast<const f2 *>(a.t.tw_short), out_ptr, seq, prev_shape, shape, lane);
+            read_positions(stage, lane, dly);
+            wave_sync();
+            if (e + kDepth < count) {
+                const float *src =
+                    a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e + kDepth].off1024) * 1024 + 2 * lane;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) xin[r] = *reinterpret_cast<const f2 *>(src + 128 * r);
+            }
+        }
+        prev_shape = shape;  // decoder.rs:371
+    };
+
+    f2 ring[kDepth][8];
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d)
+        if ((uint32_t)d < count) load_spectrum(ring[d], d);
+    for (uint32_t e0 = 0; e0 < count; e0 += kDepth) {
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d)
+            if (e0 + d < count) frame(ring[d], e0 + d);
     }
 
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int j = 4 * lane + 256 * r;
-        *reinterpret_cast<float4 *>(delay_ptr + j) =
-            make_float4(dly[8 * r + 0], dly[8 * r + 1], dly[8 * r + 2], dly[8 * r + 3]);
-        *reinterpret_cast<float4 *>(delay_ptr + 1020 - j) =
-            make_float4(dly[8 * r + 4], dly[8 * r + 5], dly[8 * r + 6], dly[8 * r + 7]);
+        *reinterpret_cast<f4 *>(delay_ptr + j) =
+            (f4){dly[8 * r + 0], dly[8 * r + 1], dly[8 * r + 2], dly[8 * r + 3]};
+        *reinterpret_cast<f4 *>(delay_ptr + 1020 - j) =
+            (f4){dly[8 * r + 4], dly[8 * r + 5], dly[8 * r + 6], dly[8 * r + 7]};
     }
-    if (lane == 0) a.prev_shape[task.state] = (uint8_t)prev_shape;
+    if (lane == 0) a.prev_shape[state] = (uint8_t)prev_shape;
 }
 
 // planar f32 [ch][1024] -> interleaved i16 [1024][ch] with float_sample_to_i16

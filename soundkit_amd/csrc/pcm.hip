@@ -34,8 +34,8 @@ __device__ __forceinline__ float clamp1(float x) {  // f32::clamp(-1, 1): NaN st
 }
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 __device__ __forceinline__ uint32_t bswap16(uint32_t v) { return ((v & 0xff) << 8) | ((v >> 8) & 0xff); }
-__device__ __forceinline__ int sext24(uint32_t v) { return (int)(v << 8) >> 8; }
-__device__ __forceinline__ int sext16(uint32_t v) { return (int)(v << 16) >> 16; }
+__device__ __forceinline__ int sext24(uint32_t v) { return (int)(((v & 0xffffffu) ^ 0x800000u) - 0x800000u); }
+__device__ __forceinline__ int sext16(uint32_t v) { return (int)(short)(unsigned short)v; }
 __device__ __forceinline__ uint32_t be24(uint32_t v) { return ((v & 0xff) << 16) | (v & 0xff00) | ((v >> 16) & 0xff); }
 
 __device__ __forceinline__ int float_sample_to_i16(float s) {  // soundkit-decoder lib.rs:1815-1827
@@ -116,13 +116,22 @@ __device__ __forceinline__ uint32_t extract(const uint32_t (&w)[IB], int s) {
     return (uint32_t)(pair >> sh) & 0xffffff;
 }
 
+// Scalar element access.  2- and 4-byte elements are naturally aligned (API contract), so they move
+// as one typed access; only 3-byte samples go byte by byte.  (Splitting a sign-extended value into
+// byte stores is also what hipcc 7.2 folds into a zero-extending v_perm_b32 -- avoid that shape.)
 __device__ __forceinline__ uint32_t load_raw_scalar(const uint8_t *p, int ib) {
-    uint32_t v = 0;
-    for (int b = 0; b < ib; ++b) v |= (uint32_t)p[b] << (8 * b);
-    return v;
+    if (ib == 4) return *reinterpret_cast<const uint32_t *>(p);
+    if (ib == 2) return *reinterpret_cast<const uint16_t *>(p);
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 }
 __device__ __forceinline__ void store_raw_scalar(uint8_t *p, uint32_t v, int ob) {
-    for (int b = 0; b < ob; ++b) p[b] = (uint8_t)(v >> (8 * b));
+    if (ob == 4) {
+        *reinterpret_cast<uint32_t *>(p) = v;
+    } else if (ob == 2) {
+        *reinterpret_cast<uint16_t *>(p) = (uint16_t)v;
+    } else {
+        p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16);
+    }
 }
 
 // grid-stride over groups of 4 samples; VEC = both buffers 16-byte aligned
@@ -135,24 +144,23 @@ __global__ __launch_bounds__(256) void k_convert(const uint8_t *in, uint8_t *out
         uint32_t w[IB];
         if (VEC) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(in + g * 4 * IB);
-            if (IB == 4) {
+            if constexpr (IB == 4) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(src);
                 w[0] = v.x; w[1] = v.y; w[2] = v.z; w[IB - 1] = v.w;
-            } else if (IB == 2) {
+            } else if constexpr (IB == 2) {
                 const uint2 v = *reinterpret_cast<const uint2 *>(src);
                 w[0] = v.x; w[IB - 1] = v.y;
             } else {
 #pragma unroll
                 for (int d = 0; d < IB; ++d) w[d] = src[d];
             }
-        } else {
-            const uint8_t *src = in + g * 4 * IB;
-#pragma unroll
-            for (int d = 0; d < IB; ++d) w[d] = load_raw_scalar(src + 4 * d, 4);
         }
         uint32_t r[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) r[s] = convert_raw<OP>(extract<IB>(w, s));
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t raw = VEC ? extract<IB>(w, s) : load_raw_scalar(in + (g * 4 + s) * IB, IB);
+            r[s] = convert_raw<OP>(raw);
+        }
         if (VEC) {
             if (OB == 4) {
                 *reinterpret_cast<uint4 *>(out + g * 16) = make_uint4(r[0], r[1], r[2], r[3]);
