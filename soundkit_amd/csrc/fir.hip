@@ -28,47 +28,76 @@ namespace sk {
 
 namespace {
 
-constexpr int kRing = 512;        // samples per row kept in LDS (two 256-sample chunks)
-constexpr int kRowStride = 520;   // dwords; 520 mod 64 == 8 makes the ds_read_b128 B loads conflict-free
+constexpr int kChunk = 128;       // samples per row per staged chunk
+constexpr int kBlockStride = 264; // dwords per (slot, row-pair) block: 2 x 128 samples + 8 pad
+constexpr int kRingDwords = 16 * kBlockStride;  // 2 slots x 8 row pairs
 constexpr int kSteps = 76;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+// LDS ring layout.  A chunk is 128 samples of each of the 16 rows; the ring holds two chunks.
+// One LDS-DMA instruction moves 1 KiB = rows (p, p+8) x 128 samples into block (slot, p):
+//     dword address = (slot*8 + (row & 7)) * 264 + (row >> 3) * 128 + (sample & 127)
+// 264 = 4 * 66 and 66 mod 16 == 2, which makes the ds_read_b128 B-operand loads conflict-free:
+// in every 16-lane read group the 16-byte slot index is 2*(row & 7) + (lane >> 4) mod 16, all distinct.
+__device__ __forceinline__ int ring_addr(int row, int sample) {
+    return (((sample >> 7) & 1) * 8 + (row & 7)) * kBlockStride + (row >> 3) * 128 + (sample & 127);
+}
+
 template <bool ALIGNED>
 __device__ __forceinline__ void stage_chunk(const FirArgs &a, float *ring, int lane, uint32_t row0, int64_t t0,
                                             int chunk) {
-    // chunk c covers local samples n'' in [256 c, 256 c + 256); stream time = n'' + t0
-    const int half = chunk & 1;
+    // chunk c covers local samples n'' in [128 c, 128 c + 128); stream time = n'' + t0
+    const int slot = chunk & 1;
+    if (ALIGNED) {
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-        const uint32_t row = row0 + rr;
-        const bool row_ok = row < a.rows;
-        const float *row_ptr = a.in + (size_t)(row_ok ? row : 0) * a.in_stride;
-        if (ALIGNED) {
-            const int64_t idx = (int64_t)256 * chunk + 4 * lane + t0 - a.in_origin;
+        for (int p = 0; p < 8; ++p) {  // lanes 0-31 -> row p, lanes 32-63 -> row p + 8, 4 samples per lane
+            const uint32_t row = row0 + p + 8 * (lane >> 5);
+            const bool row_ok = row < a.rows;
+            const float *row_ptr = a.in + (size_t)(row_ok ? row : 0) * a.in_stride;
+            const int64_t idx = (int64_t)kChunk * chunk + 4 * (lane & 31) + t0 - a.in_origin;
             const bool ok = row_ok && idx >= 0 && idx + 3 < (int64_t)a.in_frames;
             const float *src = ok ? row_ptr + idx : a.zeros + 4 * lane;
-            __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(ring + rr * kRowStride + half * 256), 16, 0,
-                                             0);
-        } else {
+            __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(ring + (slot * 8 + p) * kBlockStride), 16, 0, 0);
+        }
+    } else {
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int64_t idx = (int64_t)256 * chunk + 64 * qd + lane + t0 - a.in_origin;
+        for (int rr = 0; rr < 16; ++rr) {
+            const uint32_t row = row0 + rr;
+            const bool row_ok = row < a.rows;
+            const float *row_ptr = a.in + (size_t)(row_ok ? row : 0) * a.in_stride;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // 64 samples of one row per instruction
+                const int64_t idx = (int64_t)kChunk * chunk + 64 * h + lane + t0 - a.in_origin;
                 const bool ok = row_ok && idx >= 0 && idx < (int64_t)a.in_frames;
                 const float *src = ok ? row_ptr + idx : a.zeros + lane;
-                __builtin_amdgcn_global_load_lds((gbl_void *)src,
-                                                 (lds_void *)(ring + rr * kRowStride + half * 256 + 64 * qd), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(
+                    (gbl_void *)src, (lds_void *)(ring + (slot * 8 + (rr & 7)) * kBlockStride + (rr >> 3) * 128 + 64 * h),
+                    4, 0, 0);
             }
         }
     }
 }
 
+// s_waitcnt vmcnt(n): all but the n youngest vector-memory operations have completed.  The staged
+// chunk's LDS-DMA loads are older than the output stores issued since, so waiting down to `younger`
+// outstanding operations retires the loads without draining those stores.
+__device__ __forceinline__ void wait_vm_older_than(int younger) {
+    switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    }
+}
+
 template <bool ALIGNED>
-__global__ __launch_bounds__(64) void k_fir_48k_16k(FirArgs a, uint32_t total_blocks, uint32_t blocks_per_seg,
-                                                    uint32_t n_segs, int out_vec) {
-    __shared__ float ring[16 * kRowStride];
+__global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total_blocks, uint32_t blocks_per_seg,
+                                                       uint32_t n_segs, int out_vec) {
+    __shared__ float ring[kRingDwords];
 
     const int lane = threadIdx.x;
     const int j = lane & 15, kq = lane >> 4;
@@ -91,51 +120,73 @@ __global__ __launch_bounds__(64) void k_fir_48k_16k(FirArgs a, uint32_t total_bl
     for (int b = 0; b < 7; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int g_first = 3 * a_begin;
-    int chunk = g_first >> 4;
+    int chunk = g_first >> 3;  // 8 groups of 16 samples per chunk
     stage_chunk<ALIGNED>(a, ring, lane, row0, t0, chunk);
     stage_chunk<ALIGNED>(a, ring, lane, row0, t0, chunk + 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int stores_since_stage = 0;  // wave-uniform
 
     const uint32_t out_row = row0 + j;
     float *out_ptr = a.out + (size_t)(out_row < a.rows ? out_row : 0) * a.out_stride;
+    const int lane_base = ring_addr(j, 4 * kq);  // + slot and group offsets per read
+    auto read_group = [&](int G) {
+        return *reinterpret_cast<const f32x4 *>(&ring[lane_base + ((G >> 3) & 1) * 8 * kBlockStride + 16 * (G & 7)]);
+    };
 
-    for (int32_t A = a_begin; A < a_end + 6; ++A) {
+    // B operands are read one group ahead of the MFMAs that consume them.  Seven periods are
+    // unrolled so that block `blk` owns accumulator blk mod 7 statically (no register shuffling
+    // between periods, and no VALU reads of accumulators an MFMA has just written).
+    f32x4 xb = read_group(g_first);
+    for (int32_t A0 = a_begin - a_begin % 7; A0 < a_end + 6; A0 += 7) {
 #pragma unroll
-        for (int gi = 0; gi < 3; ++gi) {
-            const int G = 3 * A + gi;
-            if ((G & 15) == 0 && (G >> 4) != chunk) {
-                // entering chunk G>>4 (staged one chunk ago); its predecessor's half is free again
-                chunk = G >> 4;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                stage_chunk<ALIGNED>(a, ring, lane, row0, t0, chunk + 1);
-            }
-            const f32x4 xb = *reinterpret_cast<const f32x4 *>(&ring[j * kRowStride + ((16 * G + 4 * kq) & (kRing - 1))]);
+        for (int p = 0; p < 7; ++p) {
+            const int32_t A = A0 + p;  // A mod 7 == p
+            if (A < a_begin || A >= a_end + 6) continue;  // wave-uniform
+            acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};  // block A starts in this period
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int u = 4 * gi + t;
-#pragma unroll
-                for (int b = 0; b < 7; ++b) {
-                    if (12 * b + u < kSteps) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[12 * b + u], xb[t], acc[b], 0, 0, 0);
+            for (int gi = 0; gi < 3; ++gi) {
+                const int Gn = 3 * A + gi + 1;  // the group after the one computed now
+                if ((Gn & 7) == 0 && (Gn >> 3) != chunk) {
+                    // Gn opens chunk Gn>>3 (staged one chunk ago); every read of its predecessor has been
+                    // issued (the current group's operands are in xb), so that slot can be refilled
+                    chunk = Gn >> 3;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wait_vm_older_than(ALIGNED ? __builtin_amdgcn_readfirstlane(stores_since_stage) : 0);
+                    stage_chunk<ALIGNED>(a, ring, lane, row0, t0, chunk + 1);
+                    stores_since_stage = 0;
                 }
-            }
-            if (gi == 0) {
-                // block A-6 is complete after its step 75 (= u 3 of this period)
-                const int32_t blk = A - 6;
-                if (blk >= a_begin && blk < a_end && out_row < a.rows) {
-                    const uint32_t m = (uint32_t)blk * 16 + 4 * kq;  // relative to out_first
-                    if (out_vec && m + 3 < a.out_count) {
-                        *reinterpret_cast<f32x4 *>(out_ptr + m) = acc[6];
-                    } else {
+                const f32x4 xb_next = read_group(Gn);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (m + r < a.out_count) out_ptr[m + r] = acc[6][r];
+                for (int t = 0; t < 4; ++t) {
+                    const int u = 4 * gi + t;
+#pragma unroll
+                    for (int b = 0; b < 7; ++b) {  // block A - b is at step 12 b + u
+                        if (12 * b + u < kSteps)
+                            acc[(p - b + 7) % 7] =
+                                __builtin_amdgcn_mfma_f32_16x16x4f32(af[12 * b + u], xb[t], acc[(p - b + 7) % 7], 0, 0, 0);
                     }
                 }
+                if (gi == 0) {
+                    // block A-6 is complete after its step 75 (= u 3 of this period)
+                    const int32_t blk = A - 6;
+                    const f32x4 done = acc[(p + 1) % 7];
+                    if (blk >= a_begin && blk < a_end) {  // wave-uniform
+                        if (out_vec) ++stores_since_stage;
+                        if (out_row < a.rows) {
+                            const uint32_t m = (uint32_t)blk * 16 + 4 * kq;  // relative to out_first
+                            if (out_vec && m + 3 < a.out_count) {
+                                *reinterpret_cast<f32x4 *>(out_ptr + m) = done;
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (m + r < a.out_count) out_ptr[m + r] = done[r];
+                            }
+                        }
+                    }
+                }
+                xb = xb_next;
             }
         }
-#pragma unroll
-        for (int b = 6; b > 0; --b) acc[b] = acc[b - 1];
-        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -145,9 +196,9 @@ hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s) {
     if (a.rows == 0 || a.out_count == 0) return hipSuccess;
     const uint32_t total_blocks = (a.out_count + 15) / 16;
     const uint32_t groups = (a.rows + 15) / 16;
-    // one wave per SIMD across the chip (256 CUs x 4) is the residency this kernel's LDS allows;
+    // two waves per SIMD across the chip (256 CUs x 4 x 2) is the residency this kernel's LDS allows;
     // split the time axis until there are about that many waves, keeping segments >= 32 blocks
-    uint32_t n_segs = (1024 + groups - 1) / groups;
+    uint32_t n_segs = (2048 + groups - 1) / groups;
     const uint32_t max_segs = total_blocks / 32 ? total_blocks / 32 : 1;
     if (n_segs > max_segs) n_segs = max_segs;
     if (n_segs < 1) n_segs = 1;
