@@ -25,6 +25,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")  # rocprofv3 --pmc passes of this same workload
+
+
+def pmc_traffic(kind, **config):
+    """HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB), if they were
+    taken on exactly this workload; otherwise None."""
+    try:
+        entry = json.load(open(PMC_SUMMARY))[kind]
+    except (OSError, KeyError, ValueError):
+        return None
+    return entry["traffic_bytes"] if entry.get("config") == config else None
+
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak
 SEED0 = 0x12345678
 
@@ -188,11 +200,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    from soundkit_amd import sharding
+    elapsed = sharding.reduce_elapsed(time.perf_counter() - t0, device)  # max over ranks
 
     if rank == 0:
         per_kernel = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in kernel_ms.items()}
@@ -216,7 +225,7 @@ def main():
             out["roofline"] = {
                 "kernel": "k_aac_synth", "bound": "hbm", "achieved": variant_bytes / (ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": variant_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": None, "avg_launch_ms": ms,
+                "traffic": pmc_traffic("aac_synth", streams=streams, frames=frames, channels=ch), "avg_launch_ms": ms,
                 "variant": "delay on-chip: 8192 B per channel-frame + 8192 B per channel per launch",
                 "achieved_canonical_32768B_per_stereo_frame": canonical_bytes / (ms * 1e-3) / 1e9,
             }
@@ -225,7 +234,8 @@ def main():
             flops = streams * ch * eng.downsample_out_frames(48000) * 512.0
             out["roofline"] = {"kernel": "k_fir_48k_16k", "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12,
                                "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                               "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                               "traffic": pmc_traffic("fir", rows=streams * ch, frames=48000),
                                "avg_launch_ms": ms}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_fir() if args.workload == "fir" else cpu_baseline_synth()
