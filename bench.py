@@ -166,9 +166,29 @@ def main():
         units_per_step = streams * frames  # stereo frames
         unit = "frames/s"
 
-        def step():
-            timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
-        workload = "aac_lc_synth: %d streams x %d frames, 48 kHz stereo, IMDCT+window+OLA, f32 planar out, %s-major batch" % (streams, frames, args.layout)
+        if args.workload == "pipeline":
+            if args.layout == "frame":
+                stream_stride, frame_stride = ch * 1024, streams * ch * 1024
+            else:
+                stream_stride, frame_stride = frames * ch * 1024, ch * 1024
+            n_out = eng.downsample_out_frames(frames * 1024)
+            out_stride = (n_out + 3) // 4 * 4
+            fir_out = torch.empty((streams * ch, out_stride), device=device)
+            s16_out = torch.empty((streams, n_out, ch), dtype=torch.int16, device=device)
+            fmt_s16 = soundkit_amd.engine.FMT_S16LE
+
+            def step():
+                timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
+                timed("k_fir_48k_16k", lambda: eng.downsample_48k_16k_frames_dev(pcm, stream_stride, frame_stride, ch,
+                                                                                 streams, frames, fir_out, out_stride))
+                timed("k_f32_planar_stereo_to_s16le_batch",
+                      lambda: eng.f32_planar_to_bytes_batch_dev(fmt_s16, fir_out, streams, out_stride, n_out, ch, s16_out))
+            workload = ("aac_lc decode tail: %d streams x %d frames, 48 kHz stereo: IMDCT+window+OLA -> 48k->16k MFMA FIR -> "
+                        "interleaved s16, %s-major batch" % (streams, frames, args.layout))
+        else:
+            def step():
+                timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
+            workload = "aac_lc_synth: %d streams x %d frames, 48 kHz stereo, IMDCT+window+OLA, f32 planar out, %s-major batch" % (streams, frames, args.layout)
     else:
         frames_in = 48000
         rows = streams * ch
@@ -237,6 +257,19 @@ def main():
                                "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                                "traffic": pmc_traffic("fir", rows=streams * ch, frames=48000),
                                "avg_launch_ms": ms}
+        if args.workload == "pipeline":
+            n_out = eng.downsample_out_frames(frames * 1024)
+            fir_ms, cvt_ms = per_kernel["k_fir_48k_16k"], per_kernel["k_f32_planar_stereo_to_s16le_batch"]
+            fir_flops = streams * ch * n_out * 512.0
+            cvt_bytes = streams * ch * n_out * 6.0
+            out["kernels"] = {
+                "k_aac_synth": {"avg_launch_ms": per_kernel["k_aac_synth"], "bound": "hbm", "frac": out["roofline"]["frac"]},
+                "k_fir_48k_16k": {"avg_launch_ms": fir_ms, "bound": "mfma", "achieved_tflops": fir_flops / (fir_ms * 1e-3) / 1e12,
+                                  "frac": fir_flops / (fir_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF},
+                "k_f32_planar_stereo_to_s16le_batch": {"avg_launch_ms": cvt_ms, "bound": "hbm",
+                                                       "achieved_gbs": cvt_bytes / (cvt_ms * 1e-3) / 1e9,
+                                                       "frac": cvt_bytes / (cvt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+            out["roofline"]["note"] = "dominant kernel of the chain (largest share of the step); all three are in `kernels`"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_fir() if args.workload == "fir" else cpu_baseline_synth()
         print(json.dumps(out))

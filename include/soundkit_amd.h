@@ -197,6 +197,9 @@ int sk_pcm_bytes_to_f32_planar_dev(sk_engine *, int variant, int fmt, const uint
 int sk_pcm_f32_planar_to_bytes(sk_engine *, int fmt, const float *planar, size_t frames, uint32_t ch, uint8_t *out);
 int sk_pcm_f32_planar_to_bytes_dev(sk_engine *, int fmt, const float *d_planar, size_t frames, uint32_t ch,
                                    uint8_t *d_out);
+/* the same for `batch` independent signals: planar [batch][ch][plane_stride] -> [batch][frames][ch] */
+int sk_pcm_f32_planar_to_bytes_batch_dev(sk_engine *, int fmt, const float *d_planar, size_t batch, size_t plane_stride,
+                                         size_t frames, uint32_t ch, uint8_t *d_out);
 /* downmix_channels target 1 (soundkit-decoder lib.rs:3500-3509) */
 int sk_pcm_downmix_mono(sk_engine *, const float *planar, size_t frames, uint32_t ch, float *mono);
 int sk_pcm_downmix_mono_dev(sk_engine *, const float *d_planar, size_t frames, uint32_t ch, float *d_mono);
@@ -217,6 +220,14 @@ int sk_downsample_48k_16k_f32(sk_engine *, const float *in, uint32_t rows, uint3
                               uint32_t *out_frames);
 int sk_downsample_48k_16k_f32_dev(sk_engine *, const float *d_in, size_t in_stride, uint32_t rows, uint32_t frames,
                                   float *d_out, size_t out_stride, uint32_t *out_frames);
+
+/* downsample_audio over the frame-packed planar PCM that sk_aac_plan_run_f32_dev wrote, in place (no
+ * repack): sample n of (stream s, channel c) is read at
+ *   d_pcm[s * stream_stride + (n / 1024) * frame_stride + c * 1024 + n % 1024],   n < frames_per_stream * 1024
+ * and row s * channels + c of d_out receives its sk_downsample_48k_16k_out_frames(..) outputs. */
+int sk_downsample_48k_16k_frames_dev(sk_engine *, const float *d_pcm, size_t stream_stride, size_t frame_stride,
+                                     uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream, float *d_out,
+                                     size_t out_stride, uint32_t *out_frames);
 
 /* StreamingResampler (soundkit-decoder lib.rs:1917-2060), 48k->16k, fixed 4096-frame
  * chunks, history kept per stream on the device.  in: n_streams x channels x frames planar

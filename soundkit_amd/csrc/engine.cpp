@@ -781,6 +781,13 @@ int sk_pcm_f32_planar_to_bytes(sk_engine *e, int fmt, const float *planar, size_
         return sk::launch_f32_planar_to_bytes(fmt, (const float *)di, frames, ch, (uint8_t *)dout, e->stream);
     });
 }
+int sk_pcm_f32_planar_to_bytes_batch_dev(sk_engine *e, int fmt, const float *d_planar, size_t batch, size_t plane_stride,
+                                         size_t frames, uint32_t ch, uint8_t *d_out) {
+    if (!e || ch == 0 || !from_f32_fmt_ok(fmt) || plane_stride < frames || batch > 65535 ||
+        (frames && batch && (!d_planar || !d_out)))
+        return SK_ERR_INVALID_ARG;
+    SK_DEV_ENTRY(sk::launch_f32_planar_to_bytes_batch(fmt, d_planar, batch, plane_stride, frames, ch, d_out, e->stream));
+}
 int sk_pcm_downmix_mono_dev(sk_engine *e, const float *d_planar, size_t frames, uint32_t ch, float *d_mono) {
     if (!e || ch == 0 || (frames && (!d_planar || !d_mono))) return SK_ERR_INVALID_ARG;
     SK_DEV_ENTRY(sk::launch_downmix_mono(d_planar, frames, ch, d_mono, e->stream));
@@ -846,6 +853,37 @@ int sk_downsample_48k_16k_f32_dev(sk_engine *e, const float *d_in, size_t in_str
     a.out_first = 0;
     a.out_count = n_out;
     SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch fir");
+    return SK_OK;
+}
+
+int sk_downsample_48k_16k_frames_dev(sk_engine *e, const float *d_pcm, size_t stream_stride, size_t frame_stride,
+                                     uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream, float *d_out,
+                                     size_t out_stride, uint32_t *out_frames) {
+    if (!e || channels < 1 || channels > SK_MAX_CHANNELS) return SK_ERR_INVALID_ARG;
+    const uint64_t samples = (uint64_t)frames_per_stream * SK_AAC_FRAME_LEN;
+    if (samples > 0xfffffffcull) return SK_ERR_INVALID_ARG;
+    const uint32_t n_out = sk_downsample_48k_16k_out_frames((uint32_t)samples);
+    if (out_frames) *out_frames = n_out;
+    if (n_streams == 0 || n_out == 0) return SK_OK;
+    if (!d_pcm || !d_out || out_stride < n_out || frame_stride < (size_t)channels * SK_AAC_FRAME_LEN)
+        return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    sk::FirArgs a = fir_base(e);
+    a.in = d_pcm;
+    a.out = d_out;
+    a.in_stride = 0;
+    a.out_stride = out_stride;
+    a.in_block = SK_AAC_FRAME_LEN;
+    a.in_ch = channels;
+    a.in_block_stride = frame_stride;
+    a.in_group_stride = stream_stride;
+    a.rows = n_streams * channels;
+    a.in_frames = (uint32_t)samples;
+    a.in_origin = 0;
+    a.out_first = 0;
+    a.out_count = n_out;
+    SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch fir (frame-packed input)");
     return SK_OK;
 }
 

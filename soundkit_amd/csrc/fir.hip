@@ -24,6 +24,8 @@
 // 4q + t) so that one lane's four B operands are 4 contiguous floats in LDS.
 #include "sk_device.h"
 
+#include <type_traits>
+
 namespace sk {
 
 namespace {
@@ -46,7 +48,19 @@ __device__ __forceinline__ int ring_addr(int row, int sample) {
     return (((sample >> 7) & 1) * 8 + (row & 7)) * kBlockStride + (row >> 3) * 128 + (sample & 127);
 }
 
-template <bool ALIGNED>
+// element offset of sample idx of row `row`: plain rows, or the frame-packed planar layout the AAC
+// synthesis writes (FirArgs::in_block == 1024, in_ch 1 or 2) -- shifts and masks only: this runs per
+// lane per DMA instruction inside an MFMA-bound loop
+template <bool PACKED>
+__device__ __forceinline__ size_t sample_offset(const FirArgs &a, uint32_t row, int64_t idx) {
+    if (!PACKED) return (size_t)row * a.in_stride + (size_t)idx;
+    const uint32_t sh = a.in_ch - 1;  // channels 1 -> 0, 2 -> 1
+    const uint32_t g = row >> sh, c = row & sh;
+    const uint32_t i = (uint32_t)idx;
+    return (size_t)g * a.in_group_stride + (size_t)(c << 10) + (size_t)(i >> 10) * a.in_block_stride + (size_t)(i & 1023);
+}
+
+template <bool ALIGNED, bool PACKED>
 __device__ __forceinline__ void stage_chunk(const FirArgs &a, float *ring, int lane, uint32_t row0, int64_t t0,
                                             int chunk) {
     // chunk c covers local samples n'' in [128 c, 128 c + 128); stream time = n'' + t0
@@ -56,10 +70,9 @@ __device__ __forceinline__ void stage_chunk(const FirArgs &a, float *ring, int l
         for (int p = 0; p < 8; ++p) {  // lanes 0-31 -> row p, lanes 32-63 -> row p + 8, 4 samples per lane
             const uint32_t row = row0 + p + 8 * (lane >> 5);
             const bool row_ok = row < a.rows;
-            const float *row_ptr = a.in + (size_t)(row_ok ? row : 0) * a.in_stride;
             const int64_t idx = (int64_t)kChunk * chunk + 4 * (lane & 31) + t0 - a.in_origin;
             const bool ok = row_ok && idx >= 0 && idx + 3 < (int64_t)a.in_frames;
-            const float *src = ok ? row_ptr + idx : a.zeros + 4 * lane;
+            const float *src = ok ? a.in + sample_offset<PACKED>(a, row, idx) : a.zeros + 4 * lane;
             __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(ring + (slot * 8 + p) * kBlockStride), 16, 0, 0);
         }
     } else {
@@ -67,12 +80,11 @@ __device__ __forceinline__ void stage_chunk(const FirArgs &a, float *ring, int l
         for (int rr = 0; rr < 16; ++rr) {
             const uint32_t row = row0 + rr;
             const bool row_ok = row < a.rows;
-            const float *row_ptr = a.in + (size_t)(row_ok ? row : 0) * a.in_stride;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {  // 64 samples of one row per instruction
                 const int64_t idx = (int64_t)kChunk * chunk + 64 * h + lane + t0 - a.in_origin;
                 const bool ok = row_ok && idx >= 0 && idx < (int64_t)a.in_frames;
-                const float *src = ok ? row_ptr + idx : a.zeros + lane;
+                const float *src = ok ? a.in + sample_offset<PACKED>(a, row, idx) : a.zeros + lane;
                 __builtin_amdgcn_global_load_lds(
                     (gbl_void *)src, (lds_void *)(ring + (slot * 8 + (rr & 7)) * kBlockStride + (rr >> 3) * 128 + 64 * h),
                     4, 0, 0);
@@ -94,7 +106,7 @@ __device__ __forceinline__ void wait_vm_older_than(int younger) {
     }
 }
 
-template <bool ALIGNED>
+template <bool ALIGNED, bool PACKED>
 __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total_blocks, uint32_t blocks_per_seg,
                                                        uint32_t n_segs, int out_vec) {
     __shared__ float ring[kRingDwords];
@@ -121,8 +133,8 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
 
     const int g_first = 3 * a_begin;
     int chunk = g_first >> 3;  // 8 groups of 16 samples per chunk
-    stage_chunk<ALIGNED>(a, ring, lane, row0, t0, chunk);
-    stage_chunk<ALIGNED>(a, ring, lane, row0, t0, chunk + 1);
+    stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, t0, chunk);
+    stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, t0, chunk + 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int stores_since_stage = 0;  // wave-uniform
 
@@ -137,56 +149,64 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
     // unrolled so that block `blk` owns accumulator blk mod 7 statically (no register shuffling
     // between periods, and no VALU reads of accumulators an MFMA has just written).
     f32x4 xb = read_group(g_first);
-    for (int32_t A0 = a_begin - a_begin % 7; A0 < a_end + 6; A0 += 7) {
+    // one period (3 groups of 16 samples) with A mod 7 == P known at compile time
+    auto period = [&](auto ptag, int32_t A) __attribute__((always_inline)) {
+        constexpr int p = decltype(ptag)::value;
+        acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};  // block A starts in this period
 #pragma unroll
-        for (int p = 0; p < 7; ++p) {
-            const int32_t A = A0 + p;  // A mod 7 == p
-            if (A < a_begin || A >= a_end + 6) continue;  // wave-uniform
-            acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};  // block A starts in this period
+        for (int gi = 0; gi < 3; ++gi) {
+            const int Gn = 3 * A + gi + 1;  // the group after the one computed now
+            if ((Gn & 7) == 0 && (Gn >> 3) != chunk) {
+                // Gn opens chunk Gn>>3 (staged one chunk ago); every read of its predecessor has been
+                // issued (the current group's operands are in xb), so that slot can be refilled
+                chunk = Gn >> 3;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_vm_older_than(ALIGNED ? __builtin_amdgcn_readfirstlane(stores_since_stage) : 0);
+                stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, t0, chunk + 1);
+                stores_since_stage = 0;
+            }
+            const f32x4 xb_next = read_group(Gn);
 #pragma unroll
-            for (int gi = 0; gi < 3; ++gi) {
-                const int Gn = 3 * A + gi + 1;  // the group after the one computed now
-                if ((Gn & 7) == 0 && (Gn >> 3) != chunk) {
-                    // Gn opens chunk Gn>>3 (staged one chunk ago); every read of its predecessor has been
-                    // issued (the current group's operands are in xb), so that slot can be refilled
-                    chunk = Gn >> 3;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    wait_vm_older_than(ALIGNED ? __builtin_amdgcn_readfirstlane(stores_since_stage) : 0);
-                    stage_chunk<ALIGNED>(a, ring, lane, row0, t0, chunk + 1);
-                    stores_since_stage = 0;
+            for (int t = 0; t < 4; ++t) {
+                const int u = 4 * gi + t;
+#pragma unroll
+                for (int b = 0; b < 7; ++b) {  // block A - b is at step 12 b + u
+                    if (12 * b + u < kSteps)
+                        acc[(p - b + 7) % 7] =
+                            __builtin_amdgcn_mfma_f32_16x16x4f32(af[12 * b + u], xb[t], acc[(p - b + 7) % 7], 0, 0, 0);
                 }
-                const f32x4 xb_next = read_group(Gn);
+            }
+            if (gi == 0) {
+                // block A-6 is complete after its step 75 (= u 3 of this period)
+                const int32_t blk = A - 6;
+                const f32x4 done = acc[(p + 1) % 7];
+                if (blk >= a_begin && blk < a_end) {  // wave-uniform
+                    if (out_vec) ++stores_since_stage;
+                    if (out_row < a.rows) {
+                        const uint32_t m = (uint32_t)blk * 16 + 4 * kq;  // relative to out_first
+                        if (out_vec && m + 3 < a.out_count) {
+                            *reinterpret_cast<f32x4 *>(out_ptr + m) = done;
+                        } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int u = 4 * gi + t;
-#pragma unroll
-                    for (int b = 0; b < 7; ++b) {  // block A - b is at step 12 b + u
-                        if (12 * b + u < kSteps)
-                            acc[(p - b + 7) % 7] =
-                                __builtin_amdgcn_mfma_f32_16x16x4f32(af[12 * b + u], xb[t], acc[(p - b + 7) % 7], 0, 0, 0);
-                    }
-                }
-                if (gi == 0) {
-                    // block A-6 is complete after its step 75 (= u 3 of this period)
-                    const int32_t blk = A - 6;
-                    const f32x4 done = acc[(p + 1) % 7];
-                    if (blk >= a_begin && blk < a_end) {  // wave-uniform
-                        if (out_vec) ++stores_since_stage;
-                        if (out_row < a.rows) {
-                            const uint32_t m = (uint32_t)blk * 16 + 4 * kq;  // relative to out_first
-                            if (out_vec && m + 3 < a.out_count) {
-                                *reinterpret_cast<f32x4 *>(out_ptr + m) = done;
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    if (m + r < a.out_count) out_ptr[m + r] = done[r];
-                            }
+                            for (int r = 0; r < 4; ++r)
+                                if (m + r < a.out_count) out_ptr[m + r] = done[r];
                         }
                     }
                 }
-                xb = xb_next;
             }
+            xb = xb_next;
         }
+    };
+    const int32_t a_last = a_end + 6;
+    for (int32_t A0 = a_begin - a_begin % 7; A0 < a_last; A0 += 7) {
+        // skipping a period is wave-uniform; periods before a_begin only exist in the first trip
+        if (A0 + 0 >= a_begin && A0 + 0 < a_last) period(std::integral_constant<int, 0>{}, A0 + 0);
+        if (A0 + 1 >= a_begin && A0 + 1 < a_last) period(std::integral_constant<int, 1>{}, A0 + 1);
+        if (A0 + 2 >= a_begin && A0 + 2 < a_last) period(std::integral_constant<int, 2>{}, A0 + 2);
+        if (A0 + 3 >= a_begin && A0 + 3 < a_last) period(std::integral_constant<int, 3>{}, A0 + 3);
+        if (A0 + 4 >= a_begin && A0 + 4 < a_last) period(std::integral_constant<int, 4>{}, A0 + 4);
+        if (A0 + 5 >= a_begin && A0 + 5 < a_last) period(std::integral_constant<int, 5>{}, A0 + 5);
+        if (A0 + 6 >= a_begin && A0 + 6 < a_last) period(std::integral_constant<int, 6>{}, A0 + 6);
     }
 }
 
@@ -206,14 +226,22 @@ hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s) {
     n_segs = (total_blocks + blocks_per_seg - 1) / blocks_per_seg;
 
     const int64_t t0 = (int64_t)3 * a.out_first - 128;
-    const bool aligned = (((t0 - a.in_origin) & 3) == 0) && (a.in_stride % 4 == 0) && (a.in_frames % 4 == 0) &&
+    const bool strides_ok = a.in_block ? (a.in_block % 4 == 0 && a.in_block_stride % 4 == 0 && a.in_group_stride % 4 == 0)
+                                       : (a.in_stride % 4 == 0);
+    const bool aligned = (((t0 - a.in_origin) & 3) == 0) && strides_ok && (a.in_frames % 4 == 0) &&
                          (((uintptr_t)a.in & 15) == 0);
     const int out_vec = (a.out_stride % 4 == 0) && (((uintptr_t)a.out & 15) == 0);
     const dim3 grid(groups * n_segs), block(64);
-    if (aligned)
-        hipLaunchKernelGGL(k_fir_48k_16k<true>, grid, block, 0, s, a, total_blocks, blocks_per_seg, n_segs, out_vec);
+    const bool packed = a.in_block != 0;
+    if (packed && (a.in_block != 1024 || a.in_ch < 1 || a.in_ch > 2)) return hipErrorInvalidValue;
+    if (aligned && packed)
+        hipLaunchKernelGGL((k_fir_48k_16k<true, true>), grid, block, 0, s, a, total_blocks, blocks_per_seg, n_segs, out_vec);
+    else if (aligned)
+        hipLaunchKernelGGL((k_fir_48k_16k<true, false>), grid, block, 0, s, a, total_blocks, blocks_per_seg, n_segs, out_vec);
+    else if (packed)
+        hipLaunchKernelGGL((k_fir_48k_16k<false, true>), grid, block, 0, s, a, total_blocks, blocks_per_seg, n_segs, out_vec);
     else
-        hipLaunchKernelGGL(k_fir_48k_16k<false>, grid, block, 0, s, a, total_blocks, blocks_per_seg, n_segs, out_vec);
+        hipLaunchKernelGGL((k_fir_48k_16k<false, false>), grid, block, 0, s, a, total_blocks, blocks_per_seg, n_segs, out_vec);
     return hipGetLastError();
 }
 

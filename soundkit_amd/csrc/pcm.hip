@@ -324,6 +324,54 @@ __global__ __launch_bounds__(256) void k_f32_planar_stereo_to_s16le(const float 
     }
 }
 
+// batch of [2][plane_stride] planar f32 -> [frames][2] interleaved s16le.  The output of all batches is
+// one contiguous array of (L, R) dwords; a lane owns 4 consecutive dwords of it (a 16-byte aligned
+// store whatever `frames` is) and fetches its 8 samples with coalesced dword loads.
+__global__ __launch_bounds__(256) void k_f32_planar_stereo_to_s16le_batch(const float *planar, size_t plane_stride,
+                                                                          size_t frames, size_t batch, uint8_t *out) {
+    const size_t total = batch * frames;
+    const size_t groups = (total + 3) / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
+        const size_t g0 = g * 4;
+        size_t b = g0 / frames, f = g0 - b * frames;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t w = 0;
+            if (g0 + k < total) {
+                const float *src = planar + b * 2 * plane_stride + f;
+                w = ((uint32_t)float_sample_to_i16(src[0]) & 0xffff) | ((uint32_t)float_sample_to_i16(src[plane_stride]) << 16);
+            }
+            v[k] = w;
+            if (++f == frames) { f = 0; ++b; }
+        }
+        if (g0 + 3 < total) {
+            reinterpret_cast<uint4 *>(out)[g] = make_uint4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (g0 + k < total) reinterpret_cast<uint32_t *>(out)[g0 + k] = v[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_f32_planar_to_bytes_batch(int fmt, int bps, const float *planar,
+                                                                   size_t plane_stride, size_t frames, uint32_t ch,
+                                                                   uint8_t *out) {
+    const float *src = planar + (size_t)blockIdx.y * ch * plane_stride;
+    uint8_t *dst = out + (size_t)blockIdx.y * frames * ch * bps;
+    const size_t total = frames * ch;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t f = i / ch;
+        const uint32_t c = (uint32_t)(i - f * ch);
+        const uint32_t v = f32_to_sample(fmt, src[(size_t)c * plane_stride + f]);
+        if (bps == 2) reinterpret_cast<uint16_t *>(dst)[i] = (uint16_t)v;
+        else if (bps == 4) reinterpret_cast<uint32_t *>(dst)[i] = v;
+        else store_raw_scalar(dst + i * 3, v, 3);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_downmix_mono(const float *planar, size_t frames, uint32_t ch, float *mono) {
     const float scale = 1.0f / (float)ch;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -422,6 +470,25 @@ hipError_t launch_f32_planar_to_bytes(int fmt, const float *planar, size_t frame
     } else {
         hipLaunchKernelGGL(k_f32_planar_to_bytes, dim3(grid_for(frames * ch)), dim3(256), 0, s, fmt, bps, planar, frames,
                            ch, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_planar_to_bytes_batch(int fmt, const float *planar, size_t batch, size_t plane_stride, size_t frames,
+                                            uint32_t ch, uint8_t *out, hipStream_t s) {
+    if (batch == 0 || frames == 0 || ch == 0) return hipSuccess;
+    if (batch > 65535) return hipErrorInvalidValue;
+    const int bps = sk_pcm_fmt_bytes(fmt);
+    if (fmt == SK_FMT_S16LE && ch == 2 && (((uintptr_t)out & 15) == 0)) {
+        size_t blocks = ((batch * frames + 3) / 4 + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(k_f32_planar_stereo_to_s16le_batch, dim3((unsigned)blocks), dim3(256), 0, s, planar,
+                           plane_stride, frames, batch, out);
+    } else {
+        unsigned gx = (unsigned)((frames * ch + 255) / 256);
+        if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(k_f32_planar_to_bytes_batch, dim3(gx, (unsigned)batch), dim3(256), 0, s, fmt, bps, planar,
+                           plane_stride, frames, ch, out);
     }
     return hipGetLastError();
 }

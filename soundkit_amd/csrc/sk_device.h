@@ -62,6 +62,8 @@ hipError_t launch_f32_planar_to_bytes(int fmt, const float *planar, size_t frame
                                       hipStream_t s);
 hipError_t launch_downmix_mono(const float *planar, size_t frames, uint32_t ch, float *mono, hipStream_t s);
 hipError_t launch_exact_to_i16(int fmt, const uint8_t *in, size_t samples, uint8_t *out, hipStream_t s);
+hipError_t launch_f32_planar_to_bytes_batch(int fmt, const float *planar, size_t batch, size_t plane_stride, size_t frames,
+                                            uint32_t ch, uint8_t *out, hipStream_t s);
 
 // fir.hip
 struct FirArgs {
@@ -71,6 +73,10 @@ struct FirArgs {
     const float *afrag;   // [76][64] MFMA A-operand fragments of the Toeplitz tap matrix
     const float *taps;    // [256]
     size_t in_stride, out_stride;
+    // frame-packed input (in_block 0 = plain rows; otherwise 1024 with in_ch 1 or 2): sample n of row r lives at
+    //   in + (r / in_ch) * in_group_stride + (r % in_ch) * 1024 + (n / 1024) * in_block_stride + n % 1024
+    uint32_t in_block, in_ch;
+    size_t in_block_stride, in_group_stride;
     uint32_t rows;
     uint32_t in_frames;   // valid input samples per row (n >= in_frames reads as 0)
     int32_t in_origin;    // sample index of in[r][0] relative to the stream's time 0 (history rows: negative)

@@ -293,6 +293,18 @@ class Engine:
                                                 C.byref(got)), "sk_downsample_48k_16k_f32_dev", self._h)
         return got.value
 
+    def downsample_48k_16k_frames_dev(self, d_pcm, stream_stride, frame_stride, channels, n_streams, frames_per_stream,
+                                      d_out, out_stride):
+        got = C.c_uint32()
+        check(lib.sk_downsample_48k_16k_frames_dev(self._h, _ptr(d_pcm), stream_stride, frame_stride, channels, n_streams,
+                                                   frames_per_stream, _ptr(d_out), out_stride, C.byref(got)),
+              "sk_downsample_48k_16k_frames_dev", self._h)
+        return got.value
+
+    def f32_planar_to_bytes_batch_dev(self, fmt, d_planar, batch, plane_stride, frames, ch, d_out):
+        check(lib.sk_pcm_f32_planar_to_bytes_batch_dev(self._h, fmt, _ptr(d_planar), batch, plane_stride, frames, ch,
+                                                       _ptr(d_out)), "sk_pcm_f32_planar_to_bytes_batch_dev", self._h)
+
     def resampler_open(self, sid, in_hz=48000, out_hz=16000):
         check(lib.sk_resampler_open(self._h, sid, in_hz, out_hz), "sk_resampler_open", self._h)
 

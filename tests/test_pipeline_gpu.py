@@ -1,0 +1,70 @@
+"""The worker's whole device-side tail on the GPU, chained without leaving HBM:
+AAC synthesis -> 48k->16k FIR over the frame-packed planar PCM in place -> interleaved s16."""
+import numpy as np
+import pytest
+
+import soundkit_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_rms(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b * b)) or 1.0)
+
+
+@pytest.mark.parametrize("layout", ["frame", "stream"])
+@pytest.mark.parametrize("ch", [1, 2])
+def test_synth_fir_s16_chain_matches_oracle(engine, oracle, layout, ch):
+    import torch
+    n_streams, n_frames = 5, 6
+    coeffs = np.empty((n_streams, n_frames, ch, 1024), np.float32)
+    for s in range(n_streams):
+        for f in range(n_frames):
+            for c in range(ch):
+                coeffs[s, f, c] = oracle.seeded_spectrum(1024, 0x12345678 + 977 * s + 2 * f + c) * np.float32(2500.0)
+    seq_chain = [0, 1, 2, 3, 0, 0]
+    seqs = np.zeros((n_streams, n_frames, 2), np.uint8)
+    shapes = np.zeros((n_streams, n_frames, 2), np.uint8)
+    for s in range(n_streams):
+        for f in range(n_frames):
+            seqs[s, f] = seq_chain[(f + s) % 6] if s % 2 else 0
+            shapes[s, f] = (f + s) & 1
+    sids = np.array([engine.open_stream(48000, ch) for _ in range(n_streams)], np.uint32)
+    if layout == "frame":   # one tick of every stream after another
+        order = [(s, f) for f in range(n_frames) for s in range(n_streams)]
+        stream_stride, frame_stride = ch * 1024, n_streams * ch * 1024
+    else:
+        order = [(s, f) for s in range(n_streams) for f in range(n_frames)]
+        stream_stride, frame_stride = n_frames * ch * 1024, ch * 1024
+    packed = np.stack([coeffs[s, f] for s, f in order])
+    descs, n = soundkit_amd.descs_from_arrays([sids[s] for s, f in order], ch, [seqs[s, f] for s, f in order],
+                                              [shapes[s, f] for s, f in order])
+    plan = engine.plan(descs, n)
+    assert plan.frames_ok == n
+    d_coeffs = torch.from_numpy(packed).cuda()
+    d_pcm = torch.empty_like(d_coeffs)
+    n_out = engine.downsample_out_frames(n_frames * 1024)
+    out_stride = (n_out + 3) // 4 * 4
+    d_fir = torch.zeros((n_streams * ch, out_stride), device="cuda")
+    d_s16 = torch.zeros((n_streams, n_out, ch), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    plan.run_f32(d_coeffs, d_pcm)
+    got_n = engine.downsample_48k_16k_frames_dev(d_pcm, stream_stride, frame_stride, ch, n_streams, n_frames, d_fir, out_stride)
+    engine.f32_planar_to_bytes_batch_dev(soundkit_amd.engine.FMT_S16LE, d_fir, n_streams, out_stride, n_out, ch, d_s16)
+    engine.synchronize()
+    assert got_n == n_out
+    fir = d_fir.cpu().numpy()[:, :n_out].reshape(n_streams, ch, n_out)
+    s16 = d_s16.cpu().numpy()
+    for s in range(n_streams):
+        pcm, _ = oracle.synthesize_stream(coeffs[s], seqs[s], shapes[s])
+        planar = np.ascontiguousarray(pcm.transpose(1, 0, 2).reshape(ch, n_frames * 1024))
+        want = oracle.downsample_planar(planar, 48000, 16000)
+        assert want.shape == (ch, n_out)
+        assert rel_rms(fir[s], want) < 1e-6, s
+        # integer stage: bit-exact on the GPU's own float input, within 1 LSB of the all-CPU chain
+        assert np.array_equal(s16[s].ravel(), oracle.planar_f32_to_s16_interleaved(fir[s]))
+        assert np.abs(s16[s].astype(np.int32) - oracle.planar_f32_to_s16_interleaved(want).reshape(n_out, ch)).max() <= 1
+    plan.destroy()
+    for sid in sids:
+        engine.close_stream(int(sid))
