@@ -221,6 +221,17 @@ int sk_downsample_48k_16k_f32(sk_engine *, const float *in, uint32_t rows, uint3
 int sk_downsample_48k_16k_f32_dev(sk_engine *, const float *d_in, size_t in_stride, uint32_t rows, uint32_t frames,
                                   float *d_out, size_t out_stride, uint32_t *out_frames);
 
+/* downsample_audio for any pair of the reference's COMMON_SAMPLE_RATES (audio_pipeline.rs:12-13): rubato
+ * SincFixedIn<f32> with Linear interpolation between the two nearest of 256 sub-filters; one chunk = the
+ * whole input, so out_frames = number of index steps below frames - 257 - ceil(in_hz/out_hz).
+ * 48000 -> 16000 takes the MFMA path above; every other ratio the generic kernel (csrc/resample.hip).
+ * out rows have capacity out_cap; *out_frames receives the frames produced per row. */
+uint32_t sk_downsample_out_frames(uint32_t frames, uint32_t in_hz, uint32_t out_hz);
+int sk_downsample_f32(sk_engine *, const float *in, uint32_t rows, uint32_t frames, uint32_t in_hz, uint32_t out_hz,
+                      float *out, uint32_t out_cap, uint32_t *out_frames);
+int sk_downsample_f32_dev(sk_engine *, const float *d_in, size_t in_stride, uint32_t rows, uint32_t frames,
+                          uint32_t in_hz, uint32_t out_hz, float *d_out, size_t out_stride, uint32_t *out_frames);
+
 /* downsample_audio over the frame-packed planar PCM that sk_aac_plan_run_f32_dev wrote, in place (no
  * repack): sample n of (stream s, channel c) is read at
  *   d_pcm[s * stream_stride + (n / 1024) * frame_stride + c * 1024 + n % 1024],   n < frames_per_stream * 1024
@@ -229,7 +240,7 @@ int sk_downsample_48k_16k_frames_dev(sk_engine *, const float *d_pcm, size_t str
                                      uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream, float *d_out,
                                      size_t out_stride, uint32_t *out_frames);
 
-/* StreamingResampler (soundkit-decoder lib.rs:1917-2060), 48k->16k, fixed 4096-frame
+/* StreamingResampler (soundkit-decoder lib.rs:1917-2060), any pair of COMMON_SAMPLE_RATES, fixed 4096-frame
  * chunks, history kept per stream on the device.  in: n_streams x channels x frames planar
  * (stream-major); out: capacity out_cap frames per channel row; out_frames[s] receives the
  * frames produced for stream s by this call (0 until 4096 input frames have accumulated). */

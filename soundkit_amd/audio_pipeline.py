@@ -44,8 +44,8 @@ def audio_to_f32_channels(audio):
 
 
 def downsample_audio(audio, sampling_rate):
-    """audio_pipeline.rs:438-493.  Only the 48000 -> 16000 ratio is implemented on the GPU
-    (the MFMA FIR); other ratios raise SoundkitError(SK_ERR_UNSUPPORTED)."""
+    """audio_pipeline.rs:438-493: 48000 -> 16000 runs on the MFMA FIR, every other pair of common
+    rates on the generic sinc kernel."""
     if audio.channel_count == 0:
         raise ValueError("Channel count must be > 0")
     if audio.bits_per_sample not in COMMON_BITS_PER_SAMPLE:
@@ -59,7 +59,4 @@ def downsample_audio(audio, sampling_rate):
     data = audio_to_f32_channels(audio)
     if data.size == 0:
         return np.zeros((audio.channel_count, 0), np.float32)
-    if (audio.sampling_rate, sampling_rate) != (48000, 16000):
-        from ._lib import SoundkitError
-        raise SoundkitError(-6, "downsample_audio %d->%d" % (audio.sampling_rate, sampling_rate))
-    return default_engine().downsample_48k_16k(data)
+    return default_engine().downsample(data, audio.sampling_rate, sampling_rate)

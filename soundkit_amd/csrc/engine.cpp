@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <new>
@@ -54,9 +55,17 @@ struct StreamInfo {
     uint8_t channels = 0;
     // streaming resampler (soundkit-decoder lib.rs:1917-2060)
     bool rs_open = false;
-    uint32_t rs_fill = 0;     // frames waiting in the chunk area
-    uint64_t rs_chunks = 0;   // chunks already processed (q)
-    uint64_t rs_next_m = 0;   // next output index to produce
+    uint32_t rs_in_hz = 0, rs_out_hz = 0;
+    int rs_table = -1;             // index into sk_engine::ratio_tables
+    uint32_t rs_fill = 0;          // frames waiting in the chunk area
+    uint64_t rs_chunks = 0;        // chunks already processed
+    double rs_last_index = -128.0; // rubato SincFixedIn::last_index (relative to the next chunk's start)
+};
+
+struct RatioTable {
+    uint32_t in_hz = 0, out_hz = 0;
+    double ratio = 0.0;
+    float *d_sincs = nullptr;  // [256][256]
 };
 
 // ---- constant tables --------------------------------------------------------------------------
@@ -144,6 +153,30 @@ void make_taps_48k_16k(float *taps) {
     for (size_t p = 0; p < npoints; ++p) taps[p] = y[factor * p + (factor - 1)] / sum;  // sincs[0][p]
 }
 
+// rubato 0.14.1 make_sincs (T = f32): all 256 sub-filters of a ratio, sincs[sub][tap]
+void make_sinc_table(double ratio, std::vector<float> &sincs) {
+    const size_t npoints = 256, factor = 256, tot = npoints * factor;
+    const float f_cutoff = ratio >= 1.0 ? 0.95f : 0.95f * (float)ratio;
+    std::vector<float> y(tot);
+    const float pi2 = 2.0f * kPiF, pi4 = 4.0f * kPiF, pi6 = 6.0f * kPiF, np_f = (float)tot;
+    float sum = 0.0f;
+    for (size_t x = 0; x < tot; ++x) {
+        const float xf = (float)x;
+        float w = 0.35875f - 0.48829f * std::cos(pi2 * xf / np_f) + 0.14128f * std::cos(pi4 * xf / np_f) -
+                  0.01168f * std::cos(pi6 * xf / np_f);
+        w = w * w;
+        const float v = (xf - (float)(tot / 2)) * f_cutoff / (float)factor;
+        const float sinc = v == 0.0f ? 1.0f : std::sin(v * kPiF) / (v * kPiF);
+        const float val = w * sinc;
+        sum += val;
+        y[x] = val;
+    }
+    sum /= (float)factor;
+    sincs.resize(tot);
+    for (size_t p = 0; p < npoints; ++p)
+        for (size_t n = 0; n < factor; ++n) sincs[(factor - n - 1) * npoints + p] = y[factor * p + n] / sum;
+}
+
 }  // namespace
 
 struct sk_engine {
@@ -165,6 +198,7 @@ struct sk_engine {
     sk::SynthTables synth_tables{};
     float *d_pow43 = nullptr, *d_sftab = nullptr, *d_taps = nullptr, *d_afrag = nullptr, *d_zeros = nullptr;
     std::vector<float> h_taps;
+    std::vector<RatioTable> ratio_tables;
 
     // grow-only scratch
     DevBuf in_buf, out_buf, aux_buf, aux2_buf;
@@ -251,7 +285,7 @@ int build_tables(sk_engine *e) {
             if (p >= 0 && p < 256) afrag[s * 64 + l] = e->h_taps[p];
         }
     SK_HIP(upload(&e->d_afrag, afrag), "upload tap fragments");
-    std::vector<float> zeros(1024, 0.0f);
+    std::vector<float> zeros(8192, 0.0f);
     SK_HIP(upload(&e->d_zeros, zeros), "upload zeros");
     return SK_OK;
 }
@@ -340,6 +374,8 @@ void sk_engine_destroy(sk_engine *e) {
                         (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag,
                         (void *)e->d_zeros})
             if (p) (void)hipFree(p);
+        for (RatioTable &t : e->ratio_tables)
+            if (t.d_sincs) (void)hipFree(t.d_sincs);
         e->in_buf.release();
         e->out_buf.release();
         e->aux_buf.release();
@@ -403,7 +439,7 @@ int sk_stream_reset(sk_engine *e, uint32_t id) {
     StreamInfo &s = e->streams[id];
     s.rs_fill = 0;
     s.rs_chunks = 0;
-    s.rs_next_m = 0;
+    s.rs_last_index = -128.0;
     if (s.rs_open && e->d_rs)
         SK_HIP(hipMemsetAsync(e->d_rs + (size_t)id * 2 * kRsRow, 0, 2 * kRsRow * sizeof(float), e->stream), "reset rs");
     return reset_stream_state(e, id);
@@ -914,24 +950,154 @@ int sk_downsample_48k_16k_f32(sk_engine *e, const float *in, uint32_t rows, uint
     return SK_OK;
 }
 
+}  // extern "C" (helpers below are C++)
+
 // ---- StreamingResampler (soundkit-decoder lib.rs:1917-2060) ------------------------------------
+// Per stream the engine keeps rubato's SincFixedIn buffer in HBM: d_rs[stream*2 + ch][512 + 4096]
+// (2*sinc_len of history + one chunk).  A call appends input to every stream's chunk area, and every
+// time chunks fill up, all streams whose resampler is in the same state are processed by ONE launch
+// (row-indirected): the MFMA FIR for 48k->16k, the generic sinc kernel otherwise.
+
+static const uint32_t kCommonRates[9] = {8000, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000};  // audio_pipeline.rs:12-13
+static bool common_rate(uint32_t hz) {
+    for (uint32_t r : kCommonRates)
+        if (r == hz) return true;
+    return false;
+}
+
+static int ratio_table_for(sk_engine *e, uint32_t in_hz, uint32_t out_hz, int *index) {
+    for (size_t i = 0; i < e->ratio_tables.size(); ++i)
+        if (e->ratio_tables[i].in_hz == in_hz && e->ratio_tables[i].out_hz == out_hz) {
+            *index = (int)i;
+            return SK_OK;
+        }
+    RatioTable t;
+    t.in_hz = in_hz;
+    t.out_hz = out_hz;
+    t.ratio = (double)out_hz / (double)in_hz;
+    std::vector<float> sincs;
+    make_sinc_table(t.ratio, sincs);
+    SK_HIP(upload(&t.d_sincs, sincs), "upload sinc table");
+    e->ratio_tables.push_back(t);
+    *index = (int)e->ratio_tables.size() - 1;
+    return SK_OK;
+}
+
+// rubato SincFixedIn::process_into_buffer index walk for one chunk of `chunk` frames
+static void chunk_indices(double ratio, double last_index, uint32_t chunk, std::vector<double> &idx, double *new_last) {
+    const double t_ratio = 1.0 / ratio;
+    const long end_idx = (long)chunk - 257 - (long)std::ceil(t_ratio);
+    double i = last_index;
+    idx.clear();
+    while (i < (double)end_idx) {
+        i += t_ratio;
+        idx.push_back(i);
+    }
+    *new_last = i - (double)chunk;
+}
+
+extern "C" {
+
+uint32_t sk_downsample_out_frames(uint32_t frames, uint32_t in_hz, uint32_t out_hz) {
+    if (!in_hz || !out_hz) return 0;
+    std::vector<double> idx;
+    double nl = 0.0;
+    chunk_indices((double)out_hz / (double)in_hz, -128.0, frames, idx, &nl);
+    return (uint32_t)idx.size();
+}
+
+int sk_downsample_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uint32_t rows, uint32_t frames,
+                          uint32_t in_hz, uint32_t out_hz, float *d_out, size_t out_stride, uint32_t *out_frames) {
+    if (!e) return SK_ERR_INVALID_ARG;
+    if (!common_rate(in_hz) || !common_rate(out_hz)) return SK_ERR_UNSUPPORTED;
+    if (in_hz == 48000 && out_hz == 16000)
+        return sk_downsample_48k_16k_f32_dev(e, d_in, in_stride, rows, frames, d_out, out_stride, out_frames);
+    std::vector<double> idx;
+    double nl = 0.0;
+    chunk_indices((double)out_hz / (double)in_hz, -128.0, frames, idx, &nl);
+    const uint32_t n_out = (uint32_t)idx.size();
+    if (out_frames) *out_frames = n_out;
+    if (rows == 0 || n_out == 0) return SK_OK;
+    if (!d_in || !d_out || in_stride < frames || out_stride < n_out) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    int table = -1;
+    int rc = ratio_table_for(e, in_hz, out_hz, &table);
+    if (rc != SK_OK) return rc;
+    SK_HIP(e->aux2_buf.reserve(idx.size() * sizeof(double) + 4096), "alloc index scratch");
+    SK_HIP(hipMemcpyAsync(e->aux2_buf.p, idx.data(), idx.size() * sizeof(double), hipMemcpyHostToDevice, e->stream),
+           "upload time indices");
+    sk::SincArgs a{};
+    a.in = d_in;
+    a.in_stride = in_stride;
+    a.out = d_out;
+    a.out_stride = out_stride;
+    a.sincs = e->ratio_tables[(size_t)table].d_sincs;
+    a.idx = (const double *)e->aux2_buf.p;
+    a.in_frames = frames;
+    a.out_count = n_out;
+    a.in_origin = 0;
+    for (uint32_t r0 = 0; r0 < rows; r0 += 65535) {
+        sk::SincArgs part = a;
+        part.rows = std::min<uint32_t>(65535, rows - r0);
+        part.in = d_in + (size_t)r0 * in_stride;
+        part.out = d_out + (size_t)r0 * out_stride;
+        SK_HIP(sk::launch_sinc_resample(part, e->stream), "launch sinc resample");
+    }
+    SK_HIP(hipStreamSynchronize(e->stream), "resample sync");  // idx lives in host memory until the copy is done
+    return SK_OK;
+}
+
+int sk_downsample_f32(sk_engine *e, const float *in, uint32_t rows, uint32_t frames, uint32_t in_hz, uint32_t out_hz,
+                      float *out, uint32_t out_cap, uint32_t *out_frames) {
+    if (!e) return SK_ERR_INVALID_ARG;
+    if (!common_rate(in_hz) || !common_rate(out_hz)) return SK_ERR_UNSUPPORTED;
+    const uint32_t n_out = sk_downsample_out_frames(frames, in_hz, out_hz);
+    if (out_frames) *out_frames = n_out;
+    if (rows == 0 || n_out == 0) return SK_OK;
+    if (!in || !out || out_cap < n_out) return SK_ERR_INVALID_ARG;
+    const size_t in_stride = ((size_t)frames + 3) & ~(size_t)3, out_stride = ((size_t)n_out + 3) & ~(size_t)3;
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        DeviceGuard guard(e->device);
+        SK_HIP(e->in_buf.reserve(rows * in_stride * 4), "alloc staging");
+        SK_HIP(e->out_buf.reserve(rows * out_stride * 4), "alloc staging");
+        SK_HIP(hipMemcpy2DAsync(e->in_buf.p, in_stride * 4, in, (size_t)frames * 4, (size_t)frames * 4, rows,
+                                hipMemcpyHostToDevice, e->stream), "H2D resample input");
+    }
+    int rc = sk_downsample_f32_dev(e, (const float *)e->in_buf.p, in_stride, rows, frames, in_hz, out_hz,
+                                   (float *)e->out_buf.p, out_stride, nullptr);
+    if (rc != SK_OK) return rc;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    SK_HIP(hipMemcpy2DAsync(out, (size_t)out_cap * 4, e->out_buf.p, out_stride * 4, (size_t)n_out * 4, rows,
+                            hipMemcpyDeviceToHost, e->stream), "D2H resample output");
+    SK_HIP(hipStreamSynchronize(e->stream), "resample sync");
+    return SK_OK;
+}
 
 int sk_resampler_open(sk_engine *e, uint32_t id, uint32_t in_hz, uint32_t out_hz) {
     if (!e) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
-    if (in_hz != 48000 || out_hz != 16000) return SK_ERR_UNSUPPORTED;
+    if (!common_rate(in_hz) || !common_rate(out_hz)) return SK_ERR_UNSUPPORTED;  // as downsample_audio rejects them
     DeviceGuard guard(e->device);
     if (!e->d_rs) {
         const size_t bytes = (size_t)e->max_streams * 2 * kRsRow * sizeof(float);
         SK_HIP(hipMalloc((void **)&e->d_rs, bytes), "alloc resampler history");
         SK_HIP(hipMemsetAsync(e->d_rs, 0, bytes, e->stream), "clear resampler history");
     }
+    int table = -1;
+    int rc = ratio_table_for(e, in_hz, out_hz, &table);
+    if (rc != SK_OK) return rc;
     StreamInfo &s = e->streams[id];
     s.rs_open = true;
+    s.rs_in_hz = in_hz;
+    s.rs_out_hz = out_hz;
+    s.rs_table = table;
     s.rs_fill = 0;
     s.rs_chunks = 0;
-    s.rs_next_m = 0;
+    s.rs_last_index = -128.0;
     SK_HIP(hipMemsetAsync(e->d_rs + (size_t)id * 2 * kRsRow, 0, 2 * kRsRow * sizeof(float), e->stream), "clear rs rows");
     return SK_OK;
 }
@@ -944,83 +1110,215 @@ int sk_resampler_close(sk_engine *e, uint32_t id) {
     return SK_OK;
 }
 
-// outputs of chunk q: m in [next_m, last], last = ceil((3961 + 4096 q) / 3)
-static uint64_t rs_chunk_last_m(uint64_t q) { return (3961 + 4096 * q + 2) / 3; }
+}  // extern "C"
 
-// One chunk for one stream: FIR over its history rows into d_dst (row stride dst_stride, column dst_off).
-static int rs_run_chunk(sk_engine *e, uint32_t id, float *d_dst, size_t dst_stride, uint32_t dst_off, uint32_t *produced) {
-    StreamInfo &s = e->streams[id];
-    const uint64_t last = rs_chunk_last_m(s.rs_chunks);
-    const uint32_t count = (uint32_t)(last + 1 - s.rs_next_m);
-    sk::FirArgs a = fir_base(e);
-    a.in = e->d_rs + (size_t)id * 2 * kRsRow;
-    a.in_stride = kRsRow;
-    a.rows = s.channels;
-    a.in_frames = kRsRow;
-    a.in_origin = (int32_t)((int64_t)4096 * (int64_t)s.rs_chunks - (int64_t)kRsHist);
-    a.out = d_dst + dst_off;
-    a.out_stride = dst_stride;
-    a.out_first = (uint32_t)s.rs_next_m;
-    a.out_count = count;
-    SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch streaming fir");
-    // slide: the last 512 samples of this chunk become the history of the next (rubato copy_within)
-    for (uint32_t c = 0; c < s.channels; ++c) {
-        float *row = e->d_rs + ((size_t)id * 2 + c) * kRsRow;
-        SK_HIP(hipMemcpyAsync(row, row + kRsChunk, kRsHist * sizeof(float), hipMemcpyDeviceToDevice, e->stream),
-               "slide resampler history");
+namespace {
+
+struct RsCall {  // one stream's slot in a batched call
+    uint32_t id = 0, channels = 0;
+    size_t row0 = 0;        // first row of this stream in the call's input / output arrays
+    uint32_t consumed = 0;  // input frames appended so far
+    uint32_t produced = 0;  // output frames produced so far
+    uint32_t trim = 0;      // flush only: frames to drop from the end of the last chunk's output
+};
+
+// bump allocator over a device scratch buffer for the small per-round arrays
+struct AuxArena {
+    uint8_t *base = nullptr;
+    size_t cap = 0, used = 0;
+    template <typename T>
+    hipError_t put(const std::vector<T> &v, hipStream_t st, const T **out) {
+        const size_t bytes = (v.size() * sizeof(T) + 255) & ~(size_t)255;
+        if (used + bytes > cap) return hipErrorOutOfMemory;
+        *out = reinterpret_cast<const T *>(base + used);
+        used += bytes;
+        return hipMemcpyAsync((void *)*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st);
     }
-    s.rs_next_m = last + 1;
-    s.rs_chunks += 1;
-    s.rs_fill = 0;
-    *produced = count;
+};
+
+// Runs every stream of `ready` (all with a full chunk) through its resampler, grouped by resampler
+// state so that one launch covers a whole group.  Outputs go to d_out (row stride out_stride) at each
+// stream's `produced` column; history slides; state advances.
+int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector<size_t> &ready, float *d_out,
+                     size_t out_stride, uint32_t out_cap, AuxArena &aux) {
+    struct Key {
+        int table;
+        uint64_t chunks;
+        double last;
+        bool operator<(const Key &o) const {
+            if (table != o.table) return table < o.table;
+            if (chunks != o.chunks) return chunks < o.chunks;
+            return last < o.last;
+        }
+    };
+    std::map<Key, std::vector<size_t>> groups;
+    for (size_t ci : ready) {
+        const StreamInfo &s = e->streams[calls[ci].id];
+        groups[Key{s.rs_table, s.rs_chunks, s.rs_last_index}].push_back(ci);
+    }
+    std::vector<double> idx;
+    std::vector<uint32_t> row_map, out_off;
+    std::vector<sk::RowCopy> slides;
+    for (auto &g : groups) {
+        const RatioTable &tab = e->ratio_tables[(size_t)g.first.table];
+        double new_last = 0.0;
+        chunk_indices(tab.ratio, g.first.last, kRsChunk, idx, &new_last);
+        const uint32_t count = (uint32_t)idx.size();
+        row_map.clear();
+        out_off.clear();
+        for (size_t ci : g.second) {
+            RsCall &c = calls[ci];
+            if ((uint64_t)c.produced + count > out_cap) return SK_ERR_INVALID_ARG;
+            for (uint32_t ch = 0; ch < c.channels; ++ch) {
+                const uint64_t off = (uint64_t)(c.row0 + ch) * out_stride + c.produced;
+                if (off > 0xffffffffull) return SK_ERR_INVALID_ARG;
+                row_map.push_back(c.id * 2 + ch);
+                out_off.push_back((uint32_t)off);
+            }
+        }
+        if (count) {
+            const uint32_t *d_map = nullptr, *d_off = nullptr;
+            SK_HIP(aux.put(row_map, e->stream, &d_map), "upload row map");
+            SK_HIP(aux.put(out_off, e->stream, &d_off), "upload out offsets");
+            if (tab.in_hz == 48000 && tab.out_hz == 16000) {
+                // integer time base: output m sits at absolute index 3m - 125
+                const int64_t abs0 = (int64_t)std::llround(idx[0]) + (int64_t)kRsChunk * (int64_t)g.first.chunks;
+                sk::FirArgs a = fir_base(e);
+                a.in = e->d_rs;
+                a.in_stride = kRsRow;
+                a.rows = (uint32_t)row_map.size();
+                a.in_frames = kRsRow;
+                a.in_origin = (int32_t)((int64_t)kRsChunk * (int64_t)g.first.chunks - (int64_t)kRsHist);
+                a.out = d_out;
+                a.out_stride = 0;
+                a.row_map = d_map;
+                a.out_off = d_off;
+                a.out_first = (uint32_t)((abs0 + 125) / 3);
+                a.out_count = count;
+                SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch streaming fir");
+            } else {
+                const double *d_idx = nullptr;
+                SK_HIP(aux.put(idx, e->stream, &d_idx), "upload time indices");
+                sk::SincArgs a{};
+                a.in = e->d_rs;
+                a.in_stride = kRsRow;
+                a.out = d_out;
+                a.out_stride = 0;
+                a.sincs = tab.d_sincs;
+                a.idx = d_idx;
+                a.row_map = d_map;
+                a.out_off = d_off;
+                a.rows = (uint32_t)row_map.size();
+                a.in_frames = kRsRow;
+                a.out_count = count;
+                a.in_origin = -(int32_t)kRsHist;  // idx is relative to the chunk start; the row starts 512 earlier
+                for (uint32_t r0 = 0; r0 < a.rows; r0 += 65535) {  // grid.y limit
+                    sk::SincArgs part = a;
+                    part.rows = std::min<uint32_t>(65535, a.rows - r0);
+                    part.row_map = d_map + r0;
+                    part.out_off = d_off + r0;
+                    SK_HIP(sk::launch_sinc_resample(part, e->stream), "launch sinc resample");
+                }
+            }
+        }
+        // slide: the last 512 samples of the chunk become the next chunk's history (rubato copy_within)
+        slides.clear();
+        for (uint32_t phys : row_map) slides.push_back(sk::RowCopy{(uint64_t)phys * kRsRow + kRsChunk, (uint64_t)phys * kRsRow, kRsHist, 0});
+        const sk::RowCopy *d_slides = nullptr;
+        SK_HIP(aux.put(slides, e->stream, &d_slides), "upload slide jobs");
+        for (size_t j0 = 0; j0 < slides.size(); j0 += 65535)
+            SK_HIP(sk::launch_row_copies(e->d_rs, e->d_rs, d_slides + j0, (uint32_t)std::min<size_t>(65535, slides.size() - j0),
+                                         e->stream), "slide resampler history");
+        for (size_t ci : g.second) {
+            RsCall &c = calls[ci];
+            StreamInfo &s = e->streams[c.id];
+            s.rs_chunks += 1;
+            s.rs_last_index = new_last;
+            s.rs_fill = 0;
+            c.produced += count;
+        }
+    }
     return SK_OK;
 }
+
+int rs_collect(sk_engine *e, const uint32_t *streams, uint32_t n_streams, std::vector<RsCall> &calls, size_t *total_rows) {
+    calls.resize(n_streams);
+    size_t rows = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (!stream_ok(e, streams[i]) || !e->streams[streams[i]].rs_open) return SK_ERR_BAD_STREAM;
+        for (uint32_t k = 0; k < i; ++k)
+            if (streams[k] == streams[i]) return SK_ERR_INVALID_ARG;  // a stream may appear once per call
+        calls[i].id = streams[i];
+        calls[i].channels = e->streams[streams[i]].channels;
+        calls[i].row0 = rows;
+        rows += calls[i].channels;
+    }
+    *total_rows = rows;
+    return SK_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int sk_resampler_process_f32(sk_engine *e, const uint32_t *streams, uint32_t n_streams, const float *in, uint32_t frames,
                              float *out, uint32_t out_cap, uint32_t *out_frames) {
     if (!e || (n_streams && (!streams || !out_frames)) || (frames && n_streams && !in)) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e->device);
+    std::vector<RsCall> calls;
     size_t total_rows = 0;
-    for (uint32_t i = 0; i < n_streams; ++i) {
-        if (!stream_ok(e, streams[i]) || !e->streams[streams[i]].rs_open) return SK_ERR_BAD_STREAM;
-        total_rows += e->streams[streams[i]].channels;
-    }
+    int rc = rs_collect(e, streams, n_streams, calls, &total_rows);
+    if (rc != SK_OK) return rc;
     if (total_rows == 0) return SK_OK;
     const size_t out_stride = ((size_t)out_cap + 3) & ~(size_t)3;
     SK_HIP(e->in_buf.reserve(total_rows * (size_t)frames * 4 + 16), "alloc staging");
     SK_HIP(e->out_buf.reserve(total_rows * out_stride * 4 + 16), "alloc staging");
+    SK_HIP(e->aux2_buf.reserve(total_rows * 256 + (1 << 20)), "alloc round scratch");
     if (frames)
         SK_HIP(hipMemcpyAsync(e->in_buf.p, in, total_rows * (size_t)frames * 4, hipMemcpyHostToDevice, e->stream),
                "H2D resampler input");
-    size_t row0 = 0;
-    for (uint32_t i = 0; i < n_streams; ++i) {
-        const uint32_t id = streams[i];
-        StreamInfo &s = e->streams[id];
-        uint32_t consumed = 0, produced_total = 0;
-        while (consumed < frames || s.rs_fill == kRsChunk) {
-            const uint32_t take = std::min(frames - consumed, kRsChunk - s.rs_fill);
-            for (uint32_t c = 0; c < s.channels && take; ++c) {
-                float *row = e->d_rs + ((size_t)id * 2 + c) * kRsRow + kRsHist + s.rs_fill;
-                const float *src = (const float *)e->in_buf.p + (row0 + c) * frames + consumed;
-                SK_HIP(hipMemcpyAsync(row, src, (size_t)take * 4, hipMemcpyDeviceToDevice, e->stream), "append chunk");
+    std::vector<sk::RowCopy> jobs;
+    std::vector<size_t> ready;
+    for (;;) {
+        AuxArena aux{(uint8_t *)e->aux2_buf.p, e->aux2_buf.cap, 0};
+        jobs.clear();
+        ready.clear();
+        for (size_t ci = 0; ci < calls.size(); ++ci) {
+            RsCall &c = calls[ci];
+            StreamInfo &s = e->streams[c.id];
+            const uint32_t take = std::min(frames - c.consumed, kRsChunk - s.rs_fill);
+            if (take) {
+                for (uint32_t ch = 0; ch < c.channels; ++ch)
+                    jobs.push_back(sk::RowCopy{(uint64_t)(c.row0 + ch) * frames + c.consumed,
+                                               ((uint64_t)c.id * 2 + ch) * kRsRow + kRsHist + s.rs_fill, take, 0});
+                s.rs_fill += take;
+                c.consumed += take;
             }
-            s.rs_fill += take;
-            consumed += take;
-            if (s.rs_fill < kRsChunk) break;
-            const uint64_t need = rs_chunk_last_m(s.rs_chunks) + 1 - s.rs_next_m;
-            if (produced_total + need > out_cap) return SK_ERR_INVALID_ARG;
-            uint32_t got = 0;
-            int rc = rs_run_chunk(e, id, (float *)e->out_buf.p + row0 * out_stride, out_stride, produced_total, &got);
-            if (rc != SK_OK) return rc;
-            produced_total += got;
+            if (s.rs_fill == kRsChunk) ready.push_back(ci);
         }
-        out_frames[i] = produced_total;
-        for (uint32_t c = 0; c < s.channels && produced_total; ++c)
-            SK_HIP(hipMemcpyAsync(out + (row0 + c) * out_cap, (float *)e->out_buf.p + (row0 + c) * out_stride,
-                                  (size_t)produced_total * 4, hipMemcpyDeviceToHost, e->stream), "D2H resampler output");
-        row0 += s.channels;
+        if (jobs.empty() && ready.empty()) break;
+        if (!jobs.empty()) {
+            const sk::RowCopy *d_jobs = nullptr;
+            SK_HIP(aux.put(jobs, e->stream, &d_jobs), "upload append jobs");
+            for (size_t j0 = 0; j0 < jobs.size(); j0 += 65535)
+                SK_HIP(sk::launch_row_copies((const float *)e->in_buf.p, e->d_rs, d_jobs + j0,
+                                             (uint32_t)std::min<size_t>(65535, jobs.size() - j0), e->stream), "append chunk");
+        }
+        if (!ready.empty()) {
+            rc = rs_process_ready(e, calls, ready, (float *)e->out_buf.p, out_stride, out_cap, aux);
+            if (rc != SK_OK) return rc;
+        }
+        SK_HIP(hipStreamSynchronize(e->stream), "resampler round sync");  // the round's host arrays may now be reused
     }
+    size_t max_prod = 0;
+    for (size_t ci = 0; ci < calls.size(); ++ci) {
+        out_frames[ci] = calls[ci].produced;
+        max_prod = std::max<size_t>(max_prod, calls[ci].produced);
+    }
+    if (max_prod)
+        SK_HIP(hipMemcpy2DAsync(out, (size_t)out_cap * 4, e->out_buf.p, out_stride * 4, max_prod * 4, total_rows,
+                                hipMemcpyDeviceToHost, e->stream), "D2H resampler output");
     SK_HIP(hipStreamSynchronize(e->stream), "resampler sync");
     return SK_OK;
 }
@@ -1030,40 +1328,49 @@ int sk_resampler_flush_f32(sk_engine *e, const uint32_t *streams, uint32_t n_str
     if (!e || (n_streams && (!streams || !out_frames || !out))) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e->device);
+    std::vector<RsCall> calls;
     size_t total_rows = 0;
-    for (uint32_t i = 0; i < n_streams; ++i) {
-        if (!stream_ok(e, streams[i]) || !e->streams[streams[i]].rs_open) return SK_ERR_BAD_STREAM;
-        total_rows += e->streams[streams[i]].channels;
-    }
+    int rc = rs_collect(e, streams, n_streams, calls, &total_rows);
+    if (rc != SK_OK) return rc;
     if (total_rows == 0) return SK_OK;
     const size_t out_stride = ((size_t)out_cap + 3) & ~(size_t)3;
     SK_HIP(e->out_buf.reserve(total_rows * out_stride * 4 + 16), "alloc staging");
-    size_t row0 = 0;
-    for (uint32_t i = 0; i < n_streams; ++i) {
-        const uint32_t id = streams[i];
-        StreamInfo &s = e->streams[id];
-        const uint32_t remaining = s.rs_fill;
-        const uint32_t padded = kRsChunk - remaining;
-        // process_partial: the chunk is zero-padded to 4096 (lib.rs:2020-2031, 2048-2052)
-        for (uint32_t c = 0; c < s.channels && padded; ++c) {
-            float *row = e->d_rs + ((size_t)id * 2 + c) * kRsRow + kRsHist + remaining;
-            SK_HIP(hipMemsetAsync(row, 0, (size_t)padded * 4, e->stream), "pad chunk");
-        }
-        const uint64_t need = rs_chunk_last_m(s.rs_chunks) + 1 - s.rs_next_m;
-        if (need > out_cap) return SK_ERR_INVALID_ARG;
-        uint32_t got = 0;
-        int rc = rs_run_chunk(e, id, (float *)e->out_buf.p + row0 * out_stride, out_stride, 0, &got);
-        if (rc != SK_OK) return rc;
-        if (remaining > 0 && padded > 0) {  // lib.rs:2032-2039
-            const uint32_t trim = (uint32_t)std::llround(((double)padded * 16000.0) / 48000.0);
-            got = got > trim ? got - trim : 0;
-        }
-        out_frames[i] = got;
-        for (uint32_t c = 0; c < s.channels && got; ++c)
-            SK_HIP(hipMemcpyAsync(out + (row0 + c) * out_cap, (float *)e->out_buf.p + (row0 + c) * out_stride,
-                                  (size_t)got * 4, hipMemcpyDeviceToHost, e->stream), "D2H flush output");
-        row0 += s.channels;
+    SK_HIP(e->aux2_buf.reserve(total_rows * 256 + (1 << 20)), "alloc round scratch");
+    AuxArena aux{(uint8_t *)e->aux2_buf.p, e->aux2_buf.cap, 0};
+    // process_partial: the chunk is zero-padded to 4096 (lib.rs:2020-2031, 2048-2052)
+    std::vector<sk::RowCopy> pads;
+    std::vector<size_t> ready;
+    for (size_t ci = 0; ci < calls.size(); ++ci) {
+        RsCall &c = calls[ci];
+        StreamInfo &s = e->streams[c.id];
+        const uint32_t remaining = s.rs_fill, padded = kRsChunk - remaining;
+        if (remaining > 0 && padded > 0)  // lib.rs:2032-2039
+            c.trim = (uint32_t)std::llround(((double)padded * (double)s.rs_out_hz) / (double)s.rs_in_hz);
+        for (uint32_t ch = 0; ch < c.channels && padded; ++ch)
+            for (uint32_t o = 0; o < padded; o += 8192)
+                pads.push_back(sk::RowCopy{0, ((uint64_t)c.id * 2 + ch) * kRsRow + kRsHist + remaining + o,
+                                           std::min<uint32_t>(8192, padded - o), 0});
+        s.rs_fill = kRsChunk;
+        ready.push_back(ci);
     }
+    if (!pads.empty()) {
+        const sk::RowCopy *d_pads = nullptr;
+        SK_HIP(aux.put(pads, e->stream, &d_pads), "upload pad jobs");
+        for (size_t j0 = 0; j0 < pads.size(); j0 += 65535)
+            SK_HIP(sk::launch_row_copies(e->d_zeros, e->d_rs, d_pads + j0, (uint32_t)std::min<size_t>(65535, pads.size() - j0),
+                                         e->stream), "pad chunk");
+    }
+    rc = rs_process_ready(e, calls, ready, (float *)e->out_buf.p, out_stride, out_cap, aux);
+    if (rc != SK_OK) return rc;
+    size_t max_prod = 0;
+    for (size_t ci = 0; ci < calls.size(); ++ci) {
+        const uint32_t got = calls[ci].produced > calls[ci].trim ? calls[ci].produced - calls[ci].trim : 0;
+        out_frames[ci] = got;
+        max_prod = std::max<size_t>(max_prod, got);
+    }
+    if (max_prod)
+        SK_HIP(hipMemcpy2DAsync(out, (size_t)out_cap * 4, e->out_buf.p, out_stride * 4, max_prod * 4, total_rows,
+                                hipMemcpyDeviceToHost, e->stream), "D2H flush output");
     SK_HIP(hipStreamSynchronize(e->stream), "flush sync");
     return SK_OK;
 }

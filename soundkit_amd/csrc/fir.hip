@@ -61,15 +61,15 @@ __device__ __forceinline__ size_t sample_offset(const FirArgs &a, uint32_t row, 
 }
 
 template <bool ALIGNED, bool PACKED>
-__device__ __forceinline__ void stage_chunk(const FirArgs &a, float *ring, int lane, uint32_t row0, int64_t t0,
-                                            int chunk) {
+__device__ __forceinline__ void stage_chunk(const FirArgs &a, float *ring, int lane, uint32_t row0, const uint32_t (&phys)[16],
+                                            int64_t t0, int chunk) {
     // chunk c covers local samples n'' in [128 c, 128 c + 128); stream time = n'' + t0
     const int slot = chunk & 1;
     if (ALIGNED) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {  // lanes 0-31 -> row p, lanes 32-63 -> row p + 8, 4 samples per lane
-            const uint32_t row = row0 + p + 8 * (lane >> 5);
-            const bool row_ok = row < a.rows;
+            const bool row_ok = row0 + p + 8 * (lane >> 5) < a.rows;
+            const uint32_t row = (lane >> 5) ? phys[p + 8] : phys[p];
             const int64_t idx = (int64_t)kChunk * chunk + 4 * (lane & 31) + t0 - a.in_origin;
             const bool ok = row_ok && idx >= 0 && idx + 3 < (int64_t)a.in_frames;
             const float *src = ok ? a.in + sample_offset<PACKED>(a, row, idx) : a.zeros + 4 * lane;
@@ -78,8 +78,8 @@ __device__ __forceinline__ void stage_chunk(const FirArgs &a, float *ring, int l
     } else {
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
-            const uint32_t row = row0 + rr;
-            const bool row_ok = row < a.rows;
+            const bool row_ok = row0 + rr < a.rows;
+            const uint32_t row = phys[rr];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {  // 64 samples of one row per instruction
                 const int64_t idx = (int64_t)kChunk * chunk + 64 * h + lane + t0 - a.in_origin;
@@ -127,19 +127,28 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) af[s] = a.afrag[s * 64 + lane];
 
+    // physical input rows of this tile (wave-uniform, resolved once: no loads inside the MFMA loop)
+    uint32_t phys[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const uint32_t r = row0 + rr < a.rows ? row0 + rr : 0;
+        phys[rr] = a.row_map ? __builtin_amdgcn_readfirstlane(a.row_map[r]) : r;
+    }
+
     f32x4 acc[7];
 #pragma unroll
     for (int b = 0; b < 7; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int g_first = 3 * a_begin;
     int chunk = g_first >> 3;  // 8 groups of 16 samples per chunk
-    stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, t0, chunk);
-    stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, t0, chunk + 1);
+    stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, phys, t0, chunk);
+    stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, phys, t0, chunk + 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int stores_since_stage = 0;  // wave-uniform
 
     const uint32_t out_row = row0 + j;
-    float *out_ptr = a.out + (size_t)(out_row < a.rows ? out_row : 0) * a.out_stride;
+    float *out_ptr = a.out + (size_t)(out_row < a.rows ? out_row : 0) * a.out_stride +
+                     ((a.out_off && out_row < a.rows) ? a.out_off[out_row] : 0);
     const int lane_base = ring_addr(j, 4 * kq);  // + slot and group offsets per read
     auto read_group = [&](int G) {
         return *reinterpret_cast<const f32x4 *>(&ring[lane_base + ((G >> 3) & 1) * 8 * kBlockStride + 16 * (G & 7)]);
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
                 chunk = Gn >> 3;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 wait_vm_older_than(ALIGNED ? __builtin_amdgcn_readfirstlane(stores_since_stage) : 0);
-                stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, t0, chunk + 1);
+                stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, phys, t0, chunk + 1);
                 stores_since_stage = 0;
             }
             const f32x4 xb_next = read_group(Gn);
@@ -230,7 +239,7 @@ hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s) {
                                        : (a.in_stride % 4 == 0);
     const bool aligned = (((t0 - a.in_origin) & 3) == 0) && strides_ok && (a.in_frames % 4 == 0) &&
                          (((uintptr_t)a.in & 15) == 0);
-    const int out_vec = (a.out_stride % 4 == 0) && (((uintptr_t)a.out & 15) == 0);
+    const int out_vec = (a.out_stride % 4 == 0) && (((uintptr_t)a.out & 15) == 0) && a.out_off == nullptr;
     const dim3 grid(groups * n_segs), block(64);
     const bool packed = a.in_block != 0;
     if (packed && (a.in_block != 1024 || a.in_ch < 1 || a.in_ch > 2)) return hipErrorInvalidValue;

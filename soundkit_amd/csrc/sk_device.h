@@ -77,6 +77,8 @@ struct FirArgs {
     //   in + (r / in_ch) * in_group_stride + (r % in_ch) * 1024 + (n / 1024) * in_block_stride + n % 1024
     uint32_t in_block, in_ch;
     size_t in_block_stride, in_group_stride;
+    const uint32_t *row_map;  // optional: logical row r reads physical input row row_map[r]
+    const uint32_t *out_off;  // optional: logical row r writes at column out_off[r] of its output row
     uint32_t rows;
     uint32_t in_frames;   // valid input samples per row (n >= in_frames reads as 0)
     int32_t in_origin;    // sample index of in[r][0] relative to the stream's time 0 (history rows: negative)
@@ -84,5 +86,26 @@ struct FirArgs {
     uint32_t out_count;   // outputs per row
 };
 hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s);
+
+// resample.hip -- generic-ratio windowed-sinc resampling (rubato SincFixedIn<f32>, Linear interpolation)
+struct SincArgs {
+    const float *in;          // [phys rows][in_stride]
+    float *out;               // [rows][out_stride]
+    const float *sincs;       // [256][256] sub-filter table of this ratio
+    const double *idx;        // [out_count] time index of every output, relative to in_origin
+    const uint32_t *row_map;  // optional, as FirArgs
+    const uint32_t *out_off;  // optional, as FirArgs
+    size_t in_stride, out_stride;
+    uint32_t rows, in_frames, out_count;
+    int32_t in_origin;        // sample index of in[r][0] in the idx time base (history rows: negative)
+};
+hipError_t launch_sinc_resample(const SincArgs &a, hipStream_t s);
+
+// batched row copies (streaming resampler bookkeeping): job j copies count floats
+struct RowCopy {
+    uint64_t src_off, dst_off;  // element offsets from the two bases
+    uint32_t count, pad;
+};
+hipError_t launch_row_copies(const float *src_base, float *dst_base, const RowCopy *jobs, uint32_t n_jobs, hipStream_t s);
 
 }  // namespace sk

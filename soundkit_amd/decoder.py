@@ -74,7 +74,8 @@ def exact_signed_pcm_to_i16(audio):
 
 
 class StreamingResampler:
-    """lib.rs:1917-2060 for the 48000 -> 16000 ratio: fixed 4096-frame chunks, history on the GPU."""
+    """lib.rs:1917-2060: fixed 4096-frame chunks, resampler history kept on the GPU (48000 -> 16000 on
+    the MFMA FIR, other pairs of common rates on the generic sinc kernel)."""
 
     def __init__(self, input_sample_rate, output_sample_rate, channels, engine=None):
         self.engine = engine or default_engine()

@@ -293,6 +293,18 @@ class Engine:
                                                 C.byref(got)), "sk_downsample_48k_16k_f32_dev", self._h)
         return got.value
 
+    def downsample(self, rows, in_hz, out_hz):
+        """rows: [n_rows][frames] f32 -> [n_rows][out_frames], any pair of the reference's common rates."""
+        rows = np.ascontiguousarray(rows, np.float32)
+        n_rows, frames = rows.shape
+        n_out = int(lib.sk_downsample_out_frames(frames, in_hz, out_hz))
+        out = np.zeros((n_rows, n_out), np.float32)
+        got = C.c_uint32()
+        check(lib.sk_downsample_f32(self._h, _ptr(rows), n_rows, frames, in_hz, out_hz, _ptr(out), n_out, C.byref(got)),
+              "sk_downsample_f32", self._h)
+        assert got.value == n_out
+        return out
+
     def downsample_48k_16k_frames_dev(self, d_pcm, stream_stride, frame_stride, channels, n_streams, frames_per_stream,
                                       d_out, out_stride):
         got = C.c_uint32()
@@ -304,6 +316,8 @@ class Engine:
     def f32_planar_to_bytes_batch_dev(self, fmt, d_planar, batch, plane_stride, frames, ch, d_out):
         check(lib.sk_pcm_f32_planar_to_bytes_batch_dev(self._h, fmt, _ptr(d_planar), batch, plane_stride, frames, ch,
                                                        _ptr(d_out)), "sk_pcm_f32_planar_to_bytes_batch_dev", self._h)
+
+    _rs_ratio_max = 96000 / 8000  # largest ratio among the common rates: sizes host output buffers
 
     def resampler_open(self, sid, in_hz=48000, out_hz=16000):
         check(lib.sk_resampler_open(self._h, sid, in_hz, out_hz), "sk_resampler_open", self._h)
@@ -317,7 +331,7 @@ class Engine:
         data = np.ascontiguousarray(data, np.float32)
         n, ch, frames = data.shape
         assert ch == channels
-        cap = (frames + 4096) // 3 + 16
+        cap = int((frames + 4096) * self._rs_ratio_max + 64)
         out = np.zeros((n, ch, cap), np.float32)
         got = np.zeros(n, np.uint32)
         check(lib.sk_resampler_process_f32(self._h, _ptr(sids), n, _ptr(data), frames, _ptr(out), cap, _ptr(got)),
@@ -327,7 +341,7 @@ class Engine:
     def resampler_flush(self, sids, channels):
         sids = np.ascontiguousarray(sids, np.uint32)
         n = sids.size
-        cap = 4096 // 3 + 16
+        cap = int(4096 * self._rs_ratio_max + 64)
         out = np.zeros((n, channels, cap), np.float32)
         got = np.zeros(n, np.uint32)
         check(lib.sk_resampler_flush_f32(self._h, _ptr(sids), n, _ptr(out), cap, _ptr(got)),

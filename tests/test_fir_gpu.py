@@ -57,8 +57,9 @@ def test_downsample_audio_mirror(engine, oracle):
         audio_pipeline.downsample_audio(AudioData(16, 2, 12345, pcm.view(np.uint8).ravel()), 16000)
     with pytest.raises(ValueError):
         audio_pipeline.downsample_audio(AudioData(8, 2, 48000, pcm.view(np.uint8).ravel()), 16000)
-    with pytest.raises(soundkit_amd.SoundkitError):
-        audio_pipeline.downsample_audio(AudioData(16, 2, 44100, pcm.view(np.uint8).ravel()), 16000)
+    got = audio_pipeline.downsample_audio(AudioData(16, 2, 44100, pcm.view(np.uint8).ravel()), 16000)
+    want = oracle.downsample_planar(planar, 44100, 16000)
+    assert got.shape == want.shape and rel_rms(got, want) < 1e-6
 
 
 def test_device_entry_strided_rows(engine, oracle):
@@ -121,10 +122,80 @@ def test_streaming_equals_single_pass_length(engine, oracle):  # lib.rs:5188-523
     assert np.array_equal(a, b)
 
 
-def test_unsupported_ratio_is_loud(engine):
+def test_unsupported_rate_is_loud(engine):
     with pytest.raises(soundkit_amd.SoundkitError) as exc:
-        decoder.StreamingResampler(44100, 16000, 2, engine)
+        decoder.StreamingResampler(44100, 12345, 2, engine)   # not one of COMMON_SAMPLE_RATES
     assert exc.value.status == -6
+
+
+@pytest.mark.parametrize("in_hz,out_hz", [(44100, 16000), (48000, 8000), (22050, 16000), (16000, 48000), (96000, 8000),
+                                          (32000, 24000), (48000, 44100)])
+@pytest.mark.parametrize("rows,frames", [(1, 3000), (3, 8191), (2, 300)])
+def test_generic_ratio_one_shot_matches_oracle(engine, oracle, in_hz, out_hz, rows, frames):
+    rng = np.random.default_rng(in_hz + out_hz + frames)
+    x = rng.uniform(-1, 1, (rows, frames)).astype(np.float32)
+    got = engine.downsample(x, in_hz, out_hz)
+    want = oracle.downsample_planar(x, in_hz, out_hz)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    if want.size:
+        assert rel_rms(got, want) < 1e-6 and np.abs(got - want).max() < 2e-6
+
+
+@pytest.mark.parametrize("in_hz,out_hz", [(44100, 16000), (48000, 8000), (16000, 48000)])
+def test_generic_ratio_streaming_matches_oracle(engine, oracle, in_hz, out_hz):
+    rng = np.random.default_rng(in_hz)
+    x = rng.uniform(-1, 1, (2, 30000)).astype(np.float32)
+    ours = decoder.StreamingResampler(in_hz, out_hz, 2, engine)
+    ref = oracle.StreamingResampler(in_hz, out_hz, 2)
+    got, want, pos = [], [], 0
+    for size in [997, 4096, 1, 9000, 5000, 30000]:
+        blk = x[:, pos:pos + size]
+        pos += blk.shape[1]
+        a, b = ours.process(blk), ref.process(blk)
+        assert a.shape == b.shape, (size, a.shape, b.shape)
+        got.append(a), want.append(b)
+    a, b = ours.flush(), ref.flush()
+    assert a.shape == b.shape
+    got.append(a), want.append(b)
+    ours.close()
+    got, want = np.concatenate(got, 1), np.concatenate(want, 1)
+    assert got.shape[1] > 0 and rel_rms(got, want) < 1e-6 and np.abs(got - want).max() < 2e-6
+
+
+def test_streaming_batch_of_streams_one_call(engine, oracle):
+    """Many streams per call (mono and stereo, two different ratios, unequal fill levels): every stream
+    gets exactly what its own single-stream resampler would have produced."""
+    rng = np.random.default_rng(99)
+    spec = [(2, 48000, 16000)] * 5 + [(1, 48000, 16000)] * 2 + [(2, 44100, 16000)] * 3
+    sids = [engine.open_stream(r_in, ch) for ch, r_in, _ in spec]
+    for sid, (_, r_in, r_out) in zip(sids, spec):
+        engine.resampler_open(sid, r_in, r_out)
+    refs = [oracle.StreamingResampler(r_in, r_out, ch) for ch, r_in, r_out in spec]
+    # pre-load different amounts into some streams so that their chunk boundaries differ
+    for k in (1, 4, 8):
+        ch = spec[k][0]
+        pre = rng.uniform(-1, 1, (ch, 1000 + 333 * k)).astype(np.float32)
+        a = engine.resampler_process([sids[k]], pre[None], ch)[0]
+        b = refs[k].process(pre)
+        assert a.shape == b.shape
+    for frames in (5000, 4096, 700, 12000):
+        for group_ch in (2, 1):
+            members = [i for i, sp in enumerate(spec) if sp[0] == group_ch]
+            data = rng.uniform(-1, 1, (len(members), group_ch, frames)).astype(np.float32)
+            outs = engine.resampler_process([sids[i] for i in members], data, group_ch)
+            for j, i in enumerate(members):
+                want = refs[i].process(data[j])
+                assert outs[j].shape == want.shape, (i, frames, outs[j].shape, want.shape)
+                if want.size:
+                    assert rel_rms(outs[j], want) < 1e-6
+    for group_ch in (2, 1):
+        members = [i for i, sp in enumerate(spec) if sp[0] == group_ch]
+        outs = engine.resampler_flush([sids[i] for i in members], group_ch)
+        for j, i in enumerate(members):
+            want = refs[i].flush()
+            assert outs[j].shape == want.shape and rel_rms(outs[j], want) < 1e-6
+    for sid in sids:
+        engine.close_stream(sid)
 
 
 def test_full_size_dc_gain_and_linearity(engine, oracle):
