@@ -120,6 +120,39 @@ uint32_t sk_aac_plan_frames_ok(const sk_aac_plan *);
 int sk_aac_plan_run_f32_dev(sk_engine *, const sk_aac_plan *, const float *d_coeffs, float *d_pcm);
 int sk_aac_plan_run_s16_dev(sk_engine *, const sk_aac_plan *, const float *d_coeffs, int16_t *d_pcm);
 
+/* ---- AAC-LC access-unit front-end (host cores) ------------------------------------------------
+ * The entropy / side-information half of AacLcDecoder::decode_access_unit (soundkit-aac-lc/src/
+ * decoder.rs:104-334): element loop, ICS info, sections, scalefactors, pulse, Huffman spectral decode
+ * with dequantisation, PNS, intensity + mid/side stereo, TNS.  It stops where the GPU takes over:
+ * sk_aac_decoder_parse fills the dequantised spectra [channels][1024] and the window fields of one
+ * sk_aac_frame_desc (the caller sets .stream), ready for sk_aac_synthesize_* / sk_aac_plan_create.
+ * Errors mirror AacLcError (error.rs:5-18); sk_aac_decoder_last_error carries the reference's message. */
+typedef enum sk_aac_status {
+    SK_AAC_ERR_EOF = -101,                        /* UnexpectedEof */
+    SK_AAC_ERR_INVALID_AOT = -102,                /* InvalidAudioObjectType */
+    SK_AAC_ERR_UNSUPPORTED_AOT = -103,            /* UnsupportedAudioObjectType */
+    SK_AAC_ERR_UNSUPPORTED_SF_INDEX = -104,       /* UnsupportedSamplingFrequencyIndex */
+    SK_AAC_ERR_UNSUPPORTED_CHANNEL_CONFIG = -105, /* UnsupportedChannelConfig */
+    SK_AAC_ERR_UNSUPPORTED_FEATURE = -106,        /* UnsupportedFeature: callers fall back to another decoder */
+    SK_AAC_ERR_INVALID_CONFIG = -107,             /* InvalidConfig */
+    SK_AAC_ERR_INVALID_BITSTREAM = -108           /* InvalidBitstream */
+} sk_aac_status;
+typedef struct sk_aac_decoder sk_aac_decoder;
+/* AacLcDecoder::from_audio_specific_config (decoder.rs:80, config.rs:139-260) */
+int sk_aac_decoder_create(const uint8_t *asc, size_t asc_len, sk_aac_decoder **out);
+void sk_aac_decoder_destroy(sk_aac_decoder *);
+int sk_aac_decoder_info(const sk_aac_decoder *, uint32_t *sample_rate, uint8_t *channels); /* frame_info, decoder.rs:88 */
+const char *sk_aac_decoder_last_error(const sk_aac_decoder *);
+/* counters since creation: frames, EightShort channel-frames, LongStart/Stop channel-frames, channel-frames with TNS,
+ * PNS bands, intensity bands, mid/side bands, channel-frames with pulse data (aac-wasm-bench lib.rs:1955-1986) */
+int sk_aac_decoder_tool_usage(const sk_aac_decoder *, uint32_t out[8]);
+int sk_aac_decoder_parse(sk_aac_decoder *, const uint8_t *access_unit, size_t len, float *coeffs /*[ch][1024]*/,
+                         sk_aac_frame_desc *desc);
+/* parse_adts_access_unit (soundkit-decoder/src/lib.rs:1007-1027): the 2-byte ASC and the raw access unit of
+ * one ADTS frame; frame_len = bytes to the next frame header. */
+int sk_adts_parse(const uint8_t *data, size_t len, size_t *frame_len, size_t *payload_off, size_t *payload_len,
+                  uint8_t asc[2]);
+
 /* dsp.rs:389-450 dequantize_signed_scaled over a batch: out[i] = sign(q)*|q|^(4/3)*2^((sf-100)/4).
  * quant: n i16 quantised values; sf_per_band_of[i]: i16 scale factor applying to value i. */
 int sk_aac_dequantize_dev(sk_engine *, const int16_t *d_quant, const int16_t *d_scalefactor, float *d_out, size_t n);

@@ -13,7 +13,10 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "soundkit_amd.h")
 
 SK_OK = 0
 ERR_NAMES = {0: "SK_OK", -1: "SK_ERR_INVALID_ARG", -2: "SK_ERR_NO_DEVICE", -3: "SK_ERR_HIP", -4: "SK_ERR_OOM",
-             -5: "SK_ERR_BAD_STREAM", -6: "SK_ERR_UNSUPPORTED", -7: "SK_ERR_CAPACITY"}
+             -5: "SK_ERR_BAD_STREAM", -6: "SK_ERR_UNSUPPORTED", -7: "SK_ERR_CAPACITY",
+             -101: "UnexpectedEof", -102: "InvalidAudioObjectType", -103: "UnsupportedAudioObjectType",
+             -104: "UnsupportedSamplingFrequencyIndex", -105: "UnsupportedChannelConfig", -106: "UnsupportedFeature",
+             -107: "InvalidConfig", -108: "InvalidBitstream"}
 
 
 class FrameDesc(C.Structure):
@@ -87,6 +90,13 @@ _sig = {
     "sk_aac_plan_frames_ok": (_u32, [_vp]),
     "sk_aac_plan_run_f32_dev": (_i, [_vp, _vp, _vp, _vp]),
     "sk_aac_plan_run_s16_dev": (_i, [_vp, _vp, _vp, _vp]),
+    "sk_aac_decoder_create": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "sk_aac_decoder_destroy": (None, [_vp]),
+    "sk_aac_decoder_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(C.c_uint8)]),
+    "sk_aac_decoder_last_error": (C.c_char_p, [_vp]),
+    "sk_aac_decoder_tool_usage": (_i, [_vp, _vp]),
+    "sk_aac_decoder_parse": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "sk_adts_parse": (_i, [_vp, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), _vp]),
     "sk_aac_dequantize_dev": (_i, [_vp, _vp, _vp, _vp, _sz]),
     "sk_aac_dequantize": (_i, [_vp, _vp, _vp, _vp, _sz]),
     "sk_pcm_op_in_bytes": (_i, [_i]),

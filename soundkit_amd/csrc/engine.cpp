@@ -324,6 +324,14 @@ const char *sk_strerror(int status) {
     case SK_ERR_BAD_STREAM: return "stream is not open";
     case SK_ERR_UNSUPPORTED: return "unsupported configuration";
     case SK_ERR_CAPACITY: return "max_streams exhausted";
+    case SK_AAC_ERR_EOF: return "unexpected end of AAC bitstream";
+    case SK_AAC_ERR_INVALID_AOT: return "invalid AAC audio object type";
+    case SK_AAC_ERR_UNSUPPORTED_AOT: return "unsupported AAC audio object type";
+    case SK_AAC_ERR_UNSUPPORTED_SF_INDEX: return "unsupported AAC sampling frequency index";
+    case SK_AAC_ERR_UNSUPPORTED_CHANNEL_CONFIG: return "unsupported AAC channel configuration";
+    case SK_AAC_ERR_UNSUPPORTED_FEATURE: return "unsupported AAC feature";
+    case SK_AAC_ERR_INVALID_CONFIG: return "invalid AAC config";
+    case SK_AAC_ERR_INVALID_BITSTREAM: return "invalid AAC bitstream";
     default: return "unknown status";
     }
 }
