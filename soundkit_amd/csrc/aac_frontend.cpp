@@ -38,69 +38,90 @@ struct AacError {
 
 // ---- bitreader.rs ---------------------------------------------------------------------------------
 struct BitReader {
+    // data must be readable (zero-padded) for 8 bytes past len: peeks are single unaligned 64-bit loads
     const uint8_t *data;
     size_t total_bits, pos = 0;
-    BitReader(const uint8_t *d, size_t len) : data(d), total_bits(len * 8) {}
+    BitReader(const uint8_t *padded, size_t len) : data(padded), total_bits(len * 8) {}
     size_t remaining() const { return total_bits - pos; }
-    uint32_t peek(unsigned bits) const {  // caller guarantees bits <= remaining, bits <= 32
-        uint64_t v = 0;
-        size_t p = pos;
-        unsigned need = bits;
-        while (need) {
-            const unsigned in_byte = 8 - (p & 7);
-            const unsigned take = need < in_byte ? need : in_byte;
-            const uint32_t byte = data[p >> 3];
-            v = (v << take) | ((byte >> (in_byte - take)) & ((1u << take) - 1));
-            p += take;
-            need -= take;
-        }
-        return (uint32_t)v;
+    uint32_t peek32() const {  // next 32 bits, left-aligned (bits past the end read as the zero padding)
+        uint64_t w;
+        std::memcpy(&w, data + (pos >> 3), 8);
+        w = __builtin_bswap64(w);
+        return (uint32_t)((w << (pos & 7)) >> 32);
+    }
+    uint32_t peek(unsigned bits) const { return bits ? peek32() >> (32 - bits) : 0; }  // bits <= 32
+    [[noreturn]] void eof(size_t bits) const {
+        fail(SK_AAC_ERR_EOF, "unexpected end of AAC bitstream: requested " + std::to_string(bits > 255 ? 255 : bits) +
+                                 " bits, " + std::to_string(remaining()) + " bits remain");
     }
     uint32_t read(unsigned bits) {
-        if (remaining() < bits)
-            fail(SK_AAC_ERR_EOF, "unexpected end of AAC bitstream: requested " + std::to_string(bits) + " bits, " +
-                                     std::to_string(remaining()) + " bits remain");
-        if (bits == 0) return 0;
+        if (__builtin_expect(remaining() < bits, 0)) eof(bits);
         const uint32_t v = peek(bits);
         pos += bits;
         return v;
     }
     bool read_bool() { return read(1) != 0; }
     void skip(size_t bits) {
-        if (remaining() < bits)
-            fail(SK_AAC_ERR_EOF, "unexpected end of AAC bitstream: requested " +
-                                     std::to_string(bits > 255 ? 255 : bits) + " bits, " + std::to_string(remaining()) +
-                                     " bits remain");
+        if (remaining() < bits) eof(bits);
         pos += bits;
     }
 };
 
 // ---- Huffman lookup tables (built once from the ISO codebooks) ---------------------------------------
 struct Lut {
+    // two-level: the first kPrimary bits index `table`; an entry is (len << 16) | symbol for codes that fit, or
+    // 0x80000000 | (extra_bits << 24) | offset of a sub-table indexed by the following extra_bits bits; 0 = invalid
+    static constexpr int kPrimary = 9;
     int max_bits = 0;
-    std::vector<uint32_t> table;  // index = next max_bits bits; value = (len << 16) | symbol index; 0 = invalid
+    std::vector<uint32_t> table;
     void build(const uint8_t *lens, const uint32_t *codes32, const uint16_t *codes16, int n, int maxb) {
         max_bits = maxb;
-        table.assign((size_t)1 << maxb, 0);
+        const int pb = maxb < kPrimary ? maxb : kPrimary;
+        primary_bits = pb;
+        table.assign((size_t)1 << pb, 0);
+        std::vector<int> deepest((size_t)1 << pb, 0);
+        for (int i = 0; i < n; ++i)
+            if (lens[i] > pb) {
+                const uint32_t code = codes32 ? codes32[i] : codes16[i];
+                int &d = deepest[code >> (lens[i] - pb)];
+                if (lens[i] - pb > d) d = lens[i] - pb;
+            }
+        for (size_t p = 0; p < deepest.size(); ++p)
+            if (deepest[p]) {
+                table[p] = 0x80000000u | ((uint32_t)deepest[p] << 24) | (uint32_t)table.size();
+                table.resize(table.size() + ((size_t)1 << deepest[p]), 0);
+            }
         for (int i = 0; i < n; ++i) {
             const int len = lens[i];
             if (!len) continue;
             const uint32_t code = codes32 ? codes32[i] : codes16[i];
-            const size_t prefix = (size_t)code << (maxb - len), slots = (size_t)1 << (maxb - len);
-            for (size_t s = 0; s < slots; ++s) table[prefix + s] = ((uint32_t)len << 16) | (uint32_t)i;
+            const uint32_t e = ((uint32_t)len << 16) | (uint32_t)i;
+            if (len <= pb) {
+                const size_t prefix = (size_t)code << (pb - len), slots = (size_t)1 << (pb - len);
+                for (size_t k = 0; k < slots; ++k) table[prefix + k] = e;
+            } else {
+                const uint32_t link = table[code >> (len - pb)];
+                const int extra = (int)((link >> 24) & 0x7f), rest = len - pb;
+                const size_t base = link & 0xffffff;
+                const size_t prefix = (size_t)(code & ((1u << rest) - 1)) << (extra - rest), slots = (size_t)1 << (extra - rest);
+                for (size_t k = 0; k < slots; ++k) table[base + prefix + k] = e;
+            }
         }
     }
-    // scalefactor.rs:252-266 / spectral.rs read_*_tuple: peek what is there, entry must fit in it
+    // scalefactor.rs:252-266 / spectral.rs read_*_tuple: peek what is there, the entry must fit in it
     int read(BitReader &r, const char *what) const {
-        const size_t avail = r.remaining();
-        const unsigned bits = avail < (size_t)max_bits ? (unsigned)avail : (unsigned)max_bits;
-        const uint32_t look = bits ? r.peek(bits) : 0;
-        const uint32_t e = table[(size_t)look << (max_bits - bits)];
+        const uint32_t look = r.peek32();
+        uint32_t e = table[look >> (32 - primary_bits)];
+        if (e & 0x80000000u) {
+            const unsigned extra = (e >> 24) & 0x7f;
+            e = table[(e & 0xffffff) + ((look << primary_bits) >> (32 - extra))];
+        }
         const unsigned len = e >> 16;
-        if (len == 0 || len > bits) fail(SK_AAC_ERR_INVALID_BITSTREAM, what);
+        if (__builtin_expect(len == 0 || len > r.remaining(), 0)) fail(SK_AAC_ERR_INVALID_BITSTREAM, what);
         r.pos += len;
         return (int)(e & 0xffff);
     }
+    int primary_bits = 0;
 };
 
 struct Tables {
@@ -411,6 +432,7 @@ struct Decoder {
     int channels = 0;
     uint32_t pns_state = 0x1f2e3d4cu;  // spectral.rs:2459, decoder.rs:76
     std::string last_error;
+    std::vector<uint8_t> padded;  // the access unit + 8 zero bytes (BitReader's load window)
     int quantized[1024];
     // tool usage since creation (aac-wasm-bench/src/lib.rs:1955-1986 asserts this coverage on its fixture)
     uint32_t n_frames = 0, n_short = 0, n_tns = 0, n_pns_bands = 0, n_is_bands = 0, n_ms_bands = 0, n_pulse = 0, n_transition = 0;
@@ -696,7 +718,10 @@ void skip_fill(BitReader &r) {
 }
 
 void parse_access_unit(Decoder &d, const uint8_t *au, size_t len, float *coeffs, sk_aac_frame_desc *desc) {
-    BitReader r(au, len);
+    if (d.padded.size() < len + 8) d.padded.resize(len + 8 + 1024);
+    if (len) std::memcpy(d.padded.data(), au, len);
+    std::memset(d.padded.data() + len, 0, 8);
+    BitReader r(d.padded.data(), len);
     bool decoded = false;
     Channel left, right;
     while (r.remaining() >= 3) {
@@ -784,7 +809,9 @@ unsigned read_aot(BitReader &r) {  // config.rs:271-279, :43-78
 }
 
 void parse_asc(Decoder &d, const uint8_t *asc, size_t len) {
-    BitReader r(asc, len);
+    std::vector<uint8_t> padded(len + 8, 0);
+    if (len) std::memcpy(padded.data(), asc, len);
+    BitReader r(padded.data(), len);
     unsigned aot = read_aot(r);
     auto read_rate = [&](int *index) -> uint32_t {
         const unsigned idx = r.read(4);

@@ -192,7 +192,9 @@ def test_malformed_access_units_never_crash(asc):
 
 
 # ---- real fixtures -----------------------------------------------------------------------------------------
-FIXTURES = ["stereo-music-44100-192k.aac", "A_Tusk_is_used_to_make_costly_gifts_encoded.aac", "mono16k_A_Tusk.aac"]
+# aac-stereo-48k.adts = the elementary stream of testdata/mpeg-ts/aac-stereo-48k.ts (tools/ts_to_adts.py)
+FIXTURES = ["stereo-music-44100-192k.aac", "A_Tusk_is_used_to_make_costly_gifts_encoded.aac", "mono16k_A_Tusk.aac",
+            "aac-stereo-48k.adts"]
 
 
 def parse_file(name):
@@ -208,7 +210,7 @@ def test_fixture_parses_to_the_last_bit(name):
     any error in the codebooks or the syntax would desynchronise the reader within a frame or two."""
     fe, out = parse_file(name)
     assert len(out) == {"stereo-music-44100-192k.aac": 131, "A_Tusk_is_used_to_make_costly_gifts_encoded.aac": 46,
-                        "mono16k_A_Tusk.aac": 48}[name]
+                        "mono16k_A_Tusk.aac": 48, "aac-stereo-48k.adts": 48}[name]
     assert all(np.isfinite(c).all() for c, _, _ in out)
 
 
