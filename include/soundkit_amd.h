@@ -284,6 +284,40 @@ int sk_resampler_process_f32(sk_engine *, const uint32_t *streams, uint32_t n_st
 int sk_resampler_flush_f32(sk_engine *, const uint32_t *streams, uint32_t n_streams, float *out, uint32_t out_cap,
                            uint32_t *out_frames);
 
+/* ---- one scheduler tick: a batch of access units through the worker's output stage ---------------- */
+/* For every access unit of every listed stream: decode_aac_access_unit (soundkit-decoder lib.rs:1793-1813: synthesis,
+ * then float_sample_to_i16) followed by apply_output_options (lib.rs:3324-3456: fast path, or i16 -> f32 ->
+ * StreamingResampler -> downmix -> f32_channels_to_bytes), one launch sequence for the whole batch.  The outputs are
+ * the AudioData values the reference's pipeline_worker would have sent (lib.rs:3238-3259), per stream in order:
+ * one per access unit without resampling, one per completed 4096-frame chunk with it (lib.rs:1970-2003), plus
+ * the flushed tail when `flush` is set (lib.rs:2017-2058, 3307-3322). */
+typedef struct sk_tick_stream {
+    uint32_t stream;      /* engine stream; its access units are contiguous in descs / coeffs, streams in this order */
+    uint32_t n_frames;    /* access units of this stream in the batch (may be 0 with flush) */
+    uint8_t out_bits;     /* DecodeOptions::output_bits_per_sample resolved: 16 / 24 / 32 (signed little-endian) */
+    uint8_t out_channels; /* DecodeOptions::output_channels resolved (source channels when None) */
+    uint8_t resample;     /* 1: route through the stream's resampler (sk_resampler_open) */
+    uint8_t flush;        /* 1: end of stream: flush the resampler after these frames */
+} sk_tick_stream;
+
+typedef struct sk_tick_output {
+    uint32_t stream_index; /* index into the tick's stream table */
+    uint32_t frames;       /* PCM frames in this AudioData */
+    uint64_t byte_offset;  /* into out_bytes (16-byte aligned) */
+    uint32_t bytes;        /* frames * channels * bits / 8 */
+    int32_t status;        /* 0, or the sk_frame_status of an access unit the engine rejected: the stream ends there */
+    uint8_t channels, bits;
+    uint16_t reserved;
+} sk_tick_output;
+
+/* upper bounds for the two output arrays of a tick */
+size_t sk_tick_out_bound(const sk_tick_stream *streams, uint32_t n_streams, uint32_t *max_outputs);
+/* coeffs: host memory (pinned for full overlap), packed like sk_aac_synthesize_f32's.  Blocks until out_bytes holds
+ * the results.  *out_bytes_used receives the bytes written. */
+int sk_tick_run(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, const sk_aac_frame_desc *descs,
+                const float *coeffs, uint32_t n_frames, uint8_t *out_bytes, size_t out_cap, sk_tick_output *outputs,
+                uint32_t outputs_cap, uint32_t *n_outputs, size_t *out_bytes_used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,18 @@ class FrameDesc(C.Structure):
                 ("window_shape", C.c_uint8 * 2), ("reserved", C.c_uint8 * 3)]
 
 
+class TickStream(C.Structure):
+    """sk_tick_stream"""
+    _fields_ = [("stream", C.c_uint32), ("n_frames", C.c_uint32), ("out_bits", C.c_uint8), ("out_channels", C.c_uint8),
+                ("resample", C.c_uint8), ("flush", C.c_uint8)]
+
+
+class TickOutput(C.Structure):
+    """sk_tick_output"""
+    _fields_ = [("stream_index", C.c_uint32), ("frames", C.c_uint32), ("byte_offset", C.c_uint64), ("bytes", C.c_uint32),
+                ("status", C.c_int32), ("channels", C.c_uint8), ("bits", C.c_uint8), ("reserved", C.c_uint16)]
+
+
 def declared_symbols():
     """Every function name include/soundkit_amd.h declares."""
     text = open(HEADER_PATH).read()
@@ -125,6 +137,8 @@ _sig = {
     "sk_resampler_close": (_i, [_vp, _u32]),
     "sk_resampler_process_f32": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp]),
     "sk_resampler_flush_f32": (_i, [_vp, _vp, _u32, _vp, _u32, _vp]),
+    "sk_tick_out_bound": (_sz, [_vp, _u32, C.POINTER(_u32)]),
+    "sk_tick_run": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
 }
 for _name in ("sk_pcm_interleave_i16", "sk_pcm_deinterleave_i16", "sk_pcm_deinterleave_s24", "sk_pcm_deinterleave_f32",
               "sk_pcm_interleave_f32"):

@@ -202,6 +202,10 @@ struct sk_engine {
 
     // grow-only scratch
     DevBuf in_buf, out_buf, aux_buf, aux2_buf;
+    // sk_tick_run: synthesis output, resampler output, packed bytes, small-array arena (+ pinned host mirror)
+    DevBuf tick_pcm, tick_res, tick_out, tick_arena;
+    uint8_t *h_arena = nullptr;
+    size_t h_arena_cap = 0;
     std::vector<uint32_t> state_count, state_task;  // plan construction scratch
 
     int hip_fail(hipError_t e, const char *what) {
@@ -388,6 +392,11 @@ void sk_engine_destroy(sk_engine *e) {
         e->out_buf.release();
         e->aux_buf.release();
         e->aux2_buf.release();
+        e->tick_pcm.release();
+        e->tick_res.release();
+        e->tick_out.release();
+        e->tick_arena.release();
+        if (e->h_arena) (void)hipHostFree(e->h_arena);
         if (e->stream) (void)hipStreamDestroy(e->stream);
     }
     delete e;
@@ -499,12 +508,21 @@ void sk_aac_plan_destroy(sk_aac_plan *p) {
 uint64_t sk_aac_plan_elements(const sk_aac_plan *p) { return p ? p->elements : 0; }
 uint32_t sk_aac_plan_frames_ok(const sk_aac_plan *p) { return p ? p->n_frames_ok : 0; }
 
-int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, int32_t *status, sk_aac_plan **out) {
-    if (!e || !out || (n && !descs)) return SK_ERR_INVALID_ARG;
-    *out = nullptr;
-    std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+}  // extern "C"
 
+namespace {
+
+struct HostPlan {
+    std::vector<sk::SynthTask> tasks;
+    std::vector<sk::SynthEntry> entries;
+    std::vector<sk::FrameSpan> spans;
+    uint32_t frames_ok = 0;
+    uint64_t off1024 = 0;  // total packed size in units of 1024 f32
+};
+
+// Validates the descs and lays the batch out as one task per (stream, channel) state, frames of a state in
+// array order.  Caller holds e->mu.
+int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, int32_t *status, HostPlan &hp) {
     // pass 1: validate, count entries per (stream, channel) state, in first-touch order
     std::vector<uint32_t> touched;
     std::vector<uint8_t> ok(n, 0);
@@ -528,7 +546,8 @@ int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n,
         }
     }
     // tasks in first-touch order; entries grouped per task, array order kept inside a task
-    std::vector<sk::SynthTask> tasks(touched.size());
+    std::vector<sk::SynthTask> &tasks = hp.tasks;
+    tasks.assign(touched.size(), sk::SynthTask{});
     uint32_t n_entries = 0;
     for (size_t t = 0; t < touched.size(); ++t) {
         const uint32_t state = touched[t];
@@ -539,8 +558,10 @@ int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n,
         n_entries += e->state_count[state];
         e->state_task[state] = (uint32_t)t;
     }
-    std::vector<sk::SynthEntry> entries(n_entries);
-    std::vector<sk::FrameSpan> spans;
+    std::vector<sk::SynthEntry> &entries = hp.entries;
+    entries.assign(n_entries, sk::SynthEntry{});
+    std::vector<sk::FrameSpan> &spans = hp.spans;
+    spans.clear();
     spans.reserve(frames_ok);
     uint64_t off = 0;  // in units of 1024 f32; advances for failed frames too (packing follows the descs)
     bool bad_desc_channels = false;
@@ -560,18 +581,35 @@ int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n,
     }
     for (uint32_t state : touched) e->state_count[state] = 0;
     if (bad_desc_channels || off > 0xffffffffull) return SK_ERR_INVALID_ARG;
+    hp.frames_ok = frames_ok;
+    hp.off1024 = off;
+    return SK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, int32_t *status, sk_aac_plan **out) {
+    if (!e || !out || (n && !descs)) return SK_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    HostPlan hp;
+    int rc = build_plan_host(e, descs, n, status, hp);
+    if (rc != SK_OK) return rc;
 
     sk_aac_plan *p = new (std::nothrow) sk_aac_plan();
     if (!p) return SK_ERR_OOM;
     p->eng = e;
-    p->n_tasks = (uint32_t)tasks.size();
-    p->n_entries = n_entries;
-    p->n_frames_ok = frames_ok;
-    p->elements = off * 1024;
-    if (!tasks.empty()) {
-        hipError_t he = upload(&p->d_tasks, tasks);
-        if (he == hipSuccess) he = upload(&p->d_entries, entries);
-        if (he == hipSuccess) he = upload(&p->d_spans, spans);
+    p->n_tasks = (uint32_t)hp.tasks.size();
+    p->n_entries = (uint32_t)hp.entries.size();
+    p->n_frames_ok = hp.frames_ok;
+    p->elements = hp.off1024 * 1024;
+    if (!hp.tasks.empty()) {
+        hipError_t he = upload(&p->d_tasks, hp.tasks);
+        if (he == hipSuccess) he = upload(&p->d_entries, hp.entries);
+        if (he == hipSuccess) he = upload(&p->d_spans, hp.spans);
         if (he != hipSuccess) {
             sk_aac_plan_destroy(p);
             return e->hip_fail(he, "upload plan");
@@ -1134,13 +1172,20 @@ struct RsCall {  // one stream's slot in a batched call
 struct AuxArena {
     uint8_t *base = nullptr;
     size_t cap = 0, used = 0;
+    uint8_t *host = nullptr;  // optional pinned mirror of the same capacity: uploads then need no sync before v is reused
     template <typename T>
     hipError_t put(const std::vector<T> &v, hipStream_t st, const T **out) {
         const size_t bytes = (v.size() * sizeof(T) + 255) & ~(size_t)255;
         if (used + bytes > cap) return hipErrorOutOfMemory;
         *out = reinterpret_cast<const T *>(base + used);
+        const void *src = v.data();
+        if (host) {
+            std::memcpy(host + used, v.data(), v.size() * sizeof(T));
+            src = host + used;
+        }
         used += bytes;
-        return hipMemcpyAsync((void *)*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st);
+        if (v.empty()) return hipSuccess;
+        return hipMemcpyAsync((void *)*out, src, v.size() * sizeof(T), hipMemcpyHostToDevice, st);
     }
 };
 
@@ -1162,7 +1207,10 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
     std::map<Key, std::vector<size_t>> groups;
     for (size_t ci : ready) {
         const StreamInfo &s = e->streams[calls[ci].id];
-        groups[Key{s.rs_table, s.rs_chunks, s.rs_last_index}].push_back(ci);
+        // the integer-step FIR only cares where the chunk's first output sits relative to the chunk (three phases);
+        // the generic kernel's f64 index sequence depends on the whole history
+        const bool fir = s.rs_in_hz == 48000 && s.rs_out_hz == 16000;
+        groups[Key{s.rs_table, fir ? 0 : s.rs_chunks, s.rs_last_index}].push_back(ci);
     }
     std::vector<double> idx;
     std::vector<uint32_t> row_map, out_off;
@@ -1189,19 +1237,20 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
             SK_HIP(aux.put(row_map, e->stream, &d_map), "upload row map");
             SK_HIP(aux.put(out_off, e->stream, &d_off), "upload out offsets");
             if (tab.in_hz == 48000 && tab.out_hz == 16000) {
-                // integer time base: output m sits at absolute index 3m - 125
-                const int64_t abs0 = (int64_t)std::llround(idx[0]) + (int64_t)kRsChunk * (int64_t)g.first.chunks;
+                // integer time base: output m sits at index 3m - 125.  Any origin works as long as output
+                // out_first + j reads the row at chunk-relative index idx[0] + 3j (+ kRsHist of history in front)
+                const uint32_t first = 1024;
                 sk::FirArgs a = fir_base(e);
                 a.in = e->d_rs;
                 a.in_stride = kRsRow;
                 a.rows = (uint32_t)row_map.size();
                 a.in_frames = kRsRow;
-                a.in_origin = (int32_t)((int64_t)kRsChunk * (int64_t)g.first.chunks - (int64_t)kRsHist);
+                a.in_origin = (int32_t)(3 * (int64_t)first - 125 - (int64_t)std::llround(idx[0]) - (int64_t)kRsHist);
                 a.out = d_out;
                 a.out_stride = 0;
                 a.row_map = d_map;
                 a.out_off = d_off;
-                a.out_first = (uint32_t)((abs0 + 125) / 3);
+                a.out_first = first;
                 a.out_count = count;
                 SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch streaming fir");
             } else {
@@ -1380,6 +1429,309 @@ int sk_resampler_flush_f32(sk_engine *e, const uint32_t *streams, uint32_t n_str
         SK_HIP(hipMemcpy2DAsync(out, (size_t)out_cap * 4, e->out_buf.p, out_stride * 4, max_prod * 4, total_rows,
                                 hipMemcpyDeviceToHost, e->stream), "D2H flush output");
     SK_HIP(hipStreamSynchronize(e->stream), "flush sync");
+    return SK_OK;
+}
+
+}  // extern "C"
+
+// ---- one scheduler tick on the device -----------------------------------------------------------------
+// decode_aac_access_unit (soundkit-decoder lib.rs:1793-1813) followed by apply_output_options
+// (lib.rs:3324-3456) for every access unit of every stream in the batch, with the AudioData boundaries the
+// worker would have pushed to its output channel (lib.rs:3238-3259).
+
+namespace {
+
+struct TickCall {           // one sk_tick_stream
+    uint32_t ch = 0;        // source channels
+    uint32_t first = 0;     // index of its first desc
+    uint32_t good = 0;      // frames before the first rejected one (all of them if none is rejected)
+    int32_t bad_status = 0; // status of that rejected frame
+    int rs_call = -1;       // index into the RsCall vector when the stream resamples
+    std::vector<std::pair<uint32_t, uint32_t>> chunks;  // (column, frames) of each resampled AudioData
+};
+
+}  // namespace
+
+extern "C" {
+
+size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n_streams, uint32_t *max_outputs) {
+    size_t bytes = 0;
+    uint64_t outs = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        // a resampling stream emits at most one AudioData per 4096 input frames (+ one carried chunk + the flush),
+        // each at most 4096 * 6 + 2 frames (8 kHz -> 48 kHz); everything else one per access unit
+        const uint64_t n = ts[i].n_frames;
+        if (ts[i].resample) {
+            const uint64_t chunks = n / 4 + 2;
+            bytes += chunks * ((4096 * 6 + 2) * 2 * 4 + 16);
+            outs += chunks + 1;
+        } else {
+            bytes += n * (1024 * 2 * 4 + 16);
+            outs += n + 1;
+        }
+    }
+    if (max_outputs) *max_outputs = (uint32_t)std::min<uint64_t>(outs, 0xffffffffu);
+    return bytes;
+}
+
+int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs,
+                const float *coeffs, uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs,
+                uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) {
+    if (!e || !n_outs || (n_streams && !ts) || (n_frames && (!descs || !coeffs))) return SK_ERR_INVALID_ARG;
+    *n_outs = 0;
+    if (out_bytes) *out_bytes = 0;
+    if (n_streams == 0) return n_frames == 0 ? SK_OK : SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+
+    // ---- validate the stream table ----
+    std::vector<TickCall> tc(n_streams);
+    {
+        std::vector<uint8_t> seen(e->streams.size(), 0);
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            const sk_tick_stream &t = ts[i];
+            if (!stream_ok(e, t.stream)) return SK_ERR_BAD_STREAM;
+            if (seen[t.stream]++) return SK_ERR_INVALID_ARG;  // a stream appears once per tick
+            if (t.out_bits != 16 && t.out_bits != 24 && t.out_bits != 32) return SK_ERR_INVALID_ARG;
+            if (t.out_channels == 0) return SK_ERR_INVALID_ARG;
+            if (t.resample && !e->streams[t.stream].rs_open) return SK_ERR_BAD_STREAM;
+            if (total + t.n_frames > n_frames) return SK_ERR_INVALID_ARG;
+            for (uint32_t f = 0; f < t.n_frames; ++f)
+                if (descs[total + f].stream != t.stream) return SK_ERR_INVALID_ARG;
+            tc[i].ch = e->streams[t.stream].channels;
+            tc[i].first = (uint32_t)total;
+            total += t.n_frames;
+        }
+        if (total != n_frames) return SK_ERR_INVALID_ARG;
+    }
+
+    // ---- synthesis of the whole batch ----
+    std::vector<int32_t> status(n_frames, 0);
+    HostPlan hp;
+    int rc = build_plan_host(e, descs, n_frames, status.data(), hp);
+    if (rc != SK_OK) return rc;
+    std::vector<uint64_t> off1024(n_frames + 1, 0);
+    for (uint32_t i = 0; i < n_frames; ++i) off1024[i + 1] = off1024[i] + descs[i].channels;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        tc[i].good = ts[i].n_frames;
+        for (uint32_t f = 0; f < ts[i].n_frames; ++f)
+            if (status[tc[i].first + f] != 0) {
+                tc[i].good = f;
+                tc[i].bad_status = status[tc[i].first + f];
+                break;
+            }
+    }
+    const size_t elems = (size_t)hp.off1024 * 1024;
+    const size_t arena_bytes = ((size_t)16 << 20) + (size_t)n_frames * 512 + (size_t)n_streams * 1024;
+    SK_HIP(e->in_buf.reserve(elems * 4 + 16), "alloc tick coeffs");
+    SK_HIP(e->tick_pcm.reserve(elems * 4 + 16), "alloc tick pcm");
+    SK_HIP(e->tick_arena.reserve(arena_bytes), "alloc tick arena");
+    if (e->h_arena_cap < e->tick_arena.cap) {
+        if (e->h_arena) (void)hipHostFree(e->h_arena);
+        e->h_arena = nullptr;
+        e->h_arena_cap = 0;
+        SK_HIP(hipHostMalloc((void **)&e->h_arena, e->tick_arena.cap, hipHostMallocDefault), "alloc pinned arena");
+        e->h_arena_cap = e->tick_arena.cap;
+    }
+    AuxArena aux{(uint8_t *)e->tick_arena.p, e->tick_arena.cap, 0, e->h_arena};
+    float *d_pcm = (float *)e->tick_pcm.p;
+    if (!hp.tasks.empty()) {
+        SK_HIP(hipMemcpyAsync(e->in_buf.p, coeffs, elems * 4, hipMemcpyHostToDevice, e->stream), "H2D tick coeffs");
+        sk::SynthArgs a{};
+        a.coeffs = (const float *)e->in_buf.p;
+        a.pcm = d_pcm;
+        a.delay = e->d_delay;
+        a.prev_shape = e->d_prev_shape;
+        SK_HIP(aux.put(hp.tasks, e->stream, &a.tasks), "upload tick tasks");
+        SK_HIP(aux.put(hp.entries, e->stream, &a.entries), "upload tick entries");
+        a.n_tasks = (uint32_t)hp.tasks.size();
+        a.t = e->synth_tables;
+        SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth");
+    }
+
+    // ---- streaming resamplers ----
+    std::vector<RsCall> calls;
+    std::vector<uint32_t> call_stream;  // RsCall -> index into ts
+    size_t res_rows = 0;
+    uint32_t res_cap = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (!ts[i].resample) continue;
+        const StreamInfo &s = e->streams[ts[i].stream];
+        RsCall c;
+        c.id = ts[i].stream;
+        c.channels = tc[i].ch;
+        c.row0 = res_rows;
+        res_rows += c.channels;
+        tc[i].rs_call = (int)calls.size();
+        calls.push_back(c);
+        call_stream.push_back(i);
+        const uint64_t max_chunks = ((uint64_t)s.rs_fill + (uint64_t)tc[i].good * 1024) / kRsChunk + 1;
+        const uint64_t per_chunk = (uint64_t)std::ceil((double)kRsChunk * (double)s.rs_out_hz / (double)s.rs_in_hz) + 2;
+        if (max_chunks * per_chunk > 0x7fffffffull) return SK_ERR_INVALID_ARG;
+        res_cap = std::max<uint32_t>(res_cap, (uint32_t)(max_chunks * per_chunk));
+    }
+    const size_t res_stride = ((size_t)res_cap + 3) & ~(size_t)3;
+    float *d_res = nullptr;
+    if (!calls.empty()) {
+        if (res_rows * res_stride > 0xffffffffull) return SK_ERR_INVALID_ARG;
+        SK_HIP(e->tick_res.reserve(res_rows * res_stride * 4 + 16), "alloc tick resampler output");
+        d_res = (float *)e->tick_res.p;
+        std::vector<sk::RowCopy> jobs;
+        std::vector<size_t> ready;
+        std::vector<uint32_t> before;
+        for (;;) {
+            jobs.clear();
+            ready.clear();
+            for (size_t ci = 0; ci < calls.size(); ++ci) {
+                RsCall &c = calls[ci];
+                const TickCall &t = tc[call_stream[ci]];
+                StreamInfo &s = e->streams[c.id];
+                const uint32_t total_in = t.good * 1024;
+                uint32_t take = std::min(total_in - c.consumed, kRsChunk - s.rs_fill);
+                while (take) {  // pieces never straddle a frame of the packed synthesis output
+                    const uint32_t frame = c.consumed / 1024, within = c.consumed % 1024;
+                    const uint32_t n = std::min(take, 1024 - within);
+                    for (uint32_t ch = 0; ch < c.channels; ++ch)
+                        jobs.push_back(sk::RowCopy{(off1024[t.first + frame] + ch) * 1024 + within,
+                                                   ((uint64_t)c.id * 2 + ch) * kRsRow + kRsHist + s.rs_fill, n, 1});
+                    s.rs_fill += n;
+                    c.consumed += n;
+                    take -= n;
+                }
+                if (s.rs_fill == kRsChunk) ready.push_back(ci);
+            }
+            if (jobs.empty() && ready.empty()) break;
+            if (!jobs.empty()) {
+                const sk::RowCopy *d_jobs = nullptr;
+                SK_HIP(aux.put(jobs, e->stream, &d_jobs), "upload tick append jobs");
+                for (size_t j0 = 0; j0 < jobs.size(); j0 += 65535)
+                    SK_HIP(sk::launch_row_copies(d_pcm, e->d_rs, d_jobs + j0, (uint32_t)std::min<size_t>(65535, jobs.size() - j0),
+                                                 e->stream), "tick append chunk");
+            }
+            if (!ready.empty()) {
+                before.clear();
+                for (size_t ci : ready) before.push_back(calls[ci].produced);
+                rc = rs_process_ready(e, calls, ready, d_res, res_stride, res_cap, aux);
+                if (rc != SK_OK) return rc;
+                for (size_t k = 0; k < ready.size(); ++k) {
+                    const RsCall &c = calls[ready[k]];
+                    if (c.produced > before[k])
+                        tc[call_stream[ready[k]]].chunks.emplace_back(before[k], c.produced - before[k]);
+                }
+            }
+        }
+        // end of stream: StreamingResampler::flush (lib.rs:2017-2058); a stream that failed is not flushed
+        std::vector<sk::RowCopy> pads;
+        ready.clear();
+        for (size_t ci = 0; ci < calls.size(); ++ci) {
+            const uint32_t i = call_stream[ci];
+            if (!ts[i].flush || tc[i].good != ts[i].n_frames) continue;
+            RsCall &c = calls[ci];
+            StreamInfo &s = e->streams[c.id];
+            const uint32_t remaining = s.rs_fill, padded = kRsChunk - remaining;
+            c.trim = 0;
+            if (remaining > 0 && padded > 0)
+                c.trim = (uint32_t)std::llround(((double)padded * (double)s.rs_out_hz) / (double)s.rs_in_hz);
+            for (uint32_t ch = 0; ch < c.channels && padded; ++ch)
+                for (uint32_t o = 0; o < padded; o += 8192)
+                    pads.push_back(sk::RowCopy{0, ((uint64_t)c.id * 2 + ch) * kRsRow + kRsHist + remaining + o,
+                                               std::min<uint32_t>(8192, padded - o), 0});
+            s.rs_fill = kRsChunk;
+            ready.push_back(ci);
+        }
+        if (!ready.empty()) {
+            if (!pads.empty()) {
+                const sk::RowCopy *d_pads = nullptr;
+                SK_HIP(aux.put(pads, e->stream, &d_pads), "upload tick pad jobs");
+                for (size_t j0 = 0; j0 < pads.size(); j0 += 65535)
+                    SK_HIP(sk::launch_row_copies(e->d_zeros, e->d_rs, d_pads + j0,
+                                                 (uint32_t)std::min<size_t>(65535, pads.size() - j0), e->stream), "tick pad chunk");
+            }
+            before.clear();
+            for (size_t ci : ready) before.push_back(calls[ci].produced);
+            rc = rs_process_ready(e, calls, ready, d_res, res_stride, res_cap, aux);
+            if (rc != SK_OK) return rc;
+            for (size_t k = 0; k < ready.size(); ++k) {
+                const RsCall &c = calls[ready[k]];
+                const uint32_t got = c.produced - before[k];
+                if (got > c.trim) tc[call_stream[ready[k]]].chunks.emplace_back(before[k], got - c.trim);
+            }
+        }
+    }
+
+    // ---- output records and the pack jobs that fill them ----
+    std::vector<sk::PackJob> packs;
+    uint32_t n_rec = 0, max_pack_frames = 0;
+    size_t cursor = 0;
+    uint8_t *d_out = nullptr;
+    auto emit = [&](uint32_t stream_index, uint32_t frames, uint32_t ch_out, uint32_t bits, int32_t st) -> sk_tick_output * {
+        if (n_rec >= outs_cap) return nullptr;
+        sk_tick_output &o = outs[n_rec++];
+        o.stream_index = stream_index;
+        o.frames = frames;
+        o.channels = (uint8_t)ch_out;
+        o.bits = (uint8_t)bits;
+        o.reserved = 0;
+        o.status = st;
+        o.bytes = frames * ch_out * (bits / 8);
+        o.byte_offset = cursor;
+        cursor += ((size_t)o.bytes + 15) & ~(size_t)15;
+        return &o;
+    };
+    // first pass sizes the output, second creates the jobs (the device buffer may move when it grows)
+    for (int pass = 0; pass < 2; ++pass) {
+        n_rec = 0;
+        cursor = 0;
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            const sk_tick_stream &t = ts[i];
+            const uint32_t ch = tc[i].ch;
+            const uint32_t ch_out = t.out_channels < ch ? t.out_channels : ch;
+            if (!t.resample) {
+                const StreamInfo &s = e->streams[t.stream];
+                (void)s;
+                const bool direct = t.out_bits == 16 && t.out_channels == ch;
+                for (uint32_t f = 0; f < tc[i].good; ++f) {
+                    sk_tick_output *o = emit(i, 1024, ch_out, t.out_bits, 0);
+                    if (!o) return SK_ERR_INVALID_ARG;
+                    if (pass) {
+                        const float *src = d_pcm + off1024[tc[i].first + f] * 1024;
+                        packs.push_back(sk::PackJob{src, src + 1024, d_out + o->byte_offset, 1024, (uint8_t)ch, (uint8_t)ch_out,
+                                                    t.out_bits, (uint8_t)(direct ? sk::kPackDirect : sk::kPackViaS16)});
+                        max_pack_frames = std::max<uint32_t>(max_pack_frames, 1024);
+                    }
+                }
+            } else {
+                const RsCall &c = calls[(size_t)tc[i].rs_call];
+                for (const auto &chunk : tc[i].chunks) {
+                    sk_tick_output *o = emit(i, chunk.second, ch_out, t.out_bits, 0);
+                    if (!o) return SK_ERR_INVALID_ARG;
+                    if (pass) {
+                        const float *src = d_res + c.row0 * res_stride + chunk.first;
+                        packs.push_back(sk::PackJob{src, src + res_stride, d_out + o->byte_offset, chunk.second, (uint8_t)ch,
+                                                    (uint8_t)ch_out, t.out_bits, (uint8_t)sk::kPackPlain});
+                        max_pack_frames = std::max(max_pack_frames, chunk.second);
+                    }
+                }
+            }
+            if (tc[i].good != t.n_frames)  // the frame the engine rejected: Err(DecodingFailed) ends the stream
+                if (!emit(i, 0, ch_out, t.out_bits, tc[i].bad_status)) return SK_ERR_INVALID_ARG;
+        }
+        if (pass == 0) {
+            if (cursor > out_cap || (cursor && !out)) return SK_ERR_INVALID_ARG;
+            SK_HIP(e->tick_out.reserve(cursor + 16), "alloc tick output");
+            d_out = (uint8_t *)e->tick_out.p;
+        }
+    }
+    if (!packs.empty()) {
+        const sk::PackJob *d_packs = nullptr;
+        SK_HIP(aux.put(packs, e->stream, &d_packs), "upload pack jobs");
+        SK_HIP(sk::launch_pack_jobs(d_packs, (uint32_t)packs.size(), max_pack_frames, e->stream), "launch pack");
+        SK_HIP(hipMemcpyAsync(out, d_out, cursor, hipMemcpyDeviceToHost, e->stream), "D2H tick output");
+    }
+    SK_HIP(hipStreamSynchronize(e->stream), "tick sync");
+    *n_outs = n_rec;
+    if (out_bytes) *out_bytes = cursor;
     return SK_OK;
 }
 

@@ -403,7 +403,59 @@ inline unsigned grid_for(size_t items) {
     return (unsigned)blocks;
 }
 
+// one workgroup = 1024 frames of one job
+__global__ __launch_bounds__(256) void k_pack_jobs(const PackJob *jobs, uint32_t n_jobs) {
+    const uint32_t j = blockIdx.y;
+    if (j >= n_jobs) return;
+    const PackJob job = jobs[j];
+    const uint32_t f0 = blockIdx.x * 1024;
+    if (f0 >= job.frames) return;
+    const uint32_t f1 = min(f0 + 1024u, job.frames);
+    const int fmt = job.bits == 16 ? SK_FMT_S16LE : (job.bits == 24 ? SK_FMT_S24LE : SK_FMT_S32LE);
+    const uint32_t bps = job.bits / 8;
+    for (uint32_t f = f0 + threadIdx.x; f < f1; f += 256) {
+        float x[2];
+        x[0] = job.src0[f];
+        x[1] = job.ch_in > 1 ? job.src1[f] : 0.0f;
+        if (job.mode == kPackDirect) {
+            if (job.ch_in > 1) {
+                const uint32_t lo = (uint32_t)float_sample_to_i16(x[0]) & 0xffff, hi = (uint32_t)float_sample_to_i16(x[1]) & 0xffff;
+                reinterpret_cast<uint32_t *>(job.dst)[f] = lo | (hi << 16);
+            } else {
+                reinterpret_cast<uint16_t *>(job.dst)[f] = (uint16_t)float_sample_to_i16(x[0]);
+            }
+            continue;
+        }
+        if (job.mode == kPackViaS16)
+            for (int c = 0; c < 2; ++c) x[c] = (float)float_sample_to_i16(x[c]) / 32768.0f;
+        uint32_t ch = job.ch_in;
+        if (job.ch_out < job.ch_in) {  // downmix_channels(.., 1): mono += sample * (1 / channels), channels in order
+            const float scale = 1.0f / (float)job.ch_in;
+            float acc = 0.0f;
+            for (uint32_t c = 0; c < job.ch_in; ++c) acc += x[c] * scale;
+            x[0] = acc;
+            ch = 1;
+        }
+        for (uint32_t c = 0; c < ch; ++c) {
+            const uint32_t v = f32_to_sample(fmt, x[c]);
+            const size_t i = (size_t)f * ch + c;
+            if (bps == 2) reinterpret_cast<uint16_t *>(job.dst)[i] = (uint16_t)v;
+            else if (bps == 4) reinterpret_cast<uint32_t *>(job.dst)[i] = v;
+            else store_raw_scalar(job.dst + i * 3, v, 3);
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t launch_pack_jobs(const PackJob *jobs, uint32_t n_jobs, uint32_t max_frames, hipStream_t s) {
+    if (n_jobs == 0 || max_frames == 0) return hipSuccess;
+    for (uint32_t j0 = 0; j0 < n_jobs; j0 += 65535) {
+        const uint32_t n = n_jobs - j0 < 65535 ? n_jobs - j0 : 65535;
+        hipLaunchKernelGGL(k_pack_jobs, dim3((max_frames + 1023) / 1024, n), dim3(256), 0, s, jobs + j0, n);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_pcm_convert(int op, const void *in, void *out, size_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;

@@ -85,6 +85,18 @@ __global__ __launch_bounds__(256) void k_row_copies(const float *src_base, float
     const RowCopy job = jobs[j];
     const float *src = src_base + job.src_off;
     float *dst = dst_base + job.dst_off;
+    if (job.via_s16) {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < job.count; i += gridDim.x * blockDim.x) {
+            // float_sample_to_i16 (soundkit-decoder lib.rs:1815-1827), then audio_data_to_f32_channels' / 32768
+            const float x = src[i];
+            const float f = isfinite(x) ? fminf(fmaxf(x, -1.0f), 1.0f) : 0.0f;
+            const double scaled = f < 0.0f ? (double)f * 32768.0 : (double)f * 32767.0;
+            int r = (int)round(scaled);
+            r = r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+            dst[i] = (float)r / 32768.0f;
+        }
+        return;
+    }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < job.count; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 

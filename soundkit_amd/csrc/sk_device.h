@@ -104,8 +104,25 @@ hipError_t launch_sinc_resample(const SincArgs &a, hipStream_t s);
 // batched row copies (streaming resampler bookkeeping): job j copies count floats
 struct RowCopy {
     uint64_t src_off, dst_off;  // element offsets from the two bases
-    uint32_t count, pad;
+    uint32_t count;
+    uint32_t via_s16;  // 1: each sample goes through float_sample_to_i16 then / 32768 (the worker hands the resampler
+                       // the i16 AudioData of decode_aac_access_unit, soundkit-decoder lib.rs:1793-1813, 3563-3617)
 };
 hipError_t launch_row_copies(const float *src_base, float *dst_base, const RowCopy *jobs, uint32_t n_jobs, hipStream_t s);
+
+// pcm.hip -- the output stage of apply_output_options (soundkit-decoder lib.rs:3324-3456) for a batch of
+// planar f32 pieces: [s16 round trip] -> [mono downmix] -> interleaved little-endian bytes.
+enum PackMode : uint8_t {
+    kPackPlain = 0,   // src is already the f32 the reference holds (resampler output)
+    kPackViaS16 = 1,  // src is synthesis output: q = float_sample_to_i16(x); the f32 is q / 32768
+    kPackDirect = 2,  // fast path (lib.rs:3339-3345): the bytes are q itself, s16le
+};
+struct PackJob {
+    const float *src0, *src1;  // channel rows (src1 unused when ch_in == 1)
+    uint8_t *dst;              // 4-byte aligned
+    uint32_t frames;
+    uint8_t ch_in, ch_out, bits, mode;  // ch_out < ch_in: downmix to mono (lib.rs:3492-3561); bits 16 / 24 / 32
+};
+hipError_t launch_pack_jobs(const PackJob *jobs, uint32_t n_jobs, uint32_t max_frames, hipStream_t s);
 
 }  // namespace sk

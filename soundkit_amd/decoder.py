@@ -82,6 +82,7 @@ class StreamingResampler:
         self.channels = channels
         self.input_sample_rate, self.output_sample_rate = input_sample_rate, output_sample_rate
         self.stream = self.engine.open_stream(input_sample_rate, channels)
+        self._fill = 0
         try:
             self.engine.resampler_open(self.stream, input_sample_rate, output_sample_rate)
         except SoundkitError:
@@ -92,7 +93,24 @@ class StreamingResampler:
         channels = np.ascontiguousarray(channels, np.float32)
         if channels.shape[0] != self.channels:
             raise ValueError("Channel count changed mid-stream: expected %d, got %d" % (self.channels, channels.shape[0]))
+        self._fill = (self._fill + channels.shape[1]) % RESAMPLE_CHUNK_SIZE
         return self.engine.resampler_process([self.stream], channels[None], self.channels)[0]
+
+    def process_chunks(self, channels):
+        """The reference's return shape (lib.rs:1970-2003): one entry per completed 4096-frame chunk."""
+        channels = np.ascontiguousarray(channels, np.float32)
+        out, pos = [], 0
+        while pos < channels.shape[1]:
+            n = min(channels.shape[1] - pos, RESAMPLE_CHUNK_SIZE - self._fill)
+            got = self.process(channels[:, pos:pos + n])
+            if got.shape[1]:
+                out.append(got)
+            pos += n
+        return out
+
+    def flush_chunks(self):
+        got = self.flush()
+        return [got] if got.shape[1] else []
 
     def flush(self):
         return self.engine.resampler_flush([self.stream], self.channels)[0]
@@ -124,12 +142,23 @@ def apply_output_options(audio, output_bits_per_sample=None, output_sample_rate=
         elif (resampler.input_sample_rate, resampler.channels, resampler.output_sample_rate) != (
                 audio.sampling_rate, channels.shape[0], rate):
             raise ValueError("Resampler configuration changed mid-stream")
-        channels = resampler.process(channels)
-        if channels.shape[1] == 0:
-            return [], resampler
-    out_ch = channels.shape[0]
-    if chans < out_ch:
-        channels = downmix_channels(channels, chans)
-        out_ch = chans
-    data = f32_channels_to_bytes(channels, bits, out_format)
-    return [AudioData(bits, out_ch, rate, data, out_format, Endianness.LittleEndian)], resampler
+        return emit_resampled_chunks(resampler.process_chunks(channels), bits, chans, rate, out_format), resampler
+    return emit_resampled_chunks([channels], bits, chans, rate, out_format), resampler
+
+
+def emit_resampled_chunks(chunks, bits, chans, rate, out_format):
+    """lib.rs:3261-3290: downmix + byte conversion, one AudioData per chunk."""
+    out = []
+    for channels in chunks:
+        out_ch = channels.shape[0]
+        if chans < out_ch:
+            channels = downmix_channels(channels, chans)
+            out_ch = chans
+        data = f32_channels_to_bytes(channels, bits, out_format)
+        out.append(AudioData(bits, out_ch, rate, data, out_format, Endianness.LittleEndian))
+    return out
+
+
+def flush_resampler_frames(resampler, bits, chans, out_format=EncodingFlag.PCMSigned):
+    """lib.rs:3292-3305"""
+    return emit_resampled_chunks(resampler.flush_chunks(), bits, chans, resampler.output_sample_rate, out_format)

@@ -349,6 +349,32 @@ class Engine:
         return [out[i, :, :got[i]].copy() for i in range(n)]
 
 
+    def tick_run(self, streams, descs, n_frames, coeffs):
+        """One scheduler tick (sk_tick_run).  streams: list of dicts {stream, n_frames, out_bits, out_channels,
+        resample, flush}; descs / coeffs as aac_synthesize.  -> list of (stream_index, status, frames, channels,
+        bits, bytes) in the order the reference's worker would have sent them."""
+        import ctypes as C
+        from ._lib import TickStream, TickOutput
+        ts = (TickStream * max(len(streams), 1))()
+        for i, s in enumerate(streams):
+            ts[i].stream, ts[i].n_frames = int(s["stream"]), int(s["n_frames"])
+            ts[i].out_bits, ts[i].out_channels = int(s.get("out_bits", 16)), int(s["out_channels"])
+            ts[i].resample, ts[i].flush = int(bool(s.get("resample", 0))), int(bool(s.get("flush", 0)))
+        max_out = C.c_uint32()
+        cap = lib.sk_tick_out_bound(ts, len(streams), C.byref(max_out))
+        out = np.zeros(max(cap, 16), np.uint8)
+        recs = (TickOutput * max(max_out.value, 1))()
+        n_out, used = C.c_uint32(), C.c_size_t()
+        coeffs = np.ascontiguousarray(coeffs, np.float32)
+        check(lib.sk_tick_run(self._h, ts, len(streams), descs, _ptr(coeffs) if n_frames else None, n_frames, _ptr(out),
+                              out.size, recs, max_out.value, C.byref(n_out), C.byref(used)), "sk_tick_run", self._h)
+        res = []
+        for r in recs[:n_out.value]:
+            res.append((r.stream_index, r.status, r.frames, r.channels, r.bits,
+                        out[r.byte_offset:r.byte_offset + r.bytes].tobytes()))
+        return res
+
+
 _default = None
 
 
