@@ -318,6 +318,70 @@ int sk_tick_run(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, 
                 const float *coeffs, uint32_t n_frames, uint8_t *out_bytes, size_t out_cap, sk_tick_output *outputs,
                 uint32_t outputs_cap, uint32_t *n_outputs, size_t *out_bytes_used);
 
+/* ---- batch scheduler: N streams -> one submission loop per GPU ------------------------------------- */
+/* Replaces one pipeline_worker thread per stream (soundkit-decoder lib.rs:2891-3038) for ADTS AAC-LC input and keeps
+ * DecodePipelineHandle's contract (lib.rs:2788-2889): send never blocks and reports a full input queue (128 chunks /
+ * 8 MiB), an empty chunk ends the stream (flush), at most 16 undelivered AudioData per stream (a stream whose
+ * consumer does not drain it stops being scheduled: the blocking send of lib.rs:3238-3240), an error is delivered
+ * after the outputs produced before it and ends that stream only (lib.rs:3131-3134).  Entropy decoding runs on
+ * `entropy_threads` host threads, everything after it in sk_tick_run on the engine's GPU. */
+typedef struct sk_pipeline sk_pipeline;
+typedef struct sk_pipeline_config {
+    uint32_t entropy_threads;            /* 0 = hardware threads - 1 */
+    uint32_t max_streams;                /* handles open at once; 0 = 1024 (<= the engine's max_streams) */
+    uint32_t max_frames_per_tick;        /* access units per GPU tick; 0 = 16384 */
+    uint32_t max_stream_frames_per_tick; /* of one stream; 0 = 8 */
+    uint32_t input_buffer;               /* chunks per input queue; 0 = DEFAULT_INPUT_BUFFER 128 (lib.rs:77) */
+    uint32_t output_buffer;              /* AudioData per output queue; 0 = DEFAULT_OUTPUT_BUFFER 16 (lib.rs:78) */
+    uint32_t tick_wait_us;               /* how long a non-empty batch may wait for more frames; 0 = 200 */
+    uint32_t reserved;
+} sk_pipeline_config;
+
+typedef struct sk_decode_options { /* DecodeOptions, lib.rs:147-151; 0 = None */
+    uint32_t output_sample_rate;
+    uint8_t output_bits_per_sample;
+    uint8_t output_channels;
+    uint16_t reserved;
+} sk_decode_options;
+
+typedef struct sk_audio_info { /* AudioData (soundkit/src/audio_types.rs:9-61) minus its bytes, or a DecodeError */
+    uint32_t sampling_rate;
+    uint32_t frames;
+    uint32_t bytes;          /* PCM bytes (signed little-endian, interleaved), or the length of the error text */
+    int32_t status;          /* error only: the sk_status / sk_aac_status behind DecodeError::DecodingFailed */
+    uint8_t bits_per_sample, channel_count;
+    uint8_t is_error;        /* 1: the data is the error's message and the stream has ended */
+    uint8_t reserved;
+} sk_audio_info;
+
+typedef struct sk_pipeline_stats {
+    uint64_t ticks, frames, outputs, errors;
+    uint64_t parse_ns;  /* summed over entropy threads */
+    uint64_t tick_ns;   /* submission thread inside sk_tick_run */
+    uint64_t idle_ns;   /* submission thread waiting for a batch */
+    uint32_t entropy_threads, reserved;
+} sk_pipeline_stats;
+
+enum sk_pipeline_status {
+    SK_PIPE_INPUT_FULL = -201,      /* DecodeError::InputBufferFull */
+    SK_PIPE_CLOSED = -202,          /* DecodeError::PipelineClosed; from recv: the stream has ended and is drained */
+    SK_PIPE_CHUNK_TOO_LARGE = -203  /* DecodeError::InputChunkTooLarge (> 4 MiB) */
+};
+
+int sk_pipeline_create(sk_engine *, const sk_pipeline_config *cfg /* NULL = defaults */, sk_pipeline **out);
+void sk_pipeline_destroy(sk_pipeline *);
+/* DecodePipeline::spawn_with_options for an ADTS AAC-LC stream (lib.rs:2590-2700, 2750-2786) */
+int sk_pipeline_spawn(sk_pipeline *, const sk_decode_options *opt /* NULL = defaults */, uint32_t *handle);
+int sk_pipeline_send(sk_pipeline *, uint32_t handle, const uint8_t *data, size_t len);   /* lib.rs:2795-2835 */
+int sk_pipeline_finish(sk_pipeline *, uint32_t handle);                                   /* lib.rs:2838-2840 */
+/* 1 = one output copied to data / info; 0 = nothing ready; SK_PIPE_CLOSED = ended and drained; SK_ERR_CAPACITY =
+ * cap is smaller than info->bytes (the output stays queued).  lib.rs:2845-2858 */
+int sk_pipeline_try_recv(sk_pipeline *, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info);
+int sk_pipeline_recv(sk_pipeline *, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info, uint32_t timeout_ms);
+int sk_pipeline_cancel(sk_pipeline *, uint32_t handle); /* cancel() / Drop, lib.rs:2860-2889: frees the handle */
+size_t sk_pipeline_queued_input_bytes(sk_pipeline *, uint32_t handle); /* lib.rs:2863-2866 */
+int sk_pipeline_get_stats(sk_pipeline *, sk_pipeline_stats *out);
+
 #ifdef __cplusplus
 }
 #endif

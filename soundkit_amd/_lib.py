@@ -16,7 +16,8 @@ ERR_NAMES = {0: "SK_OK", -1: "SK_ERR_INVALID_ARG", -2: "SK_ERR_NO_DEVICE", -3: "
              -5: "SK_ERR_BAD_STREAM", -6: "SK_ERR_UNSUPPORTED", -7: "SK_ERR_CAPACITY",
              -101: "UnexpectedEof", -102: "InvalidAudioObjectType", -103: "UnsupportedAudioObjectType",
              -104: "UnsupportedSamplingFrequencyIndex", -105: "UnsupportedChannelConfig", -106: "UnsupportedFeature",
-             -107: "InvalidConfig", -108: "InvalidBitstream"}
+             -107: "InvalidConfig", -108: "InvalidBitstream",
+             -201: "InputBufferFull", -202: "PipelineClosed", -203: "InputChunkTooLarge"}
 
 
 class FrameDesc(C.Structure):
@@ -35,6 +36,31 @@ class TickOutput(C.Structure):
     """sk_tick_output"""
     _fields_ = [("stream_index", C.c_uint32), ("frames", C.c_uint32), ("byte_offset", C.c_uint64), ("bytes", C.c_uint32),
                 ("status", C.c_int32), ("channels", C.c_uint8), ("bits", C.c_uint8), ("reserved", C.c_uint16)]
+
+
+class PipelineConfig(C.Structure):
+    """sk_pipeline_config"""
+    _fields_ = [(n, C.c_uint32) for n in ("entropy_threads", "max_streams", "max_frames_per_tick",
+                                          "max_stream_frames_per_tick", "input_buffer", "output_buffer", "tick_wait_us",
+                                          "reserved")]
+
+
+class DecodeOptionsC(C.Structure):
+    """sk_decode_options"""
+    _fields_ = [("output_sample_rate", C.c_uint32), ("output_bits_per_sample", C.c_uint8), ("output_channels", C.c_uint8),
+                ("reserved", C.c_uint16)]
+
+
+class AudioInfo(C.Structure):
+    """sk_audio_info"""
+    _fields_ = [("sampling_rate", C.c_uint32), ("frames", C.c_uint32), ("bytes", C.c_uint32), ("status", C.c_int32),
+                ("bits_per_sample", C.c_uint8), ("channel_count", C.c_uint8), ("is_error", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class PipelineStats(C.Structure):
+    """sk_pipeline_stats"""
+    _fields_ = [(n, C.c_uint64) for n in ("ticks", "frames", "outputs", "errors", "parse_ns", "tick_ns", "idle_ns")] + [
+        ("entropy_threads", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def declared_symbols():
@@ -137,6 +163,16 @@ _sig = {
     "sk_resampler_close": (_i, [_vp, _u32]),
     "sk_resampler_process_f32": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp]),
     "sk_resampler_flush_f32": (_i, [_vp, _vp, _u32, _vp, _u32, _vp]),
+    "sk_pipeline_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "sk_pipeline_destroy": (None, [_vp]),
+    "sk_pipeline_spawn": (_i, [_vp, _vp, C.POINTER(_u32)]),
+    "sk_pipeline_send": (_i, [_vp, _u32, _vp, _sz]),
+    "sk_pipeline_finish": (_i, [_vp, _u32]),
+    "sk_pipeline_try_recv": (_i, [_vp, _u32, _vp, _sz, _vp]),
+    "sk_pipeline_recv": (_i, [_vp, _u32, _vp, _sz, _vp, _u32]),
+    "sk_pipeline_cancel": (_i, [_vp, _u32]),
+    "sk_pipeline_queued_input_bytes": (_sz, [_vp, _u32]),
+    "sk_pipeline_get_stats": (_i, [_vp, _vp]),
     "sk_tick_out_bound": (_sz, [_vp, _u32, C.POINTER(_u32)]),
     "sk_tick_run": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
 }

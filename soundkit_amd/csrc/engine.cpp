@@ -327,7 +327,10 @@ const char *sk_strerror(int status) {
     case SK_ERR_OOM: return "out of device memory";
     case SK_ERR_BAD_STREAM: return "stream is not open";
     case SK_ERR_UNSUPPORTED: return "unsupported configuration";
-    case SK_ERR_CAPACITY: return "max_streams exhausted";
+    case SK_ERR_CAPACITY: return "capacity exhausted (streams, handles or caller buffer)";
+    case SK_PIPE_INPUT_FULL: return "Input buffer full";
+    case SK_PIPE_CLOSED: return "Decode pipeline is closed";
+    case SK_PIPE_CHUNK_TOO_LARGE: return "Input chunk exceeds the 4 MiB limit";
     case SK_AAC_ERR_EOF: return "unexpected end of AAC bitstream";
     case SK_AAC_ERR_INVALID_AOT: return "invalid AAC audio object type";
     case SK_AAC_ERR_UNSUPPORTED_AOT: return "unsupported AAC audio object type";

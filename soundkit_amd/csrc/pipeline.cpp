@@ -1,0 +1,679 @@
+// pipeline.cpp -- the batch scheduler: N ADTS AAC-LC streams -> one submission loop on one GPU.
+//
+// Replaces one `pipeline_worker` OS thread per stream (soundkit-decoder/src/lib.rs:2891-3038) while keeping the
+// handle's contract (lib.rs:2788-2889): bounded input queue (128 chunks / 8 MiB, `send` never blocks and reports
+// InputBufferFull), bounded output queue (16 AudioData: a stream whose consumer does not drain it stops being
+// scheduled -- the blocking send of lib.rs:3238-3240), empty chunk = end of stream (flush), an error ends that
+// stream only after the outputs produced before it (lib.rs:3131-3134).
+//
+//   send() -> per-stream input queue -> entropy workers (host threads, one stream at a time each: ADTS framing +
+//   AAC-LC front-end, csrc/aac_frontend.cpp) -> the tick batch (pinned host memory) -> submission thread:
+//   sk_tick_run (H2D, synthesis, s16, resampler, downmix, pack, D2H) -> per-stream output queues -> try_recv().
+//
+// Two batches alternate: the workers fill one while the GPU runs the other.  A stream contributes at most
+// `max_stream_frames_per_tick` access units to a batch and is not scheduled again until that batch has been
+// delivered, so its frames reach the engine in order and its outputs never overtake each other.
+#include "../../include/soundkit_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr size_t kMaxInputChunkBytes = 4u * 1024 * 1024;   // MAX_INPUT_CHUNK_BYTES, lib.rs:80
+constexpr size_t kMaxQueuedInputBytes = 8u * 1024 * 1024;  // MAX_QUEUED_INPUT_BYTES, lib.rs:81
+constexpr uint32_t kNoStream = 0xffffffffu;
+
+struct Output {
+    bool is_error = false;
+    int32_t status = 0;
+    uint32_t rate = 0, frames = 0;
+    uint8_t bits = 0, channels = 0;
+    std::vector<uint8_t> data;  // PCM bytes, or the error text
+};
+
+struct PStream {
+    std::mutex mu;
+    std::condition_variable cv_out;
+    // guarded by mu
+    bool open = false, busy = false, queued = false, finished = false, cancelled = false;
+    std::deque<std::vector<uint8_t>> in;
+    std::deque<Output> out;
+    sk_decode_options opt{};
+    std::atomic<size_t> queued_bytes{0};
+    // owned by whichever worker holds the stream (busy)
+    std::vector<uint8_t> pending;
+    size_t pending_pos = 0;
+    bool saw_eof = false;
+    bool more = false;  // the last pass stopped at its frame limit: schedulable even with an empty input queue
+    sk_aac_decoder *fe = nullptr;
+    uint8_t asc[2] = {0, 0};
+    uint32_t rate = 0, engine_stream = kNoStream;
+    uint8_t channels = 0;
+    bool resample = false;
+};
+
+struct BatchEntry {  // bookkeeping beside one sk_tick_stream
+    uint32_t handle = 0;
+    bool eof = false;
+    bool failed = false;
+    int32_t fail_status = 0;
+    std::string fail_msg;
+};
+
+struct Batch {
+    float *coeffs = nullptr;  // pinned
+    size_t coeff_cap = 0, n_floats = 0;
+    std::vector<sk_aac_frame_desc> descs;
+    std::vector<sk_tick_stream> ts;
+    std::vector<BatchEntry> entries;
+    uint32_t writers = 0;  // claims whose memcpy is still running
+    void clear() {
+        n_floats = 0;
+        descs.clear();
+        ts.clear();
+        entries.clear();
+    }
+};
+
+}  // namespace
+
+struct sk_pipeline {
+    sk_engine *engine = nullptr;
+    sk_pipeline_config cfg{};
+    std::vector<std::unique_ptr<PStream>> streams;
+    std::mutex handles_mu;
+    std::vector<uint32_t> free_handles;
+
+    std::mutex rq_mu;
+    std::condition_variable rq_cv;
+    std::deque<uint32_t> ready;
+
+    std::mutex batch_mu;
+    std::condition_variable batch_cv;   // workers: room in the batch; submission thread: work / writers done
+    Batch batches[2];
+    int filling = 0;
+    bool stop = false;
+
+    std::vector<std::thread> workers;
+    std::thread submitter;
+
+    // submission thread scratch
+    uint8_t *out_pinned = nullptr;
+    size_t out_pinned_cap = 0;
+    std::vector<sk_tick_output> recs;
+
+    std::atomic<uint64_t> n_ticks{0}, n_frames{0}, n_outputs{0}, n_errors{0}, parse_ns{0}, tick_ns{0}, idle_ns{0};
+};
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+uint64_t ns_since(Clock::time_point t0) {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t0).count();
+}
+
+// call with s.mu held
+void maybe_schedule(sk_pipeline *p, PStream &s, uint32_t handle) {
+    if (!s.open || s.busy || s.queued || s.finished || s.cancelled) return;
+    if ((s.in.empty() && !s.more) || s.out.size() >= p->cfg.output_buffer) return;
+    s.queued = true;
+    {
+        std::lock_guard<std::mutex> lk(p->rq_mu);
+        p->ready.push_back(handle);
+    }
+    p->rq_cv.notify_one();
+}
+
+void release_device_side(sk_pipeline *p, PStream &s) {
+    if (s.engine_stream != kNoStream) {
+        (void)sk_stream_close(p->engine, s.engine_stream);  // also drops its resampler
+        s.engine_stream = kNoStream;
+    }
+    if (s.fe) {
+        sk_aac_decoder_destroy(s.fe);
+        s.fe = nullptr;
+    }
+    s.pending.clear();
+    s.pending.shrink_to_fit();
+    s.pending_pos = 0;
+}
+
+struct Parsed {  // what one worker pass produced for one stream
+    uint32_t n_frames = 0;
+    size_t n_floats = 0;
+    bool eof = false, failed = false;
+    int32_t fail_status = 0;
+    std::string fail_msg;
+};
+
+// Pulls ADTS frames out of the stream's byte queue and runs the front-end on them, at most `limit` frames.
+void parse_some(sk_pipeline *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_frame_desc *descs, Parsed &r) {
+    auto fail = [&](int32_t st, const std::string &msg) {
+        r.failed = true;
+        r.fail_status = st;
+        r.fail_msg = msg;
+    };
+    while (r.n_frames < limit && !r.failed) {
+        // make sure a whole frame is in `pending`
+        size_t avail = s.pending.size() - s.pending_pos;
+        size_t frame_len = 0, pay_off = 0, pay_len = 0;
+        uint8_t asc[2];
+        bool have = false;
+        while (avail >= 7) {
+            const uint8_t *d = s.pending.data() + s.pending_pos;
+            if (sk_adts_parse(d, avail, &frame_len, &pay_off, &pay_len, asc) != SK_OK) {  // resynchronise
+                s.pending_pos += 1;
+                avail -= 1;
+                continue;
+            }
+            have = avail >= frame_len;
+            break;
+        }
+        if (!have) {
+            if (s.saw_eof) {  // whatever is left is not a frame: flush_decoder has nothing more to give
+                r.eof = true;
+                break;
+            }
+            std::vector<uint8_t> chunk;
+            bool got = false;
+            {
+                std::lock_guard<std::mutex> lk(s.mu);
+                if (!s.in.empty()) {
+                    chunk = std::move(s.in.front());
+                    s.in.pop_front();
+                    got = true;
+                }
+            }
+            if (!got) break;  // needs more input
+            if (chunk.empty()) {
+                s.saw_eof = true;
+                continue;
+            }
+            s.queued_bytes.fetch_sub(chunk.size());
+            if (s.pending_pos > 0 && s.pending_pos >= s.pending.size() / 2) {  // compact
+                s.pending.erase(s.pending.begin(), s.pending.begin() + (ptrdiff_t)s.pending_pos);
+                s.pending_pos = 0;
+            }
+            s.pending.insert(s.pending.end(), chunk.begin(), chunk.end());
+            continue;
+        }
+        const uint8_t *frame = s.pending.data() + s.pending_pos;
+        if (!s.fe) {  // first header: AacLcDecoder::from_audio_specific_config (lib.rs:1007-1027, decoder.rs:80)
+            int rc = sk_aac_decoder_create(asc, 2, &s.fe);
+            if (rc != SK_OK) {
+                fail(rc, std::string("Decoding failed: AAC-LC decoder init: ") + sk_strerror(rc));
+                break;
+            }
+            s.asc[0] = asc[0];
+            s.asc[1] = asc[1];
+            (void)sk_aac_decoder_info(s.fe, &s.rate, &s.channels);
+            rc = sk_stream_open(p->engine, s.rate, s.channels, &s.engine_stream);
+            if (rc != SK_OK) {
+                fail(rc, std::string("Decoding failed: engine stream: ") + sk_strerror(rc));
+                break;
+            }
+            const uint32_t target = s.opt.output_sample_rate ? s.opt.output_sample_rate : s.rate;
+            s.resample = target != s.rate;
+            if (s.resample) {
+                rc = sk_resampler_open(p->engine, s.engine_stream, s.rate, target);
+                if (rc != SK_OK) {  // StreamingResampler::new failing, lib.rs:3405-3417
+                    fail(rc, "Decoding failed: Failed to create resampler: unsupported rate pair");
+                    break;
+                }
+            }
+        } else if (asc[0] != s.asc[0] || asc[1] != s.asc[1]) {
+            fail(SK_AAC_ERR_UNSUPPORTED_FEATURE, "Decoding failed: AAC configuration changed mid-stream");
+            break;
+        }
+        sk_aac_frame_desc &d = descs[r.n_frames];
+        const int rc = sk_aac_decoder_parse(s.fe, frame + pay_off, pay_len, coeffs + r.n_floats, &d);
+        if (rc != SK_OK) {
+            fail(rc, std::string("Decoding failed: ") + sk_aac_decoder_last_error(s.fe));
+            break;
+        }
+        d.stream = s.engine_stream;
+        s.pending_pos += frame_len;
+        r.n_frames += 1;
+        r.n_floats += (size_t)s.channels * 1024;
+    }
+}
+
+void worker_main(sk_pipeline *p) {
+    const uint32_t per_stream = p->cfg.max_stream_frames_per_tick;
+    std::vector<float> coeffs((size_t)per_stream * 2 * 1024);
+    std::vector<sk_aac_frame_desc> descs(per_stream);
+    for (;;) {
+        uint32_t handle;
+        {
+            std::unique_lock<std::mutex> lk(p->rq_mu);
+            p->rq_cv.wait(lk, [&] { return p->stop || !p->ready.empty(); });
+            if (p->stop) return;
+            handle = p->ready.front();
+            p->ready.pop_front();
+        }
+        PStream &s = *p->streams[handle];
+        uint32_t room;
+        {
+            std::lock_guard<std::mutex> lk(s.mu);
+            s.queued = false;
+            if (!s.open || s.busy || s.finished || s.cancelled) continue;
+            room = s.out.size() < p->cfg.output_buffer ? p->cfg.output_buffer - (uint32_t)s.out.size() : 0;
+            if (room == 0) continue;
+            s.busy = true;
+        }
+        Parsed r;
+        const Clock::time_point t0 = Clock::now();
+        const uint32_t limit = std::min(per_stream, room);
+        parse_some(p, s, limit, coeffs.data(), descs.data(), r);
+        s.more = r.n_frames == limit && !r.eof && !r.failed;
+        p->parse_ns.fetch_add(ns_since(t0));
+        if (r.n_frames == 0 && !r.eof && !r.failed) {  // nothing complete yet
+            bool dropped;
+            {
+                std::lock_guard<std::mutex> lk(s.mu);
+                s.busy = false;
+                dropped = s.cancelled;
+                if (dropped) s.open = false;
+                maybe_schedule(p, s, handle);
+            }
+            if (dropped) {  // the handle was dropped while this worker held the stream
+                release_device_side(p, s);
+                std::lock_guard<std::mutex> lk(p->handles_mu);
+                p->free_handles.push_back(handle);
+            }
+            continue;
+        }
+        // claim room in the batch being filled
+        Batch *b;
+        size_t desc_at, float_at;
+        {
+            std::unique_lock<std::mutex> lk(p->batch_mu);
+            p->batch_cv.wait(lk, [&] {
+                const Batch &f = p->batches[p->filling];
+                return p->stop || (f.descs.size() + r.n_frames <= p->cfg.max_frames_per_tick && f.n_floats + r.n_floats <= f.coeff_cap);
+            });
+            if (p->stop) return;
+            b = &p->batches[p->filling];
+            desc_at = b->descs.size();
+            float_at = b->n_floats;
+            b->descs.resize(desc_at + r.n_frames);
+            b->n_floats += r.n_floats;
+            sk_tick_stream t{};
+            t.stream = s.engine_stream == kNoStream ? 0 : s.engine_stream;
+            t.n_frames = r.n_frames;
+            t.out_bits = s.opt.output_bits_per_sample ? s.opt.output_bits_per_sample : 16;
+            t.out_channels = s.opt.output_channels ? s.opt.output_channels : s.channels;
+            t.resample = s.resample ? 1 : 0;
+            t.flush = (r.eof && s.resample) ? 1 : 0;
+            BatchEntry be;
+            be.handle = handle;
+            be.eof = r.eof;
+            be.failed = r.failed;
+            be.fail_status = r.fail_status;
+            be.fail_msg = std::move(r.fail_msg);
+            if (s.engine_stream == kNoStream) {  // ended before a single header was seen: nothing for the device
+                t.n_frames = 0;
+                t.flush = 0;
+            }
+            b->ts.push_back(t);
+            b->entries.push_back(std::move(be));
+            b->writers += 1;
+        }
+        if (r.n_frames) {
+            std::memcpy(b->descs.data() + desc_at, descs.data(), r.n_frames * sizeof(sk_aac_frame_desc));
+            std::memcpy(b->coeffs + float_at, coeffs.data(), r.n_floats * sizeof(float));
+        }
+        {
+            std::lock_guard<std::mutex> lk(p->batch_mu);
+            b->writers -= 1;
+        }
+        p->batch_cv.notify_all();
+    }
+}
+
+void push_error(PStream &s, int32_t status, const std::string &msg) {
+    Output o;
+    o.is_error = true;
+    o.status = status;
+    o.data.assign(msg.begin(), msg.end());
+    s.out.push_back(std::move(o));
+}
+
+void submit_main(sk_pipeline *p) {
+    for (;;) {
+        Batch *b;
+        {
+            std::unique_lock<std::mutex> lk(p->batch_mu);
+            const Clock::time_point t_idle = Clock::now();
+            p->batch_cv.wait(lk, [&] { return p->stop || !p->batches[p->filling].ts.empty(); });
+            if (p->stop) return;
+            // let the batch fill for a moment unless it is already full
+            const auto deadline = Clock::now() + std::chrono::microseconds(p->cfg.tick_wait_us);
+            p->batch_cv.wait_until(lk, deadline, [&] {
+                return p->stop || p->batches[p->filling].descs.size() + p->cfg.max_stream_frames_per_tick > p->cfg.max_frames_per_tick;
+            });
+            p->batch_cv.wait(lk, [&] { return p->stop || p->batches[p->filling].writers == 0; });
+            if (p->stop) return;
+            p->idle_ns.fetch_add(ns_since(t_idle));
+            b = &p->batches[p->filling];
+            p->filling ^= 1;
+        }
+        p->batch_cv.notify_all();  // room again
+
+        const Clock::time_point t0 = Clock::now();
+        const uint32_t n_streams = (uint32_t)b->ts.size(), n_frames = (uint32_t)b->descs.size();
+        // a stream may have ended without ever reaching the device: its table row must not name a stream twice
+        std::vector<sk_tick_stream> ts;
+        std::vector<uint32_t> row_of;  // tick row -> batch entry
+        ts.reserve(n_streams);
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            PStream &s = *p->streams[b->entries[i].handle];
+            if (s.engine_stream == kNoStream) continue;
+            ts.push_back(b->ts[i]);
+            row_of.push_back(i);
+        }
+        uint32_t max_out = 0, n_out = 0;
+        size_t used = 0;
+        int rc = SK_OK;
+        if (!ts.empty()) {
+            const size_t bound = sk_tick_out_bound(ts.data(), (uint32_t)ts.size(), &max_out);
+            if (bound > p->out_pinned_cap) {
+                if (p->out_pinned) (void)hipHostFree(p->out_pinned);
+                p->out_pinned = nullptr;
+                p->out_pinned_cap = 0;
+                if (hipHostMalloc((void **)&p->out_pinned, bound + bound / 4, hipHostMallocPortable) == hipSuccess)
+                    p->out_pinned_cap = bound + bound / 4;
+                else
+                    rc = SK_ERR_OOM;
+            }
+            if (p->recs.size() < max_out) p->recs.resize(max_out);
+            if (rc == SK_OK)
+                rc = sk_tick_run(p->engine, ts.data(), (uint32_t)ts.size(), b->descs.data(), b->coeffs, n_frames, p->out_pinned,
+                                 p->out_pinned_cap, p->recs.data(), max_out, &n_out, &used);
+        }
+        p->tick_ns.fetch_add(ns_since(t0));
+        p->n_ticks.fetch_add(1);
+        p->n_frames.fetch_add(n_frames);
+
+        // deliver: outputs first (in order), then the end-of-stream / error notes, then the stream is free again
+        uint32_t k = 0;
+        for (uint32_t row = 0; row < ts.size(); ++row) {  // the outputs of a tick row are contiguous in recs
+            const BatchEntry &be = b->entries[row_of[row]];
+            PStream &s = *p->streams[be.handle];
+            std::lock_guard<std::mutex> lk(s.mu);
+            while (rc == SK_OK && k < n_out && p->recs[k].stream_index == row) {
+                const sk_tick_output &r = p->recs[k++];
+                if (s.cancelled) continue;
+                if (r.status != 0) {
+                    push_error(s, r.status, "Decoding failed: invalid AAC config: frame rejected by the synthesis engine");
+                    s.finished = true;
+                    p->n_errors.fetch_add(1);
+                    continue;
+                }
+                Output o;
+                o.rate = s.opt.output_sample_rate ? s.opt.output_sample_rate : s.rate;
+                o.frames = r.frames;
+                o.bits = r.bits;
+                o.channels = r.channels;
+                o.data.assign(p->out_pinned + r.byte_offset, p->out_pinned + r.byte_offset + r.bytes);
+                s.out.push_back(std::move(o));
+                p->n_outputs.fetch_add(1);
+            }
+        }
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            BatchEntry &be = b->entries[i];
+            PStream &s = *p->streams[be.handle];
+            bool release = false;
+            {
+                std::lock_guard<std::mutex> lk(s.mu);
+                if (rc != SK_OK && !s.finished) {
+                    push_error(s, rc, std::string("Decoding failed: engine tick: ") + sk_strerror(rc));
+                    s.finished = true;
+                    p->n_errors.fetch_add(1);
+                } else if (be.failed && !s.finished) {
+                    push_error(s, be.fail_status, be.fail_msg);
+                    s.finished = true;
+                    p->n_errors.fetch_add(1);
+                } else if (be.eof) {
+                    s.finished = true;
+                }
+                s.busy = false;
+                release = s.finished || s.cancelled;
+                if (s.cancelled) {
+                    s.out.clear();
+                    s.in.clear();
+                }
+                if (!release) maybe_schedule(p, s, be.handle);
+                s.cv_out.notify_all();
+            }
+            if (release) {
+                release_device_side(p, s);
+                if (s.cancelled) {  // the handle was dropped while its frames were in flight: free the slot now
+                    {
+                        std::lock_guard<std::mutex> lk(s.mu);
+                        s.open = false;
+                    }
+                    std::lock_guard<std::mutex> lk(p->handles_mu);
+                    p->free_handles.push_back(be.handle);
+                }
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(p->batch_mu);
+            b->clear();
+        }
+        p->batch_cv.notify_all();
+    }
+}
+
+PStream *stream_of(sk_pipeline *p, uint32_t handle) {
+    if (!p || handle >= p->streams.size()) return nullptr;
+    return p->streams[handle].get();
+}
+
+}  // namespace
+
+extern "C" {
+
+int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline **out) {
+    if (!e || !out) return SK_ERR_INVALID_ARG;
+    *out = nullptr;
+    sk_pipeline *p = new (std::nothrow) sk_pipeline();
+    if (!p) return SK_ERR_OOM;
+    p->engine = e;
+    if (cfg) p->cfg = *cfg;
+    if (!p->cfg.entropy_threads) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        p->cfg.entropy_threads = hw > 2 ? hw - 1 : 1;
+    }
+    if (!p->cfg.max_streams) p->cfg.max_streams = 1024;
+    if (!p->cfg.max_frames_per_tick) p->cfg.max_frames_per_tick = 16384;
+    if (!p->cfg.max_stream_frames_per_tick) p->cfg.max_stream_frames_per_tick = 8;
+    if (p->cfg.max_stream_frames_per_tick > p->cfg.max_frames_per_tick) p->cfg.max_stream_frames_per_tick = p->cfg.max_frames_per_tick;
+    if (!p->cfg.input_buffer) p->cfg.input_buffer = 128;   // DEFAULT_INPUT_BUFFER, lib.rs:77
+    if (!p->cfg.output_buffer) p->cfg.output_buffer = 16;  // DEFAULT_OUTPUT_BUFFER, lib.rs:78
+    if (!p->cfg.tick_wait_us) p->cfg.tick_wait_us = 200;
+    if (hipSetDevice(sk_engine_device(e)) != hipSuccess) {
+        delete p;
+        return SK_ERR_NO_DEVICE;
+    }
+    for (Batch &b : p->batches) {
+        b.coeff_cap = (size_t)p->cfg.max_frames_per_tick * 2 * 1024;
+        if (hipHostMalloc((void **)&b.coeffs, b.coeff_cap * sizeof(float), hipHostMallocPortable) != hipSuccess) {
+            for (Batch &x : p->batches)
+                if (x.coeffs) (void)hipHostFree(x.coeffs);
+            delete p;
+            return SK_ERR_OOM;
+        }
+    }
+    p->streams.resize(p->cfg.max_streams);
+    for (uint32_t i = 0; i < p->cfg.max_streams; ++i) {
+        p->streams[i].reset(new PStream());
+        p->free_handles.push_back(p->cfg.max_streams - 1 - i);
+    }
+    for (uint32_t i = 0; i < p->cfg.entropy_threads; ++i) p->workers.emplace_back(worker_main, p);
+    p->submitter = std::thread(submit_main, p);
+    *out = p;
+    return SK_OK;
+}
+
+void sk_pipeline_destroy(sk_pipeline *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> a(p->rq_mu);
+        std::lock_guard<std::mutex> b(p->batch_mu);
+        p->stop = true;
+    }
+    p->rq_cv.notify_all();
+    p->batch_cv.notify_all();
+    for (std::thread &t : p->workers) t.join();
+    if (p->submitter.joinable()) p->submitter.join();
+    for (auto &s : p->streams) release_device_side(p, *s);
+    for (Batch &b : p->batches)
+        if (b.coeffs) (void)hipHostFree(b.coeffs);
+    if (p->out_pinned) (void)hipHostFree(p->out_pinned);
+    delete p;
+}
+
+int sk_pipeline_spawn(sk_pipeline *p, const sk_decode_options *opt, uint32_t *handle) {
+    if (!p || !handle) return SK_ERR_INVALID_ARG;
+    sk_decode_options o{};
+    if (opt) o = *opt;
+    // apply_output_options' argument checks (lib.rs:3360-3376), made when the pipeline is created
+    if (o.output_bits_per_sample && o.output_bits_per_sample != 16 && o.output_bits_per_sample != 24 && o.output_bits_per_sample != 32)
+        return SK_ERR_UNSUPPORTED;
+    uint32_t h;
+    {
+        std::lock_guard<std::mutex> lk(p->handles_mu);
+        if (p->free_handles.empty()) return SK_ERR_CAPACITY;
+        h = p->free_handles.back();
+        p->free_handles.pop_back();
+    }
+    PStream &s = *p->streams[h];
+    std::lock_guard<std::mutex> lk(s.mu);
+    s.open = true;
+    s.busy = s.queued = s.finished = s.cancelled = false;
+    s.in.clear();
+    s.out.clear();
+    s.opt = o;
+    s.queued_bytes.store(0);
+    s.pending.clear();
+    s.pending_pos = 0;
+    s.saw_eof = false;
+    s.more = false;
+    s.rate = 0;
+    s.channels = 0;
+    s.resample = false;
+    *handle = h;
+    return SK_OK;
+}
+
+int sk_pipeline_send(sk_pipeline *p, uint32_t handle, const uint8_t *data, size_t len) {
+    PStream *s = stream_of(p, handle);
+    if (!s || (len && !data)) return SK_ERR_INVALID_ARG;
+    if (len > kMaxInputChunkBytes) return SK_PIPE_CHUNK_TOO_LARGE;  // lib.rs:2796-2798
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->open || s->cancelled) return SK_PIPE_CLOSED;
+    if (s->finished) return SK_PIPE_CLOSED;  // the worker has ended: TrySendError::Disconnected, lib.rs:2827-2833
+    if (len && s->queued_bytes.load() + len > kMaxQueuedInputBytes) return SK_PIPE_INPUT_FULL;  // lib.rs:2800-2811
+    if (s->in.size() >= p->cfg.input_buffer) return SK_PIPE_INPUT_FULL;                         // lib.rs:2820-2826
+    s->in.emplace_back(data, data + len);
+    s->queued_bytes.fetch_add(len);
+    maybe_schedule(p, *s, handle);
+    return SK_OK;
+}
+
+int sk_pipeline_finish(sk_pipeline *p, uint32_t handle) { return sk_pipeline_send(p, handle, nullptr, 0); }  // lib.rs:2838-2840
+
+static int take_output(sk_pipeline *p, PStream &s, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info) {
+    // s.mu held
+    if (s.out.empty()) return s.finished ? SK_PIPE_CLOSED : 0;
+    Output &o = s.out.front();
+    info->sampling_rate = o.rate;
+    info->frames = o.frames;
+    info->bytes = (uint32_t)o.data.size();
+    info->bits_per_sample = o.bits;
+    info->channel_count = o.channels;
+    info->is_error = o.is_error ? 1 : 0;
+    info->reserved = 0;
+    info->status = o.status;
+    if (o.data.size() > cap) return SK_ERR_CAPACITY;
+    if (!o.data.empty()) std::memcpy(data, o.data.data(), o.data.size());
+    s.out.pop_front();
+    maybe_schedule(p, s, handle);
+    return 1;
+}
+
+int sk_pipeline_try_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info) {
+    PStream *s = stream_of(p, handle);
+    if (!s || !info || (cap && !data)) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->open || s->cancelled) return SK_PIPE_CLOSED;
+    return take_output(p, *s, handle, data, cap, info);
+}
+
+int sk_pipeline_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info, uint32_t timeout_ms) {
+    PStream *s = stream_of(p, handle);
+    if (!s || !info || (cap && !data)) return SK_ERR_INVALID_ARG;
+    std::unique_lock<std::mutex> lk(s->mu);
+    if (!s->open || s->cancelled) return SK_PIPE_CLOSED;
+    s->cv_out.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return !s->out.empty() || s->finished || s->cancelled; });
+    if (s->cancelled) return SK_PIPE_CLOSED;
+    return take_output(p, *s, handle, data, cap, info);
+}
+
+int sk_pipeline_cancel(sk_pipeline *p, uint32_t handle) {  // shutdown(), lib.rs:2868-2881: also what Drop does
+    PStream *s = stream_of(p, handle);
+    if (!s) return SK_ERR_INVALID_ARG;
+    bool release_now = false;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (!s->open || s->cancelled) return SK_PIPE_CLOSED;
+        s->cancelled = true;
+        s->in.clear();
+        s->out.clear();
+        s->queued_bytes.store(0);
+        release_now = !s->busy;  // otherwise the submission thread frees it when its batch has been delivered
+        if (release_now) s->open = false;
+        s->cv_out.notify_all();
+    }
+    if (release_now) {
+        release_device_side(p, *s);
+        std::lock_guard<std::mutex> lk(p->handles_mu);
+        p->free_handles.push_back(handle);
+    }
+    return SK_OK;
+}
+
+size_t sk_pipeline_queued_input_bytes(sk_pipeline *p, uint32_t handle) {  // lib.rs:2863-2866
+    PStream *s = stream_of(p, handle);
+    return s ? s->queued_bytes.load() : 0;
+}
+
+int sk_pipeline_get_stats(sk_pipeline *p, sk_pipeline_stats *out) {
+    if (!p || !out) return SK_ERR_INVALID_ARG;
+    out->ticks = p->n_ticks.load();
+    out->frames = p->n_frames.load();
+    out->outputs = p->n_outputs.load();
+    out->errors = p->n_errors.load();
+    out->parse_ns = p->parse_ns.load();
+    out->tick_ns = p->tick_ns.load();
+    out->idle_ns = p->idle_ns.load();
+    out->entropy_threads = p->cfg.entropy_threads;
+    out->reserved = 0;
+    return SK_OK;
+}
+
+}  // extern "C"
