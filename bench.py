@@ -125,17 +125,98 @@ def cpu_baseline_fir(target_s=10.0):
             "sample": "oracle sko_downsample_planar, %d x 1 s of 48 kHz stereo in %.1f s" % (done, dt)}
 
 
+def end_to_end(args, eng, torch, dist, world, rank, device):
+    """SURVEY 8d config 5, scaled: `--streams` ADTS AAC-LC streams (the 48 access units of the reference's 48 kHz
+    stereo TS sample, looped) through the batch scheduler: host entropy decode -> GPU ticks -> 16 kHz mono s16 out.
+    One step = one pass of the clip through every stream.  Everything is inside the timed region: framing, Huffman,
+    H2D, synthesis, resampling, packing, D2H and delivery."""
+    import ctypes as C
+    from soundkit_amd import pipeline, sharding
+    from soundkit_amd._lib import DecodeOptionsC
+    clip = open(os.path.join(ROOT, "tests", "golden", "aac", "aac-stereo-48k.adts"), "rb").read()
+    units = 48
+    lg = C.CDLL(os.path.join(ROOT, "soundkit_amd", "libsk_loadgen.so"))
+
+    class Result(C.Structure):
+        _fields_ = [("seconds", C.c_double)] + [(n, C.c_uint64) for n in ("access_units", "outputs", "pcm_frames", "pcm_bytes", "errors", "input_full")]
+    lg.sk_loadgen_run.restype = C.c_int
+    lg.sk_loadgen_run.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                  C.c_uint32, C.c_void_p]
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    share = max(4, min(cores // world, 16))  # the pool gives a one-GPU job 16 cores
+    threads = args.entropy_threads or max(1, share - 2 - args.feeders)
+    feeders = args.feeders
+    sched = pipeline.BatchScheduler(eng, entropy_threads=threads, max_streams=args.streams, max_frames_per_tick=16384,
+                                    max_stream_frames_per_tick=8)
+    opt = DecodeOptionsC(args.out_rate, 16, args.out_channels, 0)
+
+    def run(loops):
+        res = Result()
+        rc = lg.sk_loadgen_run(sched._h, clip, len(clip), units, args.streams, loops, C.byref(opt), feeders, 0, C.byref(res))
+        if rc != 0 or res.errors:
+            raise SystemExit("load generator failed: rc %d, %d stream errors" % (rc, res.errors))
+        return res
+    if args.warmup:
+        run(args.warmup)
+    before = sched.stats()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = sharding.reduce_elapsed(time.perf_counter() - t0, device)
+    after = sched.stats()
+    sched.close()
+    if rank != 0:
+        return
+    st = {k: after[k] - before[k] for k in ("ticks", "frames", "outputs", "parse_ns", "tick_ns", "idle_ns")}
+    value = world * res.access_units / elapsed
+    out = {
+        "metric": "AAC-LC 1024-sample frames/s (whole node) + xrealtime, end to end through the batch scheduler",
+        "value": value, "unit": "frames/s", "x_realtime": value / 46.875, "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "reference fixture testdata/mpeg-ts/aac-stereo-48k.ts (48 access units), looped",
+        "config": {"workload": "end_to_end: %d ADTS AAC-LC streams x %d access units, 48 kHz stereo -> %s Hz %s s16, host entropy "
+                               "decode on %d threads + GPU ticks" % (args.streams, units * args.steps, args.out_rate or 48000,
+                                                                     "mono" if args.out_channels == 1 else "source-channel", threads),
+                   "streams_per_gpu": args.streams, "entropy_threads": threads, "feeder_threads": feeders, "host_cores": cores,
+                   "parallelism": "streams sharded, %d rank(s), no collective" % world},
+        "scheduler": {"ticks": st["ticks"], "frames_per_tick": st["frames"] / max(st["ticks"], 1),
+                      "entropy_us_per_frame": st["parse_ns"] / max(st["frames"], 1) / 1e3,
+                      "entropy_thread_utilisation": st["parse_ns"] / (elapsed * 1e9 * threads),
+                      "gpu_tick_ms": st["tick_ns"] / max(st["ticks"], 1) / 1e6,
+                      "submission_thread_busy": st["tick_ns"] / (elapsed * 1e9),
+                      "input_full_events": res.input_full, "pcm_bytes_out": res.pcm_bytes},
+        "roofline": None,
+        "note": "host-bound: the entropy threads limit this number; the device-resident rooflines are the default workload's",
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "aac_synth", "fir"])
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "aac_synth", "fir", "end_to_end"])
     ap.add_argument("--streams", type=int, default=4096)
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--layout", default="frame", choices=["frame", "stream"],
                     help="packing of the batch: frame-major [frame][stream] (one tick of every stream after another) or stream-major")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--entropy-threads", type=int, default=0, help="end_to_end: host threads for the AAC front-end (0 = cores - 1, split over ranks)")
+    ap.add_argument("--feeders", type=int, default=2, help="end_to_end: producer/consumer threads of the load generator")
+    ap.add_argument("--out-rate", type=int, default=16000, help="end_to_end: DecodeOptions.output_sample_rate (0 = source rate)")
+    ap.add_argument("--out-channels", type=int, default=1, help="end_to_end: DecodeOptions.output_channels (0 = source)")
     args = ap.parse_args()
 
     import torch
@@ -157,6 +238,13 @@ def main():
     import soundkit_amd
     eng = soundkit_amd.Engine(local_rank, max(args.streams, 16))
     ext = torch.cuda.ExternalStream(eng.hip_stream, device=device)
+
+    if args.workload == "end_to_end":
+        end_to_end(args, eng, torch, dist, world, rank, device)
+        if world > 1:
+            dist.destroy_process_group()
+        eng.close()
+        return
 
     streams, frames, ch = args.streams, args.frames, 2
     kernel_ms = {}

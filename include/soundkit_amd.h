@@ -327,7 +327,7 @@ int sk_tick_run(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, 
  * `entropy_threads` host threads, everything after it in sk_tick_run on the engine's GPU. */
 typedef struct sk_pipeline sk_pipeline;
 typedef struct sk_pipeline_config {
-    uint32_t entropy_threads;            /* 0 = hardware threads - 1 */
+    uint32_t entropy_threads;            /* 0 = usable CPUs (affinity, cgroup quota) - 4, at most 64 */
     uint32_t max_streams;                /* handles open at once; 0 = 1024 (<= the engine's max_streams) */
     uint32_t max_frames_per_tick;        /* access units per GPU tick; 0 = 16384 */
     uint32_t max_stream_frames_per_tick; /* of one stream; 0 = 8 */

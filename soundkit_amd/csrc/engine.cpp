@@ -11,6 +11,8 @@
 
 #include <cmath>
 #include <cstdio>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <map>
@@ -1486,6 +1488,15 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
     if (n_streams == 0) return n_frames == 0 ? SK_OK : SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e->device);
+    static const bool trace = std::getenv("SK_TICK_TRACE") != nullptr;  // per-section host times on stderr
+    using TClock = std::chrono::steady_clock;
+    TClock::time_point t_mark = TClock::now();
+    double t_sec[6] = {0, 0, 0, 0, 0, 0};
+    auto lap = [&](int k) {
+        const TClock::time_point now = TClock::now();
+        t_sec[k] += std::chrono::duration<double, std::milli>(now - t_mark).count();
+        t_mark = now;
+    };
 
     // ---- validate the stream table ----
     std::vector<TickCall> tc(n_streams);
@@ -1525,6 +1536,7 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
                 break;
             }
     }
+    lap(0);
     const size_t elems = (size_t)hp.off1024 * 1024;
     const size_t arena_bytes = ((size_t)16 << 20) + (size_t)n_frames * 512 + (size_t)n_streams * 1024;
     SK_HIP(e->in_buf.reserve(elems * 4 + 16), "alloc tick coeffs");
@@ -1553,6 +1565,7 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
         SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth");
     }
 
+    lap(1);
     // ---- streaming resamplers ----
     std::vector<RsCall> calls;
     std::vector<uint32_t> call_stream;  // RsCall -> index into ts
@@ -1663,6 +1676,7 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
         }
     }
 
+    lap(2);
     // ---- output records and the pack jobs that fill them ----
     std::vector<sk::PackJob> packs;
     uint32_t n_rec = 0, max_pack_frames = 0;
@@ -1732,7 +1746,12 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
         SK_HIP(sk::launch_pack_jobs(d_packs, (uint32_t)packs.size(), max_pack_frames, e->stream), "launch pack");
         SK_HIP(hipMemcpyAsync(out, d_out, cursor, hipMemcpyDeviceToHost, e->stream), "D2H tick output");
     }
+    lap(3);
     SK_HIP(hipStreamSynchronize(e->stream), "tick sync");
+    lap(4);
+    if (trace)
+        std::fprintf(stderr, "sk_tick_run: %u streams %u frames | plan %.2f  h2d+synth %.2f  resample %.2f  pack %.2f  sync %.2f ms\n",
+                     n_streams, n_frames, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4]);
     *n_outs = n_rec;
     if (out_bytes) *out_bytes = cursor;
     return SK_OK;

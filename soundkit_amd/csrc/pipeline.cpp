@@ -17,9 +17,13 @@
 
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -101,7 +105,8 @@ struct sk_pipeline {
     std::deque<uint32_t> ready;
 
     std::mutex batch_mu;
-    std::condition_variable batch_cv;   // workers: room in the batch; submission thread: work / writers done
+    std::condition_variable batch_cv;   // submission thread: work arrived / writers done
+    std::condition_variable room_cv;    // workers: the filling batch has room again
     Batch batches[2];
     int filling = 0;
     bool stop = false;
@@ -300,7 +305,7 @@ void worker_main(sk_pipeline *p) {
         size_t desc_at, float_at;
         {
             std::unique_lock<std::mutex> lk(p->batch_mu);
-            p->batch_cv.wait(lk, [&] {
+            p->room_cv.wait(lk, [&] {
                 const Batch &f = p->batches[p->filling];
                 return p->stop || (f.descs.size() + r.n_frames <= p->cfg.max_frames_per_tick && f.n_floats + r.n_floats <= f.coeff_cap);
             });
@@ -339,7 +344,7 @@ void worker_main(sk_pipeline *p) {
             std::lock_guard<std::mutex> lk(p->batch_mu);
             b->writers -= 1;
         }
-        p->batch_cv.notify_all();
+        p->batch_cv.notify_one();  // only the submission thread waits on it
     }
 }
 
@@ -370,7 +375,7 @@ void submit_main(sk_pipeline *p) {
             b = &p->batches[p->filling];
             p->filling ^= 1;
         }
-        p->batch_cv.notify_all();  // room again
+        p->room_cv.notify_all();  // room again
 
         const Clock::time_point t0 = Clock::now();
         const uint32_t n_streams = (uint32_t)b->ts.size(), n_frames = (uint32_t)b->descs.size();
@@ -474,8 +479,32 @@ void submit_main(sk_pipeline *p) {
             std::lock_guard<std::mutex> lk(p->batch_mu);
             b->clear();
         }
-        p->batch_cv.notify_all();
     }
+}
+
+// CPUs this process may actually use: the affinity mask, cut down by a cgroup v2 / v1 CPU quota when there is one
+unsigned usable_cpus() {
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = (unsigned)CPU_COUNT(&set);
+    double quota = 0.0;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32];
+        long period = 0;
+        if (std::fscanf(f, "%31s %ld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) quota = std::atof(q) / (double)period;
+        std::fclose(f);
+    } else if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        long q = 0, period = 100000;
+        if (std::fscanf(g, "%ld", &q) != 1) q = 0;
+        std::fclose(g);
+        if (FILE *h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (std::fscanf(h, "%ld", &period) != 1) period = 100000;
+            std::fclose(h);
+        }
+        if (q > 0 && period > 0) quota = (double)q / (double)period;
+    }
+    if (quota >= 1.0 && quota < (double)n) n = (unsigned)quota;
+    return n ? n : 1;
 }
 
 PStream *stream_of(sk_pipeline *p, uint32_t handle) {
@@ -495,8 +524,8 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
     p->engine = e;
     if (cfg) p->cfg = *cfg;
     if (!p->cfg.entropy_threads) {
-        const unsigned hw = std::thread::hardware_concurrency();
-        p->cfg.entropy_threads = hw > 2 ? hw - 1 : 1;
+        const unsigned cpus = usable_cpus();  // leave room for the submission thread and the callers' own threads
+        p->cfg.entropy_threads = cpus > 4 ? std::min(cpus - 4, 64u) : 1;
     }
     if (!p->cfg.max_streams) p->cfg.max_streams = 1024;
     if (!p->cfg.max_frames_per_tick) p->cfg.max_frames_per_tick = 16384;
@@ -538,6 +567,7 @@ void sk_pipeline_destroy(sk_pipeline *p) {
     }
     p->rq_cv.notify_all();
     p->batch_cv.notify_all();
+    p->room_cv.notify_all();
     for (std::thread &t : p->workers) t.join();
     if (p->submitter.joinable()) p->submitter.join();
     for (auto &s : p->streams) release_device_side(p, *s);
