@@ -150,7 +150,7 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     except (OSError, ValueError):
         pass
     share = max(4, min(cores // world, 16))  # the pool gives a one-GPU job 16 cores
-    threads = args.entropy_threads or max(1, share - 2 - args.feeders)
+    threads = args.entropy_threads or max(1, share - 3 - args.feeders)
     feeders = args.feeders
     sched = pipeline.BatchScheduler(eng, entropy_threads=threads, max_streams=args.streams, max_frames_per_tick=16384,
                                     max_stream_frames_per_tick=8)
@@ -178,7 +178,7 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     sched.close()
     if rank != 0:
         return
-    st = {k: after[k] - before[k] for k in ("ticks", "frames", "outputs", "parse_ns", "tick_ns", "idle_ns")}
+    st = {k: after[k] - before[k] for k in ("ticks", "frames", "outputs", "parse_ns", "tick_ns", "idle_ns", "deliver_ns")}
     value = world * res.access_units / elapsed
     out = {
         "metric": "AAC-LC 1024-sample frames/s (whole node) + xrealtime, end to end through the batch scheduler",
@@ -195,6 +195,8 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
                       "entropy_thread_utilisation": st["parse_ns"] / (elapsed * 1e9 * threads),
                       "gpu_tick_ms": st["tick_ns"] / max(st["ticks"], 1) / 1e6,
                       "submission_thread_busy": st["tick_ns"] / (elapsed * 1e9),
+                      "delivery_thread_busy": st["deliver_ns"] / (elapsed * 1e9),
+                      "submission_thread_waiting": st["idle_ns"] / (elapsed * 1e9),
                       "input_full_events": res.input_full, "pcm_bytes_out": res.pcm_bytes},
         "roofline": None,
         "note": "host-bound: the entropy threads limit this number; the device-resident rooflines are the default workload's",

@@ -327,7 +327,7 @@ int sk_tick_run(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, 
  * `entropy_threads` host threads, everything after it in sk_tick_run on the engine's GPU. */
 typedef struct sk_pipeline sk_pipeline;
 typedef struct sk_pipeline_config {
-    uint32_t entropy_threads;            /* 0 = usable CPUs (affinity, cgroup quota) - 4, at most 64 */
+    uint32_t entropy_threads;            /* 0 = usable CPUs (affinity, cgroup quota) - 5, at most 64 */
     uint32_t max_streams;                /* handles open at once; 0 = 1024 (<= the engine's max_streams) */
     uint32_t max_frames_per_tick;        /* access units per GPU tick; 0 = 16384 */
     uint32_t max_stream_frames_per_tick; /* of one stream; 0 = 8 */
@@ -359,6 +359,7 @@ typedef struct sk_pipeline_stats {
     uint64_t parse_ns;  /* summed over entropy threads */
     uint64_t tick_ns;   /* submission thread inside sk_tick_run */
     uint64_t idle_ns;   /* submission thread waiting for a batch */
+    uint64_t deliver_ns; /* delivery thread handing outputs to the streams' queues */
     uint32_t entropy_threads, reserved;
 } sk_pipeline_stats;
 

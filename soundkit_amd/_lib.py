@@ -59,7 +59,7 @@ class AudioInfo(C.Structure):
 
 class PipelineStats(C.Structure):
     """sk_pipeline_stats"""
-    _fields_ = [(n, C.c_uint64) for n in ("ticks", "frames", "outputs", "errors", "parse_ns", "tick_ns", "idle_ns")] + [
+    _fields_ = [(n, C.c_uint64) for n in ("ticks", "frames", "outputs", "errors", "parse_ns", "tick_ns", "idle_ns", "deliver_ns")] + [
         ("entropy_threads", C.c_uint32), ("reserved", C.c_uint32)]
 
 

@@ -10,7 +10,8 @@
 //   AAC-LC front-end, csrc/aac_frontend.cpp) -> the tick batch (pinned host memory) -> submission thread:
 //   sk_tick_run (H2D, synthesis, s16, resampler, downmix, pack, D2H) -> per-stream output queues -> try_recv().
 //
-// Two batches alternate: the workers fill one while the GPU runs the other.  A stream contributes at most
+// Three batches rotate: the workers fill one while the GPU runs the second and the delivery thread hands out the
+// results of the third.  A stream contributes at most
 // `max_stream_frames_per_tick` access units to a batch and is not scheduled again until that batch has been
 // delivered, so its frames reach the engine in order and its outputs never overtake each other.
 #include "../../include/soundkit_amd.h"
@@ -83,11 +84,21 @@ struct Batch {
     std::vector<sk_tick_stream> ts;
     std::vector<BatchEntry> entries;
     uint32_t writers = 0;  // claims whose memcpy is still running
+    // the tick's results, handed from the submission thread to the delivery thread
+    uint8_t *out_pinned = nullptr;
+    size_t out_pinned_cap = 0;
+    std::vector<sk_tick_output> recs;
+    std::vector<uint32_t> row_of;  // tick row -> entry
+    uint32_t n_out = 0;
+    int rc = SK_OK;
     void clear() {
         n_floats = 0;
         descs.clear();
         ts.clear();
         entries.clear();
+        row_of.clear();
+        n_out = 0;
+        rc = SK_OK;
     }
 };
 
@@ -107,19 +118,17 @@ struct sk_pipeline {
     std::mutex batch_mu;
     std::condition_variable batch_cv;   // submission thread: work arrived / writers done
     std::condition_variable room_cv;    // workers: the filling batch has room again
-    Batch batches[2];
+    static constexpr int kBatches = 3;  // one filling, one on the GPU, one being delivered
+    Batch batches[kBatches];
     int filling = 0;
+    std::deque<int> free_batches, to_deliver;
+    std::condition_variable deliver_cv;
     bool stop = false;
 
     std::vector<std::thread> workers;
-    std::thread submitter;
+    std::thread submitter, deliverer;
 
-    // submission thread scratch
-    uint8_t *out_pinned = nullptr;
-    size_t out_pinned_cap = 0;
-    std::vector<sk_tick_output> recs;
-
-    std::atomic<uint64_t> n_ticks{0}, n_frames{0}, n_outputs{0}, n_errors{0}, parse_ns{0}, tick_ns{0}, idle_ns{0};
+    std::atomic<uint64_t> n_ticks{0}, n_frames{0}, n_outputs{0}, n_errors{0}, parse_ns{0}, tick_ns{0}, idle_ns{0}, deliver_ns{0};
 };
 
 namespace {
@@ -129,11 +138,17 @@ uint64_t ns_since(Clock::time_point t0) {
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t0).count();
 }
 
+// call with s.mu held: true = the stream has work, is free and is not in the ready queue yet (now marked as queued)
+bool mark_schedulable(sk_pipeline *p, PStream &s) {
+    if (!s.open || s.busy || s.queued || s.finished || s.cancelled) return false;
+    if ((s.in.empty() && !s.more) || s.out.size() >= p->cfg.output_buffer) return false;
+    s.queued = true;
+    return true;
+}
+
 // call with s.mu held
 void maybe_schedule(sk_pipeline *p, PStream &s, uint32_t handle) {
-    if (!s.open || s.busy || s.queued || s.finished || s.cancelled) return;
-    if ((s.in.empty() && !s.more) || s.out.size() >= p->cfg.output_buffer) return;
-    s.queued = true;
+    if (!mark_schedulable(p, s)) return;
     {
         std::lock_guard<std::mutex> lk(p->rq_mu);
         p->ready.push_back(handle);
@@ -357,8 +372,10 @@ void push_error(PStream &s, int32_t status, const std::string &msg) {
 }
 
 void submit_main(sk_pipeline *p) {
+    std::vector<sk_tick_stream> ts;
     for (;;) {
         Batch *b;
+        int index;
         {
             std::unique_lock<std::mutex> lk(p->batch_mu);
             const Clock::time_point t_idle = Clock::now();
@@ -369,57 +386,84 @@ void submit_main(sk_pipeline *p) {
             p->batch_cv.wait_until(lk, deadline, [&] {
                 return p->stop || p->batches[p->filling].descs.size() + p->cfg.max_stream_frames_per_tick > p->cfg.max_frames_per_tick;
             });
-            p->batch_cv.wait(lk, [&] { return p->stop || p->batches[p->filling].writers == 0; });
+            // the workers move on to a free batch while this one runs
+            p->batch_cv.wait(lk, [&] { return p->stop || (p->batches[p->filling].writers == 0 && !p->free_batches.empty()); });
             if (p->stop) return;
             p->idle_ns.fetch_add(ns_since(t_idle));
-            b = &p->batches[p->filling];
-            p->filling ^= 1;
+            index = p->filling;
+            b = &p->batches[index];
+            p->filling = p->free_batches.front();
+            p->free_batches.pop_front();
         }
         p->room_cv.notify_all();  // room again
 
         const Clock::time_point t0 = Clock::now();
         const uint32_t n_streams = (uint32_t)b->ts.size(), n_frames = (uint32_t)b->descs.size();
-        // a stream may have ended without ever reaching the device: its table row must not name a stream twice
-        std::vector<sk_tick_stream> ts;
-        std::vector<uint32_t> row_of;  // tick row -> batch entry
-        ts.reserve(n_streams);
+        // a stream may have ended without ever reaching the device: it gets no row in the tick's table
+        ts.clear();
+        b->row_of.clear();
         for (uint32_t i = 0; i < n_streams; ++i) {
             PStream &s = *p->streams[b->entries[i].handle];
             if (s.engine_stream == kNoStream) continue;
             ts.push_back(b->ts[i]);
-            row_of.push_back(i);
+            b->row_of.push_back(i);
         }
-        uint32_t max_out = 0, n_out = 0;
+        uint32_t max_out = 0;
         size_t used = 0;
-        int rc = SK_OK;
+        b->rc = SK_OK;
+        b->n_out = 0;
         if (!ts.empty()) {
             const size_t bound = sk_tick_out_bound(ts.data(), (uint32_t)ts.size(), &max_out);
-            if (bound > p->out_pinned_cap) {
-                if (p->out_pinned) (void)hipHostFree(p->out_pinned);
-                p->out_pinned = nullptr;
-                p->out_pinned_cap = 0;
-                if (hipHostMalloc((void **)&p->out_pinned, bound + bound / 4, hipHostMallocPortable) == hipSuccess)
-                    p->out_pinned_cap = bound + bound / 4;
+            if (bound > b->out_pinned_cap) {
+                if (b->out_pinned) (void)hipHostFree(b->out_pinned);
+                b->out_pinned = nullptr;
+                b->out_pinned_cap = 0;
+                if (hipHostMalloc((void **)&b->out_pinned, bound + bound / 4, hipHostMallocPortable) == hipSuccess)
+                    b->out_pinned_cap = bound + bound / 4;
                 else
-                    rc = SK_ERR_OOM;
+                    b->rc = SK_ERR_OOM;
             }
-            if (p->recs.size() < max_out) p->recs.resize(max_out);
-            if (rc == SK_OK)
-                rc = sk_tick_run(p->engine, ts.data(), (uint32_t)ts.size(), b->descs.data(), b->coeffs, n_frames, p->out_pinned,
-                                 p->out_pinned_cap, p->recs.data(), max_out, &n_out, &used);
+            if (b->recs.size() < max_out) b->recs.resize(max_out);
+            if (b->rc == SK_OK)
+                b->rc = sk_tick_run(p->engine, ts.data(), (uint32_t)ts.size(), b->descs.data(), b->coeffs, n_frames, b->out_pinned,
+                                    b->out_pinned_cap, b->recs.data(), max_out, &b->n_out, &used);
         }
         p->tick_ns.fetch_add(ns_since(t0));
         p->n_ticks.fetch_add(1);
         p->n_frames.fetch_add(n_frames);
+        {
+            std::lock_guard<std::mutex> lk(p->batch_mu);
+            p->to_deliver.push_back(index);
+        }
+        p->deliver_cv.notify_one();
+    }
+}
 
-        // deliver: outputs first (in order), then the end-of-stream / error notes, then the stream is free again
+// Hands a finished tick's outputs to the streams' queues: outputs first (in order), then the end-of-stream /
+// error notes, then the stream is free to be parsed again.
+void deliver_main(sk_pipeline *p) {
+    std::vector<uint32_t> wake;  // streams that can be parsed again: queued in one go, one wake-up
+    for (;;) {
+        Batch *b;
+        int index;
+        {
+            std::unique_lock<std::mutex> lk(p->batch_mu);
+            p->deliver_cv.wait(lk, [&] { return p->stop || !p->to_deliver.empty(); });
+            if (p->stop) return;
+            index = p->to_deliver.front();
+            p->to_deliver.pop_front();
+            b = &p->batches[index];
+        }
+        const Clock::time_point t_deliver = Clock::now();
+        const uint32_t n_streams = (uint32_t)b->ts.size();
+        const int rc = b->rc;
         uint32_t k = 0;
-        for (uint32_t row = 0; row < ts.size(); ++row) {  // the outputs of a tick row are contiguous in recs
-            const BatchEntry &be = b->entries[row_of[row]];
+        for (uint32_t row = 0; row < b->row_of.size(); ++row) {  // the outputs of a tick row are contiguous in recs
+            const BatchEntry &be = b->entries[b->row_of[row]];
             PStream &s = *p->streams[be.handle];
             std::lock_guard<std::mutex> lk(s.mu);
-            while (rc == SK_OK && k < n_out && p->recs[k].stream_index == row) {
-                const sk_tick_output &r = p->recs[k++];
+            while (rc == SK_OK && k < b->n_out && b->recs[k].stream_index == row) {
+                const sk_tick_output &r = b->recs[k++];
                 if (s.cancelled) continue;
                 if (r.status != 0) {
                     push_error(s, r.status, "Decoding failed: invalid AAC config: frame rejected by the synthesis engine");
@@ -432,11 +476,12 @@ void submit_main(sk_pipeline *p) {
                 o.frames = r.frames;
                 o.bits = r.bits;
                 o.channels = r.channels;
-                o.data.assign(p->out_pinned + r.byte_offset, p->out_pinned + r.byte_offset + r.bytes);
+                o.data.assign(b->out_pinned + r.byte_offset, b->out_pinned + r.byte_offset + r.bytes);
                 s.out.push_back(std::move(o));
                 p->n_outputs.fetch_add(1);
             }
         }
+        wake.clear();
         for (uint32_t i = 0; i < n_streams; ++i) {
             BatchEntry &be = b->entries[i];
             PStream &s = *p->streams[be.handle];
@@ -460,7 +505,7 @@ void submit_main(sk_pipeline *p) {
                     s.out.clear();
                     s.in.clear();
                 }
-                if (!release) maybe_schedule(p, s, be.handle);
+                if (!release && mark_schedulable(p, s)) wake.push_back(be.handle);
                 s.cv_out.notify_all();
             }
             if (release) {
@@ -475,10 +520,20 @@ void submit_main(sk_pipeline *p) {
                 }
             }
         }
+        if (!wake.empty()) {
+            {
+                std::lock_guard<std::mutex> lk(p->rq_mu);
+                p->ready.insert(p->ready.end(), wake.begin(), wake.end());
+            }
+            p->rq_cv.notify_all();
+        }
         {
             std::lock_guard<std::mutex> lk(p->batch_mu);
             b->clear();
+            p->free_batches.push_back(index);
         }
+        p->batch_cv.notify_one();  // the submission thread may be waiting for a free batch
+        p->deliver_ns.fetch_add(ns_since(t_deliver));
     }
 }
 
@@ -524,8 +579,8 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
     p->engine = e;
     if (cfg) p->cfg = *cfg;
     if (!p->cfg.entropy_threads) {
-        const unsigned cpus = usable_cpus();  // leave room for the submission thread and the callers' own threads
-        p->cfg.entropy_threads = cpus > 4 ? std::min(cpus - 4, 64u) : 1;
+        const unsigned cpus = usable_cpus();  // leave room for the submission + delivery threads and the callers' own
+        p->cfg.entropy_threads = cpus > 5 ? std::min(cpus - 5, 64u) : 1;
     }
     if (!p->cfg.max_streams) p->cfg.max_streams = 1024;
     if (!p->cfg.max_frames_per_tick) p->cfg.max_frames_per_tick = 16384;
@@ -552,8 +607,10 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
         p->streams[i].reset(new PStream());
         p->free_handles.push_back(p->cfg.max_streams - 1 - i);
     }
+    for (int i = 1; i < sk_pipeline::kBatches; ++i) p->free_batches.push_back(i);
     for (uint32_t i = 0; i < p->cfg.entropy_threads; ++i) p->workers.emplace_back(worker_main, p);
     p->submitter = std::thread(submit_main, p);
+    p->deliverer = std::thread(deliver_main, p);
     *out = p;
     return SK_OK;
 }
@@ -568,12 +625,15 @@ void sk_pipeline_destroy(sk_pipeline *p) {
     p->rq_cv.notify_all();
     p->batch_cv.notify_all();
     p->room_cv.notify_all();
+    p->deliver_cv.notify_all();
     for (std::thread &t : p->workers) t.join();
     if (p->submitter.joinable()) p->submitter.join();
+    if (p->deliverer.joinable()) p->deliverer.join();
     for (auto &s : p->streams) release_device_side(p, *s);
-    for (Batch &b : p->batches)
+    for (Batch &b : p->batches) {
         if (b.coeffs) (void)hipHostFree(b.coeffs);
-    if (p->out_pinned) (void)hipHostFree(p->out_pinned);
+        if (b.out_pinned) (void)hipHostFree(b.out_pinned);
+    }
     delete p;
 }
 
@@ -701,6 +761,7 @@ int sk_pipeline_get_stats(sk_pipeline *p, sk_pipeline_stats *out) {
     out->parse_ns = p->parse_ns.load();
     out->tick_ns = p->tick_ns.load();
     out->idle_ns = p->idle_ns.load();
+    out->deliver_ns = p->deliver_ns.load();
     out->entropy_threads = p->cfg.entropy_threads;
     out->reserved = 0;
     return SK_OK;
