@@ -64,10 +64,20 @@ struct StreamInfo {
     double rs_last_index = -128.0; // rubato SincFixedIn::last_index (relative to the next chunk's start)
 };
 
+// The time indices of one chunk's outputs in the form the generic kernel takes them (sk_device.h SincArgs): the index
+// of every 128th output; the lanes redo the additions in between.
+struct IndexSet {
+    double last_in = 0.0, new_last = 0.0;  // rubato's last_index before / after the chunk
+    uint32_t count = 0;
+    std::vector<double> starts;
+};
+
 struct RatioTable {
     uint32_t in_hz = 0, out_hz = 0;
     double ratio = 0.0;
     float *d_sincs = nullptr;  // [256][256]
+    // streaming: every stream of this ratio walks the same index sequence from -128, so chunk n's set is shared
+    std::vector<IndexSet> chunk_sets;
 };
 
 // ---- constant tables --------------------------------------------------------------------------
@@ -1047,6 +1057,25 @@ static void chunk_indices(double ratio, double last_index, uint32_t chunk, std::
     *new_last = i - (double)chunk;
 }
 
+static void make_index_set(double ratio, double last_index, uint32_t chunk, IndexSet &set) {
+    std::vector<double> idx;
+    chunk_indices(ratio, last_index, chunk, idx, &set.new_last);
+    set.last_in = last_index;
+    set.count = (uint32_t)idx.size();
+    set.starts.clear();
+    for (size_t k = 0; k < idx.size(); k += 128) set.starts.push_back(idx[k]);
+}
+
+// set of streaming chunk number n of a ratio (memoised: chunk n starts where chunk n - 1 ended)
+static const IndexSet &streaming_set(RatioTable &tab, uint64_t n) {
+    while (tab.chunk_sets.size() <= n) {
+        const double last = tab.chunk_sets.empty() ? -128.0 : tab.chunk_sets.back().new_last;
+        tab.chunk_sets.emplace_back();
+        make_index_set(tab.ratio, last, kRsChunk, tab.chunk_sets.back());
+    }
+    return tab.chunk_sets[(size_t)n];
+}
+
 extern "C" {
 
 uint32_t sk_downsample_out_frames(uint32_t frames, uint32_t in_hz, uint32_t out_hz) {
@@ -1063,10 +1092,9 @@ int sk_downsample_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uin
     if (!common_rate(in_hz) || !common_rate(out_hz)) return SK_ERR_UNSUPPORTED;
     if (in_hz == 48000 && out_hz == 16000)
         return sk_downsample_48k_16k_f32_dev(e, d_in, in_stride, rows, frames, d_out, out_stride, out_frames);
-    std::vector<double> idx;
-    double nl = 0.0;
-    chunk_indices((double)out_hz / (double)in_hz, -128.0, frames, idx, &nl);
-    const uint32_t n_out = (uint32_t)idx.size();
+    IndexSet set;
+    make_index_set((double)out_hz / (double)in_hz, -128.0, frames, set);
+    const uint32_t n_out = set.count;
     if (out_frames) *out_frames = n_out;
     if (rows == 0 || n_out == 0) return SK_OK;
     if (!d_in || !d_out || in_stride < frames || out_stride < n_out) return SK_ERR_INVALID_ARG;
@@ -1075,16 +1103,22 @@ int sk_downsample_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uin
     int table = -1;
     int rc = ratio_table_for(e, in_hz, out_hz, &table);
     if (rc != SK_OK) return rc;
-    SK_HIP(e->aux2_buf.reserve(idx.size() * sizeof(double) + 4096), "alloc index scratch");
-    SK_HIP(hipMemcpyAsync(e->aux2_buf.p, idx.data(), idx.size() * sizeof(double), hipMemcpyHostToDevice, e->stream),
+    const size_t starts_bytes = (set.starts.size() * sizeof(double) + 255) & ~(size_t)255;
+    SK_HIP(e->aux2_buf.reserve(starts_bytes + 4096), "alloc index scratch");
+    SK_HIP(hipMemcpyAsync(e->aux2_buf.p, set.starts.data(), set.starts.size() * sizeof(double), hipMemcpyHostToDevice, e->stream),
            "upload time indices");
+    SK_HIP(hipMemcpyAsync((uint8_t *)e->aux2_buf.p + starts_bytes, &set.count, sizeof(uint32_t), hipMemcpyHostToDevice, e->stream),
+           "upload output count");
     sk::SincArgs a{};
     a.in = d_in;
     a.in_stride = in_stride;
     a.out = d_out;
     a.out_stride = out_stride;
     a.sincs = e->ratio_tables[(size_t)table].d_sincs;
-    a.idx = (const double *)e->aux2_buf.p;
+    a.set_starts = (const double *)e->aux2_buf.p;
+    a.set_count = (const uint32_t *)((const uint8_t *)e->aux2_buf.p + starts_bytes);
+    a.starts_stride = (uint32_t)set.starts.size();
+    a.step = 1.0 / e->ratio_tables[(size_t)table].ratio;
     a.in_frames = frames;
     a.out_count = n_out;
     a.in_origin = 0;
@@ -1095,7 +1129,7 @@ int sk_downsample_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uin
         part.out = d_out + (size_t)r0 * out_stride;
         SK_HIP(sk::launch_sinc_resample(part, e->stream), "launch sinc resample");
     }
-    SK_HIP(hipStreamSynchronize(e->stream), "resample sync");  // idx lives in host memory until the copy is done
+    SK_HIP(hipStreamSynchronize(e->stream), "resample sync");  // the index set lives in host memory until the copy is done
     return SK_OK;
 }
 
@@ -1214,34 +1248,80 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
         const StreamInfo &s = e->streams[calls[ci].id];
         // the integer-step FIR only cares where the chunk's first output sits relative to the chunk (three phases);
         // the generic kernel's f64 index sequence depends on the whole history
+        // the generic kernel takes a time-index set per row, so streams of any age share one launch
         const bool fir = s.rs_in_hz == 48000 && s.rs_out_hz == 16000;
-        groups[Key{s.rs_table, fir ? 0 : s.rs_chunks, s.rs_last_index}].push_back(ci);
+        groups[Key{s.rs_table, 0, fir ? s.rs_last_index : 0.0}].push_back(ci);
     }
-    std::vector<double> idx;
-    std::vector<uint32_t> row_map, out_off;
+    std::vector<double> idx, starts;
+    std::vector<uint32_t> row_map, out_off, row_set, set_count, counts;
+    std::vector<double> new_lasts;
     std::vector<sk::RowCopy> slides;
     for (auto &g : groups) {
-        const RatioTable &tab = e->ratio_tables[(size_t)g.first.table];
-        double new_last = 0.0;
-        chunk_indices(tab.ratio, g.first.last, kRsChunk, idx, &new_last);
-        const uint32_t count = (uint32_t)idx.size();
+        RatioTable &tab = e->ratio_tables[(size_t)g.first.table];
+        const bool fir = tab.in_hz == 48000 && tab.out_hz == 16000;
+        // outputs and next last_index of every call of the group
+        counts.assign(g.second.size(), 0);
+        new_lasts.assign(g.second.size(), 0.0);
+        std::map<uint64_t, uint32_t> local_set;  // generic: chunk number -> set index in this launch
+        std::vector<const IndexSet *> sets;
+        std::vector<IndexSet> odd_sets;          // streams whose state does not sit on the shared walk
+        odd_sets.reserve(g.second.size());
+        uint32_t max_count = 0;
+        if (fir) {
+            double new_last = 0.0;
+            chunk_indices(tab.ratio, g.first.last, kRsChunk, idx, &new_last);
+            for (size_t k = 0; k < g.second.size(); ++k) {
+                counts[k] = (uint32_t)idx.size();
+                new_lasts[k] = new_last;
+            }
+            max_count = (uint32_t)idx.size();
+        }
+        if (!fir) {  // extend the shared walk first: the loop below keeps pointers into it
+            uint64_t deepest = 0;
+            for (size_t ci : g.second) deepest = std::max(deepest, e->streams[calls[ci].id].rs_chunks);
+            (void)streaming_set(tab, deepest);
+        }
         row_map.clear();
         out_off.clear();
-        for (size_t ci : g.second) {
-            RsCall &c = calls[ci];
-            if ((uint64_t)c.produced + count > out_cap) return SK_ERR_INVALID_ARG;
+        row_set.clear();
+        for (size_t k = 0; k < g.second.size(); ++k) {
+            RsCall &c = calls[g.second[k]];
+            uint32_t set_index = 0;
+            if (!fir) {
+                const StreamInfo &st = e->streams[c.id];
+                const IndexSet *set = &streaming_set(tab, st.rs_chunks);
+                if (set->last_in != st.rs_last_index) {
+                    odd_sets.emplace_back();
+                    make_index_set(tab.ratio, st.rs_last_index, kRsChunk, odd_sets.back());
+                    set = &odd_sets.back();
+                    set_index = (uint32_t)sets.size();
+                    sets.push_back(set);
+                } else {
+                    auto it = local_set.find(st.rs_chunks);
+                    if (it == local_set.end()) {
+                        it = local_set.emplace(st.rs_chunks, (uint32_t)sets.size()).first;
+                        sets.push_back(set);
+                    }
+                    set_index = it->second;
+                }
+                counts[k] = set->count;
+                new_lasts[k] = set->new_last;
+                max_count = std::max(max_count, set->count);
+            }
+            if ((uint64_t)c.produced + counts[k] > out_cap) return SK_ERR_INVALID_ARG;
             for (uint32_t ch = 0; ch < c.channels; ++ch) {
                 const uint64_t off = (uint64_t)(c.row0 + ch) * out_stride + c.produced;
                 if (off > 0xffffffffull) return SK_ERR_INVALID_ARG;
                 row_map.push_back(c.id * 2 + ch);
                 out_off.push_back((uint32_t)off);
+                row_set.push_back(set_index);
             }
         }
-        if (count) {
+        if (max_count) {
             const uint32_t *d_map = nullptr, *d_off = nullptr;
             SK_HIP(aux.put(row_map, e->stream, &d_map), "upload row map");
             SK_HIP(aux.put(out_off, e->stream, &d_off), "upload out offsets");
-            if (tab.in_hz == 48000 && tab.out_hz == 16000) {
+            if (fir) {
                 // integer time base: output m sits at index 3m - 125.  Any origin works as long as output
                 // out_first + j reads the row at chunk-relative index idx[0] + 3j (+ kRsHist of history in front)
                 const uint32_t first = 1024;
@@ -1256,29 +1336,45 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
                 a.row_map = d_map;
                 a.out_off = d_off;
                 a.out_first = first;
-                a.out_count = count;
+                a.out_count = max_count;
                 SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch streaming fir");
             } else {
-                const double *d_idx = nullptr;
-                SK_HIP(aux.put(idx, e->stream, &d_idx), "upload time indices");
+                uint32_t stride = 0;
+                for (const IndexSet *set : sets) stride = std::max<uint32_t>(stride, (uint32_t)set->starts.size());
+                starts.assign((size_t)stride * sets.size(), 0.0);
+                set_count.clear();
+                for (size_t i = 0; i < sets.size(); ++i) {
+                    std::copy(sets[i]->starts.begin(), sets[i]->starts.end(), starts.begin() + (ptrdiff_t)(i * stride));
+                    set_count.push_back(sets[i]->count);
+                }
+                const double *d_starts = nullptr;
+                const uint32_t *d_count = nullptr, *d_set = nullptr;
+                SK_HIP(aux.put(starts, e->stream, &d_starts), "upload time indices");
+                SK_HIP(aux.put(set_count, e->stream, &d_count), "upload output counts");
+                SK_HIP(aux.put(row_set, e->stream, &d_set), "upload row sets");
                 sk::SincArgs a{};
                 a.in = e->d_rs;
                 a.in_stride = kRsRow;
                 a.out = d_out;
                 a.out_stride = 0;
                 a.sincs = tab.d_sincs;
-                a.idx = d_idx;
+                a.set_starts = d_starts;
+                a.set_count = d_count;
+                a.row_set = d_set;
+                a.starts_stride = stride;
+                a.step = 1.0 / tab.ratio;
                 a.row_map = d_map;
                 a.out_off = d_off;
                 a.rows = (uint32_t)row_map.size();
                 a.in_frames = kRsRow;
-                a.out_count = count;
-                a.in_origin = -(int32_t)kRsHist;  // idx is relative to the chunk start; the row starts 512 earlier
+                a.out_count = max_count;
+                a.in_origin = -(int32_t)kRsHist;  // indices are relative to the chunk start; the row starts 512 earlier
                 for (uint32_t r0 = 0; r0 < a.rows; r0 += 65535) {  // grid.y limit
                     sk::SincArgs part = a;
                     part.rows = std::min<uint32_t>(65535, a.rows - r0);
                     part.row_map = d_map + r0;
                     part.out_off = d_off + r0;
+                    part.row_set = d_set + r0;
                     SK_HIP(sk::launch_sinc_resample(part, e->stream), "launch sinc resample");
                 }
             }
@@ -1291,13 +1387,13 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
         for (size_t j0 = 0; j0 < slides.size(); j0 += 65535)
             SK_HIP(sk::launch_row_copies(e->d_rs, e->d_rs, d_slides + j0, (uint32_t)std::min<size_t>(65535, slides.size() - j0),
                                          e->stream), "slide resampler history");
-        for (size_t ci : g.second) {
-            RsCall &c = calls[ci];
+        for (size_t k = 0; k < g.second.size(); ++k) {
+            RsCall &c = calls[g.second[k]];
             StreamInfo &s = e->streams[c.id];
             s.rs_chunks += 1;
-            s.rs_last_index = new_last;
+            s.rs_last_index = new_lasts[k];
             s.rs_fill = 0;
-            c.produced += count;
+            c.produced += counts[k];
         }
     }
     return SK_OK;

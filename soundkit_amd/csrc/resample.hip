@@ -26,10 +26,21 @@ __global__ __launch_bounds__(kOutPerBlock) void k_sinc_resample(SincArgs a) {
     const uint32_t phys = a.row_map ? a.row_map[row] : row;
     const float *src = a.in + (size_t)phys * a.in_stride;
 
+    // this lane's time index: the set gives the index of the block's first output, the rest is rubato's own
+    // sequence of additions (f64 addition is not associative, so no shortcut)
+    __shared__ double sidx[kOutPerBlock];
+    const uint32_t set = a.row_set ? a.row_set[row] : 0;
+    const uint32_t count = a.set_count[set];
+    if (m0 >= count) return;  // block-uniform
+    double idx = a.set_starts[(size_t)set * a.starts_stride + blockIdx.x];
+    for (uint32_t i = 0; i < threadIdx.x; ++i) idx += a.step;
+    sidx[threadIdx.x] = idx;
+    __syncthreads();
+
     // input window of this block: from floor(idx[m0]) to floor(idx[last]) + 257
-    const uint32_t m_last = min(m0 + kOutPerBlock, a.out_count) - 1;
-    const long base = (long)floor(a.idx[m0]);
-    const long need = (long)floor(a.idx[m_last]) + 257 - base + 1;
+    const uint32_t m_last = min(m0 + kOutPerBlock, count) - 1;
+    const long base = (long)floor(sidx[0]);
+    const long need = (long)floor(sidx[m_last - m0]) + 257 - base + 1;
     const bool staged = need <= kSpan;
     if (staged) {
         for (int i = threadIdx.x; i < (int)need; i += kOutPerBlock) {
@@ -38,9 +49,8 @@ __global__ __launch_bounds__(kOutPerBlock) void k_sinc_resample(SincArgs a) {
         }
     }
     __syncthreads();
-    if (m >= a.out_count) return;
+    if (m >= count) return;
 
-    const double idx = a.idx[m];
     const double fl = floor(idx);
     long index0 = (long)fl;
     long sub0 = (long)floor((idx - fl) * 256.0);

@@ -92,12 +92,20 @@ struct SincArgs {
     const float *in;          // [phys rows][in_stride]
     float *out;               // [rows][out_stride]
     const float *sincs;       // [256][256] sub-filter table of this ratio
-    const double *idx;        // [out_count] time index of every output, relative to in_origin
+    // Time indices: rubato advances an f64 index by `step` before every output.  Rows may sit at different points of
+    // that walk (streams of different ages), so indices come as "sets": set s holds the index of every 128th output
+    // (starts[s * starts_stride + b] = index of output 128 b) and its output count; a lane reproduces the additions
+    // in between.  row_set picks the set of a row (null: set 0 for every row).
+    const double *set_starts;
+    const uint32_t *set_count;
+    const uint32_t *row_set;
+    uint32_t starts_stride;
+    double step;
     const uint32_t *row_map;  // optional, as FirArgs
     const uint32_t *out_off;  // optional, as FirArgs
     size_t in_stride, out_stride;
-    uint32_t rows, in_frames, out_count;
-    int32_t in_origin;        // sample index of in[r][0] in the idx time base (history rows: negative)
+    uint32_t rows, in_frames, out_count;  // out_count: the largest count among the sets in use
+    int32_t in_origin;        // sample index of in[r][0] in the index time base (history rows: negative)
 };
 hipError_t launch_sinc_resample(const SincArgs &a, hipStream_t s);
 

@@ -198,6 +198,39 @@ def test_streaming_batch_of_streams_one_call(engine, oracle):
         engine.close_stream(sid)
 
 
+@pytest.mark.parametrize("in_hz,out_hz", [(44100, 16000), (8000, 48000), (48000, 16000)])
+def test_streams_of_different_ages_share_a_launch(engine, oracle, in_hz, out_hz):
+    """The scheduler's case: the same ratio, but every stream is a different number of chunks into its walk of the
+    f64 time index (non-integer steps never realign).  One call serves them all; each equals its own resampler."""
+    rng = np.random.default_rng(in_hz + out_hz)
+    n = 9
+    sids = [engine.open_stream(in_hz, 1) for _ in range(n)]
+    refs = [oracle.StreamingResampler(in_hz, out_hz, 1) for _ in range(n)]
+    for sid in sids:
+        engine.resampler_open(sid, in_hz, out_hz)
+    for k in range(n):  # stream k starts k chunks (and a bit) ahead
+        if k == 0:
+            continue
+        pre = rng.uniform(-1, 1, (1, 4096 * k + 100 * k)).astype(np.float32)
+        a = engine.resampler_process([sids[k]], pre[None], 1)[0]
+        b = refs[k].process(pre)
+        assert a.shape == b.shape
+    for frames in (4096, 9000, 1234):
+        data = rng.uniform(-1, 1, (n, 1, frames)).astype(np.float32)
+        outs = engine.resampler_process(sids, data, 1)
+        for k in range(n):
+            want = refs[k].process(data[k])
+            assert outs[k].shape == want.shape, (k, frames, outs[k].shape, want.shape)
+            if want.size:
+                assert rel_rms(outs[k], want) < 1e-6 and np.abs(outs[k] - want).max() < 4e-6
+    outs = engine.resampler_flush(sids, 1)
+    for k in range(n):
+        want = refs[k].flush()
+        assert outs[k].shape == want.shape and rel_rms(outs[k], want) < 1e-6
+    for sid in sids:
+        engine.close_stream(sid)
+
+
 def test_full_size_dc_gain_and_linearity(engine, oracle):
     """Config-3 scale on the device (4096 streams x 2 ch x 1 s): DC gain = sum(taps), linear, and a
     spot-checked row equals the oracle."""
