@@ -215,6 +215,7 @@ def main():
     ap.add_argument("--layout", default="frame", choices=["frame", "stream"],
                     help="packing of the batch: frame-major [frame][stream] (one tick of every stream after another) or stream-major")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-s16", action="store_true", help="pipeline: run the s16 conversion as its own kernel instead of the FIR epilogue")
     ap.add_argument("--entropy-threads", type=int, default=0, help="end_to_end: host threads for the AAC front-end (0 = cores - 1, split over ranks)")
     ap.add_argument("--feeders", type=int, default=2, help="end_to_end: producer/consumer threads of the load generator")
     ap.add_argument("--out-rate", type=int, default=16000, help="end_to_end: DecodeOptions.output_sample_rate (0 = source rate)")
@@ -284,18 +285,28 @@ def main():
                 stream_stride, frame_stride = frames * ch * 1024, ch * 1024
             n_out = eng.downsample_out_frames(frames * 1024)
             out_stride = (n_out + 3) // 4 * 4
-            fir_out = torch.empty((streams * ch, out_stride), device=device)
-            s16_out = torch.empty((streams, n_out, ch), dtype=torch.int16, device=device)
             fmt_s16 = soundkit_amd.engine.FMT_S16LE
+            if args.separate_s16:
+                fir_out = torch.empty((streams * ch, out_stride), device=device)
+                s16_out = torch.empty((streams, n_out, ch), dtype=torch.int16, device=device)
 
-            def step():
-                timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
-                timed("k_fir_48k_16k", lambda: eng.downsample_48k_16k_frames_dev(pcm, stream_stride, frame_stride, ch,
-                                                                                 streams, frames, fir_out, out_stride))
-                timed("k_f32_planar_stereo_to_s16le_batch",
-                      lambda: eng.f32_planar_to_bytes_batch_dev(fmt_s16, fir_out, streams, out_stride, n_out, ch, s16_out))
+                def step():
+                    timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
+                    timed("k_fir_48k_16k", lambda: eng.downsample_48k_16k_frames_dev(pcm, stream_stride, frame_stride, ch,
+                                                                                     streams, frames, fir_out, out_stride))
+                    timed("k_f32_planar_stereo_to_s16le_batch",
+                          lambda: eng.f32_planar_to_bytes_batch_dev(fmt_s16, fir_out, streams, out_stride, n_out, ch, s16_out))
+            else:  # the s16 output stage runs in the FIR's epilogue (same bytes, tests/test_pipeline_gpu.py)
+                s16_stride = (n_out + 7) // 8 * 8
+                s16_out = torch.empty((streams, s16_stride, ch), dtype=torch.int16, device=device)
+
+                def step():
+                    timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
+                    timed("k_fir_48k_16k", lambda: eng.downsample_48k_16k_frames_s16_dev(pcm, stream_stride, frame_stride, ch,
+                                                                                         streams, frames, s16_out, s16_stride))
             workload = ("aac_lc decode tail: %d streams x %d frames, 48 kHz stereo: IMDCT+window+OLA -> 48k->16k MFMA FIR -> "
-                        "interleaved s16, %s-major batch" % (streams, frames, args.layout))
+                        "interleaved s16 (%s), %s-major batch" % (streams, frames, "separate kernel" if args.separate_s16 else
+                                                                  "in the FIR epilogue", args.layout))
         else:
             def step():
                 timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))

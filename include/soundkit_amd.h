@@ -273,6 +273,13 @@ int sk_downsample_48k_16k_frames_dev(sk_engine *, const float *d_pcm, size_t str
                                      uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream, float *d_out,
                                      size_t out_stride, uint32_t *out_frames);
 
+/* The same with the worker's 16-bit output stage (f32_channels_to_bytes, lib.rs:3619-3647: float_sample_to_i16) fused
+ * into the FIR's epilogue: d_out[s][m][c] interleaved s16, out_stride frames per stream.  Bit-identical to
+ * sk_downsample_48k_16k_frames_dev followed by sk_pcm_f32_planar_to_bytes_batch_dev(SK_FMT_S16LE). */
+int sk_downsample_48k_16k_frames_s16_dev(sk_engine *, const float *d_pcm, size_t stream_stride, size_t frame_stride,
+                                         uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream,
+                                         int16_t *d_out, size_t out_stride, uint32_t *out_frames);
+
 /* StreamingResampler (soundkit-decoder lib.rs:1917-2060), any pair of COMMON_SAMPLE_RATES, fixed 4096-frame
  * chunks, history kept per stream on the device.  in: n_streams x channels x frames planar
  * (stream-major); out: capacity out_cap frames per channel row; out_frames[s] receives the

@@ -159,6 +159,7 @@ _sig = {
     "sk_downsample_out_frames": (_u32, [_u32, _u32, _u32]),
     "sk_downsample_f32": (_i, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _u32, C.POINTER(_u32)]),
     "sk_downsample_f32_dev": (_i, [_vp, _vp, _sz, _u32, _u32, _u32, _u32, _vp, _sz, C.POINTER(_u32)]),
+    "sk_downsample_48k_16k_frames_s16_dev": (_i, [_vp, _vp, _sz, _sz, _u32, _u32, _u32, _vp, _sz, C.POINTER(_u32)]),
     "sk_resampler_open": (_i, [_vp, _u32, _u32, _u32]),
     "sk_resampler_close": (_i, [_vp, _u32]),
     "sk_resampler_process_f32": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp]),

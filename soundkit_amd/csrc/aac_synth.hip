@@ -484,12 +484,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
 // planar f32 [ch][1024] -> interleaved i16 [1024][ch] with float_sample_to_i16
 // (soundkit-decoder/src/lib.rs:1793-1827): non-finite -> 0, clamp +-1, f64 scale by 32768
 // (negative) or 32767, round half away from zero, clamp.
-__device__ __forceinline__ int16_t float_sample_to_i16(float s) {
-    float f = (isfinite(s)) ? fminf(fmaxf(s, -1.0f), 1.0f) : 0.0f;
-    double scaled = f < 0.0f ? (double)f * 32768.0 : (double)f * 32767.0;
-    int r = (int)round(scaled);
-    r = r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
-    return (int16_t)r;
+__device__ __forceinline__ int16_t float_sample_to_i16(float s) {  // f64-free exact form, sk_device.h
+    return (int16_t)dev_float_sample_to_i16_f32(s);
 }
 
 __global__ __launch_bounds__(256) void k_frames_to_s16(const float *planar, int16_t *out, const FrameSpan *frames,

@@ -984,6 +984,40 @@ int sk_downsample_48k_16k_frames_dev(sk_engine *e, const float *d_pcm, size_t st
     return SK_OK;
 }
 
+int sk_downsample_48k_16k_frames_s16_dev(sk_engine *e, const float *d_pcm, size_t stream_stride, size_t frame_stride,
+                                         uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream, int16_t *d_out,
+                                         size_t out_stride, uint32_t *out_frames) {
+    if (!e || channels < 1 || channels > SK_MAX_CHANNELS) return SK_ERR_INVALID_ARG;
+    const uint64_t samples = (uint64_t)frames_per_stream * SK_AAC_FRAME_LEN;
+    if (samples > 0xfffffffcull) return SK_ERR_INVALID_ARG;
+    const uint32_t n_out = sk_downsample_48k_16k_out_frames((uint32_t)samples);
+    if (out_frames) *out_frames = n_out;
+    if (n_streams == 0 || n_out == 0) return SK_OK;
+    if (!d_pcm || !d_out || out_stride < n_out || frame_stride < (size_t)channels * SK_AAC_FRAME_LEN)
+        return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    sk::FirArgs a = fir_base(e);
+    a.in = d_pcm;
+    a.out = nullptr;
+    a.out16 = d_out;
+    a.out16_stride = out_stride;
+    a.out16_ch = channels;
+    a.in_stride = 0;
+    a.out_stride = 0;
+    a.in_block = SK_AAC_FRAME_LEN;
+    a.in_ch = channels;
+    a.in_block_stride = frame_stride;
+    a.in_group_stride = stream_stride;
+    a.rows = n_streams * channels;
+    a.in_frames = (uint32_t)samples;
+    a.in_origin = 0;
+    a.out_first = 0;
+    a.out_count = n_out;
+    SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch fir (frame-packed input, s16 output)");
+    return SK_OK;
+}
+
 int sk_downsample_48k_16k_f32(sk_engine *e, const float *in, uint32_t rows, uint32_t frames, float *out,
                               uint32_t *out_frames) {
     if (!e) return SK_ERR_INVALID_ARG;

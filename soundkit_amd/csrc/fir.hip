@@ -106,7 +106,8 @@ __device__ __forceinline__ void wait_vm_older_than(int younger) {
     }
 }
 
-template <bool ALIGNED, bool PACKED>
+// OUT16: 0 = f32 rows out; 1 / 2 = the worker's 16-bit output stage fused (mono rows / stereo row pairs interleaved)
+template <bool ALIGNED, bool PACKED, int OUT16>
 __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total_blocks, uint32_t blocks_per_seg,
                                                        uint32_t n_segs, int out_vec) {
     __shared__ float ring[kRingDwords];
@@ -147,8 +148,13 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
     int stores_since_stage = 0;  // wave-uniform
 
     const uint32_t out_row = row0 + j;
-    float *out_ptr = a.out + (size_t)(out_row < a.rows ? out_row : 0) * a.out_stride +
-                     ((a.out_off && out_row < a.rows) ? a.out_off[out_row] : 0);
+    constexpr bool to_s16 = OUT16 != 0;
+    float *out_ptr = to_s16 ? nullptr
+                            : a.out + (size_t)(out_row < a.rows ? out_row : 0) * a.out_stride +
+                                  ((a.out_off && out_row < a.rows) ? a.out_off[out_row] : 0);
+    // s16: the lane of a stream's first channel writes the interleaved frames of all its channels
+    int16_t *out16_ptr = to_s16 ? a.out16 + (size_t)((out_row < a.rows ? out_row : 0) / (OUT16 ? OUT16 : 1)) * a.out16_stride * OUT16
+                                : nullptr;
     const int lane_base = ring_addr(j, 4 * kq);  // + slot and group offsets per read
     auto read_group = [&](int G) {
         return *reinterpret_cast<const f32x4 *>(&ring[lane_base + ((G >> 3) & 1) * 8 * kBlockStride + 16 * (G & 7)]);
@@ -162,6 +168,10 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
     auto period = [&](auto ptag, int32_t A) __attribute__((always_inline)) {
         constexpr int p = decltype(ptag)::value;
         acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};  // block A starts in this period
+        // s16 output: block A-6 completes in group 0; its four values are converted one per MFMA step of group 1
+        // and packed / stored after group 2, so the VALU work sits between MFMAs instead of stalling the pipe
+        f32x4 pending = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int q[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int gi = 0; gi < 3; ++gi) {
             const int Gn = 3 * A + gi + 1;  // the group after the one computed now
@@ -184,21 +194,61 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
                         acc[(p - b + 7) % 7] =
                             __builtin_amdgcn_mfma_f32_16x16x4f32(af[12 * b + u], xb[t], acc[(p - b + 7) % 7], 0, 0, 0);
                 }
+                if (to_s16 && gi == 1) q[t] = dev_float_sample_to_i16_f32(pending[t]);
             }
+            const int32_t blk = A - 6;  // complete after its step 75 (= u 3 of this period)
+            const uint32_t m = (uint32_t)blk * 16 + 4 * kq;  // relative to out_first
             if (gi == 0) {
-                // block A-6 is complete after its step 75 (= u 3 of this period)
-                const int32_t blk = A - 6;
-                const f32x4 done = acc[(p + 1) % 7];
-                if (blk >= a_begin && blk < a_end) {  // wave-uniform
+                pending = acc[(p + 1) % 7];
+                if (!to_s16 && blk >= a_begin && blk < a_end) {  // wave-uniform
                     if (out_vec) ++stores_since_stage;
                     if (out_row < a.rows) {
-                        const uint32_t m = (uint32_t)blk * 16 + 4 * kq;  // relative to out_first
                         if (out_vec && m + 3 < a.out_count) {
-                            *reinterpret_cast<f32x4 *>(out_ptr + m) = done;
+                            *reinterpret_cast<f32x4 *>(out_ptr + m) = pending;
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (m + r < a.out_count) out_ptr[m + r] = done[r];
+                                if (m + r < a.out_count) out_ptr[m + r] = pending[r];
+                        }
+                    }
+                }
+            }
+            if (to_s16 && gi == 2) {
+                const uint32_t mine01 = ((uint32_t)q[0] & 0xffffu) | ((uint32_t)q[1] << 16);
+                const uint32_t mine23 = ((uint32_t)q[2] & 0xffffu) | ((uint32_t)q[3] << 16);
+                if (OUT16 == 2) {
+                    // the neighbouring row's lane (lane ^ 1) holds the other channel: two packed dwords cross by DPP
+                    // quad_perm [1,0,3,2], no LDS round trip in the middle of the MFMA stream
+                    const uint32_t other01 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine01, 0xB1, 0xF, 0xF, true);
+                    const uint32_t other23 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine23, 0xB1, 0xF, 0xF, true);
+                    uint32_t w[4];  // frame m + r: L in the low half, R in the high half
+                    w[0] = (mine01 & 0xffffu) | (other01 << 16);
+                    w[1] = (mine01 >> 16) | (other01 & 0xffff0000u);
+                    w[2] = (mine23 & 0xffffu) | (other23 << 16);
+                    w[3] = (mine23 >> 16) | (other23 & 0xffff0000u);
+                    if (blk >= a_begin && blk < a_end) {  // wave-uniform
+                        if (out_vec) ++stores_since_stage;
+                        if ((j & 1) == 0 && out_row < a.rows) {
+                            uint32_t *dst = reinterpret_cast<uint32_t *>(out16_ptr) + m;
+                            if (out_vec && m + 3 < a.out_count) {
+                                *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (m + r < a.out_count) dst[r] = w[r];
+                            }
+                        }
+                    }
+                } else if (blk >= a_begin && blk < a_end) {  // wave-uniform
+                    if (out_vec) ++stores_since_stage;
+                    if (out_row < a.rows) {
+                        int16_t *dst = out16_ptr + m;
+                        if (out_vec && m + 3 < a.out_count) {
+                            *reinterpret_cast<uint2 *>(dst) = make_uint2(mine01, mine23);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (m + r < a.out_count) dst[r] = (int16_t)q[r];
                         }
                     }
                 }
@@ -239,18 +289,25 @@ hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s) {
                                        : (a.in_stride % 4 == 0);
     const bool aligned = (((t0 - a.in_origin) & 3) == 0) && strides_ok && (a.in_frames % 4 == 0) &&
                          (((uintptr_t)a.in & 15) == 0);
-    const int out_vec = (a.out_stride % 4 == 0) && (((uintptr_t)a.out & 15) == 0) && a.out_off == nullptr;
+    if (a.out16 && (a.out16_ch < 1 || a.out16_ch > 2 || a.out_off || a.rows % a.out16_ch)) return hipErrorInvalidValue;
+    const int out_vec = a.out16 ? ((a.out16_stride * a.out16_ch) % 8 == 0 && (((uintptr_t)a.out16 & 15) == 0))
+                                : ((a.out_stride % 4 == 0) && (((uintptr_t)a.out & 15) == 0) && a.out_off == nullptr);
     const dim3 grid(groups * n_segs), block(64);
     const bool packed = a.in_block != 0;
     if (packed && (a.in_block != 1024 || a.in_ch < 1 || a.in_ch > 2)) return hipErrorInvalidValue;
-    if (aligned && packed)
-        hipLaunchKernelGGL((k_fir_48k_16k<true, true>), grid, block, 0, s, a, total_blocks, blocks_per_seg, n_segs, out_vec);
-    else if (aligned)
-        hipLaunchKernelGGL((k_fir_48k_16k<true, false>), grid, block, 0, s, a, total_blocks, blocks_per_seg, n_segs, out_vec);
-    else if (packed)
-        hipLaunchKernelGGL((k_fir_48k_16k<false, true>), grid, block, 0, s, a, total_blocks, blocks_per_seg, n_segs, out_vec);
-    else
-        hipLaunchKernelGGL((k_fir_48k_16k<false, false>), grid, block, 0, s, a, total_blocks, blocks_per_seg, n_segs, out_vec);
+#define SK_FIR_LAUNCH(AL, PK, O16) \
+    hipLaunchKernelGGL((k_fir_48k_16k<AL, PK, O16>), grid, block, 0, s, a, total_blocks, blocks_per_seg, n_segs, out_vec)
+    if (a.out16) {  // the fused 16-bit output exists for the frame-packed input of the synthesis kernel
+        if (!packed) return hipErrorInvalidValue;
+        if (aligned && a.out16_ch == 2) SK_FIR_LAUNCH(true, true, 2);
+        else if (aligned) SK_FIR_LAUNCH(true, true, 1);
+        else if (a.out16_ch == 2) SK_FIR_LAUNCH(false, true, 2);
+        else SK_FIR_LAUNCH(false, true, 1);
+    } else if (aligned && packed) SK_FIR_LAUNCH(true, true, 0);
+    else if (aligned) SK_FIR_LAUNCH(true, false, 0);
+    else if (packed) SK_FIR_LAUNCH(false, true, 0);
+    else SK_FIR_LAUNCH(false, false, 0);
+#undef SK_FIR_LAUNCH
     return hipGetLastError();
 }
 

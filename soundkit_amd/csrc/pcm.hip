@@ -38,12 +38,8 @@ __device__ __forceinline__ int sext24(uint32_t v) { return (int)(((v & 0xffffffu
 __device__ __forceinline__ int sext16(uint32_t v) { return (int)(short)(unsigned short)v; }
 __device__ __forceinline__ uint32_t be24(uint32_t v) { return ((v & 0xff) << 16) | (v & 0xff00) | ((v >> 16) & 0xff); }
 
-__device__ __forceinline__ int float_sample_to_i16(float s) {  // soundkit-decoder lib.rs:1815-1827
-    const float f = isfinite(s) ? clamp1(s) : 0.0f;
-    const double scaled = f < 0.0f ? (double)f * 32768.0 : (double)f * 32767.0;
-    int r = (int)round(scaled);
-    return r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
-}
+// soundkit-decoder lib.rs:1815-1827; the f64-free exact form of sk_device.h (exhaustively equal, tools/check_f32_rounding.c)
+__device__ __forceinline__ int float_sample_to_i16(float s) { return dev_float_sample_to_i16_f32(s); }
 __device__ __forceinline__ int mp3_f32_to_i16(float s) {  // soundkit-mp3 lib.rs:376-385
     const float scaled = roundf(s * 32767.0f);
     if (scaled > 32767.0f) return 32767;

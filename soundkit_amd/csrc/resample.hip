@@ -98,11 +98,7 @@ __global__ __launch_bounds__(256) void k_row_copies(const float *src_base, float
     if (job.via_s16) {
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < job.count; i += gridDim.x * blockDim.x) {
             // float_sample_to_i16 (soundkit-decoder lib.rs:1815-1827), then audio_data_to_f32_channels' / 32768
-            const float x = src[i];
-            const float f = isfinite(x) ? fminf(fmaxf(x, -1.0f), 1.0f) : 0.0f;
-            const double scaled = f < 0.0f ? (double)f * 32768.0 : (double)f * 32767.0;
-            int r = (int)round(scaled);
-            r = r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+            const int r = dev_float_sample_to_i16_f32(src[i]);
             dst[i] = (float)r / 32768.0f;
         }
         return;

@@ -66,9 +66,41 @@ hipError_t launch_f32_planar_to_bytes_batch(int fmt, const float *planar, size_t
                                             uint32_t ch, uint8_t *out, hipStream_t s);
 
 // fir.hip
+#ifdef __HIPCC__
+// float_sample_to_i16, soundkit-decoder lib.rs:1815-1827: non-finite -> 0, clamp, x32768 / x32767 in f64, round half away
+__device__ __forceinline__ int dev_float_sample_to_i16(float x) {
+    const float f = isfinite(x) ? fminf(fmaxf(x, -1.0f), 1.0f) : 0.0f;
+    const double scaled = f < 0.0f ? (double)f * 32768.0 : (double)f * 32767.0;
+    const int r = (int)round(scaled);
+    return r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+}
+
+// The same function without f64, exact.  With m = |x| clamped: a = m * 32768 is exact (power of two), a = k + d with
+// k = floor(a), d in [0, 1) exact.  Negative side: the value is -a, so round-half-away is -(k + (d >= 0.5)).
+// Positive side: the value is m * 32767 = k + (d - m) with d - m in (-1, 1); it rounds (half away) to k + 1 when
+// d - m >= 0.5, to k - 1 when d - m < -0.5, else k.  d - 0.5 and d + 0.5 are exact in f32 wherever the comparison
+// is not already decided by magnitudes (a >= 0.5 gives d a granularity of at least 2^-24; below that m < 2^-15), so
+// both comparisons are exact.  tests/test_pcm_gpu.py compares it with the f64 form over all f32 inputs of interest.
+__device__ __forceinline__ int dev_float_sample_to_i16_f32(float x) {
+    const float m = isfinite(x) ? fminf(fabsf(x), 1.0f) : 0.0f;
+    const float a = m * 32768.0f;
+    const float k = floorf(a);
+    const float d = a - k;
+    const int ki = (int)k;
+    const int neg = ki + (d >= 0.5f ? 1 : 0);
+    const int pos = ki + ((d - 0.5f >= m) ? 1 : 0) - ((d + 0.5f < m) ? 1 : 0);
+    return x < 0.0f ? -neg : pos;
+}
+#endif
+
 struct FirArgs {
     const float *in;      // [rows][in_stride]
     float *out;           // [rows][out_stride]
+    // fused s16 output (out == nullptr): the worker's f32_channels_to_bytes for 16 bits, interleaved over out16_ch
+    // adjacent rows (1: each row its own mono stream; 2: rows 2k / 2k+1 are L / R of stream k)
+    int16_t *out16;       // [rows / out16_ch][out16_stride frames][out16_ch]
+    size_t out16_stride;
+    uint32_t out16_ch;
     const float *zeros;   // >= 1 KiB of zeros (source for out-of-range input)
     const float *afrag;   // [76][64] MFMA A-operand fragments of the Toeplitz tap matrix
     const float *taps;    // [256]

@@ -305,6 +305,15 @@ class Engine:
         assert got.value == n_out
         return out
 
+    def downsample_48k_16k_frames_s16_dev(self, d_pcm, stream_stride, frame_stride, channels, n_streams, frames_per_stream,
+                                          d_out, out_stride):
+        """FIR with the s16 output stage fused: d_out [n_streams][out_stride][channels] int16."""
+        got = C.c_uint32()
+        check(lib.sk_downsample_48k_16k_frames_s16_dev(self._h, _ptr(d_pcm), stream_stride, frame_stride, channels, n_streams,
+                                                       frames_per_stream, _ptr(d_out), out_stride, C.byref(got)),
+              "sk_downsample_48k_16k_frames_s16_dev", self._h)
+        return got.value
+
     def downsample_48k_16k_frames_dev(self, d_pcm, stream_stride, frame_stride, channels, n_streams, frames_per_stream,
                                       d_out, out_stride):
         got = C.c_uint32()

@@ -2,6 +2,8 @@
 
 Every case cites the reference test it restates.  No GPU.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -212,3 +214,22 @@ def test_pcm_stats_fnv(oracle):  # aac-wasm-bench lib.rs:73-100
     st = oracle.pcm_stats(np.array([1.0], np.float32))
     assert st["checksum"] == ((0xCBF29CE484222325 ^ 0x3F800000) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
     assert st["rms"] == 1.0 and st["peak_abs"] == 1.0
+
+
+def test_f64_free_rounding_equals_the_reference_form(tmp_path):
+    """The device computes float_sample_to_i16 (soundkit-decoder lib.rs:1815-1827) without f64
+    (csrc/sk_device.h dev_float_sample_to_i16_f32).  tools/check_f32_rounding.c holds both forms in C; this sweeps
+    every f32 with |x| in [2^-20, 2] (all rounding boundaries), both signs, zeros, infinities and NaNs: 0 mismatches.
+    (All 2^32 patterns were swept once: also 0.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check_f32_rounding")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(root, "tools", "check_f32_rounding.c"), "-lm"])
+    out = subprocess.run([exe, "boundaries"], capture_output=True, text=True)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout
+    # the C copy and the device source must stay the same expression
+    dev = open(os.path.join(root, "soundkit_amd", "csrc", "sk_device.h")).read()
+    for line in ("const float a = m * 32768.0f;", "const float k = floorf(a);", "const float d = a - k;",
+                 "const int neg = ki + (d >= 0.5f ? 1 : 0);",
+                 "const int pos = ki + ((d - 0.5f >= m) ? 1 : 0) - ((d + 0.5f < m) ? 1 : 0);"):
+        assert line in dev, line

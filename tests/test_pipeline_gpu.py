@@ -68,3 +68,28 @@ def test_synth_fir_s16_chain_matches_oracle(engine, oracle, layout, ch):
     plan.destroy()
     for sid in sids:
         engine.close_stream(int(sid))
+
+
+@pytest.mark.parametrize("ch,n_streams,n_frames,stride_pad", [(2, 37, 5, 0), (1, 21, 3, 0), (2, 16, 2, 3), (1, 33, 4, 5)])
+def test_fused_s16_epilogue_equals_fir_then_convert(engine, ch, n_streams, n_frames, stride_pad):
+    """sk_downsample_48k_16k_frames_s16_dev = the FIR followed by f32_channels_to_bytes(16): same bytes, one kernel
+    (aligned strides take the vector stores, odd ones the scalar tail; amplitudes go past +-1 to hit the clamp)."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(7 + ch)
+    pcm = (torch.rand((n_streams, n_frames, ch, 1024), generator=g, device="cuda") * 2 - 1) * 1.3
+    pcm[0, 0, 0, :8] = torch.tensor([float("nan"), float("inf"), -float("inf"), 1.0, -1.0, 0.5 / 32767, -0.5 / 32768, 0.0])
+    n_out = engine.downsample_out_frames(n_frames * 1024)
+    f_stride = (n_out + 3) // 4 * 4
+    d_fir = torch.zeros((n_streams * ch, f_stride), device="cuda")
+    sep = torch.zeros((n_streams, n_out, ch), dtype=torch.int16, device="cuda")
+    o_stride = (n_out + 7) // 8 * 8 + stride_pad
+    fused = torch.zeros((n_streams, o_stride, ch), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    stream_stride, frame_stride = n_frames * ch * 1024, ch * 1024
+    engine.downsample_48k_16k_frames_dev(pcm, stream_stride, frame_stride, ch, n_streams, n_frames, d_fir, f_stride)
+    engine.f32_planar_to_bytes_batch_dev(soundkit_amd.engine.FMT_S16LE, d_fir, n_streams, f_stride, n_out, ch, sep)
+    got = engine.downsample_48k_16k_frames_s16_dev(pcm, stream_stride, frame_stride, ch, n_streams, n_frames, fused, o_stride)
+    engine.synchronize()
+    assert got == n_out
+    assert torch.equal(fused[:, :n_out], sep)
+    assert not fused[:, n_out:].any()  # nothing written past the end
