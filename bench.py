@@ -379,7 +379,8 @@ def main():
             rl["k_fir_48k_16k"] = {
                 "kernel": "k_fir_48k_16k", "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12,
                 "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                "traffic": pmc_traffic("fir" if args.workload == "fir" else "fir_pipeline", rows=streams * ch, frames=fir_in),
+                "traffic": pmc_traffic("fir" if args.workload == "fir" else ("fir_pipeline" if args.separate_s16 else "fir_pipeline_s16"),
+                                       rows=streams * ch, frames=fir_in),
                 "avg_launch_ms": ms}
         if "k_f32_planar_stereo_to_s16le_batch" in per_kernel:
             ms = per_kernel["k_f32_planar_stereo_to_s16le_batch"]

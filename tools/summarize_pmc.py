@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Reduce the rocprofv3 CSVs of tools/profile_bench.sh to the small files kept under profiles/:
+<tag>_kernel_stats.csv (the --stats table) and <tag>_pmc.json (per-kernel per-launch counter means, with the
+HBM bytes computed as MI355X_MICROARCH.md prescribes for gfx950: 2 * FETCH_SIZE KB + WRITE_SIZE KB)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def find(root, pattern):
+    hits = glob.glob(os.path.join(root, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    for key in ("k_aac_synth", "k_fir_48k_16k", "k_f32_planar_stereo_to_s16le_batch", "k_pack_jobs", "k_sinc_resample"):
+        if key in name:
+            return key
+    return name
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "gpurun_out", "profiles_" + tag)
+    os.makedirs(prof, exist_ok=True)
+    stats = find(os.path.join(out, "stats"), "*kernel_stats.csv")
+    if stats:
+        shutil.copy(stats, os.path.join(prof, tag + "_kernel_stats.csv"))
+    summary = {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        path = find(os.path.join(out, sub), "*counter_collection.csv")
+        if not path:
+            continue
+        acc = {}
+        for row in csv.DictReader(open(path)):
+            k = short(row["Kernel_Name"])
+            if not k.startswith("k_"):
+                continue
+            e = acc.setdefault(k, {})
+            c = e.setdefault(row["Counter_Name"], {"sum": 0.0, "ids": set()})
+            c["sum"] += float(row["Counter_Value"])
+            c["ids"].add(row["Dispatch_Id"])
+            e.setdefault("_ns", {})[row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            e["_meta"] = {m: row[m] for m in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Grid_Size",
+                                              "Workgroup_Size", "Scratch_Size") if m in row}
+        for k, e in acc.items():
+            s = summary.setdefault(k, {"counters": {}})
+            for name, c in e.items():
+                if name.startswith("_"):
+                    continue
+                s["counters"][name] = c["sum"] / max(len(c["ids"]), 1)
+            s["meta"] = e["_meta"]
+            s.setdefault("avg_ns_profiled", {})[sub] = sum(e["_ns"].values()) / max(len(e["_ns"]), 1)
+    for k, s in summary.items():
+        c = s["counters"]
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            s["hbm_read_bytes"] = 2.0 * c["FETCH_SIZE"] * 1024.0
+            s["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024.0
+            s["traffic_bytes"] = s["hbm_read_bytes"] + s["hbm_write_bytes"]
+    bench = os.path.join(out, "bench_stats.json")
+    if os.path.exists(bench):
+        try:
+            summary["_bench_line_under_profiler"] = json.loads(open(bench).read().strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            pass
+    json.dump(summary, open(os.path.join(prof, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: {"traffic_GB": round(v.get("traffic_bytes", 0) / 1e9, 3), "ns": v.get("avg_ns_profiled")}
+                      for k, v in summary.items() if k.startswith("k_")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
