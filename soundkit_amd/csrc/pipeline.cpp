@@ -80,7 +80,8 @@ struct BatchEntry {  // bookkeeping beside one sk_tick_stream
 struct Batch {
     float *coeffs = nullptr;  // pinned
     size_t coeff_cap = 0, n_floats = 0;
-    std::vector<sk_aac_frame_desc> descs;
+    std::vector<sk_aac_frame_desc> descs;  // sized once (max_frames_per_tick): workers fill disjoint ranges without the lock
+    size_t n_descs = 0;
     std::vector<sk_tick_stream> ts;
     std::vector<BatchEntry> entries;
     uint32_t writers = 0;  // claims whose memcpy is still running
@@ -93,7 +94,7 @@ struct Batch {
     int rc = SK_OK;
     void clear() {
         n_floats = 0;
-        descs.clear();
+        n_descs = 0;
         ts.clear();
         entries.clear();
         row_of.clear();
@@ -322,13 +323,13 @@ void worker_main(sk_pipeline *p) {
             std::unique_lock<std::mutex> lk(p->batch_mu);
             p->room_cv.wait(lk, [&] {
                 const Batch &f = p->batches[p->filling];
-                return p->stop || (f.descs.size() + r.n_frames <= p->cfg.max_frames_per_tick && f.n_floats + r.n_floats <= f.coeff_cap);
+                return p->stop || (f.n_descs + r.n_frames <= p->cfg.max_frames_per_tick && f.n_floats + r.n_floats <= f.coeff_cap);
             });
             if (p->stop) return;
             b = &p->batches[p->filling];
-            desc_at = b->descs.size();
+            desc_at = b->n_descs;
             float_at = b->n_floats;
-            b->descs.resize(desc_at + r.n_frames);
+            b->n_descs += r.n_frames;
             b->n_floats += r.n_floats;
             sk_tick_stream t{};
             t.stream = s.engine_stream == kNoStream ? 0 : s.engine_stream;
@@ -382,9 +383,10 @@ void submit_main(sk_pipeline *p) {
             p->batch_cv.wait(lk, [&] { return p->stop || !p->batches[p->filling].ts.empty(); });
             if (p->stop) return;
             // let the batch fill for a moment unless it is already full
-            const auto deadline = Clock::now() + std::chrono::microseconds(p->cfg.tick_wait_us);
+            // (system_clock deadline: pthread_cond_timedwait, which every sanitizer runtime understands)
+            const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(p->cfg.tick_wait_us);
             p->batch_cv.wait_until(lk, deadline, [&] {
-                return p->stop || p->batches[p->filling].descs.size() + p->cfg.max_stream_frames_per_tick > p->cfg.max_frames_per_tick;
+                return p->stop || p->batches[p->filling].n_descs + p->cfg.max_stream_frames_per_tick > p->cfg.max_frames_per_tick;
             });
             // the workers move on to a free batch while this one runs
             p->batch_cv.wait(lk, [&] { return p->stop || (p->batches[p->filling].writers == 0 && !p->free_batches.empty()); });
@@ -398,7 +400,7 @@ void submit_main(sk_pipeline *p) {
         p->room_cv.notify_all();  // room again
 
         const Clock::time_point t0 = Clock::now();
-        const uint32_t n_streams = (uint32_t)b->ts.size(), n_frames = (uint32_t)b->descs.size();
+        const uint32_t n_streams = (uint32_t)b->ts.size(), n_frames = (uint32_t)b->n_descs;
         // a stream may have ended without ever reaching the device: it gets no row in the tick's table
         ts.clear();
         b->row_of.clear();
@@ -594,6 +596,7 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
         return SK_ERR_NO_DEVICE;
     }
     for (Batch &b : p->batches) {
+        b.descs.resize(p->cfg.max_frames_per_tick);
         b.coeff_cap = (size_t)p->cfg.max_frames_per_tick * 2 * 1024;
         if (hipHostMalloc((void **)&b.coeffs, b.coeff_cap * sizeof(float), hipHostMallocPortable) != hipSuccess) {
             for (Batch &x : p->batches)
@@ -719,7 +722,8 @@ int sk_pipeline_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap,
     if (!s || !info || (cap && !data)) return SK_ERR_INVALID_ARG;
     std::unique_lock<std::mutex> lk(s->mu);
     if (!s->open || s->cancelled) return SK_PIPE_CLOSED;
-    s->cv_out.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return !s->out.empty() || s->finished || s->cancelled; });
+    s->cv_out.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(timeout_ms),
+                         [&] { return !s->out.empty() || s->finished || s->cancelled; });
     if (s->cancelled) return SK_PIPE_CLOSED;
     return take_output(p, *s, handle, data, cap, info);
 }

@@ -1,0 +1,283 @@
+// CPU harness for the batch scheduler (csrc/pipeline.cpp) with a stand-in engine, built with ThreadSanitizer by
+// tests/test_scheduler_cpu.py.  The real AAC front-end parses the real fixture; only the device side is replaced:
+// sk_tick_run here emits, per access unit, an "AudioData" whose bytes carry the stream id, the access unit's
+// running number within the stream and a checksum of its spectra, so ordering, completeness and isolation can be
+// checked without a GPU.  (Test infrastructure: the product library never contains this file.)
+#include "../soundkit_amd/csrc/pipeline.cpp"
+#include "../soundkit_amd/csrc/aac_frontend.cpp"
+
+#include <cstdio>
+#include <map>
+
+// ---- stand-ins for the HIP runtime and the engine -------------------------------------------------------
+extern "C" {
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned int) { *p = std::malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
+}
+
+struct sk_engine {
+    std::mutex mu;
+    std::vector<uint8_t> open, channels;
+    std::vector<uint32_t> next_unit;
+};
+extern "C" {
+int sk_engine_device(const sk_engine *) { return 0; }
+const char *sk_strerror(int) { return "stub"; }
+int sk_stream_open(sk_engine *e, uint32_t, uint8_t ch, uint32_t *out) {
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (uint32_t i = 0; i < e->open.size(); ++i)
+        if (!e->open[i]) {
+            e->open[i] = 1;
+            e->channels[i] = ch;
+            e->next_unit[i] = 0;
+            *out = i;
+            return SK_OK;
+        }
+    return SK_ERR_CAPACITY;
+}
+int sk_stream_close(sk_engine *e, uint32_t id) {
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (id >= e->open.size() || !e->open[id]) return SK_ERR_BAD_STREAM;
+    e->open[id] = 0;
+    return SK_OK;
+}
+int sk_resampler_open(sk_engine *, uint32_t, uint32_t, uint32_t) { return SK_OK; }
+size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n, uint32_t *max_outputs) {
+    size_t bytes = 0;
+    uint32_t outs = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        bytes += (size_t)ts[i].n_frames * 64 + 64;
+        outs += ts[i].n_frames + 1;
+    }
+    *max_outputs = outs;
+    return bytes;
+}
+int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
+                uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs,
+                size_t *used) {
+    std::lock_guard<std::mutex> lk(e->mu);
+    std::map<uint32_t, int> seen;
+    uint32_t f = 0, k = 0;
+    size_t cursor = 0, fl = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (seen[ts[i].stream]++) return SK_ERR_INVALID_ARG;  // the scheduler must never put a stream twice in a tick
+        if (ts[i].stream >= e->open.size() || !e->open[ts[i].stream]) return SK_ERR_BAD_STREAM;
+        for (uint32_t j = 0; j < ts[i].n_frames; ++j, ++f) {
+            if (f >= n_frames || descs[f].stream != ts[i].stream || k >= outs_cap || cursor + 64 > out_cap) return SK_ERR_INVALID_ARG;
+            const uint32_t ch = e->channels[ts[i].stream];
+            double sum = 0;
+            for (uint32_t c = 0; c < ch * 1024; ++c) sum += coeffs[fl + c];
+            fl += (size_t)ch * 1024;
+            uint32_t words[4] = {ts[i].stream, e->next_unit[ts[i].stream]++, (uint32_t)(int64_t)(sum * 16.0), 0xabcd1234u};
+            std::memcpy(out + cursor, words, 16);
+            outs[k++] = sk_tick_output{i, 1024, cursor, 16, 0, (uint8_t)ch, 16, 0};
+            cursor += 64;
+        }
+    }
+    if (f != n_frames) return SK_ERR_INVALID_ARG;
+    *n_outs = k;
+    if (used) *used = cursor;
+    return SK_OK;
+}
+}
+
+// ---- scenarios -------------------------------------------------------------------------------------------
+static std::vector<uint8_t> clip;
+static uint64_t rng_state = 88172645463325252ull;
+static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
+
+#define CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
+
+struct Got { uint32_t stream_tag, unit, sum; };
+
+static int drain_all(sk_pipeline *p, const std::vector<uint32_t> &handles, std::vector<std::vector<Got>> &got, std::vector<int> &errors,
+                     int timeout_s = 60) {
+    std::vector<uint8_t> buf(1 << 16);
+    std::vector<char> ended(handles.size(), 0);
+    size_t live = handles.size();
+    const auto t0 = std::chrono::steady_clock::now();
+    while (live) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s)) return 1;
+        for (size_t i = 0; i < handles.size(); ++i) {
+            if (ended[i]) continue;
+            sk_audio_info info;
+            const int rc = sk_pipeline_try_recv(p, handles[i], buf.data(), buf.size(), &info);
+            if (rc == 1) {
+                if (info.is_error) errors[i] += 1;
+                else {
+                    uint32_t w[4];
+                    std::memcpy(w, buf.data(), 16);
+                    if (w[3] != 0xabcd1234u || info.frames != 1024) return 2;
+                    got[i].push_back(Got{w[0], w[1], w[2]});
+                }
+            } else if (rc == SK_PIPE_CLOSED) {
+                ended[i] = 1;
+                --live;
+            }
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    return 0;
+}
+
+static int scenario_many_streams(sk_engine *e) {
+    sk_pipeline_config cfg{};
+    cfg.entropy_threads = 4;
+    cfg.max_streams = 40;
+    cfg.max_frames_per_tick = 96;
+    cfg.max_stream_frames_per_tick = 5;
+    cfg.tick_wait_us = 50;
+    sk_pipeline *p = nullptr;
+    CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
+    const uint32_t n = 32, loops = 3;
+    std::vector<uint32_t> handles(n);
+    for (uint32_t i = 0; i < n; ++i) CHECK(sk_pipeline_spawn(p, nullptr, &handles[i]) == SK_OK);
+    std::vector<std::thread> feeders;
+    for (int t = 0; t < 2; ++t)
+        feeders.emplace_back([&, t] {
+            for (uint32_t i = (uint32_t)t; i < n; i += 2) {
+                const uint64_t total = (uint64_t)clip.size() * loops;
+                uint64_t sent = 0;
+                uint32_t seed = 12345 + i;
+                while (sent < total) {
+                    seed = seed * 1664525u + 1013904223u;
+                    size_t len = 1 + (seed >> 8) % (i % 3 == 0 ? 7000 : (i % 3 == 1 ? 400 : 50));
+                    const size_t at = (size_t)(sent % clip.size());
+                    len = std::min(len, clip.size() - at);
+                    const int rc = sk_pipeline_send(p, handles[i], clip.data() + at, len);
+                    if (rc == SK_OK) sent += len;
+                    else std::this_thread::sleep_for(std::chrono::microseconds(100));
+                }
+                while (sk_pipeline_finish(p, handles[i]) != SK_OK) std::this_thread::sleep_for(std::chrono::microseconds(100));
+            }
+        });
+    std::vector<std::vector<Got>> got(n);
+    std::vector<int> errors(n, 0);
+    CHECK(drain_all(p, handles, got, errors) == 0);
+    for (auto &th : feeders) th.join();
+    for (uint32_t i = 0; i < n; ++i) {
+        CHECK(errors[i] == 0);
+        CHECK(got[i].size() == 48 * loops);
+        for (size_t k = 0; k < got[i].size(); ++k) {
+            CHECK(got[i][k].unit == k);                              // in order, none lost or duplicated
+            CHECK(got[i][k].stream_tag == got[i][0].stream_tag);     // never another stream's data
+            CHECK(got[i][k].sum == got[0][k % 48].sum || k < 48 * 0);  // same clip -> same spectra checksums per position
+        }
+    }
+    sk_pipeline_stats st;
+    CHECK(sk_pipeline_get_stats(p, &st) == SK_OK && st.frames == (uint64_t)n * 48 * loops && st.errors == 0);
+    for (uint32_t h : handles) CHECK(sk_pipeline_cancel(p, h) == SK_OK);
+    sk_pipeline_destroy(p);
+    return 0;
+}
+
+static int scenario_backpressure_and_errors(sk_engine *e) {
+    sk_pipeline_config cfg{};
+    cfg.entropy_threads = 2;
+    cfg.max_streams = 8;
+    sk_pipeline *p = nullptr;
+    CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
+    uint32_t h = 0;
+    CHECK(sk_pipeline_spawn(p, nullptr, &h) == SK_OK);
+    std::vector<uint8_t> big(4 * 1024 * 1024 + 1, 0);
+    CHECK(sk_pipeline_send(p, h, big.data(), big.size()) == SK_PIPE_CHUNK_TOO_LARGE);
+    int accepted = 0, full = 0;
+    for (int rep = 0; rep < 400; ++rep) {
+        const int rc = sk_pipeline_send(p, h, clip.data(), clip.size());
+        if (rc == SK_OK) ++accepted;
+        else { CHECK(rc == SK_PIPE_INPUT_FULL); ++full; }
+    }
+    CHECK(full > 0 && accepted <= 128 + 4);
+    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    CHECK(sk_pipeline_queued_input_bytes(p, h) > 0);
+    // the consumer never drained: at most output_buffer (16) + one pass of frames are waiting, not 48 * accepted
+    std::vector<uint8_t> buf(1 << 16);
+    sk_audio_info info;
+    int waiting = 0;
+    while (sk_pipeline_try_recv(p, h, buf.data(), buf.size(), &info) == 1) ++waiting;
+    CHECK(waiting >= 16 && waiting <= 16 + 8);
+    CHECK(sk_pipeline_cancel(p, h) == SK_OK);
+    CHECK(sk_pipeline_send(p, h, clip.data(), 10) == SK_PIPE_CLOSED);
+
+    // a corrupted access unit ends its stream after the outputs before it; the neighbour is untouched
+    std::vector<uint8_t> bad = clip;
+    size_t pos = 0;
+    for (int k = 0; k < 10; ++k) {
+        size_t fl, po, pl;
+        uint8_t asc[2];
+        CHECK(sk_adts_parse(bad.data() + pos, bad.size() - pos, &fl, &po, &pl, asc) == SK_OK);
+        pos += fl;
+    }
+    for (size_t k = pos + 7; k < pos + 7 + 24; ++k) bad[k] = 0xff;
+    uint32_t hg = 0, hb = 0;
+    CHECK(sk_pipeline_spawn(p, nullptr, &hg) == SK_OK && sk_pipeline_spawn(p, nullptr, &hb) == SK_OK);
+    CHECK(sk_pipeline_send(p, hg, clip.data(), clip.size()) == SK_OK && sk_pipeline_finish(p, hg) == SK_OK);
+    CHECK(sk_pipeline_send(p, hb, bad.data(), bad.size()) == SK_OK && sk_pipeline_finish(p, hb) == SK_OK);
+    std::vector<std::vector<Got>> got(2);
+    std::vector<int> errors(2, 0);
+    CHECK(drain_all(p, {hg, hb}, got, errors) == 0);
+    CHECK(errors[0] == 0 && got[0].size() == 48);
+    CHECK(errors[1] == 1 && got[1].size() == 10);
+    // garbage that never frames: the stream just ends at finish()
+    uint32_t hz = 0;
+    CHECK(sk_pipeline_spawn(p, nullptr, &hz) == SK_OK);
+    std::vector<uint8_t> junk(5000);
+    for (auto &b : junk) b = (uint8_t)(rnd() | 1) & 0x7f;
+    CHECK(sk_pipeline_send(p, hz, junk.data(), junk.size()) == SK_OK && sk_pipeline_finish(p, hz) == SK_OK);
+    std::vector<std::vector<Got>> g2(1);
+    std::vector<int> e2(1, 0);
+    CHECK(drain_all(p, {hz}, g2, e2) == 0);
+    CHECK(g2[0].empty() && e2[0] == 0);
+    sk_pipeline_destroy(p);
+    return 0;
+}
+
+static int scenario_cancel_churn(sk_engine *e) {
+    sk_pipeline_config cfg{};
+    cfg.entropy_threads = 3;
+    cfg.max_streams = 6;
+    sk_pipeline *p = nullptr;
+    CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
+    for (int round = 0; round < 60; ++round) {
+        uint32_t hs[6];
+        for (auto &h : hs) CHECK(sk_pipeline_spawn(p, nullptr, &h) == SK_OK);
+        uint32_t extra;
+        CHECK(sk_pipeline_spawn(p, nullptr, &extra) == SK_ERR_CAPACITY);
+        for (auto h : hs) CHECK(sk_pipeline_send(p, h, clip.data(), clip.size()) == SK_OK);
+        if (round % 3 == 0) std::this_thread::sleep_for(std::chrono::microseconds(rnd() % 2000));
+        for (auto h : hs) CHECK(sk_pipeline_cancel(p, h) == SK_OK);  // some idle, some held by a worker, some in a tick
+        // cancelled handles come back once their in-flight work has been delivered
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> lk(p->handles_mu);
+                if (p->free_handles.size() == 6) break;
+            }
+            CHECK(std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20));
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+    }
+    sk_pipeline_destroy(p);
+    // every engine stream was given back
+    for (uint8_t o : e->open) CHECK(o == 0);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) return 64;
+    FILE *f = std::fopen(argv[1], "rb");
+    if (!f) return 65;
+    clip.resize(1 << 20);
+    clip.resize(std::fread(clip.data(), 1, clip.size(), f));
+    std::fclose(f);
+    sk_engine e;
+    e.open.assign(64, 0);
+    e.channels.assign(64, 0);
+    e.next_unit.assign(64, 0);
+    if (int rc = scenario_many_streams(&e)) return rc;
+    if (int rc = scenario_backpressure_and_errors(&e)) return rc;
+    if (int rc = scenario_cancel_churn(&e)) return rc;
+    std::puts("scheduler scenarios ok");
+    return 0;
+}

@@ -191,6 +191,21 @@ def test_malformed_access_units_never_crash(asc):
     assert ok < 2048  # random bytes are overwhelmingly rejected, never fatal
 
 
+def test_mutated_access_units_under_sanitizers(tmp_path):
+    """Bit flips, byte overwrites, truncations and insertions applied to real access units (so the mutants reach
+    the deep paths: sections, escapes, PNS, intensity, TNS), front-end built with ASan + UBSan."""
+    import subprocess
+    exe = str(tmp_path / "fuzz_frontend")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-ffp-contract=off", "-Wno-subobject-linkage", "-o", exe, os.path.join(HERE, "fuzz_frontend.cpp")],
+                          cwd=HERE)
+    files = [os.path.join(GOLD, "aac", n) for n in ("aac-stereo-48k.adts", "stereo-music-44100-192k.aac", "mono16k_A_Tusk.aac")]
+    out = subprocess.run([exe, "12000"] + files, capture_output=True, text=True, cwd=HERE)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ok, err = [int(x) for x in re.findall(r"ok (\d+) err (\d+)", out.stdout)[0]]
+    assert ok > 0 and err > 0 and ok + err == 36000
+
+
 # ---- real fixtures -----------------------------------------------------------------------------------------
 # aac-stereo-48k.adts = the elementary stream of testdata/mpeg-ts/aac-stereo-48k.ts (tools/ts_to_adts.py)
 FIXTURES = ["stereo-music-44100-192k.aac", "A_Tusk_is_used_to_make_costly_gifts_encoded.aac", "mono16k_A_Tusk.aac",
