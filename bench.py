@@ -133,8 +133,14 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     import ctypes as C
     from soundkit_amd import pipeline, sharding
     from soundkit_amd._lib import DecodeOptionsC
-    clip = open(os.path.join(ROOT, "tests", "golden", "aac", "aac-stereo-48k.adts"), "rb").read()
-    units = 48
+    from soundkit_amd import aac_lc
+    clip = open(os.path.join(ROOT, "tests", "golden", "aac", args.clip), "rb").read()
+    adts = aac_lc.split_adts(clip)
+    units = len(adts)
+    clip = clip[:sum(len(au) + 7 for _, au in adts)]  # whole frames only: the clip is looped
+    src = aac_lc.AacLcFrontEnd(adts[0][0])
+    src_rate, src_ch = src.sample_rate, src.channels
+    src.close()
     lg = C.CDLL(os.path.join(ROOT, "soundkit_amd", "libsk_loadgen.so"))
 
     class Result(C.Structure):
@@ -182,11 +188,12 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     value = world * res.access_units / elapsed
     out = {
         "metric": "AAC-LC 1024-sample frames/s (whole node) + xrealtime, end to end through the batch scheduler",
-        "value": value, "unit": "frames/s", "x_realtime": value / 46.875, "n_gpus": world, "steps": args.steps,
+        "value": value, "unit": "frames/s", "x_realtime": value / (src_rate / 1024.0), "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "reference fixture testdata/mpeg-ts/aac-stereo-48k.ts (48 access units), looped",
-        "config": {"workload": "end_to_end: %d ADTS AAC-LC streams x %d access units, 48 kHz stereo -> %s Hz %s s16, host entropy "
-                               "decode on %d threads + GPU ticks" % (args.streams, units * args.steps, args.out_rate or 48000,
+        "vs_baseline": None, "dtype": "f32", "data": "reference fixture %s (%d access units), looped" % (args.clip, units),
+        "config": {"workload": "end_to_end: %d ADTS AAC-LC streams x %d access units, %d Hz %d ch -> %s Hz %s s16, host entropy "
+                               "decode on %d threads + GPU ticks" % (args.streams, units * args.steps, src_rate, src_ch,
+                                                                     args.out_rate or src_rate,
                                                                      "mono" if args.out_channels == 1 else "source-channel", threads),
                    "streams_per_gpu": args.streams, "entropy_threads": threads, "feeder_threads": feeders, "host_cores": cores,
                    "parallelism": "streams sharded, %d rank(s), no collective" % world},
@@ -217,6 +224,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--separate-s16", action="store_true", help="pipeline: run the s16 conversion as its own kernel instead of the FIR epilogue")
     ap.add_argument("--entropy-threads", type=int, default=0, help="end_to_end: host threads for the AAC front-end (0 = cores - 1, split over ranks)")
+    ap.add_argument("--clip", default="aac-stereo-48k.adts", help="end_to_end: ADTS file under tests/golden/aac to loop")
     ap.add_argument("--feeders", type=int, default=2, help="end_to_end: producer/consumer threads of the load generator")
     ap.add_argument("--out-rate", type=int, default=16000, help="end_to_end: DecodeOptions.output_sample_rate (0 = source rate)")
     ap.add_argument("--out-channels", type=int, default=1, help="end_to_end: DecodeOptions.output_channels (0 = source)")
