@@ -124,8 +124,20 @@ struct Lut {
     int primary_bits = 0;
 };
 
+// the values a spectral codeword stands for, unpacked once (spectral.rs tuple readers: idx -> digits of base 3 / 9 / 8 / 13 / 17)
+struct Tuple {
+    float mag[4];        // |v|^(4/3) from the reference's table (0 for v = 0)
+    uint32_t sign[4];    // signed books: 0x80000000 where v < 0
+    uint8_t sshift[4];   // unsigned books: which of the sign bits that follow the codeword belongs to value k (31: none)
+    int8_t v[4];         // signed books: the values; unsigned books: the magnitudes
+    uint8_t nsign;       // unsigned books: how many magnitudes are non-zero (= sign bits that follow the codeword)
+    uint8_t escape;      // book 11: a magnitude of 16 (an escape sequence follows the sign bits)
+    uint8_t pad[2];
+};
+
 struct Tables {
     Lut sf, cb[12];
+    Tuple tuples[12][289];
     float pow43[8192];      // dsp.rs:420-429
     float sf_mult[768];     // dsp.rs:439-450, scale factors -256..511
     Tables() {
@@ -143,6 +155,31 @@ struct Tables {
         cb[11].build(kCb11Len, nullptr, kCb11Code, 289, 12);
         for (int v = 0; v < 8192; ++v) pow43[v] = std::pow((float)v, 4.0f / 3.0f);
         for (int s = -256; s <= 511; ++s) sf_mult[s + 256] = std::pow(2.0f, ((float)s - 100.0f) * 0.25f);
+        static const int kSymbols[12] = {0, 81, 81, 81, 81, 81, 81, 64, 64, 169, 169, 289};
+        for (int book = 1; book <= 11; ++book)
+            for (int idx = 0; idx < kSymbols[book]; ++idx) {
+                Tuple &t = tuples[book][idx];
+                t = Tuple{};
+                if (book <= 4) {
+                    const int d[4] = {idx / 27, (idx / 9) % 3, (idx / 3) % 3, idx % 3};
+                    for (int k = 0; k < 4; ++k) t.v[k] = (int8_t)(book <= 2 ? d[k] - 1 : d[k]);
+                } else {
+                    const int dim = book <= 6 ? 9 : (book <= 8 ? 8 : (book <= 10 ? 13 : 17));
+                    const int d[2] = {idx / dim, idx % dim};
+                    for (int k = 0; k < 2; ++k) t.v[k] = (int8_t)(book <= 6 ? d[k] - 4 : d[k]);
+                }
+                const bool is_unsigned = book == 3 || book == 4 || book >= 7;
+                if (is_unsigned)
+                    for (int k = 0; k < 4; ++k) t.nsign += t.v[k] != 0;
+                int seen = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const int v = t.v[k];
+                    t.mag[k] = pow43[v < 0 ? -v : v];
+                    t.sign[k] = (!is_unsigned && v < 0) ? 0x80000000u : 0u;
+                    t.sshift[k] = (is_unsigned && v != 0) ? (uint8_t)(t.nsign - 1 - seen++) : 31;
+                    t.escape |= book == 11 && v == 16;
+                }
+            }
     }
 };
 const Tables &tables() {
@@ -426,6 +463,87 @@ void read_band_quantized(BitReader &r, int cb, int *q, int n) {
     }
 }
 
+// The same band, dequantised on the way (the reference fuses this too: write_scaled_tuple, spectral.rs:723-727).
+// Codeword, sign bits and values come out of one 64-bit window per tuple, without data-dependent branches; anything
+// unusual (fewer than 32 bits left, an invalid codeword, an escape, a non-finite scale) goes through the bit-exact
+// slow readers above so that errors and their messages are the reference's.
+template <int DIM, bool UNSIGNED>
+void read_band_scaled_t(const Tables &t, BitReader &r, int cb, float scale, float *out, int n) {
+    const Lut &lut = t.cb[cb];
+    const Tuple *tuples = t.tuples[cb];
+    const int pb = lut.primary_bits;
+    const uint32_t *table = lut.table.data();
+    const uint8_t *data = r.data;
+    const size_t total = r.total_bits;
+    size_t pos = r.pos;
+    for (int i = 0; i + DIM <= n; i += DIM) {
+        if (__builtin_expect(total - pos >= 32, 1)) {
+            uint64_t w;
+            std::memcpy(&w, data + (pos >> 3), 8);
+            w = __builtin_bswap64(w) << (pos & 7);  // at least 57 valid bits at the top
+            const uint32_t look = (uint32_t)(w >> 32);
+            uint32_t e = table[look >> (32 - pb)];
+            if (e & 0x80000000u) {
+                const unsigned extra = (e >> 24) & 0x7f;
+                e = table[(e & 0xffffff) + ((look << pb) >> (32 - extra))];
+            }
+            const unsigned len = e >> 16;
+            if (__builtin_expect(len != 0, 1)) {
+                const Tuple &tu = tuples[e & 0xffff];
+                uint32_t signs = 0;
+                unsigned used = len;
+                if (UNSIGNED) {
+                    signs = (uint32_t)((w << len) >> 60) >> (4 - tu.nsign);  // the nsign (<= 4) bits after the codeword
+                    used += tu.nsign;
+                }
+                for (int k = 0; k < DIM; ++k) {
+                    uint32_t bits;
+                    std::memcpy(&bits, &tu.mag[k], 4);
+                    bits ^= tu.sign[k] ^ ((signs >> tu.sshift[k]) << 31);
+                    float m;
+                    std::memcpy(&m, &bits, 4);
+                    out[i + k] = m * scale;
+                }
+                pos += used;
+                if (__builtin_expect(tu.escape, 0)) {  // finish_unsigned_escape_pair (spectral.rs:191-212): escapes follow the signs
+                    r.pos = pos;
+                    for (int k = 0; k < 2; ++k) {
+                        if (tu.v[k] != 16) continue;
+                        const bool neg = (signs >> tu.sshift[k]) & 1;
+                        const int esc = read_escape(r);
+                        out[i + k] = dequantize(neg ? -esc : esc, scale);
+                    }
+                    pos = r.pos;
+                }
+                continue;
+            }
+        }
+        int q[4];
+        r.pos = pos;
+        read_band_quantized(r, cb, q, DIM);
+        for (int k = 0; k < DIM; ++k) out[i + k] = dequantize(q[k], scale);
+        pos = r.pos;
+    }
+    r.pos = pos;
+}
+
+void read_band_scaled(const Tables &t, BitReader &r, int cb, float scale, float *out, int n) {
+    if (__builtin_expect(!std::isfinite(scale), 0)) {  // 0 * inf must stay 0 (dsp.rs:397-399): exact path
+        for (int i = 0; i + (cb <= 4 ? 4 : 2) <= n; i += (cb <= 4 ? 4 : 2)) {
+            int q[4];
+            read_band_quantized(r, cb, q, cb <= 4 ? 4 : 2);
+            for (int k = 0; k < (cb <= 4 ? 4 : 2); ++k) out[i + k] = dequantize(q[k], scale);
+        }
+        return;
+    }
+    switch (cb) {
+    case 1: case 2: read_band_scaled_t<4, false>(t, r, cb, scale, out, n); break;
+    case 3: case 4: read_band_scaled_t<4, true>(t, r, cb, scale, out, n); break;
+    case 5: case 6: read_band_scaled_t<2, false>(t, r, cb, scale, out, n); break;
+    default: read_band_scaled_t<2, true>(t, r, cb, scale, out, n); break;
+    }
+}
+
 struct Decoder {
     uint32_t sample_rate = 0;
     int sf_index = -1;  // -1: explicit rate (no band tables)
@@ -470,6 +588,7 @@ void decode_spectrum(Decoder &d, BitReader &r, const Channel &ch, bool allow_int
                 if (ch.cb[g][sfb] == CB_INTENSITY || ch.cb[g][sfb] == CB_INTENSITY_NEG)
                     fail(SK_AAC_ERR_INVALID_BITSTREAM, "intensity stereo is only valid in the right channel of a channel pair");
     const Layout lay = layout_for(d, info);
+    const Tables &t = tables();
     std::memset(coef, 0, sizeof(float) * 1024);
     if (info.window_sequence == SK_EIGHT_SHORT) {
         if (ch.pulse.present) fail(SK_AAC_ERR_INVALID_BITSTREAM, "pulse data is not allowed for short windows");
@@ -484,10 +603,8 @@ void decode_spectrum(Decoder &d, BitReader &r, const Channel &ch, bool allow_int
                 if (e > 128) fail(SK_AAC_ERR_INVALID_CONFIG, "short scale-factor band exceeds window length");
                 const int cb = ch.cb[g][sfb];
                 if (cb >= 1 && cb <= 11) {
-                    for (int w = window_start; w < window_start + glen; ++w) {
-                        read_band_quantized(r, cb, d.quantized, e - s);
-                        for (int i = 0; i < e - s; ++i) coef[w * 128 + s + i] = dequantize(d.quantized[i], ch.mult[g][sfb]);
-                    }
+                    for (int w = window_start; w < window_start + glen; ++w)
+                        read_band_scaled(t, r, cb, ch.mult[g][sfb], coef + w * 128 + s, e - s);
                 } else if (cb == CB_NOISE) {
                     d.n_pns_bands += 1;
                     for (int w = window_start; w < window_start + glen; ++w)
@@ -506,8 +623,7 @@ void decode_spectrum(Decoder &d, BitReader &r, const Channel &ch, bool allow_int
             if (e > 1024) fail(SK_AAC_ERR_INVALID_CONFIG, "scale-factor band exceeds coefficient buffer");
             const int cb = ch.cb[0][sfb];
             if (cb >= 1 && cb <= 11) {
-                read_band_quantized(r, cb, d.quantized, e - s);
-                for (int i = 0; i < e - s; ++i) coef[s + i] = dequantize(d.quantized[i], ch.mult[0][sfb]);
+                read_band_scaled(t, r, cb, ch.mult[0][sfb], coef + s, e - s);
             } else if (cb == CB_NOISE) {
                 d.n_pns_bands += 1;
                 synthesize_noise_band(ch.mult[0][sfb], d.pns_state, coef + s, e - s);
