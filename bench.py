@@ -222,7 +222,9 @@ def main():
     ap.add_argument("--layout", default="frame", choices=["frame", "stream"],
                     help="packing of the batch: frame-major [frame][stream] (one tick of every stream after another) or stream-major")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--separate-s16", action="store_true", help="pipeline: run the s16 conversion as its own kernel instead of the FIR epilogue")
+    ap.add_argument("--fused-s16", action="store_true",
+                    help="pipeline: convert to interleaved s16 in the FIR epilogue instead of a separate kernel (same bytes; +8 %% "
+                         "frames/s, but the conversion's VALU work takes issue slots from the f32 MFMA stream, DESIGN.md 4.2)")
     ap.add_argument("--entropy-threads", type=int, default=0, help="end_to_end: host threads for the AAC front-end (0 = cores - 1, split over ranks)")
     ap.add_argument("--clip", default="aac-stereo-48k.adts", help="end_to_end: ADTS file under tests/golden/aac to loop")
     ap.add_argument("--feeders", type=int, default=2, help="end_to_end: producer/consumer threads of the load generator")
@@ -294,7 +296,7 @@ def main():
             n_out = eng.downsample_out_frames(frames * 1024)
             out_stride = (n_out + 3) // 4 * 4
             fmt_s16 = soundkit_amd.engine.FMT_S16LE
-            if args.separate_s16:
+            if not args.fused_s16:
                 fir_out = torch.empty((streams * ch, out_stride), device=device)
                 s16_out = torch.empty((streams, n_out, ch), dtype=torch.int16, device=device)
 
@@ -313,8 +315,7 @@ def main():
                     timed("k_fir_48k_16k", lambda: eng.downsample_48k_16k_frames_s16_dev(pcm, stream_stride, frame_stride, ch,
                                                                                          streams, frames, s16_out, s16_stride))
             workload = ("aac_lc decode tail: %d streams x %d frames, 48 kHz stereo: IMDCT+window+OLA -> 48k->16k MFMA FIR -> "
-                        "interleaved s16 (%s), %s-major batch" % (streams, frames, "separate kernel" if args.separate_s16 else
-                                                                  "in the FIR epilogue", args.layout))
+                        "interleaved s16 (%s), %s-major batch" % (streams, frames, "in the FIR epilogue" if args.fused_s16 else "separate kernel", args.layout))
         else:
             def step():
                 timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
@@ -387,7 +388,7 @@ def main():
             rl["k_fir_48k_16k"] = {
                 "kernel": "k_fir_48k_16k", "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12,
                 "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                "traffic": pmc_traffic("fir" if args.workload == "fir" else ("fir_pipeline" if args.separate_s16 else "fir_pipeline_s16"),
+                "traffic": pmc_traffic("fir" if args.workload == "fir" else ("fir_pipeline_s16" if args.fused_s16 else "fir_pipeline"),
                                        rows=streams * ch, frames=fir_in),
                 "avg_launch_ms": ms}
         if "k_f32_planar_stereo_to_s16le_batch" in per_kernel:

@@ -60,19 +60,47 @@ __device__ __forceinline__ size_t sample_offset(const FirArgs &a, uint32_t row, 
     return (size_t)g * a.in_group_stride + (size_t)(c << 10) + (size_t)(i >> 10) * a.in_block_stride + (size_t)(i & 1023);
 }
 
+// Per-lane constants of the aligned staging path, computed once per wave: f32 MFMA issues through the same vector
+// pipeline as ordinary VALU work on this part (equal f32 matrix and vector peaks; profiles/r01_pmc_pipeline.md: every
+// VALU instruction added to the loop showed up 1:1 in the launch time), so the per-chunk address arithmetic is kept
+// to one offset shared by the eight DMA instructions plus a pointer add and select each.
+struct StageLane {
+    const float *base[8];  // row p (lanes 0-31) or p + 8 (lanes 32-63): address of its sample 0
+    uint32_t ok_mask;      // bit p: that row exists
+};
+
+template <bool PACKED>
+__device__ __forceinline__ void stage_lane_init(const FirArgs &a, int lane, uint32_t row0, const uint32_t (&phys)[16], StageLane &st) {
+    st.ok_mask = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const uint32_t row = (lane >> 5) ? phys[p + 8] : phys[p];
+        if (row0 + p + 8 * (lane >> 5) < a.rows) st.ok_mask |= 1u << p;
+        st.base[p] = a.in + sample_offset<PACKED>(a, row, 0);
+    }
+}
+
 template <bool ALIGNED, bool PACKED>
 __device__ __forceinline__ void stage_chunk(const FirArgs &a, float *ring, int lane, uint32_t row0, const uint32_t (&phys)[16],
-                                            int64_t t0, int chunk) {
+                                            int64_t t0, int chunk, const StageLane &st) {
     // chunk c covers local samples n'' in [128 c, 128 c + 128); stream time = n'' + t0
     const int slot = chunk & 1;
     if (ALIGNED) {
+        // lanes 0-31 -> row p, lanes 32-63 -> row p + 8, 4 samples per lane; the sample index is the same for every p
+        const int64_t idx = (int64_t)kChunk * chunk + 4 * (lane & 31) + t0 - a.in_origin;
+        const bool in_range = (uint64_t)idx + 3 < (uint64_t)a.in_frames;  // idx < 0 wraps far above
+        const uint32_t i = (uint32_t)idx;
+        size_t off = PACKED ? (size_t)(i >> 10) * a.in_block_stride + (size_t)(i & 1023) : (size_t)i;
+        asm volatile("" : "+v"(off));  // one sum, added once per instruction below (not re-associated into each of them)
+        const float *zero = a.zeros + 4 * lane;
+        const uint32_t sel = in_range ? st.ok_mask : 0u;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {  // lanes 0-31 -> row p, lanes 32-63 -> row p + 8, 4 samples per lane
-            const bool row_ok = row0 + p + 8 * (lane >> 5) < a.rows;
-            const uint32_t row = (lane >> 5) ? phys[p + 8] : phys[p];
-            const int64_t idx = (int64_t)kChunk * chunk + 4 * (lane & 31) + t0 - a.in_origin;
-            const bool ok = row_ok && idx >= 0 && idx + 3 < (int64_t)a.in_frames;
-            const float *src = ok ? a.in + sample_offset<PACKED>(a, row, idx) : a.zeros + 4 * lane;
+        for (int p = 0; p < 8; ++p) {
+            // a select, not a branch: an LDS-DMA instruction must be issued once for the whole wave (the asm keeps the
+            // compiler from unswitching the loop on the lane's range test, which doubled every DMA instruction)
+            uint32_t okp = (sel >> p) & 1u;
+            asm volatile("" : "+v"(okp));
+            const float *src = okp ? st.base[p] + off : zero;
             __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(ring + (slot * 8 + p) * kBlockStride), 16, 0, 0);
         }
     } else {
@@ -110,7 +138,10 @@ __device__ __forceinline__ void wait_vm_older_than(int younger) {
 template <bool ALIGNED, bool PACKED, int OUT16>
 __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total_blocks, uint32_t blocks_per_seg,
                                                        uint32_t n_segs, int out_vec) {
-    __shared__ float ring[kRingDwords];
+    // + 2 KiB: 18.5 KiB per wave caps residency at 8 waves per CU (160 KiB LDS) = 2 per SIMD whatever the register
+    // count; the launcher sizes the grid to exactly that many waves, and a ninth wave on some CUs (which 160 VGPRs
+    // would allow) leaves one SIMD with three waves and the launch waiting for it (measured: 0.97 -> 1.35 ms)
+    __shared__ float ring[kRingDwords + 512];
 
     const int lane = threadIdx.x;
     const int j = lane & 15, kq = lane >> 4;
@@ -142,8 +173,10 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
 
     const int g_first = 3 * a_begin;
     int chunk = g_first >> 3;  // 8 groups of 16 samples per chunk
-    stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, phys, t0, chunk);
-    stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, phys, t0, chunk + 1);
+    StageLane st;
+    if (ALIGNED) stage_lane_init<PACKED>(a, lane, row0, phys, st);
+    stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, phys, t0, chunk, st);
+    stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, phys, t0, chunk + 1, st);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int stores_since_stage = 0;  // wave-uniform
 
@@ -181,7 +214,7 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
                 chunk = Gn >> 3;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 wait_vm_older_than(ALIGNED ? __builtin_amdgcn_readfirstlane(stores_since_stage) : 0);
-                stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, phys, t0, chunk + 1);
+                stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, phys, t0, chunk + 1, st);
                 stores_since_stage = 0;
             }
             const f32x4 xb_next = read_group(Gn);

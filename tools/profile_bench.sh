@@ -10,6 +10,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+# (pass --fused-s16 to profile the fused chain)
 # the stats pass runs the bench's own default step counts, so its per-kernel averages are those of the bench line
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline $* > "$OUT/bench_stats.json" 2> "$OUT/stats.err"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_fetch.err"
