@@ -100,7 +100,11 @@ __device__ __forceinline__ void stage_chunk(const FirArgs &a, float *ring, int l
             // compiler from unswitching the loop on the lane's range test, which doubled every DMA instruction)
             uint32_t okp = (sel >> p) & 1u;
             asm volatile("" : "+v"(okp));
+#ifdef SK_FIR_ABLATE_ZEROSRC
+            const float *src = okp == 77u ? st.base[p] + off : zero;
+#else
             const float *src = okp ? st.base[p] + off : zero;
+#endif
             __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(ring + (slot * 8 + p) * kBlockStride), 16, 0, 0);
         }
     } else {
@@ -190,7 +194,11 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
                                 : nullptr;
     const int lane_base = ring_addr(j, 4 * kq);  // + slot and group offsets per read
     auto read_group = [&](int G) {
+#ifdef SK_FIR_ABLATE_LDSREAD
+        return (f32x4){(float)G, 1.f, 2.f, 3.f};
+#else
         return *reinterpret_cast<const f32x4 *>(&ring[lane_base + ((G >> 3) & 1) * 8 * kBlockStride + 16 * (G & 7)]);
+#endif
     };
 
     // B operands are read one group ahead of the MFMAs that consume them.  Seven periods are
@@ -213,8 +221,12 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
                 // issued (the current group's operands are in xb), so that slot can be refilled
                 chunk = Gn >> 3;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef SK_FIR_ABLATE_VMWAIT
                 wait_vm_older_than(ALIGNED ? __builtin_amdgcn_readfirstlane(stores_since_stage) : 0);
+#endif
+#ifndef SK_FIR_ABLATE_STAGE
                 stage_chunk<ALIGNED, PACKED>(a, ring, lane, row0, phys, t0, chunk + 1, st);
+#endif
                 stores_since_stage = 0;
             }
             const f32x4 xb_next = read_group(Gn);
@@ -233,7 +245,11 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
             const uint32_t m = (uint32_t)blk * 16 + 4 * kq;  // relative to out_first
             if (gi == 0) {
                 pending = acc[(p + 1) % 7];
+#ifdef SK_FIR_ABLATE_STORE
+                if (!to_s16 && blk >= a_begin && blk < a_end && pending[0] == 1.2345e30f) {
+#else
                 if (!to_s16 && blk >= a_begin && blk < a_end) {  // wave-uniform
+#endif
                     if (out_vec) ++stores_since_stage;
                     if (out_row < a.rows) {
                         if (out_vec && m + 3 < a.out_count) {
