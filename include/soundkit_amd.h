@@ -153,6 +153,23 @@ int sk_aac_decoder_parse(sk_aac_decoder *, const uint8_t *access_unit, size_t le
 int sk_adts_parse(const uint8_t *data, size_t len, size_t *frame_len, size_t *payload_off, size_t *payload_len,
                   uint8_t asc[2]);
 
+/* ---- the audio_packet::Decoder surface for one ADTS AAC-LC stream ------------------------------------ */
+/* soundkit::audio_packet::Decoder (soundkit/src/audio_packet.rs:22-26) as soundkit-aac's AacDecoder implements it
+ * (soundkit-aac/src/lib.rs:108-266) and the worker drives it (decode_i16_with_drain, soundkit-decoder lib.rs:
+ * 2150-2181): each call appends `input` (<= 4 MiB per call and buffered) and decodes every whole frame that is
+ * buffered and fits in `output`; *written = interleaved samples; 0 = needs more input / drained.  Call once with
+ * data, then with len 0 until it returns 0.  decode_i32 is "Not implemented." in the reference and absent here. */
+typedef struct sk_adts_decoder sk_adts_decoder;
+int sk_adts_decoder_create(sk_engine *, sk_adts_decoder **out);
+void sk_adts_decoder_destroy(sk_adts_decoder *);
+int sk_adts_decoder_decode_i16(sk_adts_decoder *, const uint8_t *input, size_t len, int16_t *output, size_t out_cap,
+                               size_t *written);
+int sk_adts_decoder_decode_f32(sk_adts_decoder *, const uint8_t *input, size_t len, float *output, size_t out_cap,
+                               size_t *written);
+/* sample_rate() / channels() (lib.rs:133-139): 0 until the first frame has been decoded */
+int sk_adts_decoder_info(const sk_adts_decoder *, uint32_t *sample_rate, uint8_t *channels);
+const char *sk_adts_decoder_last_error(const sk_adts_decoder *);
+
 /* dsp.rs:389-450 dequantize_signed_scaled over a batch: out[i] = sign(q)*|q|^(4/3)*2^((sf-100)/4).
  * quant: n i16 quantised values; sf_per_band_of[i]: i16 scale factor applying to value i. */
 int sk_aac_dequantize_dev(sk_engine *, const int16_t *d_quant, const int16_t *d_scalefactor, float *d_out, size_t n);

@@ -164,6 +164,12 @@ _sig = {
     "sk_resampler_close": (_i, [_vp, _u32]),
     "sk_resampler_process_f32": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp]),
     "sk_resampler_flush_f32": (_i, [_vp, _vp, _u32, _vp, _u32, _vp]),
+    "sk_adts_decoder_create": (_i, [_vp, C.POINTER(_vp)]),
+    "sk_adts_decoder_destroy": (None, [_vp]),
+    "sk_adts_decoder_decode_i16": (_i, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "sk_adts_decoder_decode_f32": (_i, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "sk_adts_decoder_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(C.c_uint8)]),
+    "sk_adts_decoder_last_error": (C.c_char_p, [_vp]),
     "sk_pipeline_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
     "sk_pipeline_destroy": (None, [_vp]),
     "sk_pipeline_spawn": (_i, [_vp, _vp, C.POINTER(_u32)]),
