@@ -206,6 +206,16 @@ def test_mutated_access_units_under_sanitizers(tmp_path):
     assert ok > 0 and err > 0 and ok + err == 36000
 
 
+def test_no_heap_allocation_after_warm_up(tmp_path):
+    """soundkit-aac-lc/tests/no_alloc_decode.rs: decoding must not allocate once the decoder is warm."""
+    import subprocess
+    exe = str(tmp_path / "noalloc_frontend")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wno-subobject-linkage", "-o", exe,
+                           os.path.join(HERE, "noalloc_frontend.cpp")], cwd=HERE)
+    out = subprocess.run([exe] + [os.path.join(GOLD, "aac", n) for n in FIXTURES], capture_output=True, text=True)
+    assert out.returncode == 0 and "273 frames, 0 allocations after warm-up" in out.stdout, out.stdout
+
+
 # ---- real fixtures -----------------------------------------------------------------------------------------
 # aac-stereo-48k.adts = the elementary stream of testdata/mpeg-ts/aac-stereo-48k.ts (tools/ts_to_adts.py)
 FIXTURES = ["stereo-music-44100-192k.aac", "A_Tusk_is_used_to_make_costly_gifts_encoded.aac", "mono16k_A_Tusk.aac",
