@@ -403,6 +403,11 @@ int sk_pipeline_finish(sk_pipeline *, uint32_t handle);                         
  * cap is smaller than info->bytes (the output stays queued).  lib.rs:2845-2858 */
 int sk_pipeline_try_recv(sk_pipeline *, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info);
 int sk_pipeline_recv(sk_pipeline *, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info, uint32_t timeout_ms);
+/* For a caller that serves many handles from few threads (the reference gives every stream its own thread and a
+ * blocking recv): blocks up to timeout_ms for handles that have something to receive -- outputs, or the end of their
+ * stream -- and returns how many were written to `handles`.  A handle is reported once per batch of news: drain it with
+ * try_recv until 0 / SK_PIPE_CLOSED; a handle left with outputs is reported again. */
+int sk_pipeline_wait_outputs(sk_pipeline *, uint32_t *handles, uint32_t cap, uint32_t timeout_ms);
 int sk_pipeline_cancel(sk_pipeline *, uint32_t handle); /* cancel() / Drop, lib.rs:2860-2889: frees the handle */
 size_t sk_pipeline_queued_input_bytes(sk_pipeline *, uint32_t handle); /* lib.rs:2863-2866 */
 int sk_pipeline_get_stats(sk_pipeline *, sk_pipeline_stats *out);

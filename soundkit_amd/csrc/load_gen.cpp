@@ -4,6 +4,7 @@
 // Built as libsk_loadgen.so next to libsoundkit_amd.so; bench.py --workload end_to_end drives it.
 #include "../../include/soundkit_amd.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -34,35 +35,45 @@ int sk_loadgen_run(sk_pipeline *p, const uint8_t *clip, size_t clip_len, uint32_
         }
     }
     std::atomic<uint64_t> outputs{0}, pcm_frames{0}, pcm_bytes{0}, errors{0}, input_full{0};
+    std::atomic<uint32_t> live{n_streams};
+    uint32_t max_handle = 0;
+    for (uint32_t h : handles) max_handle = std::max(max_handle, h);
+    std::vector<std::atomic<char>> ended(max_handle + 1);
+    for (auto &e : ended) e.store(0);
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> threads;
-    for (uint32_t t = 0; t < feeder_threads; ++t) {
+    // producers: each owns a slice of the streams and keeps their input queues fed (send never blocks: back off when full)
+    const uint32_t producers = std::max(1u, feeder_threads / 2), consumers = std::max(1u, feeder_threads - producers);
+    for (uint32_t t = 0; t < producers; ++t) {
         threads.emplace_back([&, t] {
             struct St {
                 uint32_t handle;
-                uint64_t sent = 0;  // bytes of the looped clip already accepted
-                bool finished = false, ended = false;
+                uint64_t sent = 0;
+                bool finished = false;
             };
             std::vector<St> mine;
-            for (uint32_t i = t; i < n_streams; i += feeder_threads) {
+            for (uint32_t i = t; i < n_streams; i += producers) {
                 St s;
                 s.handle = handles[i];
                 mine.push_back(s);
             }
             const uint64_t total = (uint64_t)clip_len * loops;
-            std::vector<uint8_t> buf(1 << 20);
-            sk_audio_info info;
-            size_t live = mine.size();
-            uint64_t o = 0, f = 0, b = 0, e = 0, full = 0;
-            while (live) {
+            size_t open = mine.size();
+            uint64_t full = 0;
+            while (open) {
                 bool progressed = false;
                 for (St &s : mine) {
-                    if (s.ended) continue;
-                    for (int burst = 0; burst < 4 && !s.finished; ++burst) {  // producer side
+                    if (s.finished) continue;
+                    for (int burst = 0; burst < 4; ++burst) {
                         if (s.sent >= total) {
                             const int rc = sk_pipeline_finish(p, s.handle);
-                            if (rc == SK_OK || rc == SK_PIPE_CLOSED) s.finished = true;
-                            else ++full;
+                            if (rc == SK_OK || rc == SK_PIPE_CLOSED) {
+                                s.finished = true;
+                                --open;
+                                progressed = true;
+                            } else {
+                                ++full;
+                            }
                             break;
                         }
                         const size_t at = (size_t)(s.sent % clip_len);
@@ -73,15 +84,33 @@ int sk_loadgen_run(sk_pipeline *p, const uint8_t *clip, size_t clip_len, uint32_
                             progressed = true;
                         } else if (rc == SK_PIPE_CLOSED) {
                             s.finished = true;
+                            --open;
+                            break;
                         } else {
                             ++full;
                             break;
                         }
                     }
-                    for (;;) {  // consumer side
-                        const int rc = sk_pipeline_try_recv(p, s.handle, buf.data(), buf.size(), &info);
+                }
+                if (!progressed) std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+            input_full += full;
+        });
+    }
+    // consumers: block on sk_pipeline_wait_outputs and drain whatever handles it reports
+    for (uint32_t t = 0; t < consumers; ++t) {
+        threads.emplace_back([&] {
+            std::vector<uint8_t> buf(1 << 20);
+            std::vector<uint32_t> ready(1024);
+            sk_audio_info info;
+            uint64_t o = 0, f = 0, b = 0, e = 0;
+            while (live.load() > 0) {
+                const int n = sk_pipeline_wait_outputs(p, ready.data(), (uint32_t)ready.size(), 20);
+                for (int k = 0; k < n; ++k) {
+                    const uint32_t h = ready[(size_t)k];
+                    for (;;) {
+                        const int rc = sk_pipeline_try_recv(p, h, buf.data(), buf.size(), &info);
                         if (rc == 1) {
-                            progressed = true;
                             if (info.is_error) ++e;
                             else {
                                 ++o;
@@ -90,20 +119,15 @@ int sk_loadgen_run(sk_pipeline *p, const uint8_t *clip, size_t clip_len, uint32_
                             }
                             continue;
                         }
-                        if (rc == SK_PIPE_CLOSED) {
-                            s.ended = true;
-                            --live;
-                        }
+                        if (rc == SK_PIPE_CLOSED && h <= max_handle && !ended[h].exchange(1)) live.fetch_sub(1);
                         break;
                     }
                 }
-                if (!progressed) std::this_thread::sleep_for(std::chrono::microseconds(50));
             }
             outputs += o;
             pcm_frames += f;
             pcm_bytes += b;
             errors += e;
-            input_full += full;
         });
     }
     for (std::thread &th : threads) th.join();

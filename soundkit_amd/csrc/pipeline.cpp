@@ -53,6 +53,7 @@ struct PStream {
     std::condition_variable cv_out;
     // guarded by mu
     bool open = false, busy = false, queued = false, finished = false, cancelled = false;
+    bool out_listed = false;  // the handle sits in sk_pipeline::out_ready (or has been handed to a waiter and not taken from since)
     std::deque<std::vector<uint8_t>> in;
     std::deque<Output> out;
     sk_decode_options opt{};
@@ -125,6 +126,11 @@ struct sk_pipeline {
     std::deque<int> free_batches, to_deliver;
     std::condition_variable deliver_cv;
     bool stop = false;
+
+    // handles with something to receive (outputs or the end of the stream), for callers that serve many handles
+    std::mutex oq_mu;
+    std::condition_variable oq_cv;
+    std::deque<uint32_t> out_ready;
 
     std::vector<std::thread> workers;
     std::thread submitter, deliverer;
@@ -445,6 +451,7 @@ void submit_main(sk_pipeline *p) {
 // error notes, then the stream is free to be parsed again.
 void deliver_main(sk_pipeline *p) {
     std::vector<uint32_t> wake;  // streams that can be parsed again: queued in one go, one wake-up
+    std::vector<uint32_t> listed;  // handles that now have something to receive
     for (;;) {
         Batch *b;
         int index;
@@ -484,6 +491,7 @@ void deliver_main(sk_pipeline *p) {
             }
         }
         wake.clear();
+        listed.clear();
         for (uint32_t i = 0; i < n_streams; ++i) {
             BatchEntry &be = b->entries[i];
             PStream &s = *p->streams[be.handle];
@@ -508,6 +516,10 @@ void deliver_main(sk_pipeline *p) {
                     s.in.clear();
                 }
                 if (!release && mark_schedulable(p, s)) wake.push_back(be.handle);
+                if (!s.cancelled && !s.out_listed && (!s.out.empty() || s.finished)) {
+                    s.out_listed = true;
+                    listed.push_back(be.handle);
+                }
                 s.cv_out.notify_all();
             }
             if (release) {
@@ -528,6 +540,13 @@ void deliver_main(sk_pipeline *p) {
                 p->ready.insert(p->ready.end(), wake.begin(), wake.end());
             }
             p->rq_cv.notify_all();
+        }
+        if (!listed.empty()) {
+            {
+                std::lock_guard<std::mutex> lk(p->oq_mu);
+                p->out_ready.insert(p->out_ready.end(), listed.begin(), listed.end());
+            }
+            p->oq_cv.notify_all();
         }
         {
             std::lock_guard<std::mutex> lk(p->batch_mu);
@@ -629,6 +648,7 @@ void sk_pipeline_destroy(sk_pipeline *p) {
     p->batch_cv.notify_all();
     p->room_cv.notify_all();
     p->deliver_cv.notify_all();
+    p->oq_cv.notify_all();
     for (std::thread &t : p->workers) t.join();
     if (p->submitter.joinable()) p->submitter.join();
     if (p->deliverer.joinable()) p->deliverer.join();
@@ -658,6 +678,7 @@ int sk_pipeline_spawn(sk_pipeline *p, const sk_decode_options *opt, uint32_t *ha
     std::lock_guard<std::mutex> lk(s.mu);
     s.open = true;
     s.busy = s.queued = s.finished = s.cancelled = false;
+    s.out_listed = false;
     s.in.clear();
     s.out.clear();
     s.opt = o;
@@ -706,6 +727,14 @@ static int take_output(sk_pipeline *p, PStream &s, uint32_t handle, uint8_t *dat
     if (!o.data.empty()) std::memcpy(data, o.data.data(), o.data.size());
     s.out.pop_front();
     maybe_schedule(p, s, handle);
+    if (!s.out_listed && (!s.out.empty() || s.finished)) {  // a waiter that stops early hears about the rest again
+        s.out_listed = true;
+        {
+            std::lock_guard<std::mutex> lk(p->oq_mu);
+            p->out_ready.push_back(handle);
+        }
+        p->oq_cv.notify_one();
+    }
     return 1;
 }
 
@@ -749,6 +778,26 @@ int sk_pipeline_cancel(sk_pipeline *p, uint32_t handle) {  // shutdown(), lib.rs
         p->free_handles.push_back(handle);
     }
     return SK_OK;
+}
+
+int sk_pipeline_wait_outputs(sk_pipeline *p, uint32_t *handles, uint32_t cap, uint32_t timeout_ms) {
+    if (!p || !handles || !cap) return SK_ERR_INVALID_ARG;
+    uint32_t n = 0;
+    {
+        std::unique_lock<std::mutex> lk(p->oq_mu);
+        p->oq_cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(timeout_ms),
+                            [&] { return p->stop || !p->out_ready.empty(); });
+        while (n < cap && !p->out_ready.empty()) {
+            handles[n++] = p->out_ready.front();
+            p->out_ready.pop_front();
+        }
+    }
+    for (uint32_t i = 0; i < n; ++i) {  // handed out: the next delivery (or a partial drain) lists the handle again
+        PStream &s = *p->streams[handles[i]];
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.out_listed = false;
+    }
+    return (int)n;
 }
 
 size_t sk_pipeline_queued_input_bytes(sk_pipeline *p, uint32_t handle) {  // lib.rs:2863-2866

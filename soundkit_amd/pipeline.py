@@ -64,6 +64,15 @@ class BatchScheduler:
             raise SoundkitError(rc, "sk_pipeline_spawn")
         return DecodePipelineHandle(self, handle.value)
 
+    def wait_outputs(self, timeout_ms=100, cap=256):
+        """Handles (as spawned: `handle.id`) that have outputs or have ended; blocks up to timeout_ms.  For callers that
+        serve many streams from one thread."""
+        arr = (C.c_uint32 * cap)()
+        n = lib.sk_pipeline_wait_outputs(self._h, arr, cap, timeout_ms)
+        if n < 0:
+            raise SoundkitError(n, "sk_pipeline_wait_outputs")
+        return list(arr[:n])
+
     def stats(self):
         st = PipelineStats()
         check(lib.sk_pipeline_get_stats(self._h, C.byref(st)), "sk_pipeline_get_stats")
@@ -75,6 +84,7 @@ class DecodePipelineHandle:
 
     def __init__(self, scheduler, handle):
         self._s, self._id = scheduler, handle
+        self.id = handle
         self._buf = np.empty(1 << 16, np.uint8)
         self._info = AudioInfo()
 

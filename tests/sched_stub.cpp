@@ -6,6 +6,7 @@
 #include "../soundkit_amd/csrc/pipeline.cpp"
 #include "../soundkit_amd/csrc/aac_frontend.cpp"
 
+#include <atomic>
 #include <cstdio>
 #include <map>
 
@@ -172,6 +173,64 @@ static int scenario_many_streams(sk_engine *e) {
     return 0;
 }
 
+// many handles served by two consumer threads that block in sk_pipeline_wait_outputs instead of polling every handle
+static int scenario_wait_outputs(sk_engine *e) {
+    sk_pipeline_config cfg{};
+    cfg.entropy_threads = 3;
+    cfg.max_streams = 24;
+    cfg.max_stream_frames_per_tick = 3;
+    sk_pipeline *p = nullptr;
+    CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
+    const uint32_t n = 24;
+    std::vector<uint32_t> handles(n);
+    for (auto &h : handles) CHECK(sk_pipeline_spawn(p, nullptr, &h) == SK_OK);
+    std::vector<std::atomic<uint32_t>> count(64), closed(64);
+    for (auto &c : count) c.store(0);
+    for (auto &c : closed) c.store(0);
+    std::atomic<uint32_t> live{n};
+    std::atomic<int> bad{0};
+    std::vector<std::thread> consumers;
+    for (int t = 0; t < 2; ++t)
+        consumers.emplace_back([&] {
+            std::vector<uint8_t> buf(1 << 16);
+            uint32_t ready[8];
+            sk_audio_info info;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (live.load() > 0) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { bad.store(1); return; }
+                const int k = sk_pipeline_wait_outputs(p, ready, 8, 50);
+                for (int i = 0; i < k; ++i) {
+                    int taken = 0;
+                    for (;;) {
+                        const int rc = sk_pipeline_try_recv(p, ready[i], buf.data(), buf.size(), &info);
+                        if (rc == 1) {
+                            count[ready[i]].fetch_add(1);
+                            if (++taken == 2) break;  // leave some behind on purpose: the handle must be reported again
+                            continue;
+                        }
+                        if (rc == SK_PIPE_CLOSED && !closed[ready[i]].exchange(1)) live.fetch_sub(1);
+                        break;
+                    }
+                }
+            }
+        });
+    for (uint32_t i = 0; i < n; ++i) {
+        size_t pos = 0;
+        while (pos < clip.size()) {
+            const size_t len = std::min<size_t>(1 + (i * 131 + pos) % 3000, clip.size() - pos);
+            if (sk_pipeline_send(p, handles[i], clip.data() + pos, len) == SK_OK) pos += len;
+            else std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+        while (sk_pipeline_finish(p, handles[i]) != SK_OK) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    for (auto &th : consumers) th.join();
+    CHECK(bad.load() == 0);
+    for (uint32_t h : handles) CHECK(count[h].load() == 48 && closed[h].load() == 1);
+    for (uint32_t h : handles) CHECK(sk_pipeline_cancel(p, h) == SK_OK);
+    sk_pipeline_destroy(p);
+    return 0;
+}
+
 static int scenario_backpressure_and_errors(sk_engine *e) {
     sk_pipeline_config cfg{};
     cfg.entropy_threads = 2;
@@ -276,6 +335,7 @@ int main(int argc, char **argv) {
     e.channels.assign(64, 0);
     e.next_unit.assign(64, 0);
     if (int rc = scenario_many_streams(&e)) return rc;
+    if (int rc = scenario_wait_outputs(&e)) return rc;
     if (int rc = scenario_backpressure_and_errors(&e)) return rc;
     if (int rc = scenario_cancel_churn(&e)) return rc;
     std::puts("scheduler scenarios ok");

@@ -166,3 +166,31 @@ def test_cancel_frees_handles(engine):
     st = s.stats()
     assert st["errors"] == 0
     s.close()
+
+
+def test_wait_outputs_serves_many_handles_from_one_thread(engine, sched):
+    """sk_pipeline_wait_outputs: block until some handle has news instead of polling every handle."""
+    data = open(os.path.join(GOLD, "aac-stereo-48k.adts"), "rb").read()
+    handles = {h.id: h for h in (sched.spawn(pipeline.DecodeOptions(16, 16000, 1)) for _ in range(10))}
+    for h in handles.values():
+        h.send(data)
+        h.finish()
+    got = {i: [] for i in handles}
+    live = set(handles)
+    t0 = time.time()
+    while live:
+        assert time.time() - t0 < 60
+        for i in sched.wait_outputs(timeout_ms=200):
+            if i not in handles:
+                continue
+            while True:
+                a = handles[i].try_recv()
+                if a is None:
+                    break
+                got[i].append(a.data.tobytes())
+            if handles[i].ended():
+                live.discard(i)
+    first = got[next(iter(got))]
+    assert len(first) == 13 and all(v == first for v in got.values())  # 12 full chunks + the flushed tail
+    for h in handles.values():
+        h.cancel()
