@@ -168,6 +168,30 @@ def test_parse_adts_access_unit():
             aac_lc.parse_adts_access_unit(bad)
 
 
+def with_crc(data):
+    """The same ADTS stream with protection_absent = 0: two CRC bytes after each 7-byte header (not verified by the
+    reference's parse_adts_access_unit either, lib.rs:1007-1027), frame length + 2."""
+    out = bytearray()
+    pos = 0
+    while pos + 7 <= len(data):
+        flen = ((data[pos + 3] & 3) << 11) | (data[pos + 4] << 3) | (data[pos + 5] >> 5)
+        h = bytearray(data[pos:pos + 7])
+        h[1] &= 0xFE
+        n = flen + 2
+        h[3] = (h[3] & 0xFC) | ((n >> 11) & 3)
+        h[4] = (n >> 3) & 0xFF
+        h[5] = (h[5] & 0x1F) | ((n & 7) << 5)
+        out += h + b"\xAB\xCD" + data[pos + 7:pos + flen]
+        pos += flen
+    return bytes(out)
+
+
+def test_adts_with_crc_header():
+    data = open(os.path.join(GOLD, "aac", "aac-stereo-48k.adts"), "rb").read()
+    plain, crc = aac_lc.split_adts(data), aac_lc.split_adts(with_crc(data))
+    assert len(plain) == len(crc) == 48 and all(a == b for a, b in zip(plain, crc))
+
+
 # ---- robustness: soundkit-aac-lc/tests/malformed_decode.rs:5-39 ----------------------------------------------
 @pytest.mark.parametrize("asc", [bytes([0x12, 0x10]), bytes([0x11, 0x88])])
 def test_malformed_access_units_never_crash(asc):

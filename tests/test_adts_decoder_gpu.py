@@ -73,3 +73,15 @@ def test_output_limits_and_errors(engine):
     assert na == nb == 48 * 2048 and np.array_equal(b[:nb], a[:na].astype(np.float32) / np.float32(32768.0))
     for d in (dec, d2, d3):
         d.close()
+
+
+def test_crc_protected_adts_decodes_the_same(engine):
+    from test_aac_frontend import with_crc
+    data = open(os.path.join(GOLD, "aac-stereo-48k.adts"), "rb").read()
+    out = np.zeros(SCRATCH, np.int16)
+    a, b = aac.AacDecoder(engine), aac.AacDecoder(engine)
+    na = a.decode_i16(data, out)
+    want = out[:na].copy()
+    nb = b.decode_i16(with_crc(data), out)
+    assert na == nb == 48 * 2048 and np.array_equal(out[:nb], want)
+    a.close(), b.close()
