@@ -1,0 +1,649 @@
+"""oracle/aac_frontend.py -- CPU restatement of the AAC-LC access-unit front-end of the reference
+(soundkit-aac-lc/src: bitreader.rs, config.rs, syntax.rs, channel.rs, ics.rs, section.rs, scalefactor.rs,
+spectral.rs, pulse.rs, stereo.rs, tns.rs, sfb.rs, decoder.rs).
+
+TEST INFRASTRUCTURE ONLY (tests/ use it as the checker for the product's csrc/aac_frontend.cpp; nothing under
+soundkit_amd/ imports it).  Written for obviousness, not speed: the bitstream is one Python integer, Huffman codes
+are matched bit by bit against a dictionary, every f32 operation is an explicit numpy float32 operation in the
+reference's order, and powf / sinf come from the C library the way Rust's f32::powf / f32::sin do on Linux.
+
+Pinned by the reference's own in-file vectors (tests/test_oracle_frontend.py): the (value, width) access units of
+decoder.rs:481-736 and the AudioSpecificConfig cases.  The Huffman code tables are ISO/IEC 14496-3 data, read from
+the same transcription the product uses (soundkit_amd/csrc/aac_tables.h; Kraft-checked in the tests); everything that
+is logic -- tuple unpacking, sign and escape order, scalefactor deltas, PNS, stereo tools, TNS -- is restated here
+independently of the product's C++.
+"""
+import ctypes
+import ctypes.util
+import os
+import re
+
+import numpy as np
+
+F = np.float32
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.powf.restype = ctypes.c_float
+_libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+_libm.sinf.restype = ctypes.c_float
+_libm.sinf.argtypes = [ctypes.c_float]
+
+
+def powf(a, b):
+    return F(_libm.powf(float(F(a)), float(F(b))))
+
+
+def sinf(a):
+    return F(_libm.sinf(float(F(a))))
+
+
+class AacError(Exception):
+    """error.rs:5-18"""
+
+    def __init__(self, kind, message):
+        self.kind = kind
+        super().__init__(message)
+
+
+def _eof(requested, remaining):  # bitreader.rs: UnexpectedEof { requested_bits: u8, remaining_bits }
+    return AacError("UnexpectedEof", "unexpected end of AAC bitstream: requested %d bits, %d bits remain" % (min(requested, 255), remaining))
+
+
+class Bits:
+    """bitreader.rs:4-185: MSB first"""
+
+    def __init__(self, data):
+        self.total = len(data) * 8
+        self.value = int.from_bytes(bytes(data), "big")
+        self.pos = 0
+
+    def remaining(self):
+        return self.total - self.pos
+
+    def peek(self, n):
+        if n == 0:
+            return 0
+        return (self.value >> (self.total - self.pos - n)) & ((1 << n) - 1)
+
+    def read(self, n):
+        if self.remaining() < n:
+            raise _eof(n, self.remaining())
+        v = self.peek(n)
+        self.pos += n
+        return v
+
+    def flag(self):
+        return self.read(1) == 1
+
+    def copy(self):
+        b = Bits(b"")
+        b.total, b.value, b.pos = self.total, self.value, self.pos
+        return b
+
+
+# ---- ISO tables (data) ------------------------------------------------------------------------------------
+def _load_tables():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "soundkit_amd", "csrc", "aac_tables.h")).read()
+
+    def arr(name):
+        body = re.search(r"\b%s\[\d*\]\s*=\s*\{(.*?)\};" % name, text, re.S).group(1)
+        return [int(x, 0) for x in re.findall(r"0x[0-9a-fA-F]+|\d+", body)]
+    books = {"sf": (arr("kSfLen"), arr("kSfCode"))}
+    for b in range(1, 12):
+        books[b] = (arr("kCb%dLen" % b), arr("kCb%dCode" % b))
+    swb = {name: arr(name) for name in re.findall(r"\b(kSwb(?:1024|128)_\d+)\[", text)}
+    tns = (arr("kTnsMaxBands1024"), arr("kTnsMaxBands128"))
+    return books, swb, tns
+
+
+_BOOKS, _SWB, _TNS_MAX = _load_tables()
+_CODES = {}
+for _name, (_lens, _codes) in _BOOKS.items():
+    _CODES[_name] = ({(l, c): i for i, (l, c) in enumerate(zip(_lens, _codes)) if l}, max(_lens))
+
+
+def huffman(bits, book, what):
+    """scalefactor.rs:252-266 and the spectral tuple readers: look at what is there (zero-extended to the longest
+    codeword), the matching codeword must fit in the bits that remain."""
+    table, longest = _CODES[book]
+    avail = min(bits.remaining(), longest)
+    window = bits.peek(avail) << (longest - avail)
+    for length in range(1, longest + 1):
+        index = table.get((length, window >> (longest - length)))
+        if index is not None:
+            if length > avail:
+                break
+            bits.pos += length
+            return index
+    raise AacError("InvalidBitstream", what)
+
+
+# ---- sfb.rs:52-152 ------------------------------------------------------------------------------------------
+def long_offsets(sf_index):
+    name = {0: "96", 1: "96", 2: "64", 3: "48", 4: "48", 5: "32", 6: "24", 7: "24", 8: "16", 9: "16", 10: "16", 11: "8", 12: "8"}.get(sf_index)
+    if name is None:
+        raise AacError("UnsupportedSamplingFrequencyIndex", "unsupported AAC sampling frequency index %d" % sf_index)
+    return _SWB["kSwb1024_" + name]
+
+
+def short_offsets(sf_index):
+    name = {0: "96", 1: "96", 2: "96", 3: "48", 4: "48", 5: "48", 6: "24", 7: "24", 8: "16", 9: "16", 10: "16", 11: "8", 12: "8"}.get(sf_index)
+    if name is None:
+        raise AacError("UnsupportedSamplingFrequencyIndex", "unsupported AAC sampling frequency index %d" % sf_index)
+    return _SWB["kSwb128_" + name]
+
+
+RATES = [96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000, 7350]
+ONLY_LONG, LONG_START, EIGHT_SHORT, LONG_STOP = 0, 1, 2, 3
+NOISE, INTENSITY, INTENSITY_NEG = 13, 14, 15  # section.rs:17-34
+
+
+# ---- config.rs:121-319 ---------------------------------------------------------------------------------------
+def parse_asc(asc):
+    """AudioSpecificConfig::read + validate_aac_lc_packet_path (config.rs:194-260, 271-319)"""
+    r = Bits(asc)
+
+    def aot():  # config.rs:271-279
+        v = r.read(5)
+        if v == 31:
+            v = 32 + r.read(6)
+        if v == 0:
+            raise AacError("InvalidAudioObjectType", "invalid AAC audio object type 0")
+        return v
+
+    def rate():  # config.rs:281-288
+        idx = r.read(4)
+        if idx == 15:
+            return -1, r.read(24)
+        if idx > 12:
+            raise AacError("UnsupportedSamplingFrequencyIndex", "unsupported AAC sampling frequency index %d" % idx)
+        return idx, RATES[idx]
+    kind = aot()
+    sf_index, hz = rate()
+    channel_config = r.read(4)
+    sbr = ps = False
+    if kind in (5, 29):
+        sbr, ps = True, kind == 29
+        rate()
+        kind = aot()
+    if kind not in (1, 2, 3, 4, 6, 17, 19, 20):  # read_ga_specific_config, config.rs:290-319
+        raise AacError("UnsupportedAudioObjectType", "unsupported AAC audio object type %d" % kind)
+    frame_length_flag = r.flag()
+    if r.flag():
+        r.read(14)
+    r.flag()
+    if kind != 2:
+        raise AacError("UnsupportedAudioObjectType", "unsupported AAC audio object type %d" % kind)
+    if ps:
+        raise AacError("UnsupportedFeature", "parametric stereo")
+    if sbr:
+        raise AacError("UnsupportedFeature", "SBR/HE-AAC")
+    if frame_length_flag:
+        raise AacError("UnsupportedFeature", "960-sample AAC frames")
+    if channel_config == 0:
+        raise AacError("UnsupportedFeature", "program config element channels")
+    if channel_config not in (1, 2):
+        raise AacError("UnsupportedChannelConfig", "unsupported AAC channel configuration %d" % channel_config)
+    return sf_index, hz, channel_config
+
+
+# ---- side information --------------------------------------------------------------------------------------
+class Ics:
+    """ics.rs:57-110"""
+
+    def __init__(self, r):
+        if r.flag():
+            raise AacError("InvalidConfig", "ICS reserved bit is set")
+        self.sequence = r.read(2)
+        self.shape = r.read(1)
+        if self.sequence == EIGHT_SHORT:
+            self.max_sfb = r.read(4)
+            grouping = r.read(7)
+            lens = [1]
+            for bit in range(7):
+                if (grouping >> (6 - bit)) & 1:
+                    lens[-1] += 1
+                else:
+                    lens.append(1)
+            self.num_windows, self.group_len = 8, lens
+        else:
+            self.max_sfb = r.read(6)
+            if r.flag():
+                raise AacError("UnsupportedFeature", "AAC prediction")
+            self.num_windows, self.group_len = 1, [1]
+        self.groups = len(self.group_len)
+
+
+class Channel:
+    """IndividualChannelStream::read, channel.rs:36-75"""
+
+    def __init__(self, r, common):
+        self.global_gain = r.read(8)
+        self.ics = common if common is not None else Ics(r)
+        self.books = self.read_sections(r)                 # section.rs:60-120
+        self.scale = self.read_scalefactors(r)             # scalefactor.rs:80-153
+        self.pulse = self.read_pulse(r) if r.flag() else None
+        self.tns = self.read_tns(r) if r.flag() else None
+        if r.flag():
+            raise AacError("UnsupportedFeature", "gain control")
+
+    def read_sections(self, r):
+        ics = self.ics
+        if ics.max_sfb > 64:
+            raise AacError("InvalidBitstream", "max_sfb exceeds parser capacity")
+        width = 3 if ics.sequence == EIGHT_SHORT else 5
+        escape = (1 << width) - 1
+        books = []
+        for _ in range(ics.groups):
+            row = []
+            while len(row) < ics.max_sfb:
+                book = r.read(4)
+                if book == 12:
+                    raise AacError("InvalidBitstream", "reserved AAC section codebook")
+                length = 0
+                while True:
+                    step = r.read(width)
+                    length += step
+                    if step != escape:
+                        break
+                if length == 0:
+                    raise AacError("InvalidBitstream", "zero-length section")
+                if len(row) + length > ics.max_sfb:
+                    raise AacError("InvalidBitstream", "section length exceeds max_sfb")
+                row += [book] * length
+            books.append(row)
+        return books
+
+    def read_scalefactors(self, r):
+        def checked(a, b, what):  # i16::checked_add
+            s = a + b
+            if not -32768 <= s <= 32767:
+                raise AacError("InvalidBitstream", what)
+            return s
+
+        def delta():
+            return huffman(r, "sf", "invalid AAC scalefactor codeword") - 60   # index - LAV, scalefactor.rs:212-214
+        spectral, noise, intensity, first_noise = self.global_gain, self.global_gain - 90, 0, True
+        scale = []
+        for g in range(self.ics.groups):
+            row = []
+            for sfb in range(self.ics.max_sfb):
+                book = self.books[g][sfb]
+                if book == 0:
+                    row.append(F(0.0))
+                elif book == NOISE:
+                    if first_noise:
+                        noise = checked(noise, r.read(9) - 256, "noise scalefactor overflow")
+                        first_noise = False
+                    else:
+                        noise = checked(noise, delta(), "noise scalefactor overflow")
+                    row.append(scalefactor_multiplier(noise))
+                elif book in (INTENSITY, INTENSITY_NEG):
+                    intensity = checked(intensity, delta(), "intensity scalefactor overflow")
+                    row.append(powf(F(2.0), F(-0.25) * F(intensity)))          # scalefactor.rs:208-210
+                else:
+                    spectral = checked(spectral, delta(), "spectral scalefactor overflow")
+                    row.append(scalefactor_multiplier(spectral))
+            scale.append(row)
+        return scale
+
+    @staticmethod
+    def read_pulse(r):  # pulse.rs:20-35
+        count = r.read(2) + 1
+        start = r.read(6)
+        return start, [(r.read(5), r.read(4)) for _ in range(count)]
+
+    def read_tns(self, r):  # tns.rs:34-83
+        short = self.ics.sequence == EIGHT_SHORT
+        n_bits, len_bits, order_bits = (1, 4, 3) if short else (2, 6, 5)
+        windows = []
+        for _ in range(self.ics.num_windows):
+            n = r.read(n_bits)
+            filters, res = [], False
+            if n:
+                res = r.flag()
+                for _ in range(n):
+                    length, order = r.read(len_bits), r.read(order_bits)
+                    if order > 20:
+                        raise AacError("UnsupportedFeature", "TNS order above 20")
+                    direction, bits, coeffs = False, 0, []
+                    if order:
+                        direction = r.flag()
+                        compress = r.flag()
+                        bits = (4 if res else 3) - (1 if compress else 0)
+                        for _ in range(order):
+                            raw = r.read(bits)
+                            coeffs.append(raw - (1 << bits) if raw >= (1 << (bits - 1)) else raw)  # read_signed, tns.rs:278-282
+                    filters.append((length, order, direction, bits, coeffs))
+            windows.append((res, filters))
+        return windows
+
+
+def scalefactor_multiplier(sf):  # dsp.rs:407-450
+    return powf(F(2.0), (F(sf) - F(100.0)) * F(0.25))
+
+
+def pow43(mag):  # dsp.rs:420-429
+    return powf(F(mag), F(4.0) / F(3.0))
+
+
+def dequantize(q, scale):  # dsp.rs:397-405
+    if q == 0:
+        return F(0.0)
+    sign = F(-1.0) if q < 0 else F(1.0)
+    return sign * pow43(abs(q)) * scale
+
+
+# ---- spectral data (spectral.rs) ---------------------------------------------------------------------------
+def read_escape(r):  # spectral.rs:214-230
+    extra = 4
+    while r.flag():
+        extra += 1
+        if extra > 16:
+            raise AacError("UnsupportedFeature", "AAC escape value above 16 extra bits")
+    return (1 << extra) + r.read(extra)
+
+
+def read_band(r, book, count):
+    """quantised values of `count` coefficients coded with spectral codebook `book` (spectral.rs:117-212, 327-423)"""
+    out = []
+    what = "invalid AAC spectral codeword"
+    if book <= 4:
+        for _ in range(count // 4):
+            idx = huffman(r, book, what)
+            v = [idx // 27, idx // 9 % 3, idx // 3 % 3, idx % 3]
+            if book <= 2:
+                v = [x - 1 for x in v]
+            else:
+                v = [(-x if x != 0 and r.flag() else x) for x in v]
+            out += v
+    else:
+        dim = 9 if book <= 6 else 8 if book <= 8 else 13 if book <= 10 else 17
+        for _ in range(count // 2):
+            idx = huffman(r, book, what)
+            v = [idx // dim, idx % dim]
+            if book <= 6:
+                v = [x - 4 for x in v]
+            elif book <= 10:
+                v = [(-x if x != 0 and r.flag() else x) for x in v]
+            else:  # signs of both first, then the escapes, then the signs are applied
+                signs = [x != 0 and r.flag() for x in v]
+                v = [read_escape(r) if x == 16 else x for x in v]
+                v = [-x if s else x for x, s in zip(v, signs)]
+            out += v
+    return out
+
+
+class Decoder:
+    """AacLcDecoder up to the hand-over to synthesis (decoder.rs:46-334): access unit -> spectra + window fields"""
+
+    def __init__(self, asc):
+        self.sf_index, self.sample_rate, self.channels = parse_asc(asc)
+        self.pns_state = 0x1F2E3D4C  # spectral.rs:2459, decoder.rs:76
+
+    def offsets(self, ics):  # decoder.rs:376-383
+        if self.sf_index < 0:
+            raise AacError("UnsupportedFeature", "explicit sample-rate scalefactor bands")
+        return short_offsets(self.sf_index) if ics.sequence == EIGHT_SHORT else long_offsets(self.sf_index)
+
+    def noise(self, scale, count):  # spectral.rs:2416-2450
+        if count == 0:
+            return []
+        vals, energy = [], F(0.0)
+        for _ in range(count):
+            self.pns_state = (self.pns_state * 1664525 + 1013904223) & 0xFFFFFFFF
+            top = self.pns_state >> 16
+            v = F(top - 65536 if top >= 32768 else top)
+            vals.append(v)
+            energy = energy + v * v
+        if energy <= F(1.1920929e-07):
+            raise AacError("InvalidBitstream", "PNS noise band has zero energy")
+        norm = scale / np.sqrt(energy)
+        return [v * norm for v in vals]
+
+    def spectrum(self, r, ch, allow_intensity):
+        """decode_channel_spectrum (decoder.rs:220-244) + decode_standard_with_pulse_and_pns (spectral.rs:1907-2294)"""
+        ics = ch.ics
+        if not allow_intensity and any(b in (INTENSITY, INTENSITY_NEG) for row in ch.books for b in row):
+            raise AacError("InvalidBitstream", "intensity stereo is only valid in the right channel of a channel pair")
+        off = self.offsets(ics)
+        coef = np.zeros(1024, np.float32)
+
+        def band(sfb, limit, what):
+            if sfb + 1 >= len(off):
+                raise AacError("InvalidConfig", "missing scale-factor band offset")
+            if off[sfb + 1] > limit:
+                raise AacError("InvalidConfig", what)
+            return off[sfb], off[sfb + 1]
+        if ics.sequence == EIGHT_SHORT:
+            if ch.pulse is not None:
+                raise AacError("InvalidBitstream", "pulse data is not allowed for short windows")
+            w0 = 0
+            for g, glen in enumerate(ics.group_len):
+                if w0 + glen > 8:
+                    raise AacError("InvalidBitstream", "short-window groups exceed eight windows")
+                for sfb in range(ics.max_sfb):
+                    s, e = band(sfb, 128, "short scale-factor band exceeds window length")
+                    book = ch.books[g][sfb]
+                    for w in range(w0, w0 + glen):
+                        if 1 <= book <= 11:
+                            q = read_band(r, book, e - s)
+                            coef[w * 128 + s:w * 128 + e] = [dequantize(x, ch.scale[g][sfb]) for x in q]
+                        elif book == NOISE:
+                            coef[w * 128 + s:w * 128 + e] = self.noise(ch.scale[g][sfb], e - s)
+                w0 += glen
+            if w0 != 8:
+                raise AacError("InvalidBitstream", "short-window groups do not cover eight windows")
+            return coef
+        quant = [0] * 1024
+        for sfb in range(ics.max_sfb):  # noiseless coding first ...
+            s, e = band(sfb, 1024, "scale-factor band exceeds coefficient buffer")
+            book = ch.books[0][sfb]
+            if 1 <= book <= 11:
+                quant[s:e] = read_band(r, book, e - s)
+            elif book == NOISE and ch.pulse is None:  # without pulse data the reference synthesises noise in band order
+                coef[s:e] = self.noise(ch.scale[0][sfb], e - s)
+        if ch.pulse is not None:  # ... apply_pulse_data, spectral.rs:2198-2247
+            start_sfb, pulses = ch.pulse
+            if start_sfb >= ics.max_sfb:
+                raise AacError("InvalidBitstream", "pulse start scale-factor band exceeds max_sfb")
+            index = band(start_sfb, 1024, "scale-factor band exceeds coefficient buffer")[0]
+            for offset, amp in pulses:
+                index += offset
+                if index >= 1024:
+                    raise AacError("InvalidBitstream", "pulse target exceeds spectral coefficient buffer")
+                target = next((b for b in range(ics.max_sfb) if off[b] <= index < off[b + 1]), None)
+                if target is None:
+                    raise AacError("InvalidBitstream", "pulse target exceeds coded scale-factor bands")
+                if not 1 <= ch.books[0][target] <= 11:
+                    raise AacError("InvalidBitstream", "pulse target is not in a spectral band")
+                quant[index] += amp if quant[index] > 0 else -amp
+        for sfb in range(ics.max_sfb):
+            s, e = off[sfb], off[sfb + 1]
+            book = ch.books[0][sfb]
+            if 1 <= book <= 11:
+                coef[s:e] = [dequantize(x, ch.scale[0][sfb]) for x in quant[s:e]]
+            elif book == NOISE and ch.pulse is not None:
+                coef[s:e] = self.noise(ch.scale[0][sfb], e - s)
+        return coef
+
+    def stereo(self, mask, ics, left_ch, right_ch, left, right):
+        """apply_common_stereo_tools (decoder.rs:268-334): intensity (stereo.rs:114-241), then mid/side on the bands
+        that are neither intensity-coded on the right nor noise on either side (stereo.rs:44-112, 410-417)"""
+        off = self.offsets(ics)
+        short = ics.sequence == EIGHT_SHORT
+        wlen = 128 if short else 1024
+        mode, used = mask
+
+        def selected(g, sfb):
+            return mode == 2 or (mode == 1 and used[g][sfb])
+        for tool in ("intensity", "mid_side"):
+            w0 = 0
+            for g, glen in enumerate(ics.group_len if short else [1]):
+                for sfb in range(ics.max_sfb):
+                    s, e = off[sfb], off[sfb + 1]
+                    if e > wlen:
+                        raise AacError("InvalidConfig", "scale-factor band exceeds window length")
+                    rb, lb = right_ch.books[g][sfb], left_ch.books[g][sfb]
+                    for w in range(w0, w0 + glen):
+                        a, b = w * wlen + s, w * wlen + e
+                        if tool == "intensity" and rb in (INTENSITY, INTENSITY_NEG):
+                            sign = F(1.0) if rb == INTENSITY else F(-1.0)   # stereo.rs:431-437
+                            if selected(g, sfb):
+                                sign = -sign                               # stereo.rs:145-149
+                            right[a:b] = left[a:b] * right_ch.scale[g][sfb] * sign
+                        elif tool == "mid_side" and selected(g, sfb) and rb not in (INTENSITY, INTENSITY_NEG) \
+                                and lb != NOISE and rb != NOISE:
+                            mid, side = left[a:b].copy(), right[a:b].copy()
+                            left[a:b] = mid + side
+                            right[a:b] = mid - side
+                w0 += glen
+
+    def tns(self, ch, coef):
+        """apply_tns (tns.rs:103-276)"""
+        ics = ch.ics
+        if self.sf_index < 0:
+            raise AacError("UnsupportedFeature", "explicit sample-rate TNS max bands")
+        short = ics.sequence == EIGHT_SHORT
+        off = self.offsets(ics)
+        bands = len(off) - 1
+        wlen = 128 if short else 1024
+        limit = min(_TNS_MAX[1 if short else 0][self.sf_index], ics.max_sfb, bands)
+        for w, (res, filters) in enumerate(ch.tns):
+            res_bits = 4 if res else 3
+            bottom = bands
+            for length, order, direction, bits, coeffs in filters:
+                top = bottom
+                bottom = max(top - length, 0)
+                if order == 0:
+                    continue
+                start, end = off[min(bottom, limit)], off[min(top, limit)]
+                if end <= start:
+                    continue
+                lpc, prev = [F(0.0)] * 20, [F(0.0)] * 20   # tns_lpc_coefficients, tns.rs:176-206
+                for i in range(order):
+                    refl = -self.tns_coefficient(coeffs[i], bits, res_bits)
+                    lpc[i] = refl
+                    for k in range((i + 1) >> 1):
+                        fwd, bwd = prev[k], prev[i - 1 - k]
+                        lpc[k] = fwd + refl * bwd
+                        lpc[i - 1 - k] = bwd + refl * fwd
+                    prev[:i + 1] = lpc[:i + 1]
+                base = w * wlen
+                positions = range(base + end - 1, base + start - 1, -1) if direction else range(base + start, base + end)
+                step = 1 if direction else -1
+                for done, pos in enumerate(positions):  # apply_tns_filter, tns.rs:237-276
+                    v = coef[pos]
+                    for o in range(1, min(done, order) + 1):
+                        v = v - coef[pos + step * o] * lpc[o - 1]
+                    coef[pos] = v
+
+    @staticmethod
+    def tns_coefficient(encoded, bits, res_bits):  # tns.rs:208-235
+        if bits == 0 or bits > 4 or res_bits not in (3, 4):
+            raise AacError("InvalidBitstream", "invalid TNS coefficient resolution")
+        raw = encoded & ((1 << bits) - 1)
+        signed = -raw if raw < (1 << (bits - 1)) else (1 << bits) - raw
+        if signed == 0:
+            return F(0.0)
+        divisor = F((1 << res_bits) - 1 if signed < 0 else (1 << res_bits) + 1)
+        return sinf(F(signed) * F(3.14159274101257324219) / divisor)
+
+    def decode_access_unit(self, data):
+        """decoder.rs:104-164 -> (coeffs [channels][1024] f32, window_sequence[], window_shape[])"""
+        r = Bits(data)
+        result = None
+
+        def zeros_left():  # remaining_bits_are_zero, decoder.rs:421-438
+            return r.peek(r.remaining()) == 0
+        while r.remaining() >= 3:
+            if result is not None and zeros_left():
+                break
+            element = r.read(3)
+            tag = r.read(4) if element not in (6, 7) else None  # syntax.rs:54-63: FIL and END carry no instance tag
+            if element in (0, 1):
+                if result is not None:
+                    raise AacError("InvalidBitstream", "raw access unit contains multiple channel elements")
+                result = self.single(r) if element == 0 else self.pair(r)
+            elif element in (2, 3, 4, 5):
+                raise AacError("UnsupportedFeature", {2: "channel coupling element", 3: "low frequency element",
+                                                      4: "data stream element", 5: "program config element"}[element])
+            elif element == 6:
+                self.skip_fill(r)
+            else:
+                break
+        if result is None:
+            raise AacError("InvalidBitstream", "raw access unit does not contain an AAC-LC channel element")
+        if not zeros_left():
+            raise AacError("InvalidBitstream", "raw access unit has non-zero trailing bits")
+        return result
+
+    @staticmethod
+    def skip_fill(r):  # decoder.rs:393-419
+        count = r.read(4)
+        if count == 15:
+            ext = r.read(8)
+            if ext == 0:
+                raise AacError("InvalidBitstream", "invalid fill element length")
+            count += ext - 1
+        if count == 0:
+            return
+        if r.remaining() < count * 8:
+            raise _eof(count * 8, r.remaining())
+        if r.peek(4) in (13, 14):
+            raise AacError("UnsupportedFeature", "SBR/HE-AAC extension payload")
+        r.pos += count * 8
+
+    def single(self, r):  # decoder.rs:165-183
+        if self.channels != 1:
+            raise AacError("InvalidBitstream", "single channel element does not match configured channel count")
+        ch = Channel(r, None)
+        coef = self.spectrum(r, ch, False)
+        if ch.tns is not None:
+            self.tns(ch, coef)
+        return coef[None], [ch.ics.sequence], [ch.ics.shape]
+
+    def pair(self, r):  # decoder.rs:185-218
+        if self.channels != 2:
+            raise AacError("InvalidBitstream", "channel pair element does not match configured channel count")
+        common, mask = None, (0, None)
+        common_window = r.flag()
+        if common_window:
+            common = Ics(r)
+            mode = r.read(2)  # read_mid_side_mask, channel.rs:222-251
+            if mode == 3:
+                raise AacError("InvalidBitstream", "reserved mid/side mask mode")
+            used = None
+            if mode == 1:
+                used = [[r.flag() for _ in range(common.max_sfb)] for _ in range(common.groups)]
+            mask = (mode, used)
+        left_ch = Channel(r, common)
+        left = self.spectrum(r, left_ch, False)
+        right_ch = Channel(r, common)
+        right = self.spectrum(r, right_ch, True)
+        if not common_window:
+            if any(b in (INTENSITY, INTENSITY_NEG) for row in right_ch.books for b in row):
+                raise AacError("InvalidBitstream", "common stereo tools require common window")
+        else:
+            self.stereo(mask, left_ch.ics, left_ch, right_ch, left, right)
+        if left_ch.tns is not None:
+            self.tns(left_ch, left)
+        if right_ch.tns is not None:
+            self.tns(right_ch, right)
+        return np.stack([left, right]), [left_ch.ics.sequence, right_ch.ics.sequence], [left_ch.ics.shape, right_ch.ics.shape]
+
+
+def split_adts(data):
+    """parse_adts_access_unit (soundkit-decoder lib.rs:1007-1027) over a whole file -> [(asc, access unit)]"""
+    out, pos = [], 0
+    while pos + 7 <= len(data):
+        h = data[pos:pos + 7]
+        if h[0] != 0xFF or (h[1] & 0xF6) != 0xF0:
+            raise ValueError("invalid ADTS access unit")
+        header = 7 if h[1] & 1 else 9
+        length = ((h[3] & 3) << 11) | (h[4] << 3) | (h[5] >> 5)
+        profile, sr, ch = (h[2] >> 6) + 1, (h[2] >> 2) & 15, ((h[2] & 1) << 2) | (h[3] >> 6)
+        asc = bytes([(profile << 3) | (sr >> 1), ((sr & 1) << 7) | (ch << 3)])
+        out.append((asc, data[pos + header:pos + length]))
+        pos += length
+    return out
