@@ -267,8 +267,10 @@ class Engine:
 
     # ---- resampling ---------------------------------------------------------------------
     @staticmethod
-    def downsample_out_frames(frames):
-        return int(lib.sk_downsample_48k_16k_out_frames(frames))
+    def downsample_out_frames(frames, in_hz=48000, out_hz=16000):
+        if (in_hz, out_hz) == (48000, 16000):
+            return int(lib.sk_downsample_48k_16k_out_frames(frames))
+        return int(lib.sk_downsample_out_frames(frames, in_hz, out_hz))
 
     def taps(self):
         t = np.zeros(256, np.float32)

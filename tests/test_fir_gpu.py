@@ -141,6 +141,28 @@ def test_generic_ratio_one_shot_matches_oracle(engine, oracle, in_hz, out_hz, ro
         assert rel_rms(got, want) < 1e-6 and np.abs(got - want).max() < 2e-6
 
 
+COMMON_SAMPLE_RATES = [8000, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000]  # audio_pipeline.rs:12-13
+
+
+def test_every_pair_of_common_rates_matches_oracle(engine, oracle):
+    """All 72 ordered pairs of the reference's COMMON_SAMPLE_RATES, one short signal each: output length and samples."""
+    rng = np.random.default_rng(2024)
+    x = rng.uniform(-1, 1, (2, 2500)).astype(np.float32)
+    worst = 0.0
+    for in_hz in COMMON_SAMPLE_RATES:
+        for out_hz in COMMON_SAMPLE_RATES:
+            if in_hz == out_hz:
+                continue
+            got = engine.downsample(x, in_hz, out_hz)
+            want = oracle.downsample_planar(x, in_hz, out_hz)
+            assert got.shape == want.shape, (in_hz, out_hz, got.shape, want.shape)
+            assert got.shape[1] == engine.downsample_out_frames(x.shape[1], in_hz, out_hz)
+            if want.size:
+                worst = max(worst, rel_rms(got, want))
+                assert np.abs(got - want).max() < 4e-6, (in_hz, out_hz)
+    assert worst < 1e-6
+
+
 @pytest.mark.parametrize("in_hz,out_hz", [(44100, 16000), (48000, 8000), (16000, 48000)])
 def test_generic_ratio_streaming_matches_oracle(engine, oracle, in_hz, out_hz):
     rng = np.random.default_rng(in_hz)
