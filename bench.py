@@ -113,6 +113,37 @@ def cpu_baseline_pipeline(target_s=15.0):
             "sample": "oracle synth + sko_downsample_planar + s16 interleave, %d stereo frames (1 stream x 64 frames looped) in %.1f s" % (done, dt)}
 
 
+def usable_cores():
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline_all_cores(workload, target_s=8.0):
+    """The same single-thread oracle loop in one process per usable core (affinity and cgroup quota), started as
+    child processes before this process touches the GPU; the sum of their rates."""
+    import subprocess
+    cores = usable_cores()
+    code = ("import json, sys; sys.path.insert(0, %r); import bench; "
+            "print(json.dumps(bench.CPU_BASELINES[%r](%f)))" % (ROOT, workload, target_s))
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for _ in range(cores)]
+    results = []
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode == 0 and out.strip():
+            results.append(json.loads(out.strip().splitlines()[-1]))
+    if not results:
+        return None
+    return {"value": sum(r["value"] for r in results), "unit": results[0]["unit"], "cores": len(results), "kind": "port",
+            "sample": "%d processes, each: %s" % (len(results), results[0]["sample"])}
+
+
 def cpu_baseline_fir(target_s=10.0):
     from oracle import oracle as O
     x = np.random.default_rng(0).uniform(-1, 1, (2, 48000)).astype(np.float32)
@@ -123,6 +154,9 @@ def cpu_baseline_fir(target_s=10.0):
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "stream-seconds/s", "cores": 1, "kind": "port",
             "sample": "oracle sko_downsample_planar, %d x 1 s of 48 kHz stereo in %.1f s" % (done, dt)}
+
+
+CPU_BASELINES = {"fir": cpu_baseline_fir, "aac_synth": cpu_baseline_synth, "pipeline": cpu_baseline_pipeline}
 
 
 def end_to_end(args, eng, torch, dist, world, rank, device):
@@ -222,6 +256,8 @@ def main():
     ap.add_argument("--layout", default="frame", choices=["frame", "stream"],
                     help="packing of the batch: frame-major [frame][stream] (one tick of every stream after another) or stream-major")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-all-cores", action="store_true",
+                    help="also time the oracle in one process per usable core (adds ~10 s; cpu_baseline_all_cores in the JSON)")
     ap.add_argument("--fused-s16", action="store_true",
                     help="pipeline: convert to interleaved s16 in the FIR epilogue instead of a separate kernel (same bytes; +8 %% "
                          "frames/s, but the conversion's VALU work takes issue slots from the f32 MFMA stream, DESIGN.md 4.2)")
@@ -231,6 +267,12 @@ def main():
     ap.add_argument("--out-rate", type=int, default=16000, help="end_to_end: DecodeOptions.output_sample_rate (0 = source rate)")
     ap.add_argument("--out-channels", type=int, default=1, help="end_to_end: DecodeOptions.output_channels (0 = source)")
     args = ap.parse_args()
+
+    # child processes are started before anything here initialises the GPU
+    all_cores = None
+    if (args.cpu_baseline_all_cores and not args.no_cpu_baseline and args.workload in CPU_BASELINES
+            and int(os.environ.get("WORLD_SIZE", "1")) == 1):
+        all_cores = cpu_baseline_all_cores(args.workload)
 
     import torch
     import torch.distributed as dist
@@ -404,7 +446,9 @@ def main():
             out["roofline"]["note"] = "dominant kernel of the step (largest launch time); every kernel of the chain is in `kernels`"
             out["kernels"] = rl
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = {"fir": cpu_baseline_fir, "aac_synth": cpu_baseline_synth, "pipeline": cpu_baseline_pipeline}[args.workload]()
+            out["cpu_baseline"] = CPU_BASELINES[args.workload]()
+            if all_cores:
+                out["cpu_baseline_all_cores"] = all_cores
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
