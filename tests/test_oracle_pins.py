@@ -233,3 +233,37 @@ def test_f64_free_rounding_equals_the_reference_form(tmp_path):
                  "const int neg = ki + (d >= 0.5f ? 1 : 0);",
                  "const int pos = ki + ((d - 0.5f >= m) ? 1 : 0) - ((d + 0.5f < m) ? 1 : 0);"):
         assert line in dev, line
+
+
+def test_config1_wav_stereo_plumbing_on_the_cpu_path(oracle):
+    """BASELINE configs[0] ("plumbing, no GPU"): the reference's testdata/wav_stereo file (fixture copy) through
+    s16le_to_i16 -> deinterleave_vecs_i16 -> vec_i16_to_f32 -> vec_f32_to_i16 -> interleave_vecs_i16 as restated by
+    the oracle, checked against the definitions (audio_bytes.rs:231, :264, :250; audio_pipeline.rs:17-38).  The GPU
+    suite runs the same chain through the product (tests/test_pcm_gpu.py::test_config1_wav_stereo_plumbing)."""
+    import struct
+    data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wav_stereo_A_Tusk.wav"), "rb").read()
+    assert len(data) == 189518 and data[:4] == b"RIFF" and data[8:12] == b"WAVE"
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):  # walk the chunks as WavStreamProcessor::add does (wav.rs:95-262): no 44-byte assumption
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        if cid == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", data[pos + 8:pos + 24])
+        elif cid == b"data":
+            pcm = data[pos + 8:pos + 8 + size]
+        pos += 8 + size + (size & 1)
+    assert fmt == (1, 2, 16000, 64000, 4, 16) and len(pcm) == 189440
+    src = np.frombuffer(pcm, "<i2")
+    i16 = oracle.pcm_convert("S16LE_TO_I16", pcm)
+    assert np.array_equal(i16, src)
+    planes = oracle.deinterleave("i16", pcm, 2)
+    assert planes.shape == (2, 47360) and np.array_equal(planes[0], src[0::2]) and np.array_equal(planes[1], src[1::2])
+    f = np.stack([oracle.pcm_convert("VEC_I16_TO_F32", planes[c]) for c in range(2)])
+    assert f.dtype == np.float32 and np.array_equal(f, planes.astype(np.float32) / np.float32(32768.0))
+    back = np.stack([oracle.pcm_convert("VEC_F32_TO_I16", f[c]) for c in range(2)])
+    # (x / 32768) * 32767 truncated toward zero: never larger in magnitude than the source, off by at most one
+    want = np.trunc(f.astype(np.float64) * 32767.0).astype(np.int16)
+    assert np.all(np.abs(back.astype(np.int32)) <= np.abs(planes.astype(np.int32)))
+    assert np.abs(back.astype(np.int32) - planes.astype(np.int32)).max() <= 1
+    assert np.abs(back.astype(np.int32) - want.astype(np.int32)).max() <= 1
+    inter = np.asarray(oracle.interleave_i16(back)).view("<i2")  # interleave_vecs_i16 returns little-endian bytes
+    assert inter.shape == (2 * 47360,) and np.array_equal(inter[0::2], back[0]) and np.array_equal(inter[1::2], back[1])
