@@ -342,6 +342,20 @@ int sk_tick_run(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, 
                 const float *coeffs, uint32_t n_frames, uint8_t *out_bytes, size_t out_cap, sk_tick_output *outputs,
                 uint32_t outputs_cap, uint32_t *n_outputs, size_t *out_bytes_used);
 
+/* The same tick with the entropy front-end on the GPU too (SURVEY 8f ranks 1 + 4): instead of spectra, the raw access
+ * units (ADTS headers stripped) of every stream.  units[k] addresses unit k in au_bytes; units are listed stream by
+ * stream in the order of `streams`, byte_offset is a multiple of 4 and every unit is followed by >= 8 zero bytes.
+ * The streams must have been opened with the AudioSpecificConfig's sample rate and channel count.  A unit the
+ * front-end rejects yields an output record with its sk_aac_status in `status` and ends that stream's tick, exactly
+ * like a unit sk_aac_decoder_parse would have rejected on the host (same codes; the message text is host-only). */
+typedef struct sk_au_item {
+    uint32_t byte_offset;
+    uint32_t byte_len;
+} sk_au_item;
+int sk_tick_run_au(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, const sk_au_item *units, uint32_t n_units,
+                   const uint8_t *au_bytes, size_t au_bytes_len, uint8_t *out_bytes, size_t out_cap, sk_tick_output *outputs,
+                   uint32_t outputs_cap, uint32_t *n_outputs, size_t *out_bytes_used);
+
 /* ---- batch scheduler: N streams -> one submission loop per GPU ------------------------------------- */
 /* Replaces one pipeline_worker thread per stream (soundkit-decoder lib.rs:2891-3038) for ADTS AAC-LC input and keeps
  * DecodePipelineHandle's contract (lib.rs:2788-2889): send never blocks and reports a full input queue (128 chunks /

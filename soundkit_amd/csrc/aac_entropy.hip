@@ -1,0 +1,48 @@
+// aac_entropy.hip -- the AAC-LC access-unit front-end on gfx950, one stream per lane (SURVEY 8f ranks 1 + 4).
+//
+// A lane walks the access units of its stream in order (the PNS generator and the synthesis overlap make them
+// sequential anyway) through aac_entropy_core.h -- the same source that tests/entropy_core_check.cpp proves equal to
+// the host front-end under AddressSanitizer -- and writes the dequantised, stereo- and TNS-processed spectra straight
+// into the synthesis kernel's input buffer, plus the window fields into the synthesis schedule.  A unit that fails
+// gets its status recorded, zero spectra and a plain long window (so the synthesis launch that follows needs no
+// special case), and ends its stream for this launch: later units of the stream are marked skipped.
+#include "aac_entropy_core.h"
+#include "sk_device.h"
+
+namespace sk {
+
+namespace {
+
+__global__ __launch_bounds__(64) void k_aac_entropy(EntropyArgs a) {
+    const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
+    if (task >= a.n_tasks) return;
+    const EntropyTask tk = a.tasks[task];
+    sk_ec::Stream st{tk.sf_index, (int)tk.channels, a.pns_state[tk.stream]};
+    sk_ec::Scratch scratch;
+    bool dead = false;
+    for (uint32_t k = 0; k < tk.count; ++k) {
+        const EntropyUnit u = a.units[tk.first + k];
+        float *coef = a.coeffs + (size_t)u.off1024 * 1024;
+        uint8_t seq[2] = {0, 0}, shape[2] = {0, 0};
+        int status = EC_SKIPPED;
+        if (!dead) status = sk_ec::decode_access_unit(a.t, st, a.words + u.word_offset, u.byte_len, coef, seq, shape, scratch);
+        if (status != sk_ec::EC_OK) {
+            dead = true;
+            for (uint32_t i = 0; i < tk.channels * 1024u; ++i) coef[i] = 0.0f;
+            seq[0] = seq[1] = shape[0] = shape[1] = 0;
+        }
+        a.status[tk.first + k] = status;
+        for (uint32_t c = 0; c < tk.channels; ++c) a.entries[u.entry[c]].win = (uint32_t)seq[c] | ((uint32_t)shape[c] << 2);
+    }
+    a.pns_state[tk.stream] = st.pns_state;
+}
+
+}  // namespace
+
+hipError_t launch_aac_entropy(const EntropyArgs &a, hipStream_t s) {
+    if (a.n_tasks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_aac_entropy, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace sk

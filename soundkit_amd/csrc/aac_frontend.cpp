@@ -23,6 +23,7 @@
 #include <string>
 #include <vector>
 
+#include "aac_entropy_tables.h"
 #include "aac_tables.h"
 
 namespace {
@@ -969,7 +970,55 @@ void parse_asc(Decoder &d, const uint8_t *asc, size_t len) {
     d.channels = (int)channel_config;
 }
 
+
 }  // namespace
+
+// the same tables in the flat form aac_entropy_core.h takes (aac_entropy_tables.h)
+namespace sk_ec {
+const HostTables &host_tables() {
+    static const HostTables flat = [] {
+        HostTables h;
+        const Tables &t = tables();
+        for (int book = 0; book < 12; ++book) {
+            const Lut &lut = book == 0 ? t.sf : t.cb[book];
+            h.lut_offset[book] = (uint32_t)h.lut.size();
+            h.primary_bits[book] = (uint32_t)lut.primary_bits;
+            h.lut.insert(h.lut.end(), lut.table.begin(), lut.table.end());
+            h.tuple_offset[book] = (uint32_t)h.tuples.size();
+            if (book == 0) continue;
+            for (int i = 0; i < 289; ++i) {
+                const Tuple &tu = t.tuples[book][i];
+                uint64_t packed = 0;
+                for (int k = 0; k < 4; ++k) packed |= (uint64_t)(uint8_t)tu.v[k] << (8 * k);
+                packed |= (uint64_t)tu.nsign << 32;
+                packed |= (uint64_t)tu.escape << 40;
+                h.tuples.push_back(packed);
+            }
+        }
+        h.pow43.assign(t.pow43, t.pow43 + 8192);
+        h.sf_mult.assign(t.sf_mult, t.sf_mult + 768);
+        for (int pos = -256; pos <= 255; ++pos) h.is_mult.push_back(std::pow(2.0f, -0.25f * (float)pos));
+        for (int res_bits = 3; res_bits <= 4; ++res_bits)
+            for (int sgn = -8; sgn <= 8; ++sgn) {
+                const float divisor = (float)(sgn < 0 ? (1 << res_bits) - 1 : (1 << res_bits) + 1);
+                h.tns_sin.push_back(sgn == 0 ? 0.0f : std::sin((float)sgn * 3.14159274101257324219f / divisor));
+            }
+        for (int sf = 0; sf < 13; ++sf) {
+            const Layout l = long_layout(sf), sh = short_layout(sf);
+            h.swb_long_offset[sf] = (uint32_t)h.swb.size();
+            h.swb.insert(h.swb.end(), l.off, l.off + l.bands + 1);
+            h.bands_long[sf] = (uint8_t)l.bands;
+            h.swb_short_offset[sf] = (uint32_t)h.swb.size();
+            h.swb.insert(h.swb.end(), sh.off, sh.off + sh.bands + 1);
+            h.bands_short[sf] = (uint8_t)sh.bands;
+            h.tns_max_long[sf] = kTnsMaxBands1024[sf];
+            h.tns_max_short[sf] = kTnsMaxBands128[sf];
+        }
+        return h;
+    }();
+    return flat;
+}
+}  // namespace sk_ec
 
 struct sk_aac_decoder {
     Decoder d;

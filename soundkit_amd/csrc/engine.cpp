@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 
+#include "aac_entropy_tables.h"
 #include "sk_device.h"
 
 namespace {
@@ -215,7 +216,12 @@ struct sk_engine {
     // grow-only scratch
     DevBuf in_buf, out_buf, aux_buf, aux2_buf;
     // sk_tick_run: synthesis output, resampler output, packed bytes, small-array arena (+ pinned host mirror)
-    DevBuf tick_pcm, tick_res, tick_out, tick_arena;
+    DevBuf tick_pcm, tick_res, tick_out, tick_arena, tick_au;
+    // entropy decode on the device (sk_tick_run_au): per-stream PNS generator state and the front-end's tables
+    uint32_t *d_pns = nullptr;
+    void *d_ec_blob = nullptr;
+    sk_ec::Tables ec_tables{};
+    bool ec_ready = false;
     uint8_t *h_arena = nullptr;
     size_t h_arena_cap = 0;
     std::vector<uint32_t> state_count, state_task;  // plan construction scratch
@@ -376,6 +382,8 @@ int sk_engine_create(int device, uint32_t max_streams, sk_engine **out) {
         if (he != hipSuccess) { rc = e->hip_fail(he, "alloc prev_shape"); break; }
         (void)hipMemset(e->d_delay, 0, states * 1024 * sizeof(float));
         (void)hipMemset(e->d_prev_shape, 0, states);
+        he = hipMalloc((void **)&e->d_pns, (size_t)max_streams * sizeof(uint32_t));
+        if (he != hipSuccess) { rc = e->hip_fail(he, "alloc pns state"); break; }
         rc = build_tables(e);
         if (rc != SK_OK) break;
         e->streams.resize(max_streams);
@@ -397,7 +405,7 @@ void sk_engine_destroy(sk_engine *e) {
     {
         DeviceGuard guard(e->device);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
-        for (void *p : {(void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
+        for (void *p : {(void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
                         (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag,
                         (void *)e->d_zeros})
             if (p) (void)hipFree(p);
@@ -411,6 +419,7 @@ void sk_engine_destroy(sk_engine *e) {
         e->tick_res.release();
         e->tick_out.release();
         e->tick_arena.release();
+        e->tick_au.release();
         if (e->h_arena) (void)hipHostFree(e->h_arena);
         if (e->stream) (void)hipStreamDestroy(e->stream);
     }
@@ -433,6 +442,7 @@ int sk_engine_synchronize(sk_engine *e) {
 static int reset_stream_state(sk_engine *e, uint32_t id) {
     SK_HIP(hipMemsetAsync(e->d_delay + (size_t)id * 2048, 0, 2048 * sizeof(float), e->stream), "reset delay");
     SK_HIP(hipMemsetAsync(e->d_prev_shape + (size_t)id * 2, 0, 2, e->stream), "reset shape");
+    SK_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->d_pns + id), 0x1f2e3d4c, 1, e->stream), "reset pns state");  // spectral.rs:2459
     return SK_OK;
 }
 
@@ -531,6 +541,7 @@ struct HostPlan {
     std::vector<sk::SynthTask> tasks;
     std::vector<sk::SynthEntry> entries;
     std::vector<sk::FrameSpan> spans;
+    std::vector<uint32_t> entry_of;  // [frame * 2 + channel] -> index into entries (valid frames only)
     uint32_t frames_ok = 0;
     uint64_t off1024 = 0;  // total packed size in units of 1024 f32
 };
@@ -578,6 +589,7 @@ int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, in
     std::vector<sk::FrameSpan> &spans = hp.spans;
     spans.clear();
     spans.reserve(frames_ok);
+    hp.entry_of.assign((size_t)n * 2, 0);
     uint64_t off = 0;  // in units of 1024 f32; advances for failed frames too (packing follows the descs)
     bool bad_desc_channels = false;
     for (uint32_t i = 0; i < n; ++i) {
@@ -585,6 +597,7 @@ int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, in
         if (ok[i]) {
             for (uint32_t c = 0; c < d.channels; ++c) {
                 sk::SynthTask &t = tasks[e->state_task[d.stream * 2 + c]];
+                hp.entry_of[(size_t)i * 2 + c] = t.begin + t.count;
                 sk::SynthEntry &en = entries[t.begin + t.count++];
                 en.off1024 = (uint32_t)(off + c);
                 en.win = (uint32_t)d.window_sequence[c] | ((uint32_t)d.window_shape[c] << 2);
@@ -1609,15 +1622,91 @@ size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n_streams, uint32_t 
     return bytes;
 }
 
-int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs,
-                const float *coeffs, uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs,
-                uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) {
-    if (!e || !n_outs || (n_streams && !ts) || (n_frames && (!descs || !coeffs))) return SK_ERR_INVALID_ARG;
+}  // extern "C"
+
+namespace {
+
+// the front-end's tables, flattened and uploaded once
+int ensure_entropy_tables(sk_engine *e) {
+    if (e->ec_ready) return SK_OK;
+    const sk_ec::HostTables &h = sk_ec::host_tables();
+    auto pad = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    const size_t b_lut = 0, b_tup = b_lut + pad(h.lut.size() * 4), b_pow = b_tup + pad(h.tuples.size() * 8),
+                 b_sf = b_pow + pad(h.pow43.size() * 4), b_is = b_sf + pad(h.sf_mult.size() * 4),
+                 b_tns = b_is + pad(h.is_mult.size() * 4), b_swb = b_tns + pad(h.tns_sin.size() * 4),
+                 total = b_swb + pad(h.swb.size() * 2);
+    std::vector<uint8_t> blob(total, 0);
+    std::memcpy(blob.data() + b_lut, h.lut.data(), h.lut.size() * 4);
+    std::memcpy(blob.data() + b_tup, h.tuples.data(), h.tuples.size() * 8);
+    std::memcpy(blob.data() + b_pow, h.pow43.data(), h.pow43.size() * 4);
+    std::memcpy(blob.data() + b_sf, h.sf_mult.data(), h.sf_mult.size() * 4);
+    std::memcpy(blob.data() + b_is, h.is_mult.data(), h.is_mult.size() * 4);
+    std::memcpy(blob.data() + b_tns, h.tns_sin.data(), h.tns_sin.size() * 4);
+    std::memcpy(blob.data() + b_swb, h.swb.data(), h.swb.size() * 2);
+    SK_HIP(hipMalloc(&e->d_ec_blob, total), "alloc entropy tables");
+    SK_HIP(hipMemcpy(e->d_ec_blob, blob.data(), total, hipMemcpyHostToDevice), "upload entropy tables");
+    const uint8_t *base = (const uint8_t *)e->d_ec_blob;
+    sk_ec::Tables &t = e->ec_tables;
+    for (int b = 0; b < 12; ++b) {
+        t.lut[b] = (const uint32_t *)(base + b_lut) + h.lut_offset[b];
+        t.primary_bits[b] = h.primary_bits[b];
+        t.tuples[b] = (const uint64_t *)(base + b_tup) + h.tuple_offset[b];
+    }
+    t.pow43 = (const float *)(base + b_pow);
+    t.sf_mult = (const float *)(base + b_sf);
+    t.is_mult = (const float *)(base + b_is);
+    t.tns_sin = (const float *)(base + b_tns);
+    for (int sf = 0; sf < 13; ++sf) {
+        t.swb_long[sf] = (const uint16_t *)(base + b_swb) + h.swb_long_offset[sf];
+        t.swb_short[sf] = (const uint16_t *)(base + b_swb) + h.swb_short_offset[sf];
+        t.bands_long[sf] = h.bands_long[sf];
+        t.bands_short[sf] = h.bands_short[sf];
+        t.tns_max_long[sf] = h.tns_max_long[sf];
+        t.tns_max_short[sf] = h.tns_max_short[sf];
+    }
+    e->ec_ready = true;
+    return SK_OK;
+}
+
+int sf_index_of(uint32_t rate) {
+    static const uint32_t rates[13] = {96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000, 7350};
+    for (int i = 0; i < 13; ++i)
+        if (rates[i] == rate) return i;
+    return -1;
+}
+
+// Both tick entry points.  units == nullptr: the spectra come from the host (descs / coeffs).  Otherwise the access
+// units themselves do, and the front-end runs on the device before the synthesis.
+int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
+              const sk_au_item *units, const uint8_t *au_bytes, size_t au_len, uint32_t n_frames, uint8_t *out, size_t out_cap,
+              sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) {
+    const bool au_mode = units != nullptr;
+    std::vector<sk_aac_frame_desc> au_descs;
+    if (!e || !n_outs || (n_streams && !ts)) return SK_ERR_INVALID_ARG;
+    if (!au_mode && n_frames && (!descs || !coeffs)) return SK_ERR_INVALID_ARG;
+    if (au_mode && n_frames && !au_bytes) return SK_ERR_INVALID_ARG;
     *n_outs = 0;
     if (out_bytes) *out_bytes = 0;
     if (n_streams == 0) return n_frames == 0 ? SK_OK : SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e->device);
+    if (au_mode) {  // the descs are implied: every unit of a stream carries that stream's channel count
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < n_streams; ++i) total += ts[i].n_frames;
+        if (total != n_frames) return SK_ERR_INVALID_ARG;
+        au_descs.resize(n_frames);
+        uint32_t k = 0;
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            if (!stream_ok(e, ts[i].stream)) return SK_ERR_BAD_STREAM;
+            for (uint32_t f = 0; f < ts[i].n_frames; ++f, ++k) {
+                au_descs[k] = sk_aac_frame_desc{};
+                au_descs[k].stream = ts[i].stream;
+                au_descs[k].channels = e->streams[ts[i].stream].channels;
+                if (units[k].byte_offset % 4 || (size_t)units[k].byte_offset + units[k].byte_len + 8 > au_len) return SK_ERR_INVALID_ARG;
+            }
+        }
+        descs = au_descs.data();
+    }
     static const bool trace = std::getenv("SK_TICK_TRACE") != nullptr;  // per-section host times on stderr
     using TClock = std::chrono::steady_clock;
     TClock::time_point t_mark = TClock::now();
@@ -1682,7 +1771,6 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
     AuxArena aux{(uint8_t *)e->tick_arena.p, e->tick_arena.cap, 0, e->h_arena};
     float *d_pcm = (float *)e->tick_pcm.p;
     if (!hp.tasks.empty()) {
-        SK_HIP(hipMemcpyAsync(e->in_buf.p, coeffs, elems * 4, hipMemcpyHostToDevice, e->stream), "H2D tick coeffs");
         sk::SynthArgs a{};
         a.coeffs = (const float *)e->in_buf.p;
         a.pcm = d_pcm;
@@ -1692,7 +1780,57 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
         SK_HIP(aux.put(hp.entries, e->stream, &a.entries), "upload tick entries");
         a.n_tasks = (uint32_t)hp.tasks.size();
         a.t = e->synth_tables;
+        if (!au_mode) {
+            SK_HIP(hipMemcpyAsync(e->in_buf.p, coeffs, elems * 4, hipMemcpyHostToDevice, e->stream), "H2D tick coeffs");
+        } else {
+            // the front-end on the device: one lane per stream, spectra straight into the synthesis input
+            rc = ensure_entropy_tables(e);
+            if (rc != SK_OK) return rc;
+            SK_HIP(e->tick_au.reserve(au_len + 16), "alloc tick access units");
+            SK_HIP(hipMemcpyAsync(e->tick_au.p, au_bytes, au_len, hipMemcpyHostToDevice, e->stream), "H2D access units");
+            std::vector<sk::EntropyUnit> eu(n_frames);
+            std::vector<sk::EntropyTask> et;
+            for (uint32_t i = 0; i < n_streams; ++i) {
+                if (ts[i].n_frames == 0) continue;
+                const StreamInfo &si = e->streams[ts[i].stream];
+                et.push_back(sk::EntropyTask{ts[i].stream, tc[i].first, ts[i].n_frames, sf_index_of(si.sample_rate), si.channels});
+                for (uint32_t f = 0; f < ts[i].n_frames; ++f) {
+                    const uint32_t k = tc[i].first + f;
+                    eu[k] = sk::EntropyUnit{units[k].byte_offset / 4, units[k].byte_len, (uint32_t)off1024[k],
+                                            {hp.entry_of[(size_t)k * 2], hp.entry_of[(size_t)k * 2 + (si.channels > 1 ? 1 : 0)]}};
+                }
+            }
+            std::vector<int32_t> st_init(n_frames, 0);
+            sk::EntropyArgs ea{};
+            ea.t = e->ec_tables;
+            ea.words = (const uint32_t *)e->tick_au.p;
+            SK_HIP(aux.put(eu, e->stream, &ea.units), "upload entropy units");
+            SK_HIP(aux.put(et, e->stream, &ea.tasks), "upload entropy tasks");
+            const int32_t *d_status = nullptr;
+            SK_HIP(aux.put(st_init, e->stream, &d_status), "upload entropy status");
+            ea.n_tasks = (uint32_t)et.size();
+            ea.pns_state = e->d_pns;
+            ea.coeffs = (float *)e->in_buf.p;
+            ea.entries = const_cast<sk::SynthEntry *>(a.entries);
+            ea.status = const_cast<int32_t *>(d_status);
+            SK_HIP(sk::launch_aac_entropy(ea, e->stream), "launch entropy decode");
+            SK_HIP(hipMemcpyAsync(status.data(), d_status, (size_t)n_frames * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream),
+                   "D2H entropy status");
+        }
         SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth");
+        if (au_mode) {  // which units failed decides what the later stages may use
+            SK_HIP(hipStreamSynchronize(e->stream), "entropy sync");
+            for (uint32_t i = 0; i < n_streams; ++i) {
+                tc[i].good = ts[i].n_frames;
+                tc[i].bad_status = 0;
+                for (uint32_t f = 0; f < ts[i].n_frames; ++f)
+                    if (status[tc[i].first + f] != 0) {
+                        tc[i].good = f;
+                        tc[i].bad_status = status[tc[i].first + f];
+                        break;
+                    }
+            }
+        }
     }
 
     lap(1);
@@ -1885,6 +2023,25 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
     *n_outs = n_rec;
     if (out_bytes) *out_bytes = cursor;
     return SK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs,
+                const float *coeffs, uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs,
+                uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) {
+    return tick_impl(e, ts, n_streams, descs, coeffs, nullptr, nullptr, 0, n_frames, out, out_cap, outs, outs_cap, n_outs, out_bytes);
+}
+
+int sk_tick_run_au(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_au_item *units, uint32_t n_units,
+                   const uint8_t *au_bytes, size_t au_bytes_len, uint8_t *out, size_t out_cap, sk_tick_output *outs,
+                   uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) {
+    if (n_units && !units) return SK_ERR_INVALID_ARG;
+    static const sk_au_item none{};
+    return tick_impl(e, ts, n_streams, nullptr, nullptr, units ? units : &none, au_bytes, au_bytes_len, n_units, out, out_cap, outs,
+                     outs_cap, n_outs, out_bytes);
 }
 
 }  // extern "C"

@@ -150,6 +150,35 @@ struct RowCopy {
 };
 hipError_t launch_row_copies(const float *src_base, float *dst_base, const RowCopy *jobs, uint32_t n_jobs, hipStream_t s);
 
+// aac_entropy.hip -- the AAC-LC front-end on the device, one stream per lane
+}  // namespace sk
+#include "aac_entropy_core.h"
+namespace sk {
+constexpr int EC_SKIPPED = -199;  // a unit after a failed one of the same stream in the same launch
+struct EntropyUnit {
+    uint32_t word_offset;  // of the access unit in `words` (each unit 4-byte aligned, followed by >= 8 zero bytes)
+    uint32_t byte_len;
+    uint32_t off1024;      // where its spectra go (units of 1024 f32)
+    uint32_t entry[2];     // synthesis schedule entries of its channels (their `win` is filled in here)
+};
+struct EntropyTask {       // one stream
+    uint32_t stream, first, count;
+    int32_t sf_index;
+    uint32_t channels;
+};
+struct EntropyArgs {
+    sk_ec::Tables t;       // device pointers
+    const uint32_t *words;
+    const EntropyUnit *units;
+    const EntropyTask *tasks;
+    uint32_t n_tasks;
+    uint32_t *pns_state;   // [max_streams]
+    float *coeffs;
+    SynthEntry *entries;
+    int32_t *status;       // per unit
+};
+hipError_t launch_aac_entropy(const EntropyArgs &a, hipStream_t s);
+
 // pcm.hip -- the output stage of apply_output_options (soundkit-decoder lib.rs:3324-3456) for a batch of
 // planar f32 pieces: [s16 round trip] -> [mono downmix] -> interleaved little-endian bytes.
 enum PackMode : uint8_t {

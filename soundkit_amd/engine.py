@@ -386,6 +386,34 @@ class Engine:
         return res
 
 
+    def tick_run_au(self, streams, access_units):
+        """sk_tick_run_au: as tick_run, but the entropy front-end runs on the GPU.  access_units: the raw access
+        units (bytes) of all streams, stream by stream in the order of `streams`."""
+        import ctypes as C
+        from ._lib import TickStream, TickOutput
+        ts = (TickStream * max(len(streams), 1))()
+        for i, s in enumerate(streams):
+            ts[i].stream, ts[i].n_frames = int(s["stream"]), int(s["n_frames"])
+            ts[i].out_bits, ts[i].out_channels = int(s.get("out_bits", 16)), int(s["out_channels"])
+            ts[i].resample, ts[i].flush = int(bool(s.get("resample", 0))), int(bool(s.get("flush", 0)))
+        n = len(access_units)
+        items = np.zeros((max(n, 1), 2), np.uint32)
+        blob = bytearray()
+        for k, au in enumerate(access_units):
+            items[k] = (len(blob), len(au))
+            blob += bytes(au) + b"\0" * (8 + (-len(au)) % 4)   # >= 8 zero bytes, next unit 4-byte aligned
+        blob = np.frombuffer(bytes(blob) + b"\0" * 8, np.uint8)
+        max_out = C.c_uint32()
+        cap = lib.sk_tick_out_bound(ts, len(streams), C.byref(max_out))
+        out = np.zeros(max(cap, 16), np.uint8)
+        recs = (TickOutput * max(max_out.value, 1))()
+        n_out, used = C.c_uint32(), C.c_size_t()
+        check(lib.sk_tick_run_au(self._h, ts, len(streams), _ptr(items), n, _ptr(blob), blob.size, _ptr(out), out.size, recs,
+                                 max_out.value, C.byref(n_out), C.byref(used)), "sk_tick_run_au", self._h)
+        return [(r.stream_index, r.status, r.frames, r.channels, r.bits, out[r.byte_offset:r.byte_offset + r.bytes].tobytes())
+                for r in recs[:n_out.value]]
+
+
 _default = None
 
 

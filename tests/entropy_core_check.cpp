@@ -1,0 +1,124 @@
+// CPU equivalence check of the host+device entropy core (csrc/aac_entropy_core.h) against the product front-end
+// (csrc/aac_frontend.cpp): same status code, bit-identical spectra and the same window fields on every access unit of
+// the fixtures and on mutated access units.  Built with AddressSanitizer + UBSan by tests/test_entropy_core.py.
+//   usage: entropy_core_check MUTANTS_PER_FILE file.adts...
+#include "../soundkit_amd/csrc/aac_frontend.cpp"
+#include "../soundkit_amd/csrc/aac_entropy_core.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+static uint64_t rng = 0x9E3779B97F4A7C15ull;
+static uint32_t next() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)(rng >> 16); }
+
+static sk_ec::Tables make_tables() {
+    const sk_ec::HostTables &h = sk_ec::host_tables();
+    sk_ec::Tables t{};
+    for (int b = 0; b < 12; ++b) {
+        t.lut[b] = h.lut.data() + h.lut_offset[b];
+        t.primary_bits[b] = h.primary_bits[b];
+        t.tuples[b] = h.tuples.data() + h.tuple_offset[b];
+    }
+    t.pow43 = h.pow43.data();
+    t.sf_mult = h.sf_mult.data();
+    t.is_mult = h.is_mult.data();
+    t.tns_sin = h.tns_sin.data();
+    for (int sf = 0; sf < 13; ++sf) {
+        t.swb_long[sf] = h.swb.data() + h.swb_long_offset[sf];
+        t.swb_short[sf] = h.swb.data() + h.swb_short_offset[sf];
+        t.bands_long[sf] = h.bands_long[sf];
+        t.bands_short[sf] = h.bands_short[sf];
+        t.tns_max_long[sf] = h.tns_max_long[sf];
+        t.tns_max_short[sf] = h.tns_max_short[sf];
+    }
+    return t;
+}
+
+int main(int argc, char **argv) {
+    const int mutants = atoi(argv[1]);
+    const sk_ec::Tables tables = make_tables();
+    size_t checked = 0, accepted = 0;
+    for (int a = 2; a < argc; ++a) {
+        FILE *f = fopen(argv[a], "rb");
+        if (!f) return 2;
+        std::vector<uint8_t> d(1 << 20);
+        const size_t n = fread(d.data(), 1, d.size(), f);
+        fclose(f);
+        std::vector<std::vector<uint8_t>> aus;
+        uint8_t asc[2];
+        size_t pos = 0;
+        while (pos + 7 <= n) {
+            size_t fl, po, pl;
+            if (sk_adts_parse(d.data() + pos, n - pos, &fl, &po, &pl, asc) != 0 || pos + fl > n) break;
+            aus.emplace_back(d.begin() + pos + po, d.begin() + pos + po + pl);
+            pos += fl;
+        }
+        sk_aac_decoder *dec = nullptr;
+        if (sk_aac_decoder_create(asc, 2, &dec) != 0) return 3;
+        sk_ec::Stream st{dec->d.sf_index, dec->d.channels, 0x1f2e3d4cu};
+        std::vector<float> want(2048), got(2048);
+        std::vector<uint32_t> words;
+        sk_ec::Scratch scratch;
+        auto compare = [&](const std::vector<uint8_t> &au, const char *what, size_t index) -> bool {
+            // both decoders carry PNS state across access units: keep them in step
+            dec->d.pns_state = st.pns_state;
+            sk_aac_frame_desc desc{};
+            std::fill(want.begin(), want.end(), 0.0f);
+            std::fill(got.begin(), got.end(), 0.0f);
+            const int rc_want = sk_aac_decoder_parse(dec, au.data(), au.size(), want.data(), &desc);
+            words.assign((au.size() + 3) / 4 + 2, 0);  // 4-byte aligned, >= 8 bytes of zero padding
+            memcpy(words.data(), au.data(), au.size());
+            uint8_t seq[2] = {0, 0}, shape[2] = {0, 0};
+            const int rc_got = sk_ec::decode_access_unit(tables, st, words.data(), (uint32_t)au.size(), got.data(), seq, shape, scratch);
+            ++checked;
+            if (rc_want != rc_got) {
+                printf("%s %zu: status %d vs %d (%s)\n", what, index, rc_want, rc_got, sk_aac_decoder_last_error(dec));
+                return false;
+            }
+            if (rc_want != 0) {
+                st.pns_state = 0x1f2e3d4cu;  // a failed access unit leaves the generators wherever they stopped: restart both
+                return true;
+            }
+            ++accepted;
+            if (memcmp(want.data(), got.data(), sizeof(float) * 1024 * (size_t)st.channels) != 0) {
+                for (int i = 0; i < 1024 * st.channels; ++i)
+                    if (memcmp(&want[i], &got[i], 4) != 0) {
+                        printf("%s %zu: coefficient %d differs: %a vs %a\n", what, index, i, want[i], got[i]);
+                        break;
+                    }
+                return false;
+            }
+            for (int c = 0; c < st.channels; ++c)
+                if (desc.window_sequence[c] != seq[c] || desc.window_shape[c] != shape[c]) {
+                    printf("%s %zu: window fields differ\n", what, index);
+                    return false;
+                }
+            if (dec->d.pns_state != st.pns_state) {
+                printf("%s %zu: PNS state differs\n", what, index);
+                return false;
+            }
+            return true;
+        };
+        for (size_t i = 0; i < aus.size(); ++i)
+            if (!compare(aus[i], "frame", i)) return 1;
+        for (int it = 0; it < mutants; ++it) {
+            std::vector<uint8_t> au = aus[next() % aus.size()];
+            const int flips = 1 + next() % 5;
+            for (int k = 0; k < flips; ++k) {
+                const uint32_t r = next();
+                if (au.empty()) break;
+                switch (r % 4) {
+                case 0: au[(r >> 8) % au.size()] ^= (uint8_t)(1u << ((r >> 4) & 7)); break;
+                case 1: au[(r >> 8) % au.size()] = (uint8_t)(r >> 20); break;
+                case 2: au.resize((r >> 8) % (au.size() + 1)); break;
+                default: { const size_t p = (r >> 8) % au.size(); au.insert(au.begin() + (ptrdiff_t)p, (uint8_t)(r >> 20)); } break;
+                }
+            }
+            if (!compare(au, "mutant", (size_t)it)) return 1;
+        }
+        sk_aac_decoder_destroy(dec);
+    }
+    printf("checked %zu access units, %zu accepted: identical\n", checked, accepted);
+    return 0;
+}

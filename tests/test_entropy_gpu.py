@@ -1,0 +1,118 @@
+"""The AAC-LC front-end on the GPU (csrc/aac_entropy.hip over csrc/aac_entropy_core.h, sk_tick_run_au): the whole
+worker path from raw access units to output bytes without the host touching the bitstream, checked against the same
+tick fed by the host front-end (bit-identical bytes) and for error behaviour."""
+import os
+
+import numpy as np
+import pytest
+
+from soundkit_amd import aac_lc
+from soundkit_amd.engine import make_descs
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aac")
+FILES = ["aac-stereo-48k.adts", "mono16k_A_Tusk.aac", "stereo-music-44100-192k.aac", "A_Tusk_is_used_to_make_costly_gifts_encoded.aac"]
+
+
+def load(name):
+    frames = aac_lc.split_adts(open(os.path.join(GOLD, name), "rb").read())
+    fe = aac_lc.AacLcFrontEnd(frames[0][0])
+    return fe, [au for _, au in frames]
+
+
+def run(engine, mode, specs, per_tick):
+    """specs: [(front-end, access units, out_bits, out_rate, out_channels)]; mode 'host' parses on the CPU and calls
+    sk_tick_run, mode 'gpu' hands the access units to sk_tick_run_au.  -> per stream list of (status, bits, ch, bytes)"""
+    sids, pos, outs = [], [0] * len(specs), [[] for _ in specs]
+    fes = []
+    for fe, aus, bits, rate, ch in specs:
+        sid = engine.open_stream(fe.sample_rate, fe.channels)
+        if rate and rate != fe.sample_rate:
+            engine.resampler_open(sid, fe.sample_rate, rate)
+        sids.append(sid)
+        fes.append(aac_lc.AacLcFrontEnd(bytes([((2 << 3) | (sf_index(fe.sample_rate) >> 1)) & 0xFF,
+                                                ((sf_index(fe.sample_rate) & 1) << 7) | (fe.channels << 3)])))
+    alive = [True] * len(specs)
+    while any(alive[i] and pos[i] < len(specs[i][1]) for i in range(len(specs))):
+        table, units, descs_in, coeffs, index = [], [], [], [], []
+        for i, (fe, aus, bits, rate, ch) in enumerate(specs):
+            if not alive[i] or pos[i] >= len(aus):
+                continue
+            take = aus[pos[i]:pos[i] + per_tick[i]]
+            pos[i] += len(take)
+            last = pos[i] >= len(aus)
+            resample = bool(rate and rate != fe.sample_rate)
+            n_ok = len(take)
+            if mode == "host":
+                parsed = []
+                for au in take:
+                    try:
+                        parsed.append(fes[i].parse(au))
+                    except aac_lc.AacLcError as e:
+                        outs[i].append(("error", e.status))
+                        alive[i] = False
+                        break
+                n_ok = len(parsed)
+                for c, seqs, shapes in parsed:
+                    descs_in.append((sids[i], fe.channels, list(seqs) + [0] * (2 - fe.channels), list(shapes) + [0] * (2 - fe.channels)))
+                    coeffs.append(c.ravel())
+            else:
+                units += take
+            table.append({"stream": sids[i], "n_frames": n_ok, "out_bits": bits or 16, "out_channels": ch or fe.channels,
+                          "resample": resample, "flush": last and resample and alive[i]})
+            index.append(i)
+        if mode == "host":
+            descs, n = make_descs(descs_in)
+            res = engine.tick_run(table, descs, n, np.concatenate(coeffs) if coeffs else np.zeros(0, np.float32))
+        else:
+            res = engine.tick_run_au(table, units)
+        pending_error = {}
+        for idx, status, nframes, ch_o, bits_o, data in res:
+            i = index[idx]
+            if status != 0:
+                outs[i].append(("error", status))
+                alive[i] = False
+            else:
+                outs[i].append((bits_o, ch_o, data))
+    for sid in sids:
+        engine.close_stream(sid)
+    return outs
+
+
+def sf_index(rate):
+    return [96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000, 7350].index(rate)
+
+
+@pytest.mark.parametrize("bits,rate,ch", [(None, None, None), (16, 16000, 1), (24, None, 1), (32, 8000, None)])
+def test_gpu_front_end_equals_host_front_end(engine, bits, rate, ch):
+    specs = []
+    for name in FILES:
+        fe, aus = load(name)
+        specs.append((fe, aus, bits, rate, ch))
+    per_tick = [5, 3, 8, 1]
+    want = run(engine, "host", specs, per_tick)
+    got = run(engine, "gpu", specs, per_tick)
+    for name, w, g in zip(FILES, want, got):
+        assert len(w) == len(g) and len(w) > 0, name
+        assert w == g, name
+
+
+def test_damaged_access_units_fail_with_the_host_codes(engine):
+    """Mutated units: the GPU front-end rejects exactly the units the host front-end rejects, with the same status
+    code, and delivers identical bytes for everything before them; the neighbouring stream is untouched."""
+    fe, aus = load("aac-stereo-48k.adts")
+    state = 0x853C49E6748FEA9B
+    for trial in range(24):
+        damaged = list(aus)
+        state = (state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        k = 3 + (state >> 33) % 30
+        au = bytearray(damaged[k])
+        for j in range(1 + (state >> 20) % 4):
+            r = (state >> (7 * j + 3)) & 0xFFFFF
+            au[(r >> 3) % len(au)] ^= 1 << (r & 7)
+        damaged[k] = bytes(au)
+        specs = [(fe, damaged, None, 16000, 1), (fe, aus, None, None, None)]
+        want = run(engine, "host", specs, [4, 6])
+        got = run(engine, "gpu", specs, [4, 6])
+        assert want[1] == got[1] and len(got[1]) == 48
+        assert want[0] == got[0], (trial, k, [x for x in want[0] if x[0] == "error"], [x for x in got[0] if x[0] == "error"])
