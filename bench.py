@@ -193,7 +193,7 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     threads = args.entropy_threads or max(1, share - 3 - args.feeders)
     feeders = args.feeders
     sched = pipeline.BatchScheduler(eng, entropy_threads=threads, max_streams=args.streams, max_frames_per_tick=16384,
-                                    max_stream_frames_per_tick=8)
+                                    max_stream_frames_per_tick=8, gpu_entropy=int(args.gpu_entropy))
     opt = DecodeOptionsC(args.out_rate, 16, args.out_channels, 0)
 
     def run(loops):
@@ -230,6 +230,7 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
                                                                      args.out_rate or src_rate,
                                                                      "mono" if args.out_channels == 1 else "source-channel", threads),
                    "streams_per_gpu": args.streams, "entropy_threads": threads, "feeder_threads": feeders, "host_cores": cores,
+                   "front_end": "gpu (k_aac_entropy, one stream per lane)" if args.gpu_entropy else "host threads",
                    "parallelism": "streams sharded, %d rank(s), no collective" % world},
         "scheduler": {"ticks": st["ticks"], "frames_per_tick": st["frames"] / max(st["ticks"], 1),
                       "entropy_us_per_frame": st["parse_ns"] / max(st["frames"], 1) / 1e3,
@@ -262,6 +263,7 @@ def main():
                     help="pipeline: convert to interleaved s16 in the FIR epilogue instead of a separate kernel (same bytes; +8 %% "
                          "frames/s, but the conversion's VALU work takes issue slots from the f32 MFMA stream, DESIGN.md 4.2)")
     ap.add_argument("--entropy-threads", type=int, default=0, help="end_to_end: host threads for the AAC front-end (0 = cores - 1, split over ranks)")
+    ap.add_argument("--gpu-entropy", action="store_true", help="end_to_end: run the AAC front-end on the GPU too (host threads only frame ADTS)")
     ap.add_argument("--clip", default="aac-stereo-48k.adts", help="end_to_end: ADTS file under tests/golden/aac to loop")
     ap.add_argument("--feeders", type=int, default=2, help="end_to_end: producer/consumer threads of the load generator")
     ap.add_argument("--out-rate", type=int, default=16000, help="end_to_end: DecodeOptions.output_sample_rate (0 = source rate)")

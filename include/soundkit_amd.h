@@ -372,7 +372,8 @@ typedef struct sk_pipeline_config {
     uint32_t input_buffer;               /* chunks per input queue; 0 = DEFAULT_INPUT_BUFFER 128 (lib.rs:77) */
     uint32_t output_buffer;              /* AudioData per output queue; 0 = DEFAULT_OUTPUT_BUFFER 16 (lib.rs:78) */
     uint32_t tick_wait_us;               /* how long a non-empty batch may wait for more frames; 0 = 200 */
-    uint32_t reserved;
+    uint32_t gpu_entropy;                /* 1: the host threads only frame the ADTS stream; Huffman decode, stereo tools and TNS
+                                          * run on the GPU too (sk_tick_run_au).  0 (default): host front-end (sk_tick_run) */
 } sk_pipeline_config;
 
 typedef struct sk_decode_options { /* DecodeOptions, lib.rs:147-151; 0 = None */

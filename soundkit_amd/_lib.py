@@ -42,7 +42,7 @@ class PipelineConfig(C.Structure):
     """sk_pipeline_config"""
     _fields_ = [(n, C.c_uint32) for n in ("entropy_threads", "max_streams", "max_frames_per_tick",
                                           "max_stream_frames_per_tick", "input_buffer", "output_buffer", "tick_wait_us",
-                                          "reserved")]
+                                          "gpu_entropy")]
 
 
 class DecodeOptionsC(C.Structure):

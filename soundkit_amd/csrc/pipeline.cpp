@@ -83,6 +83,10 @@ struct Batch {
     size_t coeff_cap = 0, n_floats = 0;
     std::vector<sk_aac_frame_desc> descs;  // sized once (max_frames_per_tick): workers fill disjoint ranges without the lock
     size_t n_descs = 0;
+    // gpu_entropy mode: the raw access units instead of spectra (each unit 4-byte aligned, >= 8 zero bytes after it)
+    uint8_t *au_bytes = nullptr;  // pinned
+    size_t au_cap = 0, au_used = 0;
+    std::vector<sk_au_item> units;  // sized once, indexed like descs
     std::vector<sk_tick_stream> ts;
     std::vector<BatchEntry> entries;
     uint32_t writers = 0;  // claims whose memcpy is still running
@@ -96,6 +100,7 @@ struct Batch {
     void clear() {
         n_floats = 0;
         n_descs = 0;
+        au_used = 0;
         ts.clear();
         entries.clear();
         row_of.clear();
@@ -180,13 +185,16 @@ void release_device_side(sk_pipeline *p, PStream &s) {
 struct Parsed {  // what one worker pass produced for one stream
     uint32_t n_frames = 0;
     size_t n_floats = 0;
+    size_t n_au_bytes = 0;  // gpu_entropy: bytes staged (units padded as the device wants them)
     bool eof = false, failed = false;
     int32_t fail_status = 0;
     std::string fail_msg;
 };
 
 // Pulls ADTS frames out of the stream's byte queue and runs the front-end on them, at most `limit` frames.
-void parse_some(sk_pipeline *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_frame_desc *descs, Parsed &r) {
+void parse_some(sk_pipeline *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_frame_desc *descs, std::vector<uint8_t> &au_stage,
+                sk_au_item *au_items, Parsed &r) {
+    const bool gpu_entropy = p->cfg.gpu_entropy != 0;
     auto fail = [&](int32_t st, const std::string &msg) {
         r.failed = true;
         r.fail_status = st;
@@ -264,13 +272,22 @@ void parse_some(sk_pipeline *p, PStream &s, uint32_t limit, float *coeffs, sk_aa
             fail(SK_AAC_ERR_UNSUPPORTED_FEATURE, "Decoding failed: AAC configuration changed mid-stream");
             break;
         }
-        sk_aac_frame_desc &d = descs[r.n_frames];
-        const int rc = sk_aac_decoder_parse(s.fe, frame + pay_off, pay_len, coeffs + r.n_floats, &d);
-        if (rc != SK_OK) {
-            fail(rc, std::string("Decoding failed: ") + sk_aac_decoder_last_error(s.fe));
-            break;
+        if (gpu_entropy) {  // framing only: the access unit itself goes to the device
+            const size_t padded = (pay_len + 8 + 3) & ~(size_t)3;
+            if (au_stage.size() < r.n_au_bytes + padded) au_stage.resize(r.n_au_bytes + padded + 4096);
+            std::memcpy(au_stage.data() + r.n_au_bytes, frame + pay_off, pay_len);
+            std::memset(au_stage.data() + r.n_au_bytes + pay_len, 0, padded - pay_len);
+            au_items[r.n_frames] = sk_au_item{(uint32_t)r.n_au_bytes, (uint32_t)pay_len};
+            r.n_au_bytes += padded;
+        } else {
+            sk_aac_frame_desc &d = descs[r.n_frames];
+            const int rc = sk_aac_decoder_parse(s.fe, frame + pay_off, pay_len, coeffs + r.n_floats, &d);
+            if (rc != SK_OK) {
+                fail(rc, std::string("Decoding failed: ") + sk_aac_decoder_last_error(s.fe));
+                break;
+            }
+            d.stream = s.engine_stream;
         }
-        d.stream = s.engine_stream;
         s.pending_pos += frame_len;
         r.n_frames += 1;
         r.n_floats += (size_t)s.channels * 1024;
@@ -279,8 +296,11 @@ void parse_some(sk_pipeline *p, PStream &s, uint32_t limit, float *coeffs, sk_aa
 
 void worker_main(sk_pipeline *p) {
     const uint32_t per_stream = p->cfg.max_stream_frames_per_tick;
-    std::vector<float> coeffs((size_t)per_stream * 2 * 1024);
+    const bool gpu_entropy = p->cfg.gpu_entropy != 0;
+    std::vector<float> coeffs(gpu_entropy ? 0 : (size_t)per_stream * 2 * 1024);
     std::vector<sk_aac_frame_desc> descs(per_stream);
+    std::vector<uint8_t> au_stage;
+    std::vector<sk_au_item> au_items(per_stream);
     for (;;) {
         uint32_t handle;
         {
@@ -303,7 +323,7 @@ void worker_main(sk_pipeline *p) {
         Parsed r;
         const Clock::time_point t0 = Clock::now();
         const uint32_t limit = std::min(per_stream, room);
-        parse_some(p, s, limit, coeffs.data(), descs.data(), r);
+        parse_some(p, s, limit, coeffs.data(), descs.data(), au_stage, au_items.data(), r);
         s.more = r.n_frames == limit && !r.eof && !r.failed;
         p->parse_ns.fetch_add(ns_since(t0));
         if (r.n_frames == 0 && !r.eof && !r.failed) {  // nothing complete yet
@@ -324,19 +344,22 @@ void worker_main(sk_pipeline *p) {
         }
         // claim room in the batch being filled
         Batch *b;
-        size_t desc_at, float_at;
+        size_t desc_at, float_at, au_at;
         {
             std::unique_lock<std::mutex> lk(p->batch_mu);
             p->room_cv.wait(lk, [&] {
                 const Batch &f = p->batches[p->filling];
-                return p->stop || (f.n_descs + r.n_frames <= p->cfg.max_frames_per_tick && f.n_floats + r.n_floats <= f.coeff_cap);
+                return p->stop || (f.n_descs + r.n_frames <= p->cfg.max_frames_per_tick &&
+                                   (gpu_entropy ? f.au_used + r.n_au_bytes <= f.au_cap : f.n_floats + r.n_floats <= f.coeff_cap));
             });
             if (p->stop) return;
             b = &p->batches[p->filling];
             desc_at = b->n_descs;
             float_at = b->n_floats;
+            au_at = b->au_used;
             b->n_descs += r.n_frames;
             b->n_floats += r.n_floats;
+            b->au_used += r.n_au_bytes;
             sk_tick_stream t{};
             t.stream = s.engine_stream == kNoStream ? 0 : s.engine_stream;
             t.n_frames = r.n_frames;
@@ -358,7 +381,11 @@ void worker_main(sk_pipeline *p) {
             b->entries.push_back(std::move(be));
             b->writers += 1;
         }
-        if (r.n_frames) {
+        if (r.n_frames && gpu_entropy) {
+            std::memcpy(b->au_bytes + au_at, au_stage.data(), r.n_au_bytes);
+            for (uint32_t k = 0; k < r.n_frames; ++k)
+                b->units[desc_at + k] = sk_au_item{(uint32_t)(au_at + au_items[k].byte_offset), au_items[k].byte_len};
+        } else if (r.n_frames) {
             std::memcpy(b->descs.data() + desc_at, descs.data(), r.n_frames * sizeof(sk_aac_frame_desc));
             std::memcpy(b->coeffs + float_at, coeffs.data(), r.n_floats * sizeof(float));
         }
@@ -432,7 +459,10 @@ void submit_main(sk_pipeline *p) {
                     b->rc = SK_ERR_OOM;
             }
             if (b->recs.size() < max_out) b->recs.resize(max_out);
-            if (b->rc == SK_OK)
+            if (b->rc == SK_OK && p->cfg.gpu_entropy)
+                b->rc = sk_tick_run_au(p->engine, ts.data(), (uint32_t)ts.size(), b->units.data(), n_frames, b->au_bytes,
+                                       b->au_used + 8, b->out_pinned, b->out_pinned_cap, b->recs.data(), max_out, &b->n_out, &used);
+            else if (b->rc == SK_OK)
                 b->rc = sk_tick_run(p->engine, ts.data(), (uint32_t)ts.size(), b->descs.data(), b->coeffs, n_frames, b->out_pinned,
                                     b->out_pinned_cap, b->recs.data(), max_out, &b->n_out, &used);
         }
@@ -475,7 +505,28 @@ void deliver_main(sk_pipeline *p) {
                 const sk_tick_output &r = b->recs[k++];
                 if (s.cancelled) continue;
                 if (r.status != 0) {
-                    push_error(s, r.status, "Decoding failed: invalid AAC config: frame rejected by the synthesis engine");
+                    std::string msg = "Decoding failed: invalid AAC config: frame rejected by the synthesis engine";
+                    if (p->cfg.gpu_entropy && r.status <= -101 && r.status >= -108) {
+                        // the device reports codes; the reference's text comes from parsing the stream's units of this
+                        // tick once more on the host (errors are rare, <= max_stream_frames_per_tick units)
+                        msg = std::string("Decoding failed: ") + sk_strerror(r.status);
+                        size_t first = 0;
+                        for (uint32_t q = 0; q < b->row_of[row]; ++q) first += b->ts[q].n_frames;
+                        sk_aac_decoder *probe = nullptr;
+                        if (sk_aac_decoder_create(s.asc, 2, &probe) == SK_OK) {
+                            std::vector<float> sink(2048);
+                            sk_aac_frame_desc d;
+                            for (uint32_t u = 0; u < b->ts[b->row_of[row]].n_frames; ++u) {
+                                const sk_au_item &it = b->units[first + u];
+                                if (sk_aac_decoder_parse(probe, b->au_bytes + it.byte_offset, it.byte_len, sink.data(), &d) != SK_OK) {
+                                    msg = std::string("Decoding failed: ") + sk_aac_decoder_last_error(probe);
+                                    break;
+                                }
+                            }
+                            sk_aac_decoder_destroy(probe);
+                        }
+                    }
+                    push_error(s, r.status, msg);
                     s.finished = true;
                     p->n_errors.fetch_add(1);
                     continue;
@@ -616,13 +667,24 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
     }
     for (Batch &b : p->batches) {
         b.descs.resize(p->cfg.max_frames_per_tick);
-        b.coeff_cap = (size_t)p->cfg.max_frames_per_tick * 2 * 1024;
-        if (hipHostMalloc((void **)&b.coeffs, b.coeff_cap * sizeof(float), hipHostMallocPortable) != hipSuccess) {
-            for (Batch &x : p->batches)
+        b.units.resize(p->cfg.max_frames_per_tick);
+        hipError_t he;
+        if (p->cfg.gpu_entropy) {  // access units are ~0.4-0.8 KiB; 2 KiB each on average leaves room for any legal mix
+            b.au_cap = (size_t)p->cfg.max_frames_per_tick * 2048 + 16384;
+            he = hipHostMalloc((void **)&b.au_bytes, b.au_cap + 64, hipHostMallocPortable);
+        } else {
+            b.coeff_cap = (size_t)p->cfg.max_frames_per_tick * 2 * 1024;
+            he = hipHostMalloc((void **)&b.coeffs, b.coeff_cap * sizeof(float), hipHostMallocPortable);
+        }
+        if (he != hipSuccess) {
+            for (Batch &x : p->batches) {
                 if (x.coeffs) (void)hipHostFree(x.coeffs);
+                if (x.au_bytes) (void)hipHostFree(x.au_bytes);
+            }
             delete p;
             return SK_ERR_OOM;
         }
+        if (b.au_bytes) std::memset(b.au_bytes, 0, b.au_cap + 64);
     }
     p->streams.resize(p->cfg.max_streams);
     for (uint32_t i = 0; i < p->cfg.max_streams; ++i) {
@@ -655,6 +717,7 @@ void sk_pipeline_destroy(sk_pipeline *p) {
     for (auto &s : p->streams) release_device_side(p, *s);
     for (Batch &b : p->batches) {
         if (b.coeffs) (void)hipHostFree(b.coeffs);
+        if (b.au_bytes) (void)hipHostFree(b.au_bytes);
         if (b.out_pinned) (void)hipHostFree(b.out_pinned);
     }
     delete p;

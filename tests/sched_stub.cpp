@@ -54,6 +54,10 @@ size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n, uint32_t *max_out
     *max_outputs = outs;
     return bytes;
 }
+int sk_tick_run_au(sk_engine *, const sk_tick_stream *, uint32_t, const sk_au_item *, uint32_t, const uint8_t *, size_t, uint8_t *, size_t,
+                   sk_tick_output *, uint32_t, uint32_t *, size_t *) {
+    return SK_ERR_UNSUPPORTED;  // the stand-in engine has no device front-end: the scenarios run with gpu_entropy = 0
+}
 int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
                 uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs,
                 size_t *used) {

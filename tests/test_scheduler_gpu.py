@@ -14,9 +14,11 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aac")
 
 
-@pytest.fixture(scope="module")
-def sched(engine):
-    s = pipeline.BatchScheduler(engine, entropy_threads=4, max_streams=64, max_frames_per_tick=256, max_stream_frames_per_tick=4)
+@pytest.fixture(scope="module", params=["host_front_end", "gpu_front_end"])
+def sched(engine, request):
+    """Every scenario runs twice: entropy decode on host threads (sk_tick_run), and on the GPU (sk_tick_run_au)."""
+    s = pipeline.BatchScheduler(engine, entropy_threads=4, max_streams=64, max_frames_per_tick=256, max_stream_frames_per_tick=4,
+                                gpu_entropy=int(request.param == "gpu_front_end"))
     yield s
     s.close()
 
