@@ -13,7 +13,20 @@ namespace sk {
 
 namespace {
 
-__global__ __launch_bounds__(64) void k_aac_entropy(EntropyArgs a) {
+__global__ __launch_bounds__(256) void k_aac_entropy(EntropyArgs a) {
+    // Every codeword costs two dependent table lookups: the Huffman tables and the tuple table live in LDS (~60 KB per
+    // workgroup of four waves), addressed through the same flat pointers the host build uses.
+    extern __shared__ uint4 lds_raw[];
+    uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
+    for (uint32_t i = threadIdx.x; i < a.lds_bytes / 16; i += blockDim.x)
+        lds_raw[i] = reinterpret_cast<const uint4 *>(a.lds_blob)[i];
+    __syncthreads();
+    sk_ec::Tables t = a.t;
+    t.meta = reinterpret_cast<const uint32_t *>(lds + a.lds_meta_off);
+    t.lut = reinterpret_cast<const uint32_t *>(lds + a.lds_lut_off);
+    t.tuples = reinterpret_cast<const uint64_t *>(lds + a.lds_tuple_off);
+    t.sf_mult = reinterpret_cast<const float *>(lds + a.lds_sf_off);
+    t.swb = reinterpret_cast<const uint16_t *>(lds + a.lds_swb_off);
     const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
     if (task >= a.n_tasks) return;
     const EntropyTask tk = a.tasks[task];
@@ -25,7 +38,7 @@ __global__ __launch_bounds__(64) void k_aac_entropy(EntropyArgs a) {
         float *coef = a.coeffs + (size_t)u.off1024 * 1024;
         uint8_t seq[2] = {0, 0}, shape[2] = {0, 0};
         int status = EC_SKIPPED;
-        if (!dead) status = sk_ec::decode_access_unit(a.t, st, a.words + u.word_offset, u.byte_len, coef, seq, shape, scratch);
+        if (!dead) status = sk_ec::decode_access_unit(t, st, a.words + u.word_offset, u.byte_len, coef, seq, shape, scratch);
         if (status != sk_ec::EC_OK) {
             dead = true;
             for (uint32_t i = 0; i < tk.channels * 1024u; ++i) coef[i] = 0.0f;
@@ -41,7 +54,7 @@ __global__ __launch_bounds__(64) void k_aac_entropy(EntropyArgs a) {
 
 hipError_t launch_aac_entropy(const EntropyArgs &a, hipStream_t s) {
     if (a.n_tasks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_aac_entropy, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_aac_entropy, dim3((a.n_tasks + 255) / 256), dim3(256), a.lds_bytes, s, a);
     return hipGetLastError();
 }
 

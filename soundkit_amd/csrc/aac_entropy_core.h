@@ -40,31 +40,54 @@ enum : int {
         if (_st != EC_OK) return _st; \
     } while (0)
 
+// Everything is reached through a handful of base pointers plus one small index block, so that a device build keeps the
+// whole structure in scalar registers whatever book or sampling-frequency index a lane happens to use.
+enum MetaIndex : int {  // offsets into Tables::meta (uint32 each)
+    META_LUT_OFFSET = 0,         // [12] start of each two-level Huffman table in `lut` ([0] scalefactors, [1..11] spectral)
+    META_TUPLE_OFFSET = 12,      // [12] start of each book's tuples in `tuples`
+    META_SWB_LONG_OFFSET = 24,   // [13] start of each long band-offset table in `swb`, by sampling-frequency index
+    META_SWB_SHORT_OFFSET = 37,  // [13]
+    META_BANDS_LONG = 50,        // [13] bands in that table (the table has bands + 1 entries)
+    META_BANDS_SHORT = 63,       // [13]
+    META_TNS_MAX_LONG = 76,      // [13] tns.rs:284-285
+    META_TNS_MAX_SHORT = 89,     // [13]
+    META_WORDS = 102,
+};
+constexpr uint32_t kPrimaryBits = 9;  // of every two-level table (aac_frontend.cpp Lut::kPrimary; every book's longest code >= 9)
+
 struct Tables {
-    const uint32_t *lut[12];   // two-level Huffman tables as aac_frontend.cpp builds them: [0] scalefactors, [1..11] spectral
-    uint32_t primary_bits[12];
-    const uint64_t *tuples[12];  // per symbol: bytes 0-3 the values (int8), byte 4 sign-bit count, byte 5 escape flag
-    const float *pow43;          // [8192]
-    const float *sf_mult;        // [768]: scale factor -256..511
-    const float *is_mult;        // [512]: 2^(-position / 4) for intensity positions -256..255 (scalefactor.rs:208-210)
-    const float *tns_sin;        // [2][17]: sin(signed * pi / divisor) for coef_res 3 / 4 bits, signed -8..8 (tns.rs:208-235)
-    const uint16_t *swb_long[13], *swb_short[13];  // band offsets per sampling-frequency index (bands + 1 entries)
-    uint8_t bands_long[13], bands_short[13];
-    uint8_t tns_max_long[13], tns_max_short[13];
+    const uint32_t *meta;     // [META_WORDS]
+    const uint32_t *lut;      // the twelve two-level Huffman tables as aac_frontend.cpp builds them, back to back
+    const uint64_t *tuples;   // per spectral symbol: bytes 0-3 the values (int8), byte 4 sign-bit count, byte 5 escape flag
+    const uint16_t *swb;      // every band-offset table back to back
+    const float *pow43;       // [8192]
+    const float *sf_mult;     // [768]: scale factor -256..511
+    const float *is_mult;     // [512]: 2^(-position / 4) for intensity positions -256..255 (scalefactor.rs:208-210)
+    const float *tns_sin;     // [2][17]: sin(signed * pi / divisor) for coef_res 3 / 4 bits, signed -8..8 (tns.rs:208-235)
 };
 
 // ---- bit reader over 32-bit big-endian-packed words (the buffer is 4-byte aligned and zero-padded by >= 8 bytes) ----
 struct Bits {
     const uint32_t *words;
     uint32_t total, pos;
+    // the two words around `pos`, kept in registers: on a GPU every lane reads its own access unit, so a load is an
+    // uncoalesced, dependent round trip -- one per 32 bits consumed instead of two per peek
+    uint32_t cached;  // index of the first cached word (0xffffffff: nothing cached yet)
+    uint64_t window;  // bswap(words[cached]) << 32 | bswap(words[cached + 1])
 };
+
+SKE Bits make_bits(const uint32_t *words, uint32_t len_bytes) { return Bits{words, len_bytes * 8, 0, 0xffffffffu, 0}; }
 
 SKE uint32_t ec_bswap(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
 
-SKE uint32_t peek32(const Bits &b) {  // next 32 bits, left-aligned; bits past the end read as the padding (zero)
+SKE uint32_t peek32(Bits &b) {  // next 32 bits, left-aligned; bits past the end read as the padding (zero)
     const uint32_t i = b.pos >> 5, s = b.pos & 31;
-    const uint64_t w = ((uint64_t)ec_bswap(b.words[i]) << 32) | ec_bswap(b.words[i + 1]);
-    return (uint32_t)((w << s) >> 32);
+    if (i != b.cached) {
+        if (b.cached != 0xffffffffu && i == b.cached + 1) b.window = (b.window << 32) | ec_bswap(b.words[i + 1]);
+        else b.window = ((uint64_t)ec_bswap(b.words[i]) << 32) | ec_bswap(b.words[i + 1]);
+        b.cached = i;
+    }
+    return (uint32_t)((b.window << s) >> 32);
 }
 
 SKE int read_bits(Bits &b, uint32_t n, uint32_t *out) {  // n <= 32
@@ -81,19 +104,22 @@ SKE int read_flag(Bits &b, bool *out) {
     return EC_OK;
 }
 
-SKE int huffman(const Tables &t, int book, Bits &b, uint32_t *symbol) {  // scalefactor.rs:252-266, spectral tuple readers
+SKE int huffman_in(const uint32_t *lut, Bits &b, uint32_t *symbol) {  // scalefactor.rs:252-266, spectral tuple readers
     const uint32_t look = peek32(b);
-    const uint32_t pb = t.primary_bits[book];
-    uint32_t e = t.lut[book][look >> (32 - pb)];
+    uint32_t e = lut[look >> (32 - kPrimaryBits)];
     if (e & 0x80000000u) {
         const uint32_t extra = (e >> 24) & 0x7f;
-        e = t.lut[book][(e & 0xffffffu) + ((look << pb) >> (32 - extra))];
+        e = lut[(e & 0xffffffu) + ((look << kPrimaryBits) >> (32 - extra))];
     }
     const uint32_t len = e >> 16;
     if (len == 0 || len > b.total - b.pos) return EC_INVALID_BITSTREAM;
     b.pos += len;
     *symbol = e & 0xffffu;
     return EC_OK;
+}
+
+SKE int huffman(const Tables &t, int book, Bits &b, uint32_t *symbol) {
+    return huffman_in(t.lut + t.meta[META_LUT_OFFSET + book], b, symbol);
 }
 
 // ---- side information -----------------------------------------------------------------------------------
@@ -339,10 +365,20 @@ SKE int read_escape(Bits &b, int *value) {  // spectral.rs:214-230
 }
 
 // one codeword of spectral book `book` -> its 4 (books 1-4) or 2 quantised values (spectral.rs:117-212)
-SKE int read_tuple(const Tables &t, Bits &b, int book, int *q) {
+struct BookRef {  // a band's codebook, resolved once per band (the index block and both tables may sit in LDS)
+    const uint32_t *lut;
+    const uint64_t *tuples;
+    int book;
+};
+SKE BookRef book_ref(const Tables &t, int book) {
+    return BookRef{t.lut + t.meta[META_LUT_OFFSET + book], t.tuples + t.meta[META_TUPLE_OFFSET + book], book};
+}
+
+SKE int read_tuple(const BookRef &br, Bits &b, int *q) {
+    const int book = br.book;
     uint32_t sym;
-    EC_TRY(huffman(t, book, b, &sym));
-    const uint64_t tu = t.tuples[book][sym];
+    EC_TRY(huffman_in(br.lut, b, &sym));
+    const uint64_t tu = br.tuples[sym];
     const int dim = book <= 4 ? 4 : 2;
     const bool is_unsigned = book == 3 || book == 4 || book >= 7;
     for (int k = 0; k < dim; ++k) q[k] = (int8_t)(tu >> (8 * k));
@@ -365,18 +401,26 @@ SKE int band_range(const uint16_t *off, int bands, int sfb, int *s, int *e) {  /
     return EC_OK;
 }
 
-SKE int noise_band(float scale, uint32_t &state, float *out, int n) {  // spectral.rs:2416-2450
+SKE int noise_band(float scale, uint32_t &state, float *__restrict__ out, int n) {  // spectral.rs:2416-2450
     if (n == 0) return EC_OK;
+    // the reference writes the raw noise, sums its energy, then scales in place; here the generator runs twice from the
+    // same state (energy first, then the scaled values) so that nothing is read back from memory: same values
+    uint32_t probe = state;
     float energy = 0.0f;
     for (int i = 0; i < n; ++i) {
-        state = state * 1664525u + 1013904223u;
-        const float v = (float)(int16_t)((int32_t)state >> 16);
-        out[i] = v;
+        probe = probe * 1664525u + 1013904223u;
+        const float v = (float)(int16_t)((int32_t)probe >> 16);
         energy += v * v;
     }
-    if (energy <= 1.1920929e-07f) return EC_INVALID_BITSTREAM;
+    if (energy <= 1.1920929e-07f) {
+        state = probe;
+        return EC_INVALID_BITSTREAM;
+    }
     const float normalizer = scale / ec_sqrtf(energy);
-    for (int i = 0; i < n; ++i) out[i] *= normalizer;
+    for (int i = 0; i < n; ++i) {
+        state = state * 1664525u + 1013904223u;
+        out[i] = (float)(int16_t)((int32_t)state >> 16) * normalizer;
+    }
     return EC_OK;
 }
 
@@ -390,22 +434,26 @@ SKE int layout(const Tables &t, const Stream &st, const Ics &ics, const uint16_t
     if (st.sf_index < 0) return EC_UNSUPPORTED_FEATURE;
     if (st.sf_index > 12) return EC_UNSUPPORTED_SF_INDEX;
     if (ics.sequence == SEQ_EIGHT_SHORT) {
-        *off = t.swb_short[st.sf_index];
-        *bands = t.bands_short[st.sf_index];
+        *off = t.swb + t.meta[META_SWB_SHORT_OFFSET + st.sf_index];
+        *bands = (int)t.meta[META_BANDS_SHORT + st.sf_index];
     } else {
-        *off = t.swb_long[st.sf_index];
-        *bands = t.bands_long[st.sf_index];
+        *off = t.swb + t.meta[META_SWB_LONG_OFFSET + st.sf_index];
+        *bands = (int)t.meta[META_BANDS_LONG + st.sf_index];
     }
     return EC_OK;
 }
 
-// decode_channel_spectrum (decoder.rs:220-244) + decode_standard_with_pulse_and_pns (spectral.rs:1907-2294)
-SKE int decode_spectrum(const Tables &t, Stream &st, Bits &b, const Channel &ch, bool allow_intensity, float *coef) {
-    const Ics &ics = ch.ics;
+// decode_channel_spectrum (decoder.rs:220-244) + decode_standard_with_pulse_and_pns (spectral.rs:1907-2294).
+// `coef` is written, never read, and cannot overlap the side information: it is declared restrict and everything the
+// inner loops need is copied into locals first, so that on the device (where `ch` lives in private memory and `coef` is a
+// flat pointer that could in principle alias it) a coefficient store does not force the side information to be re-read.
+SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef) {
+    const Ics ics = ch.ics;
     const int stride = band_stride(ics);
+    const int max_sfb = ics.max_sfb, num_groups = ics.num_groups;
     if (!allow_intensity)
-        for (int g = 0; g < ics.num_groups; ++g)
-            for (int sfb = 0; sfb < ics.max_sfb; ++sfb) {
+        for (int g = 0; g < num_groups; ++g)
+            for (int sfb = 0; sfb < max_sfb; ++sfb) {
                 const int book = ch.book[g * stride + sfb];
                 if (book == BOOK_INTENSITY || book == BOOK_INTENSITY_NEG) return EC_INVALID_BITSTREAM;
             }
@@ -413,81 +461,104 @@ SKE int decode_spectrum(const Tables &t, Stream &st, Bits &b, const Channel &ch,
     int bands;
     EC_TRY(layout(t, st, ics, &off, &bands));
     for (int i = 0; i < 1024; ++i) coef[i] = 0.0f;
+    Bits b = bits;  // a local copy: its fields stay in registers across the stores below
+    uint32_t pns = st.pns_state;
     int q[4];
+    int status = EC_OK;
     if (ics.sequence == SEQ_EIGHT_SHORT) {
         if (ch.pulse_present) return EC_INVALID_BITSTREAM;
         int w0 = 0;
-        for (int g = 0; g < ics.num_groups; ++g) {
+        for (int g = 0; g < num_groups && status == EC_OK; ++g) {
             const int glen = ics.group_len[g];
-            if (glen == 0) return EC_INVALID_BITSTREAM;
-            if (w0 + glen > 8) return EC_INVALID_BITSTREAM;
-            for (int sfb = 0; sfb < ics.max_sfb; ++sfb) {
+            if (glen == 0 || w0 + glen > 8) {
+                status = EC_INVALID_BITSTREAM;
+                break;
+            }
+            for (int sfb = 0; sfb < max_sfb && status == EC_OK; ++sfb) {
                 int s, e;
-                EC_TRY(band_range(off, bands, sfb, &s, &e));
-                if (e > 128) return EC_INVALID_CONFIG;
+                status = band_range(off, bands, sfb, &s, &e);
+                if (status != EC_OK) break;
+                if (e > 128) {
+                    status = EC_INVALID_CONFIG;
+                    break;
+                }
                 const int book = ch.book[g * stride + sfb];
                 const float scale = ch.mult[g * stride + sfb];
                 if (book >= 1 && book <= 11) {
+                    const BookRef br = book_ref(t, book);
                     const int dim = book <= 4 ? 4 : 2;
-                    for (int w = w0; w < w0 + glen; ++w)
+                    for (int w = w0; w < w0 + glen && status == EC_OK; ++w)
                         for (int i = s; i + dim <= e; i += dim) {
-                            EC_TRY(read_tuple(t, b, book, q));
+                            status = read_tuple(br, b, q);
+                            if (status != EC_OK) break;
                             for (int k = 0; k < dim; ++k) coef[w * 128 + i + k] = dequantize(t, q[k], scale);
                         }
                 } else if (book == BOOK_NOISE) {
-                    for (int w = w0; w < w0 + glen; ++w) EC_TRY(noise_band(scale, st.pns_state, coef + w * 128 + s, e - s));
+                    for (int w = w0; w < w0 + glen && status == EC_OK; ++w) status = noise_band(scale, pns, coef + w * 128 + s, e - s);
                 }
             }
             w0 += glen;
         }
-        return w0 == 8 ? EC_OK : EC_INVALID_BITSTREAM;
+        if (status == EC_OK && w0 != 8) status = EC_INVALID_BITSTREAM;
+        bits = b;
+        st.pns_state = pns;
+        return status;
     }
     // long windows.  With pulse data the reference reads every band, then validates and adds the pulses, then
     // dequantises; the pulses only touch <= 4 coefficients, so they are tracked by position instead of keeping all
     // 1024 quantised values: targets are known before the spectral data (offsets from the start band), the value
     // read at a target is adjusted before it is dequantised, and the validity checks run after the last band so that a
     // damaged spectral codeword is reported first, as the reference does.
-    int target[4] = {-1, -1, -1, -1};
-    bool start_ok = true, start_known = false;
-    if (ch.pulse_present && ch.pulse_start < ics.max_sfb && ch.pulse_start + 1 <= bands) {
+    const bool pulse_present = ch.pulse_present != 0;
+    const int pulse_count = pulse_present ? ch.pulse_count : 0;
+    int target[4] = {-1, -1, -1, -1}, amp[4] = {0, 0, 0, 0};
+    bool start_known = false;
+    if (pulse_present && ch.pulse_start < max_sfb && ch.pulse_start + 1 <= bands) {
         int index = off[ch.pulse_start];
         start_known = true;
-        for (int i = 0; i < ch.pulse_count; ++i) {
+        for (int i = 0; i < pulse_count; ++i) {
             index += ch.pulse_offset[i];
             target[i] = index;  // may be >= 1024 or outside the coded bands: checked after the spectral data
+            amp[i] = ch.pulse_amp[i];
         }
     }
-    (void)start_ok;
-    for (int sfb = 0; sfb < ics.max_sfb; ++sfb) {
+    for (int sfb = 0; sfb < max_sfb && status == EC_OK; ++sfb) {
         int s, e;
-        EC_TRY(band_range(off, bands, sfb, &s, &e));
-        if (e > 1024) return EC_INVALID_CONFIG;
+        status = band_range(off, bands, sfb, &s, &e);
+        if (status != EC_OK) break;
+        if (e > 1024) {
+            status = EC_INVALID_CONFIG;
+            break;
+        }
         const int book = ch.book[sfb];
         const float scale = ch.mult[sfb];
         if (book >= 1 && book <= 11) {
+            const BookRef br = book_ref(t, book);
             const int dim = book <= 4 ? 4 : 2;
             for (int i = s; i + dim <= e; i += dim) {
-                EC_TRY(read_tuple(t, b, book, q));
-                if (ch.pulse_present)
-                    for (int p = 0; p < ch.pulse_count; ++p) {  // pulses apply in order; two may hit the same coefficient
-                        const int k = target[p] - i;
-                        if (k >= 0 && k < dim) q[k] += q[k] > 0 ? ch.pulse_amp[p] : -(int)ch.pulse_amp[p];
-                    }
+                status = read_tuple(br, b, q);
+                if (status != EC_OK) break;
+                for (int p = 0; p < pulse_count; ++p) {  // pulses apply in order; two may hit the same coefficient
+                    const int k = target[p] - i;
+                    if (k >= 0 && k < dim) q[k] += q[k] > 0 ? amp[p] : -amp[p];
+                }
                 for (int k = 0; k < dim; ++k) coef[i + k] = dequantize(t, q[k], scale);
             }
-        } else if (book == BOOK_NOISE && !ch.pulse_present) {
-            EC_TRY(noise_band(scale, st.pns_state, coef + s, e - s));
+        } else if (book == BOOK_NOISE && !pulse_present) {
+            status = noise_band(scale, pns, coef + s, e - s);
         }
     }
-    if (!ch.pulse_present) return EC_OK;
+    bits = b;
+    st.pns_state = pns;
+    if (status != EC_OK || !pulse_present) return status;
     // apply_pulse_data's checks (spectral.rs:2198-2247), in its order
-    if (ch.pulse_start >= ics.max_sfb) return EC_INVALID_BITSTREAM;
+    if (ch.pulse_start >= max_sfb) return EC_INVALID_BITSTREAM;
     if (!start_known) return EC_INVALID_CONFIG;  // band_range(start_sfb) failed
-    for (int p = 0; p < ch.pulse_count; ++p) {
+    for (int p = 0; p < pulse_count; ++p) {
         const int index = target[p];
         if (index >= 1024) return EC_INVALID_BITSTREAM;
         int band = -1;
-        for (int sfb = 0; sfb < ics.max_sfb; ++sfb) {
+        for (int sfb = 0; sfb < max_sfb; ++sfb) {
             int s, e;
             EC_TRY(band_range(off, bands, sfb, &s, &e));
             if (index >= s && index < e) {
@@ -499,7 +570,7 @@ SKE int decode_spectrum(const Tables &t, Stream &st, Bits &b, const Channel &ch,
         const int book = ch.book[band];
         if (!(book >= 1 && book <= 11)) return EC_INVALID_BITSTREAM;
     }
-    for (int sfb = 0; sfb < ics.max_sfb; ++sfb) {  // the noise bands of the pulse path come last
+    for (int sfb = 0; sfb < max_sfb; ++sfb) {  // the noise bands of the pulse path come last
         if (ch.book[sfb] != BOOK_NOISE) continue;
         int s, e;
         EC_TRY(band_range(off, bands, sfb, &s, &e));
@@ -601,7 +672,7 @@ SKE int apply_tns(const Tables &t, const Stream &st, const Channel &ch, float *c
     int bands;
     EC_TRY(layout(t, st, ics, &off, &bands));
     const int wlen = is_short ? 128 : 1024;
-    int limit = is_short ? t.tns_max_short[st.sf_index] : t.tns_max_long[st.sf_index];
+    int limit = (int)t.meta[(is_short ? META_TNS_MAX_SHORT : META_TNS_MAX_LONG) + st.sf_index];
     if (limit > ics.max_sfb) limit = ics.max_sfb;
     if (limit > bands) limit = bands;
     for (int w = 0; w < ics.num_windows; ++w) {
@@ -629,21 +700,22 @@ SKE int apply_tns(const Tables &t, const Stream &st, const Channel &ch, float *c
                 }
                 for (int k = 0; k <= i; ++k) prev[k] = lpc[k];
             }
-            float *c = coef + w * wlen;  // apply_tns_filter, tns.rs:237-276
-            if (flt.direction) {
-                for (int pos = end - 1; pos >= start; --pos) {
-                    const int done = end - 1 - pos, mo = done < flt.order ? done : flt.order;
-                    float v = c[pos];
-                    for (int o = 1; o <= mo; ++o) v -= c[pos + o] * lpc[o - 1];
-                    c[pos] = v;
-                }
-            } else {
-                for (int pos = start; pos < end; ++pos) {
-                    const int done = pos - start, mo = done < flt.order ? done : flt.order;
-                    float v = c[pos];
-                    for (int o = 1; o <= mo; ++o) v -= c[pos - o] * lpc[o - 1];
-                    c[pos] = v;
-                }
+            // apply_tns_filter, tns.rs:237-276.  The recursion reads the `order` outputs it has just produced: they stay
+            // in a register shift line (newest first) instead of being read back from memory -- on a GPU every such
+            // read would be a dependent, uncoalesced load.  Same operations in the same order as the reference's loop.
+            float *c = coef + w * wlen;
+            float hist[20];
+            for (int i = 0; i < 20; ++i) hist[i] = 0.0f;
+            const int n = end - start, step = flt.direction ? -1 : 1;
+            int pos = flt.direction ? end - 1 : start;
+            for (int done = 0; done < n; ++done, pos += step) {
+                const int mo = done < flt.order ? done : flt.order;
+                float v = c[pos];
+                for (int o = 1; o <= 20; ++o)
+                    if (o <= mo) v -= hist[o - 1] * lpc[o - 1];
+                c[pos] = v;
+                for (int k = 19; k > 0; --k) hist[k] = hist[k - 1];
+                hist[0] = v;
             }
         }
     }
@@ -669,7 +741,7 @@ struct Scratch {  // per-lane working storage (two channels' side information)
 // One access unit -> spectra [channels][1024] and the window fields.  `au` is the word buffer described at Bits.
 SKE int decode_access_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len_bytes, float *coef, uint8_t *sequence,
                            uint8_t *shape, Scratch &s) {
-    Bits b{au, len_bytes * 8, 0};
+    Bits b = make_bits(au, len_bytes);
     bool decoded = false;
     while (b.total - b.pos >= 3) {  // each pass consumes >= 3 bits: bounded by the length of the access unit
         if (decoded && rest_is_zero(b)) break;

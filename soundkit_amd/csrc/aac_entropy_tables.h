@@ -21,6 +21,7 @@ struct HostTables {
     uint32_t swb_long_offset[13], swb_short_offset[13];
     uint8_t bands_long[13], bands_short[13];
     uint8_t tns_max_long[13], tns_max_short[13];
+    std::vector<uint32_t> meta;     // the index block of sk_ec::Tables (aac_entropy_core.h MetaIndex)
 };
 
 const HostTables &host_tables();  // aac_frontend.cpp

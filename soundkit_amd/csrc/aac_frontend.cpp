@@ -1014,6 +1014,19 @@ const HostTables &host_tables() {
             h.tns_max_long[sf] = kTnsMaxBands1024[sf];
             h.tns_max_short[sf] = kTnsMaxBands128[sf];
         }
+        h.meta.assign(102, 0);  // sk_ec::META_WORDS
+        for (int b = 0; b < 12; ++b) {
+            h.meta[0 + b] = h.lut_offset[b];
+            h.meta[12 + b] = h.tuple_offset[b];
+        }
+        for (int sf = 0; sf < 13; ++sf) {
+            h.meta[24 + sf] = h.swb_long_offset[sf];
+            h.meta[37 + sf] = h.swb_short_offset[sf];
+            h.meta[50 + sf] = h.bands_long[sf];
+            h.meta[63 + sf] = h.bands_short[sf];
+            h.meta[76 + sf] = h.tns_max_long[sf];
+            h.meta[89 + sf] = h.tns_max_short[sf];
+        }
         return h;
     }();
     return flat;

@@ -221,6 +221,7 @@ struct sk_engine {
     uint32_t *d_pns = nullptr;
     void *d_ec_blob = nullptr;
     sk_ec::Tables ec_tables{};
+    sk::EntropyArgs ec_args{};  // the table part of the kernel arguments (pointers, LDS blob layout)
     bool ec_ready = false;
     uint8_t *h_arena = nullptr;
     size_t h_arena_cap = 0;
@@ -1631,11 +1632,16 @@ int ensure_entropy_tables(sk_engine *e) {
     if (e->ec_ready) return SK_OK;
     const sk_ec::HostTables &h = sk_ec::host_tables();
     auto pad = [](size_t n) { return (n + 255) & ~(size_t)255; };
-    const size_t b_lut = 0, b_tup = b_lut + pad(h.lut.size() * 4), b_pow = b_tup + pad(h.tuples.size() * 8),
-                 b_sf = b_pow + pad(h.pow43.size() * 4), b_is = b_sf + pad(h.sf_mult.size() * 4),
-                 b_tns = b_is + pad(h.is_mult.size() * 4), b_swb = b_tns + pad(h.tns_sin.size() * 4),
-                 total = b_swb + pad(h.swb.size() * 2);
+    for (int b = 0; b < 12; ++b)
+        if (h.primary_bits[b] != sk_ec::kPrimaryBits) return SK_ERR_INVALID_ARG;
+    // LDS part first (index block, Huffman tables, tuples, scale-factor multipliers, band offsets), then what stays in
+    // global memory
+    const size_t b_meta = 0, b_lut = b_meta + pad(h.meta.size() * 4), b_tup = b_lut + pad(h.lut.size() * 4),
+                 b_sf = b_tup + pad(h.tuples.size() * 8), b_swb = b_sf + pad(h.sf_mult.size() * 4),
+                 lds_end = b_swb + pad(h.swb.size() * 2), b_pow = lds_end, b_is = b_pow + pad(h.pow43.size() * 4),
+                 b_tns = b_is + pad(h.is_mult.size() * 4), total = b_tns + pad(h.tns_sin.size() * 4);
     std::vector<uint8_t> blob(total, 0);
+    std::memcpy(blob.data() + b_meta, h.meta.data(), h.meta.size() * 4);
     std::memcpy(blob.data() + b_lut, h.lut.data(), h.lut.size() * 4);
     std::memcpy(blob.data() + b_tup, h.tuples.data(), h.tuples.size() * 8);
     std::memcpy(blob.data() + b_pow, h.pow43.data(), h.pow43.size() * 4);
@@ -1647,23 +1653,23 @@ int ensure_entropy_tables(sk_engine *e) {
     SK_HIP(hipMemcpy(e->d_ec_blob, blob.data(), total, hipMemcpyHostToDevice), "upload entropy tables");
     const uint8_t *base = (const uint8_t *)e->d_ec_blob;
     sk_ec::Tables &t = e->ec_tables;
-    for (int b = 0; b < 12; ++b) {
-        t.lut[b] = (const uint32_t *)(base + b_lut) + h.lut_offset[b];
-        t.primary_bits[b] = h.primary_bits[b];
-        t.tuples[b] = (const uint64_t *)(base + b_tup) + h.tuple_offset[b];
-    }
+    t.meta = (const uint32_t *)(base + b_meta);
+    t.lut = (const uint32_t *)(base + b_lut);
+    t.tuples = (const uint64_t *)(base + b_tup);
+    t.swb = (const uint16_t *)(base + b_swb);
     t.pow43 = (const float *)(base + b_pow);
     t.sf_mult = (const float *)(base + b_sf);
     t.is_mult = (const float *)(base + b_is);
     t.tns_sin = (const float *)(base + b_tns);
-    for (int sf = 0; sf < 13; ++sf) {
-        t.swb_long[sf] = (const uint16_t *)(base + b_swb) + h.swb_long_offset[sf];
-        t.swb_short[sf] = (const uint16_t *)(base + b_swb) + h.swb_short_offset[sf];
-        t.bands_long[sf] = h.bands_long[sf];
-        t.bands_short[sf] = h.bands_short[sf];
-        t.tns_max_long[sf] = h.tns_max_long[sf];
-        t.tns_max_short[sf] = h.tns_max_short[sf];
-    }
+    sk::EntropyArgs &ea = e->ec_args;
+    ea.t = t;
+    ea.lds_blob = base;
+    ea.lds_bytes = (uint32_t)lds_end;
+    ea.lds_meta_off = (uint32_t)b_meta;
+    ea.lds_lut_off = (uint32_t)b_lut;
+    ea.lds_tuple_off = (uint32_t)b_tup;
+    ea.lds_sf_off = (uint32_t)b_sf;
+    ea.lds_swb_off = (uint32_t)b_swb;
     e->ec_ready = true;
     return SK_OK;
 }
@@ -1801,8 +1807,7 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 }
             }
             std::vector<int32_t> st_init(n_frames, 0);
-            sk::EntropyArgs ea{};
-            ea.t = e->ec_tables;
+            sk::EntropyArgs ea = e->ec_args;
             ea.words = (const uint32_t *)e->tick_au.p;
             SK_HIP(aux.put(eu, e->stream, &ea.units), "upload entropy units");
             SK_HIP(aux.put(et, e->stream, &ea.tasks), "upload entropy tasks");

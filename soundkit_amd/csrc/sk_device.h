@@ -168,6 +168,11 @@ struct EntropyTask {       // one stream
 };
 struct EntropyArgs {
     sk_ec::Tables t;       // device pointers
+    // the part of the tables every codeword touches, as one blob the kernel copies into LDS: index block, Huffman tables,
+    // tuple table, scale-factor multipliers, band offsets (byte offsets from lds_blob)
+    const uint8_t *lds_blob;
+    uint32_t lds_bytes;
+    uint32_t lds_meta_off, lds_lut_off, lds_tuple_off, lds_sf_off, lds_swb_off;
     const uint32_t *words;
     const EntropyUnit *units;
     const EntropyTask *tasks;

@@ -14,28 +14,22 @@ static uint32_t next() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; re
 
 static sk_ec::Tables make_tables() {
     const sk_ec::HostTables &h = sk_ec::host_tables();
+    for (int b = 0; b < 12; ++b)
+        if (h.primary_bits[b] != sk_ec::kPrimaryBits) abort();
     sk_ec::Tables t{};
-    for (int b = 0; b < 12; ++b) {
-        t.lut[b] = h.lut.data() + h.lut_offset[b];
-        t.primary_bits[b] = h.primary_bits[b];
-        t.tuples[b] = h.tuples.data() + h.tuple_offset[b];
-    }
+    t.meta = h.meta.data();
+    t.lut = h.lut.data();
+    t.tuples = h.tuples.data();
+    t.swb = h.swb.data();
     t.pow43 = h.pow43.data();
     t.sf_mult = h.sf_mult.data();
     t.is_mult = h.is_mult.data();
     t.tns_sin = h.tns_sin.data();
-    for (int sf = 0; sf < 13; ++sf) {
-        t.swb_long[sf] = h.swb.data() + h.swb_long_offset[sf];
-        t.swb_short[sf] = h.swb.data() + h.swb_short_offset[sf];
-        t.bands_long[sf] = h.bands_long[sf];
-        t.bands_short[sf] = h.bands_short[sf];
-        t.tns_max_long[sf] = h.tns_max_long[sf];
-        t.tns_max_short[sf] = h.tns_max_short[sf];
-    }
     return t;
 }
 
 int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     const int mutants = atoi(argv[1]);
     const sk_ec::Tables tables = make_tables();
     size_t checked = 0, accepted = 0;
