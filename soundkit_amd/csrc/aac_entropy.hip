@@ -50,7 +50,94 @@ __global__ __launch_bounds__(256) void k_aac_entropy(EntropyArgs a) {
     a.pns_state[tk.stream] = st.pns_state;
 }
 
+// ---- frame-parallel form ---------------------------------------------------------------------------------------------
+// The only thing that orders the access units of a stream is the PNS generator.  Phase 1 decodes every unit in its own
+// lane with the noise bands left open (and counted), phase 2 walks each stream once to hand every unit its generator
+// state by LCG jump-ahead, phase 3 fills the noise and finishes (stereo tools, TNS, rest of the unit) per unit again.
+// The composition equals decode_access_unit: tests/entropy_core_check.cpp checks that on the CPU for every unit it sees.
+
+__device__ __forceinline__ sk_ec::Tables lds_tables(const EntropyArgs &a, uint4 *lds_raw) {
+    uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
+    for (uint32_t i = threadIdx.x; i < a.lds_bytes / 16; i += blockDim.x)
+        lds_raw[i] = reinterpret_cast<const uint4 *>(a.lds_blob)[i];
+    __syncthreads();
+    sk_ec::Tables t = a.t;
+    t.meta = reinterpret_cast<const uint32_t *>(lds + a.lds_meta_off);
+    t.lut = reinterpret_cast<const uint32_t *>(lds + a.lds_lut_off);
+    t.tuples = reinterpret_cast<const uint64_t *>(lds + a.lds_tuple_off);
+    t.sf_mult = reinterpret_cast<const float *>(lds + a.lds_sf_off);
+    t.swb = reinterpret_cast<const uint16_t *>(lds + a.lds_swb_off);
+    return t;
+}
+
+__global__ __launch_bounds__(256) void k_aac_entropy_parse(EntropyArgs a) {
+    extern __shared__ uint4 lds_raw[];
+    const sk_ec::Tables t = lds_tables(a, lds_raw);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_units) return;
+    const EntropyUnit u = a.units[k];
+    const EntropyTask tk = a.tasks[u.task];
+    sk_ec::Stream st{tk.sf_index, (int)tk.channels, 0u};
+    sk_ec::Scratch side;
+    uint8_t seq[2] = {0, 0}, shape[2] = {0, 0};
+    const int status = sk_ec::parse_unit(t, st, a.words + u.word_offset, u.byte_len, a.coeffs + (size_t)u.off1024 * 1024, seq, shape, side,
+                                         sk_ec::PNS_COUNT);
+    a.status[k] = status;
+    a.side[k] = side;
+    for (uint32_t c = 0; c < tk.channels; ++c) a.entries[u.entry[c]].win = (uint32_t)seq[c] | ((uint32_t)shape[c] << 2);
+}
+
+__global__ __launch_bounds__(64) void k_aac_entropy_link(EntropyArgs a) {
+    const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
+    if (task >= a.n_tasks) return;
+    const EntropyTask tk = a.tasks[task];
+    uint32_t state = a.pns_state[tk.stream];
+    bool dead = false;
+    for (uint32_t k = tk.first; k < tk.first + tk.count; ++k) {
+        if (dead) {
+            a.status[k] = EC_SKIPPED;
+            continue;
+        }
+        if (a.status[k] != sk_ec::EC_OK) {
+            dead = true;
+            continue;
+        }
+        a.pns_start[k] = state;
+        state = sk_ec::pns_advance(state, a.side[k].noise_samples);
+    }
+    a.pns_state[tk.stream] = state;
+}
+
+__global__ __launch_bounds__(256) void k_aac_entropy_finish(EntropyArgs a) {
+    extern __shared__ uint4 lds_raw[];
+    const sk_ec::Tables t = lds_tables(a, lds_raw);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_units) return;
+    const EntropyUnit u = a.units[k];
+    const EntropyTask tk = a.tasks[u.task];
+    float *coef = a.coeffs + (size_t)u.off1024 * 1024;
+    int status = a.status[k];
+    if (status == sk_ec::EC_OK) {
+        sk_ec::Stream st{tk.sf_index, (int)tk.channels, a.pns_start[k]};
+        sk_ec::Scratch side = a.side[k];
+        status = sk_ec::finish_unit(t, st, a.words + u.word_offset, u.byte_len, coef, side, true);
+        a.status[k] = status;
+    }
+    if (status != sk_ec::EC_OK) {  // failed or skipped: silence for the synthesis launch that follows
+        for (uint32_t i = 0; i < tk.channels * 1024u; ++i) coef[i] = 0.0f;
+        for (uint32_t c = 0; c < tk.channels; ++c) a.entries[u.entry[c]].win = 0;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_aac_entropy_parallel(const EntropyArgs &a, hipStream_t s) {
+    if (a.n_units == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_aac_entropy_parse, dim3((a.n_units + 255) / 256), dim3(256), a.lds_bytes, s, a);
+    hipLaunchKernelGGL(k_aac_entropy_link, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_aac_entropy_finish, dim3((a.n_units + 255) / 256), dim3(256), a.lds_bytes, s, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_aac_entropy(const EntropyArgs &a, hipStream_t s) {
     if (a.n_tasks == 0) return hipSuccess;

@@ -447,7 +447,13 @@ SKE int layout(const Tables &t, const Stream &st, const Ics &ics, const uint16_t
 // `coef` is written, never read, and cannot overlap the side information: it is declared restrict and everything the
 // inner loops need is copied into locals first, so that on the device (where `ch` lives in private memory and `coef` is a
 // flat pointer that could in principle alias it) a coefficient store does not force the side information to be re-read.
-SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef) {
+enum PnsMode {
+    PNS_GENERATE,  // as the reference: noise bands are synthesised where they occur
+    PNS_COUNT,     // frame-parallel decode: only count the samples (the generator state is not known yet)
+};
+
+SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
+                        PnsMode mode, uint32_t *noise_samples) {
     const Ics ics = ch.ics;
     const int stride = band_stride(ics);
     const int max_sfb = ics.max_sfb, num_groups = ics.num_groups;
@@ -494,7 +500,9 @@ SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &
                             for (int k = 0; k < dim; ++k) coef[w * 128 + i + k] = dequantize(t, q[k], scale);
                         }
                 } else if (book == BOOK_NOISE) {
-                    for (int w = w0; w < w0 + glen && status == EC_OK; ++w) status = noise_band(scale, pns, coef + w * 128 + s, e - s);
+                    if (mode == PNS_COUNT) *noise_samples += (uint32_t)(glen * (e - s));
+                    else
+                        for (int w = w0; w < w0 + glen && status == EC_OK; ++w) status = noise_band(scale, pns, coef + w * 128 + s, e - s);
                 }
             }
             w0 += glen;
@@ -545,7 +553,8 @@ SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &
                 for (int k = 0; k < dim; ++k) coef[i + k] = dequantize(t, q[k], scale);
             }
         } else if (book == BOOK_NOISE && !pulse_present) {
-            status = noise_band(scale, pns, coef + s, e - s);
+            if (mode == PNS_COUNT) *noise_samples += (uint32_t)(e - s);
+            else status = noise_band(scale, pns, coef + s, e - s);
         }
     }
     bits = b;
@@ -574,9 +583,44 @@ SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &
         if (ch.book[sfb] != BOOK_NOISE) continue;
         int s, e;
         EC_TRY(band_range(off, bands, sfb, &s, &e));
-        EC_TRY(noise_band(ch.mult[sfb], st.pns_state, coef + s, e - s));
+        if (mode == PNS_COUNT) *noise_samples += (uint32_t)(e - s);
+        else EC_TRY(noise_band(ch.mult[sfb], st.pns_state, coef + s, e - s));
     }
     return EC_OK;
+}
+
+// the noise bands of one channel, in the order decode_spectrum generates them (PNS_COUNT left them open)
+SKE int fill_noise(const Tables &t, Stream &st, const Channel &ch, float *__restrict__ coef) {
+    const Ics ics = ch.ics;
+    const int stride = band_stride(ics), max_sfb = ics.max_sfb;
+    const uint16_t *off;
+    int bands;
+    EC_TRY(layout(t, st, ics, &off, &bands));
+    uint32_t pns = st.pns_state;
+    int status = EC_OK;
+    if (ics.sequence == SEQ_EIGHT_SHORT) {
+        int w0 = 0;
+        for (int g = 0; g < ics.num_groups && status == EC_OK; ++g) {
+            const int glen = ics.group_len[g];
+            for (int sfb = 0; sfb < max_sfb && status == EC_OK; ++sfb) {
+                if (ch.book[g * stride + sfb] != BOOK_NOISE) continue;
+                int s, e;
+                status = band_range(off, bands, sfb, &s, &e);
+                for (int w = w0; w < w0 + glen && status == EC_OK; ++w)
+                    status = noise_band(ch.mult[g * stride + sfb], pns, coef + w * 128 + s, e - s);
+            }
+            w0 += glen;
+        }
+    } else {
+        for (int sfb = 0; sfb < max_sfb && status == EC_OK; ++sfb) {
+            if (ch.book[sfb] != BOOK_NOISE) continue;
+            int s, e;
+            status = band_range(off, bands, sfb, &s, &e);
+            if (status == EC_OK) status = noise_band(ch.mult[sfb], pns, coef + s, e - s);
+        }
+    }
+    st.pns_state = pns;
+    return status;
 }
 
 // ---- stereo tools (decoder.rs:268-334, stereo.rs) ----------------------------------------------------------------
@@ -733,34 +777,38 @@ SKE bool rest_is_zero(const Bits &b) {
     return rem == 0 || (peek32(p) >> (32 - rem)) == 0;
 }
 
-struct Scratch {  // per-lane working storage (two channels' side information)
+struct Scratch {  // an access unit's side information: per-lane working storage, and what the first phase hands to the second
     Channel ch[2];
     MsMask mask;
+    uint8_t is_pair, common_window;
+    uint32_t resume_pos;     // bit position after the channel element
+    uint32_t noise_samples;  // PNS samples the unit consumes (both channels)
 };
 
-// One access unit -> spectra [channels][1024] and the window fields.  `au` is the word buffer described at Bits.
-SKE int decode_access_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len_bytes, float *coef, uint8_t *sequence,
-                           uint8_t *shape, Scratch &s) {
+// First phase: everything up to and including the spectral data of the channel element.  With PNS_GENERATE the noise
+// bands are filled on the way (the reference's order); with PNS_COUNT they are left open and only counted, which makes
+// the phase independent of every other access unit of the stream.
+SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len_bytes, float *coef, uint8_t *sequence, uint8_t *shape,
+                   Scratch &s, PnsMode mode) {
     Bits b = make_bits(au, len_bytes);
-    bool decoded = false;
+    s.noise_samples = 0;
     while (b.total - b.pos >= 3) {  // each pass consumes >= 3 bits: bounded by the length of the access unit
-        if (decoded && rest_is_zero(b)) break;
         uint32_t id, tag;
         EC_TRY(read_bits(b, 3, &id));
         if (id <= 5) EC_TRY(read_bits(b, 4, &tag));  // syntax.rs:54-63
         if (id == 0) {  // single channel element, decoder.rs:165-183
-            if (decoded) return EC_INVALID_BITSTREAM;
             if (st.channels != 1) return EC_INVALID_BITSTREAM;
             Channel &ch = s.ch[0];
             EC_TRY(read_channel(t, b, ch, nullptr));
-            EC_TRY(decode_spectrum(t, st, b, ch, false, coef));
-            if (ch.tns_present) EC_TRY(apply_tns(t, st, ch, coef));
+            EC_TRY(decode_spectrum(t, st, b, ch, false, coef, mode, &s.noise_samples));
+            s.is_pair = 0;
+            s.common_window = 0;
             sequence[0] = ch.ics.sequence;
             shape[0] = ch.ics.shape;
             sequence[1] = shape[1] = 0;
-            decoded = true;
+            s.resume_pos = b.pos;
+            return EC_OK;
         } else if (id == 1) {  // channel pair element, decoder.rs:185-218
-            if (decoded) return EC_INVALID_BITSTREAM;
             if (st.channels != 2) return EC_INVALID_BITSTREAM;
             bool common_window;
             EC_TRY(read_flag(b, &common_window));
@@ -772,26 +820,17 @@ SKE int decode_access_unit(const Tables &t, Stream &st, const uint32_t *au, uint
             }
             Channel &left = s.ch[0], &right = s.ch[1];
             EC_TRY(read_channel(t, b, left, common_window ? &common : nullptr));
-            EC_TRY(decode_spectrum(t, st, b, left, false, coef));
+            EC_TRY(decode_spectrum(t, st, b, left, false, coef, mode, &s.noise_samples));
             EC_TRY(read_channel(t, b, right, common_window ? &common : nullptr));
-            EC_TRY(decode_spectrum(t, st, b, right, true, coef + 1024));
-            if (!common_window) {  // decoder.rs:275-285
-                const int stride = band_stride(right.ics);
-                for (int g = 0; g < right.ics.num_groups; ++g)
-                    for (int sfb = 0; sfb < right.ics.max_sfb; ++sfb) {
-                        const int book = right.book[g * stride + sfb];
-                        if (book == BOOK_INTENSITY || book == BOOK_INTENSITY_NEG) return EC_INVALID_BITSTREAM;
-                    }
-            } else {
-                EC_TRY(stereo_tools(t, st, s.mask, left.ics, left, right, coef, coef + 1024));
-            }
-            if (left.tns_present) EC_TRY(apply_tns(t, st, left, coef));
-            if (right.tns_present) EC_TRY(apply_tns(t, st, right, coef + 1024));
+            EC_TRY(decode_spectrum(t, st, b, right, true, coef + 1024, mode, &s.noise_samples));
+            s.is_pair = 1;
+            s.common_window = common_window;
             sequence[0] = left.ics.sequence;
             shape[0] = left.ics.shape;
             sequence[1] = right.ics.sequence;
             shape[1] = right.ics.shape;
-            decoded = true;
+            s.resume_pos = b.pos;
+            return EC_OK;
         } else if (id >= 2 && id <= 5) {
             return EC_UNSUPPORTED_FEATURE;  // CCE / LFE / DSE / PCE
         } else if (id == 6) {  // fill element, decoder.rs:393-419
@@ -809,12 +848,82 @@ SKE int decode_access_unit(const Tables &t, Stream &st, const uint32_t *au, uint
             if (ext_type == 13 || ext_type == 14) return EC_UNSUPPORTED_FEATURE;  // SBR
             b.pos += count * 8;
         } else {
-            break;  // END
+            break;  // END before any channel element
         }
     }
-    if (!decoded) return EC_INVALID_BITSTREAM;
+    return EC_INVALID_BITSTREAM;  // "raw access unit does not contain an AAC-LC channel element"
+}
+
+// Second phase: [the noise bands, if the first phase only counted them,] stereo tools, TNS, then the rest of the access
+// unit (fill elements, END, the trailing-zero rule) from where the first phase stopped.
+SKE int finish_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len_bytes, float *coef, Scratch &s, bool fill) {
+    Channel &left = s.ch[0], &right = s.ch[1];
+    if (fill) {
+        EC_TRY(fill_noise(t, st, left, coef));
+        if (s.is_pair) EC_TRY(fill_noise(t, st, right, coef + 1024));
+    }
+    if (s.is_pair) {
+        if (!s.common_window) {  // decoder.rs:275-285
+            const int stride = band_stride(right.ics);
+            for (int g = 0; g < right.ics.num_groups; ++g)
+                for (int sfb = 0; sfb < right.ics.max_sfb; ++sfb) {
+                    const int book = right.book[g * stride + sfb];
+                    if (book == BOOK_INTENSITY || book == BOOK_INTENSITY_NEG) return EC_INVALID_BITSTREAM;
+                }
+        } else {
+            EC_TRY(stereo_tools(t, st, s.mask, left.ics, left, right, coef, coef + 1024));
+        }
+    }
+    if (left.tns_present) EC_TRY(apply_tns(t, st, left, coef));
+    if (s.is_pair && right.tns_present) EC_TRY(apply_tns(t, st, right, coef + 1024));
+    Bits b = make_bits(au, len_bytes);
+    b.pos = s.resume_pos;
+    while (b.total - b.pos >= 3) {
+        if (rest_is_zero(b)) break;
+        uint32_t id, tag;
+        EC_TRY(read_bits(b, 3, &id));
+        if (id <= 5) EC_TRY(read_bits(b, 4, &tag));
+        if (id <= 1) return EC_INVALID_BITSTREAM;  // "raw access unit contains multiple channel elements"
+        if (id <= 5) return EC_UNSUPPORTED_FEATURE;
+        if (id == 7) break;
+        uint32_t count;  // fill element
+        EC_TRY(read_bits(b, 4, &count));
+        if (count == 15) {
+            uint32_t ext;
+            EC_TRY(read_bits(b, 8, &ext));
+            if (ext == 0) return EC_INVALID_BITSTREAM;
+            count += ext - 1;
+        }
+        if (count == 0) continue;
+        if (b.total - b.pos < count * 8) return EC_EOF;
+        const uint32_t ext_type = peek32(b) >> 28;
+        if (ext_type == 13 || ext_type == 14) return EC_UNSUPPORTED_FEATURE;  // SBR
+        b.pos += count * 8;
+    }
     if (!rest_is_zero(b)) return EC_INVALID_BITSTREAM;
     return EC_OK;
+}
+
+// One access unit -> spectra [channels][1024] and the window fields, in the reference's order of operations.
+SKE int decode_access_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len_bytes, float *coef, uint8_t *sequence,
+                           uint8_t *shape, Scratch &s) {
+    EC_TRY(parse_unit(t, st, au, len_bytes, coef, sequence, shape, s, PNS_GENERATE));
+    return finish_unit(t, st, au, len_bytes, coef, s, false);
+}
+
+// LCG jump-ahead: the generator state after `n` steps of state = state * 1664525 + 1013904223 (spectral.rs:2447-2450)
+SKE uint32_t pns_advance(uint32_t state, uint32_t n) {
+    uint32_t mul = 1664525u, add = 1013904223u, acc_mul = 1u, acc_add = 0u;
+    for (int bit = 0; bit < 32; ++bit) {
+        if (n & 1u) {
+            acc_add = acc_add * mul + add;
+            acc_mul *= mul;
+        }
+        add = add * mul + add;
+        mul *= mul;
+        n >>= 1;
+    }
+    return state * acc_mul + acc_add;
 }
 
 }  // namespace sk_ec

@@ -216,7 +216,7 @@ struct sk_engine {
     // grow-only scratch
     DevBuf in_buf, out_buf, aux_buf, aux2_buf;
     // sk_tick_run: synthesis output, resampler output, packed bytes, small-array arena (+ pinned host mirror)
-    DevBuf tick_pcm, tick_res, tick_out, tick_arena, tick_au;
+    DevBuf tick_pcm, tick_res, tick_out, tick_arena, tick_au, tick_side;
     // entropy decode on the device (sk_tick_run_au): per-stream PNS generator state and the front-end's tables
     uint32_t *d_pns = nullptr;
     void *d_ec_blob = nullptr;
@@ -421,6 +421,7 @@ void sk_engine_destroy(sk_engine *e) {
         e->tick_out.release();
         e->tick_arena.release();
         e->tick_au.release();
+        e->tick_side.release();
         if (e->h_arena) (void)hipHostFree(e->h_arena);
         if (e->stream) (void)hipStreamDestroy(e->stream);
     }
@@ -1803,7 +1804,8 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 for (uint32_t f = 0; f < ts[i].n_frames; ++f) {
                     const uint32_t k = tc[i].first + f;
                     eu[k] = sk::EntropyUnit{units[k].byte_offset / 4, units[k].byte_len, (uint32_t)off1024[k],
-                                            {hp.entry_of[(size_t)k * 2], hp.entry_of[(size_t)k * 2 + (si.channels > 1 ? 1 : 0)]}};
+                                            {hp.entry_of[(size_t)k * 2], hp.entry_of[(size_t)k * 2 + (si.channels > 1 ? 1 : 0)]},
+                                            (uint32_t)et.size() - 1};
                 }
             }
             std::vector<int32_t> st_init(n_frames, 0);
@@ -1818,7 +1820,17 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             ea.coeffs = (float *)e->in_buf.p;
             ea.entries = const_cast<sk::SynthEntry *>(a.entries);
             ea.status = const_cast<int32_t *>(d_status);
-            SK_HIP(sk::launch_aac_entropy(ea, e->stream), "launch entropy decode");
+            static const bool serial = std::getenv("SK_ENTROPY_SERIAL") != nullptr;  // the one-lane-per-stream form, for A/B runs
+            if (serial) {
+                SK_HIP(sk::launch_aac_entropy(ea, e->stream), "launch entropy decode");
+            } else {
+                SK_HIP(e->tick_side.reserve((size_t)n_frames * (sizeof(sk_ec::Scratch) + sizeof(uint32_t)) + 128),
+                       "alloc entropy side information");
+                ea.n_units = n_frames;
+                ea.side = (sk_ec::Scratch *)e->tick_side.p;
+                ea.pns_start = (uint32_t *)((uint8_t *)e->tick_side.p + (((size_t)n_frames * sizeof(sk_ec::Scratch) + 15) & ~(size_t)15));
+                SK_HIP(sk::launch_aac_entropy_parallel(ea, e->stream), "launch entropy decode");
+            }
             SK_HIP(hipMemcpyAsync(status.data(), d_status, (size_t)n_frames * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream),
                    "D2H entropy status");
         }

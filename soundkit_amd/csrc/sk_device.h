@@ -160,6 +160,7 @@ struct EntropyUnit {
     uint32_t byte_len;
     uint32_t off1024;      // where its spectra go (units of 1024 f32)
     uint32_t entry[2];     // synthesis schedule entries of its channels (their `win` is filled in here)
+    uint32_t task;         // its stream's EntropyTask
 };
 struct EntropyTask {       // one stream
     uint32_t stream, first, count;
@@ -181,8 +182,13 @@ struct EntropyArgs {
     float *coeffs;
     SynthEntry *entries;
     int32_t *status;       // per unit
+    // frame-parallel form: one lane per access unit in the first and third kernel, one per stream in between
+    uint32_t n_units;
+    sk_ec::Scratch *side;  // [n_units] side information handed from the first phase to the third
+    uint32_t *pns_start;   // [n_units] generator state each unit starts from
 };
-hipError_t launch_aac_entropy(const EntropyArgs &a, hipStream_t s);
+hipError_t launch_aac_entropy(const EntropyArgs &a, hipStream_t s);           // one lane per stream, units in sequence
+hipError_t launch_aac_entropy_parallel(const EntropyArgs &a, hipStream_t s);  // parse | link | finish
 
 // pcm.hip -- the output stage of apply_output_options (soundkit-decoder lib.rs:3324-3456) for a batch of
 // planar f32 pieces: [s16 round trip] -> [mono downmix] -> interleaved little-endian bytes.

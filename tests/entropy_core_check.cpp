@@ -64,8 +64,29 @@ int main(int argc, char **argv) {
             words.assign((au.size() + 3) / 4 + 2, 0);  // 4-byte aligned, >= 8 bytes of zero padding
             memcpy(words.data(), au.data(), au.size());
             uint8_t seq[2] = {0, 0}, shape[2] = {0, 0};
+            const uint32_t pns_before = st.pns_state;
             const int rc_got = sk_ec::decode_access_unit(tables, st, words.data(), (uint32_t)au.size(), got.data(), seq, shape, scratch);
             ++checked;
+            {  // the frame-parallel composition: count the noise, jump the generator, fill and finish -- must equal the above
+                sk_ec::Stream st2{st.sf_index, st.channels, pns_before};
+                std::vector<float> split(2048, 0.0f);
+                uint8_t seq2[2] = {0, 0}, shape2[2] = {0, 0};
+                sk_ec::Scratch scratch2;
+                int rc2 = sk_ec::parse_unit(tables, st2, words.data(), (uint32_t)au.size(), split.data(), seq2, shape2, scratch2, sk_ec::PNS_COUNT);
+                if (rc2 == 0 && st2.pns_state != pns_before) { printf("%s %zu: counting phase moved the generator\n", what, index); return false; }
+                if (rc2 == 0) rc2 = sk_ec::finish_unit(tables, st2, words.data(), (uint32_t)au.size(), split.data(), scratch2, true);
+                if (rc2 != rc_got) { printf("%s %zu: split status %d vs %d\n", what, index, rc2, rc_got); return false; }
+                if (rc2 == 0) {
+                    if (memcmp(split.data(), got.data(), sizeof(float) * 1024 * (size_t)st.channels) != 0 || memcmp(seq, seq2, 2) || memcmp(shape, shape2, 2)) {
+                        printf("%s %zu: split decode differs\n", what, index);
+                        return false;
+                    }
+                    if (st2.pns_state != st.pns_state || sk_ec::pns_advance(pns_before, scratch2.noise_samples) != st.pns_state) {
+                        printf("%s %zu: generator state after the split decode / jump-ahead differs\n", what, index);
+                        return false;
+                    }
+                }
+            }
             if (rc_want != rc_got) {
                 printf("%s %zu: status %d vs %d (%s)\n", what, index, rc_want, rc_got, sk_aac_decoder_last_error(dec));
                 return false;
