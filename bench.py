@@ -193,7 +193,8 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     threads = args.entropy_threads or max(1, share - 3 - args.feeders)
     feeders = args.feeders
     sched = pipeline.BatchScheduler(eng, entropy_threads=threads, max_streams=args.streams, max_frames_per_tick=args.tick_frames,
-                                    max_stream_frames_per_tick=args.stream_frames_per_tick, gpu_entropy=int(args.gpu_entropy))
+                                    max_stream_frames_per_tick=args.stream_frames_per_tick, gpu_entropy=int(args.gpu_entropy),
+                                    tick_wait_us=args.tick_wait_us)
     opt = DecodeOptionsC(args.out_rate, 16, args.out_channels, 0)
 
     def run(loops):
@@ -263,8 +264,9 @@ def main():
                     help="pipeline: convert to interleaved s16 in the FIR epilogue instead of a separate kernel (same bytes; +8 %% "
                          "frames/s, but the conversion's VALU work takes issue slots from the f32 MFMA stream, DESIGN.md 4.2)")
     ap.add_argument("--entropy-threads", type=int, default=0, help="end_to_end: host threads for the AAC front-end (0 = cores - 1, split over ranks)")
-    ap.add_argument("--tick-frames", type=int, default=16384, help="end_to_end: access units per GPU tick (whole batch)")
-    ap.add_argument("--stream-frames-per-tick", type=int, default=8, help="end_to_end: access units one stream may contribute to a tick")
+    ap.add_argument("--tick-wait-us", type=int, default=0, help="end_to_end: how long a non-empty batch waits for more frames (0 = library default 200)")
+    ap.add_argument("--tick-frames", type=int, default=0, help="end_to_end: access units per GPU tick, whole batch (0 = library default)")
+    ap.add_argument("--stream-frames-per-tick", type=int, default=0, help="end_to_end: access units one stream may contribute to a tick (0 = library default)")
     ap.add_argument("--gpu-entropy", action="store_true", help="end_to_end: run the AAC front-end on the GPU too (host threads only frame ADTS)")
     ap.add_argument("--clip", default="aac-stereo-48k.adts", help="end_to_end: ADTS file under tests/golden/aac to loop")
     ap.add_argument("--feeders", type=int, default=2, help="end_to_end: producer/consumer threads of the load generator")

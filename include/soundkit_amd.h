@@ -367,11 +367,11 @@ typedef struct sk_pipeline sk_pipeline;
 typedef struct sk_pipeline_config {
     uint32_t entropy_threads;            /* 0 = usable CPUs (affinity, cgroup quota) - 5, at most 64 */
     uint32_t max_streams;                /* handles open at once; 0 = 1024 (<= the engine's max_streams) */
-    uint32_t max_frames_per_tick;        /* access units per GPU tick; 0 = 16384 */
-    uint32_t max_stream_frames_per_tick; /* of one stream; 0 = 8 */
+    uint32_t max_frames_per_tick;        /* access units per GPU tick; 0 = 16384 (65536 with gpu_entropy) */
+    uint32_t max_stream_frames_per_tick; /* of one stream; 0 = 8 (16 with gpu_entropy) */
     uint32_t input_buffer;               /* chunks per input queue; 0 = DEFAULT_INPUT_BUFFER 128 (lib.rs:77) */
     uint32_t output_buffer;              /* AudioData per output queue; 0 = DEFAULT_OUTPUT_BUFFER 16 (lib.rs:78) */
-    uint32_t tick_wait_us;               /* how long a non-empty batch may wait for more frames; 0 = 200 */
+    uint32_t tick_wait_us;               /* how long a non-empty batch may wait for more frames; 0 = 200 (2000 with gpu_entropy) */
     uint32_t gpu_entropy;                /* 1: the host threads only frame the ADTS stream; Huffman decode, stereo tools and TNS
                                           * run on the GPU too (sk_tick_run_au).  0 (default): host front-end (sk_tick_run) */
 } sk_pipeline_config;

@@ -95,8 +95,10 @@ struct Batch {
     size_t out_pinned_cap = 0;
     std::vector<sk_tick_output> recs;
     std::vector<uint32_t> row_of;  // tick row -> entry
+    std::vector<uint32_t> rec_begin;  // tick row -> its first output record (rows + 1 entries)
     uint32_t n_out = 0;
     int rc = SK_OK;
+    uint32_t next_slice = 0, slices_done = 0;  // delivery threads share a batch row-wise (guarded by batch_mu)
     void clear() {
         n_floats = 0;
         n_descs = 0;
@@ -104,8 +106,10 @@ struct Batch {
         ts.clear();
         entries.clear();
         row_of.clear();
+        rec_begin.clear();
         n_out = 0;
         rc = SK_OK;
+        next_slice = slices_done = 0;
     }
 };
 
@@ -138,7 +142,9 @@ struct sk_pipeline {
     std::deque<uint32_t> out_ready;
 
     std::vector<std::thread> workers;
-    std::thread submitter, deliverer;
+    std::thread submitter;
+    std::vector<std::thread> deliverers;
+    uint32_t n_deliver = 1;
 
     std::atomic<uint64_t> n_ticks{0}, n_frames{0}, n_outputs{0}, n_errors{0}, parse_ns{0}, tick_ns{0}, idle_ns{0}, deliver_ns{0};
 };
@@ -469,11 +475,19 @@ void submit_main(sk_pipeline *p) {
         p->tick_ns.fetch_add(ns_since(t0));
         p->n_ticks.fetch_add(1);
         p->n_frames.fetch_add(n_frames);
+        b->rec_begin.assign(b->row_of.size() + 1, b->n_out);
+        {
+            uint32_t k = 0;
+            for (uint32_t row = 0; row < b->row_of.size(); ++row) {
+                b->rec_begin[row] = k;
+                while (b->rc == SK_OK && k < b->n_out && b->recs[k].stream_index == row) ++k;
+            }
+        }
         {
             std::lock_guard<std::mutex> lk(p->batch_mu);
-            p->to_deliver.push_back(index);
+            for (uint32_t d = 0; d < p->n_deliver; ++d) p->to_deliver.push_back(index);  // one slice per delivery thread
         }
-        p->deliver_cv.notify_one();
+        p->deliver_cv.notify_all();
     }
 }
 
@@ -485,6 +499,7 @@ void deliver_main(sk_pipeline *p) {
     for (;;) {
         Batch *b;
         int index;
+        uint32_t slice;
         {
             std::unique_lock<std::mutex> lk(p->batch_mu);
             p->deliver_cv.wait(lk, [&] { return p->stop || !p->to_deliver.empty(); });
@@ -492,17 +507,18 @@ void deliver_main(sk_pipeline *p) {
             index = p->to_deliver.front();
             p->to_deliver.pop_front();
             b = &p->batches[index];
+            slice = b->next_slice++;  // this thread serves the rows / entries congruent to `slice`
         }
+        const uint32_t n_slices = p->n_deliver;
         const Clock::time_point t_deliver = Clock::now();
         const uint32_t n_streams = (uint32_t)b->ts.size();
         const int rc = b->rc;
-        uint32_t k = 0;
-        for (uint32_t row = 0; row < b->row_of.size(); ++row) {  // the outputs of a tick row are contiguous in recs
+        for (uint32_t row = slice; row < b->row_of.size(); row += n_slices) {  // the outputs of a tick row are contiguous in recs
             const BatchEntry &be = b->entries[b->row_of[row]];
             PStream &s = *p->streams[be.handle];
             std::lock_guard<std::mutex> lk(s.mu);
-            while (rc == SK_OK && k < b->n_out && b->recs[k].stream_index == row) {
-                const sk_tick_output &r = b->recs[k++];
+            for (uint32_t k = b->rec_begin[row]; rc == SK_OK && k < b->rec_begin[row + 1]; ++k) {
+                const sk_tick_output &r = b->recs[k];
                 if (s.cancelled) continue;
                 if (r.status != 0) {
                     std::string msg = "Decoding failed: invalid AAC config: frame rejected by the synthesis engine";
@@ -543,7 +559,7 @@ void deliver_main(sk_pipeline *p) {
         }
         wake.clear();
         listed.clear();
-        for (uint32_t i = 0; i < n_streams; ++i) {
+        for (uint32_t i = slice; i < n_streams; i += n_slices) {
             BatchEntry &be = b->entries[i];
             PStream &s = *p->streams[be.handle];
             bool release = false;
@@ -599,12 +615,16 @@ void deliver_main(sk_pipeline *p) {
             }
             p->oq_cv.notify_all();
         }
+        bool last;
         {
             std::lock_guard<std::mutex> lk(p->batch_mu);
-            b->clear();
-            p->free_batches.push_back(index);
+            last = ++b->slices_done == n_slices;
+            if (last) {
+                b->clear();
+                p->free_batches.push_back(index);
+            }
         }
-        p->batch_cv.notify_one();  // the submission thread may be waiting for a free batch
+        if (last) p->batch_cv.notify_one();  // the submission thread may be waiting for a free batch
         p->deliver_ns.fetch_add(ns_since(t_deliver));
     }
 }
@@ -655,12 +675,15 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
         p->cfg.entropy_threads = cpus > 5 ? std::min(cpus - 5, 64u) : 1;
     }
     if (!p->cfg.max_streams) p->cfg.max_streams = 1024;
-    if (!p->cfg.max_frames_per_tick) p->cfg.max_frames_per_tick = 16384;
-    if (!p->cfg.max_stream_frames_per_tick) p->cfg.max_stream_frames_per_tick = 8;
+    // With the front-end on the GPU every access unit is a lane of its own and a tick costs about the same whatever its
+    // size (the time of one unit), so ticks should be big; with the host front-end the tick is PCIe-bound and the host
+    // threads want their results back soon.
+    if (!p->cfg.max_frames_per_tick) p->cfg.max_frames_per_tick = p->cfg.gpu_entropy ? 65536 : 16384;
+    if (!p->cfg.max_stream_frames_per_tick) p->cfg.max_stream_frames_per_tick = p->cfg.gpu_entropy ? 16 : 8;
     if (p->cfg.max_stream_frames_per_tick > p->cfg.max_frames_per_tick) p->cfg.max_stream_frames_per_tick = p->cfg.max_frames_per_tick;
     if (!p->cfg.input_buffer) p->cfg.input_buffer = 128;   // DEFAULT_INPUT_BUFFER, lib.rs:77
     if (!p->cfg.output_buffer) p->cfg.output_buffer = 16;  // DEFAULT_OUTPUT_BUFFER, lib.rs:78
-    if (!p->cfg.tick_wait_us) p->cfg.tick_wait_us = 200;
+    if (!p->cfg.tick_wait_us) p->cfg.tick_wait_us = p->cfg.gpu_entropy ? 2000 : 200;
     if (hipSetDevice(sk_engine_device(e)) != hipSuccess) {
         delete p;
         return SK_ERR_NO_DEVICE;
@@ -694,7 +717,13 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
     for (int i = 1; i < sk_pipeline::kBatches; ++i) p->free_batches.push_back(i);
     for (uint32_t i = 0; i < p->cfg.entropy_threads; ++i) p->workers.emplace_back(worker_main, p);
     p->submitter = std::thread(submit_main, p);
-    p->deliverer = std::thread(deliver_main, p);
+    // with the front-end on the GPU the entropy threads have little to do and delivery is the busiest host stage
+    p->n_deliver = p->cfg.gpu_entropy ? std::max(1u, std::min(4u, p->cfg.entropy_threads / 2)) : 1;
+    if (const char *env = std::getenv("SK_PIPELINE_DELIVER_THREADS")) {  // tuning / test override
+        const int n = std::atoi(env);
+        if (n >= 1 && n <= 16) p->n_deliver = (uint32_t)n;
+    }
+    for (uint32_t d = 0; d < p->n_deliver; ++d) p->deliverers.emplace_back(deliver_main, p);
     *out = p;
     return SK_OK;
 }
@@ -713,7 +742,7 @@ void sk_pipeline_destroy(sk_pipeline *p) {
     p->oq_cv.notify_all();
     for (std::thread &t : p->workers) t.join();
     if (p->submitter.joinable()) p->submitter.join();
-    if (p->deliverer.joinable()) p->deliverer.join();
+    for (std::thread &t : p->deliverers) t.join();
     for (auto &s : p->streams) release_device_side(p, *s);
     for (Batch &b : p->batches) {
         if (b.coeffs) (void)hipHostFree(b.coeffs);

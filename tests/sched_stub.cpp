@@ -296,6 +296,7 @@ static int scenario_backpressure_and_errors(sk_engine *e) {
     return 0;
 }
 
+static int scenario_cancel_churn(sk_engine *e);
 static int scenario_cancel_churn(sk_engine *e) {
     sk_pipeline_config cfg{};
     cfg.entropy_threads = 3;
@@ -339,6 +340,10 @@ int main(int argc, char **argv) {
     e.channels.assign(64, 0);
     e.next_unit.assign(64, 0);
     if (int rc = scenario_many_streams(&e)) return rc;
+    setenv("SK_PIPELINE_DELIVER_THREADS", "3", 1);  // the sliced delivery path, as the GPU front-end mode uses it
+    if (int rc = scenario_many_streams(&e)) return rc;
+    if (int rc = scenario_cancel_churn(&e)) return rc;
+    unsetenv("SK_PIPELINE_DELIVER_THREADS");
     if (int rc = scenario_wait_outputs(&e)) return rc;
     if (int rc = scenario_backpressure_and_errors(&e)) return rc;
     if (int rc = scenario_cancel_churn(&e)) return rc;
