@@ -378,19 +378,30 @@ SKE int read_tuple(const BookRef &br, Bits &b, int *q) {
     const int book = br.book;
     uint32_t sym;
     EC_TRY(huffman_in(br.lut, b, &sym));
-    const uint64_t tu = br.tuples[sym];
+    const uint64_t tu = br.tuples[sym];  // bytes 0-3 values, byte 4 sign-bit count, byte 5 escape flag, bits 48.. sign positions
     const int dim = book <= 4 ? 4 : 2;
-    const bool is_unsigned = book == 3 || book == 4 || book >= 7;
     for (int k = 0; k < dim; ++k) q[k] = (int8_t)(tu >> (8 * k));
-    if (!is_unsigned) return EC_OK;
-    bool neg[4] = {false, false, false, false};
-    for (int k = 0; k < dim; ++k)
-        if (q[k] != 0) EC_TRY(read_flag(b, &neg[k]));
-    if (book == 11)  // the escapes follow both sign bits (finish_unsigned_escape_pair, spectral.rs:191-212)
-        for (int k = 0; k < 2; ++k)
-            if (q[k] == 16) EC_TRY(read_escape(b, &q[k]));
-    for (int k = 0; k < dim; ++k)
-        if (neg[k]) q[k] = -q[k];
+    const uint32_t nsign = (uint32_t)(tu >> 32) & 0xffu;  // 0 for the signed books
+    if (nsign == 0) return EC_OK;
+    // the sign bits of the non-zero magnitudes follow the codeword, in order: taken in one read and handed out by
+    // position (no per-value branch; lanes of a wave sit in different tuples)
+    uint32_t signs;
+    EC_TRY(read_bits(b, nsign, &signs));
+    for (int k = 0; k < dim; ++k) {
+        const uint32_t at = (uint32_t)(tu >> (48 + 4 * k)) & 15u;  // 15: this value has no sign bit (signs < 16 >> 15 == 0)
+        const int neg = (int)((signs >> at) & 1u);
+        q[k] = (q[k] ^ -neg) + neg;
+    }
+    if ((tu >> 40) & 1u) {  // book 11 escapes follow both sign bits (finish_unsigned_escape_pair, spectral.rs:191-212)
+        for (int k = 0; k < 2; ++k) {
+            const int mag = q[k] < 0 ? -q[k] : q[k];
+            if (mag == 16) {
+                int esc;
+                EC_TRY(read_escape(b, &esc));
+                q[k] = q[k] < 0 ? -esc : esc;
+            }
+        }
+    }
     return EC_OK;
 }
 

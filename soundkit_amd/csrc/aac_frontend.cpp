@@ -992,6 +992,10 @@ const HostTables &host_tables() {
                 for (int k = 0; k < 4; ++k) packed |= (uint64_t)(uint8_t)tu.v[k] << (8 * k);
                 packed |= (uint64_t)tu.nsign << 32;
                 packed |= (uint64_t)tu.escape << 40;
+                for (int k = 0; k < 4; ++k) {  // which of the sign bits after the codeword belongs to value k (15: none)
+                    const unsigned at = tu.sshift[k] == 31 ? 15u : (unsigned)tu.sshift[k];
+                    packed |= (uint64_t)at << (48 + 4 * k);
+                }
                 h.tuples.push_back(packed);
             }
         }
