@@ -192,20 +192,47 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     share = max(4, min(cores // world, 16))  # the pool gives a one-GPU job 16 cores
     threads = args.entropy_threads or max(1, share - 3 - args.feeders)
     feeders = args.feeders
-    sched = pipeline.BatchScheduler(eng, entropy_threads=threads, max_streams=args.streams, max_frames_per_tick=args.tick_frames,
-                                    max_stream_frames_per_tick=args.stream_frames_per_tick, gpu_entropy=int(args.gpu_entropy),
-                                    tick_wait_us=args.tick_wait_us)
+    import threading
+    import soundkit_amd
+    n_sched = max(1, args.schedulers)
+    per_streams = args.streams // n_sched
+    engines = [eng] + [soundkit_amd.Engine(eng.device if hasattr(eng, "device") else 0, max(per_streams, 16)) for _ in range(n_sched - 1)]
+    scheds = [pipeline.BatchScheduler(engines[i], entropy_threads=max(1, threads // n_sched), max_streams=per_streams,
+                                      max_frames_per_tick=args.tick_frames, max_stream_frames_per_tick=args.stream_frames_per_tick,
+                                      gpu_entropy=int(args.gpu_entropy), tick_wait_us=args.tick_wait_us) for i in range(n_sched)]
     opt = DecodeOptionsC(args.out_rate, 16, args.out_channels, 0)
 
+    class Summed:
+        pass
+
     def run(loops):
-        res = Result()
-        rc = lg.sk_loadgen_run(sched._h, clip, len(clip), units, args.streams, loops, C.byref(opt), feeders, 0, C.byref(res))
-        if rc != 0 or res.errors:
-            raise SystemExit("load generator failed: rc %d, %d stream errors" % (rc, res.errors))
-        return res
+        results = [Result() for _ in scheds]
+        rcs = [0] * n_sched
+
+        def one(i):
+            rcs[i] = lg.sk_loadgen_run(scheds[i]._h, clip, len(clip), units, per_streams, loops, C.byref(opt), max(2, feeders // n_sched), 0,
+                                       C.byref(results[i]))
+        ths = [threading.Thread(target=one, args=(i,)) for i in range(n_sched)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if any(rcs) or any(r.errors for r in results):
+            raise SystemExit("load generator failed: rc %s, %d stream errors" % (rcs, sum(r.errors for r in results)))
+        tot = Summed()
+        for name in ("access_units", "outputs", "pcm_frames", "pcm_bytes", "errors", "input_full"):
+            setattr(tot, name, sum(getattr(r, name) for r in results))
+        return tot
+
+    def all_stats():
+        acc = {}
+        for sc in scheds:
+            for k, v in sc.stats().items():
+                acc[k] = acc.get(k, 0) + v
+        return acc
     if args.warmup:
         run(args.warmup)
-    before = sched.stats()
+    before = all_stats()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -215,8 +242,12 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     if world > 1:
         dist.barrier()
     elapsed = sharding.reduce_elapsed(time.perf_counter() - t0, device)
-    after = sched.stats()
-    sched.close()
+    after = all_stats()
+    for sc in scheds:
+        sc.close()
+    for extra in engines[1:]:
+        extra.close()
+    threads = max(1, threads // n_sched) * n_sched
     if rank != 0:
         return
     st = {k: after[k] - before[k] for k in ("ticks", "frames", "outputs", "parse_ns", "tick_ns", "idle_ns", "deliver_ns")}
@@ -231,7 +262,8 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
                                                                      args.out_rate or src_rate,
                                                                      "mono" if args.out_channels == 1 else "source-channel", threads),
                    "streams_per_gpu": args.streams, "entropy_threads": threads, "feeder_threads": feeders, "host_cores": cores,
-                   "front_end": "gpu (k_aac_entropy, one stream per lane)" if args.gpu_entropy else "host threads",
+                   "front_end": "gpu (k_aac_entropy_parse/link/finish, one access unit per lane)" if args.gpu_entropy else "host threads",
+                   "schedulers": n_sched,
                    "parallelism": "streams sharded, %d rank(s), no collective" % world},
         "scheduler": {"ticks": st["ticks"], "frames_per_tick": st["frames"] / max(st["ticks"], 1),
                       "entropy_us_per_frame": st["parse_ns"] / max(st["frames"], 1) / 1e3,
@@ -267,6 +299,9 @@ def main():
     ap.add_argument("--tick-wait-us", type=int, default=0, help="end_to_end: how long a non-empty batch waits for more frames (0 = library default 200)")
     ap.add_argument("--tick-frames", type=int, default=0, help="end_to_end: access units per GPU tick, whole batch (0 = library default)")
     ap.add_argument("--stream-frames-per-tick", type=int, default=0, help="end_to_end: access units one stream may contribute to a tick (0 = library default)")
+    ap.add_argument("--schedulers", type=int, default=1,
+                    help="end_to_end: independent engine + scheduler pairs on the GPU, each with its share of the streams and threads "
+                         "(their ticks overlap on the device)")
     ap.add_argument("--gpu-entropy", action="store_true", help="end_to_end: run the AAC front-end on the GPU too (host threads only frame ADTS)")
     ap.add_argument("--clip", default="aac-stereo-48k.adts", help="end_to_end: ADTS file under tests/golden/aac to loop")
     ap.add_argument("--feeders", type=int, default=2, help="end_to_end: producer/consumer threads of the load generator")
