@@ -210,6 +210,7 @@ struct sk_engine {
     float *d_tables = nullptr;
     sk::SynthTables synth_tables{};
     float *d_pow43 = nullptr, *d_sftab = nullptr, *d_taps = nullptr, *d_afrag = nullptr, *d_zeros = nullptr;
+    uint32_t *d_afrag16 = nullptr;
     std::vector<float> h_taps;
     std::vector<RatioTable> ratio_tables;
 
@@ -308,6 +309,26 @@ int build_tables(sk_engine *e) {
             if (p >= 0 && p < 256) afrag[s * 64 + l] = e->h_taps[p];
         }
     SK_HIP(upload(&e->d_afrag, afrag), "upload tap fragments");
+    // bf16 A fragments (fir_bf16.hip): h = h1 + h2 + h3 exactly, each the top 16 bits of an f32 (truncation);
+    // window s, plane k, lane l (i = l & 15, q = l >> 4), element e: tap p = 32 s + 8 q + e - 3 i - 3
+    std::vector<uint32_t> afrag16((size_t)10 * 3 * 64 * 4, 0u);
+    for (int s = 0; s < 10; ++s)
+        for (int l = 0; l < 64; ++l)
+            for (int el = 0; el < 8; ++el) {
+                const int p = 32 * s + 8 * (l >> 4) + el - 3 * (l & 15) - 3;
+                if (p < 0 || p >= 256) continue;
+                float rest = e->h_taps[p];
+                for (int k = 0; k < 3; ++k) {
+                    uint32_t bits;
+                    std::memcpy(&bits, &rest, 4);
+                    bits &= 0xffff0000u;
+                    float piece;
+                    std::memcpy(&piece, &bits, 4);
+                    rest -= piece;  // exact: the piece is the leading 8 significand bits of rest
+                    afrag16[((size_t)(s * 3 + k) * 64 + l) * 4 + el / 2] |= (bits >> 16) << (16 * (el & 1));
+                }
+            }
+    SK_HIP(upload(&e->d_afrag16, afrag16), "upload bf16 tap fragments");
     std::vector<float> zeros(8192, 0.0f);
     SK_HIP(upload(&e->d_zeros, zeros), "upload zeros");
     return SK_OK;
@@ -407,7 +428,7 @@ void sk_engine_destroy(sk_engine *e) {
         DeviceGuard guard(e->device);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         for (void *p : {(void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
-                        (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag,
+                        (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag, (void *)e->d_afrag16,
                         (void *)e->d_zeros})
             if (p) (void)hipFree(p);
         for (RatioTable &t : e->ratio_tables)
@@ -941,6 +962,7 @@ static sk::FirArgs fir_base(sk_engine *e) {
     sk::FirArgs a{};
     a.zeros = e->d_zeros;
     a.afrag = e->d_afrag;
+    a.afrag16 = e->d_afrag16;
     a.taps = e->d_taps;
     return a;
 }

@@ -24,6 +24,7 @@
 // 4q + t) so that one lane's four B operands are 4 contiguous floats in LDS.
 #include "sk_device.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace sk {
@@ -322,6 +323,9 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k(FirArgs a, uint32_t total
 
 hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s) {
     if (a.rows == 0 || a.out_count == 0) return hipSuccess;
+    // SK_FIR_F32=1 keeps the f32-MFMA kernel below (A/B runs, profiles/r01_ab_fir.md)
+    static const bool force_f32 = [] { const char *v = std::getenv("SK_FIR_F32"); return v && v[0] == '1'; }();
+    if (!force_f32 && fir_bf16_supported(a)) return launch_fir_48k_16k_bf16(a, s);
     const uint32_t total_blocks = (a.out_count + 15) / 16;
     const uint32_t groups = (a.rows + 15) / 16;
     // two waves per SIMD across the chip (256 CUs x 4 x 2) is the residency this kernel's LDS allows;

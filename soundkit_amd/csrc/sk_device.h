@@ -103,6 +103,7 @@ struct FirArgs {
     uint32_t out16_ch;
     const float *zeros;   // >= 1 KiB of zeros (source for out-of-range input)
     const float *afrag;   // [76][64] MFMA A-operand fragments of the Toeplitz tap matrix
+    const uint32_t *afrag16;  // [10][3][64][4] bf16 A-operand fragments (fir_bf16.hip); null = f32 kernel only
     const float *taps;    // [256]
     size_t in_stride, out_stride;
     // frame-packed input (in_block 0 = plain rows; otherwise 1024 with in_ch 1 or 2): sample n of row r lives at
@@ -118,6 +119,9 @@ struct FirArgs {
     uint32_t out_count;   // outputs per row
 };
 hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s);
+// fir_bf16.hip: the same filter on the bf16 matrix cores (three-way exact split of both operands, six products)
+bool fir_bf16_supported(const FirArgs &a);
+hipError_t launch_fir_48k_16k_bf16(const FirArgs &a, hipStream_t s);
 
 // resample.hip -- generic-ratio windowed-sinc resampling (rubato SincFixedIn<f32>, Linear interpolation)
 struct SincArgs {

@@ -31,7 +31,7 @@ def main():
     if stats:
         shutil.copy(stats, os.path.join(prof, tag + "_kernel_stats.csv"))
     summary = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_inst"):
         path = find(os.path.join(out, sub), "*counter_collection.csv")
         if not path:
             continue
