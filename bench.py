@@ -40,6 +40,7 @@ def pmc_traffic(kind, **config):
     return entry["traffic_bytes"] if entry.get("config") == config else None
 
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak
 SEED0 = 0x12345678
 
 
@@ -292,9 +293,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-all-cores", action="store_true",
                     help="also time the oracle in one process per usable core (adds ~10 s; cpu_baseline_all_cores in the JSON)")
-    ap.add_argument("--fused-s16", action="store_true",
-                    help="pipeline: convert to interleaved s16 in the FIR epilogue instead of a separate kernel (same bytes; +8 %% "
-                         "frames/s, but the conversion's VALU work takes issue slots from the f32 MFMA stream, DESIGN.md 4.2)")
+    ap.add_argument("--separate-s16", action="store_true",
+                    help="pipeline: f32 FIR output and a separate f32 -> interleaved s16 kernel instead of the conversion in the FIR's "
+                         "epilogue (same bytes out, tests/test_pipeline_gpu.py; the chain measured before the bf16 FIR, DESIGN.md 4.2)")
+    ap.add_argument("--fused-s16", action="store_true", help="(default now; kept so that older command lines still run)")
     ap.add_argument("--entropy-threads", type=int, default=0, help="end_to_end: host threads for the AAC front-end (0 = cores - 1, split over ranks)")
     ap.add_argument("--tick-wait-us", type=int, default=0, help="end_to_end: how long a non-empty batch waits for more frames (0 = library default 200)")
     ap.add_argument("--tick-frames", type=int, default=0, help="end_to_end: access units per GPU tick, whole batch (0 = library default)")
@@ -379,7 +381,7 @@ def main():
             n_out = eng.downsample_out_frames(frames * 1024)
             out_stride = (n_out + 3) // 4 * 4
             fmt_s16 = soundkit_amd.engine.FMT_S16LE
-            if not args.fused_s16:
+            if args.separate_s16:
                 fir_out = torch.empty((streams * ch, out_stride), device=device)
                 s16_out = torch.empty((streams, n_out, ch), dtype=torch.int16, device=device)
 
@@ -398,7 +400,7 @@ def main():
                     timed("k_fir_48k_16k", lambda: eng.downsample_48k_16k_frames_s16_dev(pcm, stream_stride, frame_stride, ch,
                                                                                          streams, frames, s16_out, s16_stride))
             workload = ("aac_lc decode tail: %d streams x %d frames, 48 kHz stereo: IMDCT+window+OLA -> 48k->16k MFMA FIR -> "
-                        "interleaved s16 (%s), %s-major batch" % (streams, frames, "in the FIR epilogue" if args.fused_s16 else "separate kernel", args.layout))
+                        "interleaved s16 (%s), %s-major batch" % (streams, frames, "separate kernel" if args.separate_s16 else "in the FIR epilogue", args.layout))
         else:
             def step():
                 timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
@@ -467,13 +469,26 @@ def main():
         if "k_fir_48k_16k" in per_kernel:
             ms = per_kernel["k_fir_48k_16k"]
             fir_in = frames * 1024 if args.workload == "pipeline" else 48000
-            flops = streams * ch * eng.downsample_out_frames(fir_in) * 512.0  # 512 flop per output sample
-            rl["k_fir_48k_16k"] = {
-                "kernel": "k_fir_48k_16k", "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12,
-                "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                "traffic": pmc_traffic("fir" if args.workload == "fir" else ("fir_pipeline_s16" if args.fused_s16 else "fir_pipeline"),
-                                       rows=streams * ch, frames=fir_in),
-                "avg_launch_ms": ms}
+            n_fir_out = eng.downsample_out_frames(fir_in)
+            flops = streams * ch * n_fir_out * 512.0  # 512 flop per output sample
+            fused = args.workload == "pipeline" and not args.separate_s16
+            pmc_kind = "fir" if args.workload == "fir" else ("fir_pipeline" if args.separate_s16 else "fir_pipeline_s16")
+            if os.environ.get("SK_FIR_F32") == "1":  # the f32-MFMA kernel (fir.hip), bounded by the f32 matrix peak
+                rl["k_fir_48k_16k"] = {
+                    "kernel": "k_fir_48k_16k", "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12,
+                    "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                    "traffic": pmc_traffic(pmc_kind + "_f32", rows=streams * ch, frames=fir_in), "avg_launch_ms": ms}
+            else:
+                # fir_bf16.hip: six bf16 products per tap at 80 % useful MACs = 3840 issued flop per output, 1/16 of the time
+                # they would take on the f32 matrix path; what bounds the launch now is its own HBM traffic:
+                # 4 B per input sample + 4 B (f32) or 2 B (s16) per output sample
+                fir_bytes = streams * ch * (fir_in * 4.0 + n_fir_out * (2.0 if fused else 4.0))
+                rl["k_fir_48k_16k"] = {
+                    "kernel": "k_fir_48k_16k_bf16", "bound": "hbm", "achieved": fir_bytes / (ms * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fir_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic(pmc_kind, rows=streams * ch, frames=fir_in), "avg_launch_ms": ms,
+                    "algorithmic_tflops": flops / (ms * 1e-3) / 1e12,
+                    "issued_bf16_tflops": flops * 7.5 / (ms * 1e-3) / 1e12, "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TF}
         if "k_f32_planar_stereo_to_s16le_batch" in per_kernel:
             ms = per_kernel["k_f32_planar_stereo_to_s16le_batch"]
             cvt_bytes = streams * ch * eng.downsample_out_frames(frames * 1024) * 6.0  # 4 B in + 2 B out per sample

@@ -1395,7 +1395,12 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
             if (fir) {
                 // integer time base: output m sits at index 3m - 125.  Any origin works as long as output
                 // out_first + j reads the row at chunk-relative index idx[0] + 3j (+ kRsHist of history in front)
-                const uint32_t first = 1024;
+                // ... and the origin that makes the row's sample 0 fall on a multiple of four lets the kernel stage with
+                // 16-byte loads (a function of the stream's own phase only, so a stream's samples do not depend on
+                // which launch it shares)
+                const int64_t fixed = 125 + (int64_t)std::llround(idx[0]) + (int64_t)kRsHist;
+                uint32_t first = 1024;
+                while ((3 * (int64_t)first - fixed) & 3) ++first;
                 sk::FirArgs a = fir_base(e);
                 a.in = e->d_rs;
                 a.in_stride = kRsRow;
