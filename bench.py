@@ -196,24 +196,25 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     import threading
     import soundkit_amd
     n_sched = max(1, args.schedulers)
+    n_gen = n_sched  # one load generator (its own producer and consumer threads) per scheduler: wait_outputs is per pipeline
     per_streams = args.streams // n_sched
     engines = [eng] + [soundkit_amd.Engine(eng.device if hasattr(eng, "device") else 0, max(per_streams, 16)) for _ in range(n_sched - 1)]
     scheds = [pipeline.BatchScheduler(engines[i], entropy_threads=max(1, threads // n_sched), max_streams=per_streams,
                                       max_frames_per_tick=args.tick_frames, max_stream_frames_per_tick=args.stream_frames_per_tick,
-                                      gpu_entropy=int(args.gpu_entropy), tick_wait_us=args.tick_wait_us) for i in range(n_sched)]
+                                      gpu_entropy=int(args.gpu_entropy), tick_wait_us=args.tick_wait_us, lanes=args.lanes) for i in range(n_sched)]
     opt = DecodeOptionsC(args.out_rate, 16, args.out_channels, 0)
 
     class Summed:
         pass
 
     def run(loops):
-        results = [Result() for _ in scheds]
-        rcs = [0] * n_sched
+        results = [Result() for _ in range(n_gen)]
+        rcs = [0] * n_gen
 
         def one(i):
-            rcs[i] = lg.sk_loadgen_run(scheds[i]._h, clip, len(clip), units, per_streams, loops, C.byref(opt), max(2, feeders // n_sched), 0,
-                                       C.byref(results[i]))
-        ths = [threading.Thread(target=one, args=(i,)) for i in range(n_sched)]
+            rcs[i] = lg.sk_loadgen_run(scheds[i % n_sched]._h, clip, len(clip), units, args.streams // n_gen, loops, C.byref(opt),
+                                       max(2, feeders // n_gen), 0, C.byref(results[i]))
+        ths = [threading.Thread(target=one, args=(i,)) for i in range(n_gen)]
         for t in ths:
             t.start()
         for t in ths:
@@ -237,8 +238,10 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    cpu0 = os.times()
     t0 = time.perf_counter()
     res = run(args.steps)
+    cpu1 = os.times()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -264,7 +267,9 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
                                                                      "mono" if args.out_channels == 1 else "source-channel", threads),
                    "streams_per_gpu": args.streams, "entropy_threads": threads, "feeder_threads": feeders, "host_cores": cores,
                    "front_end": "gpu (k_aac_entropy_parse/link/finish, one access unit per lane)" if args.gpu_entropy else "host threads",
-                   "schedulers": n_sched,
+                   "schedulers": n_sched, "lanes": int(after.get("lanes", n_sched)),
+                   "host_cores_busy": ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / elapsed,
+                   "host_cores_busy_system": (cpu1.system - cpu0.system) / elapsed,
                    "parallelism": "streams sharded, %d rank(s), no collective" % world},
         "scheduler": {"ticks": st["ticks"], "frames_per_tick": st["frames"] / max(st["ticks"], 1),
                       "entropy_us_per_frame": st["parse_ns"] / max(st["frames"], 1) / 1e3,
@@ -304,6 +309,7 @@ def main():
     ap.add_argument("--schedulers", type=int, default=1,
                     help="end_to_end: independent engine + scheduler pairs on the GPU, each with its share of the streams and threads "
                          "(their ticks overlap on the device)")
+    ap.add_argument("--lanes", type=int, default=0, help="end_to_end: engines per scheduler (sk_pipeline_config.lanes; 0 = library default: 2 with --gpu-entropy, else 1)")
     ap.add_argument("--gpu-entropy", action="store_true", help="end_to_end: run the AAC front-end on the GPU too (host threads only frame ADTS)")
     ap.add_argument("--clip", default="aac-stereo-48k.adts", help="end_to_end: ADTS file under tests/golden/aac to loop")
     ap.add_argument("--feeders", type=int, default=2, help="end_to_end: producer/consumer threads of the load generator")

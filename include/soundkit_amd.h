@@ -79,6 +79,7 @@ typedef struct sk_aac_frame_desc {
 int sk_engine_create(int device, uint32_t max_streams, sk_engine **out);
 void sk_engine_destroy(sk_engine *);
 int sk_engine_device(const sk_engine *);
+uint32_t sk_engine_max_streams(const sk_engine *);
 void *sk_engine_hip_stream(sk_engine *); /* hipStream_t */
 int sk_engine_synchronize(sk_engine *);
 const char *sk_engine_last_hip_error(const sk_engine *);
@@ -374,6 +375,11 @@ typedef struct sk_pipeline_config {
     uint32_t tick_wait_us;               /* how long a non-empty batch may wait for more frames; 0 = 200 (2000 with gpu_entropy) */
     uint32_t gpu_entropy;                /* 1: the host threads only frame the ADTS stream; Huffman decode, stereo tools and TNS
                                           * run on the GPU too (sk_tick_run_au).  0 (default): host front-end (sk_tick_run) */
+    uint32_t lanes;                      /* engines the streams are spread over, each with its own batches and submission
+                                          * thread, so that ticks overlap on the device; lane 0 is the caller's engine, the
+                                          * others are created on the same device.  0 = 2 with gpu_entropy and max_streams >= four ticks' worth of
+                                          * streams (16384 at the defaults), else 1; at most 8.
+                                          * entropy_threads and max_streams are totals, split over the lanes */
 } sk_pipeline_config;
 
 typedef struct sk_decode_options { /* DecodeOptions, lib.rs:147-151; 0 = None */
@@ -399,7 +405,8 @@ typedef struct sk_pipeline_stats {
     uint64_t tick_ns;   /* submission thread inside sk_tick_run */
     uint64_t idle_ns;   /* submission thread waiting for a batch */
     uint64_t deliver_ns; /* delivery thread handing outputs to the streams' queues */
-    uint32_t entropy_threads, reserved;
+    uint32_t entropy_threads; /* summed over lanes */
+    uint32_t lanes;
 } sk_pipeline_stats;
 
 enum sk_pipeline_status {

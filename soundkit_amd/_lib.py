@@ -42,7 +42,7 @@ class PipelineConfig(C.Structure):
     """sk_pipeline_config"""
     _fields_ = [(n, C.c_uint32) for n in ("entropy_threads", "max_streams", "max_frames_per_tick",
                                           "max_stream_frames_per_tick", "input_buffer", "output_buffer", "tick_wait_us",
-                                          "gpu_entropy")]
+                                          "gpu_entropy", "lanes")]
 
 
 class DecodeOptionsC(C.Structure):
@@ -60,7 +60,7 @@ class AudioInfo(C.Structure):
 class PipelineStats(C.Structure):
     """sk_pipeline_stats"""
     _fields_ = [(n, C.c_uint64) for n in ("ticks", "frames", "outputs", "errors", "parse_ns", "tick_ns", "idle_ns", "deliver_ns")] + [
-        ("entropy_threads", C.c_uint32), ("reserved", C.c_uint32)]
+        ("entropy_threads", C.c_uint32), ("lanes", C.c_uint32)]
 
 
 def declared_symbols():

@@ -450,6 +450,7 @@ void sk_engine_destroy(sk_engine *e) {
 }
 
 int sk_engine_device(const sk_engine *e) { return e ? e->device : -1; }
+uint32_t sk_engine_max_streams(const sk_engine *e) { return e ? e->max_streams : 0; }
 void *sk_engine_hip_stream(sk_engine *e) { return e ? (void *)e->stream : nullptr; }
 const char *sk_engine_last_hip_error(const sk_engine *e) { return e ? e->last_hip_error.c_str() : ""; }
 

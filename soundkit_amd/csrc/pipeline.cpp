@@ -53,7 +53,7 @@ struct PStream {
     std::condition_variable cv_out;
     // guarded by mu
     bool open = false, busy = false, queued = false, finished = false, cancelled = false;
-    bool out_listed = false;  // the handle sits in sk_pipeline::out_ready (or has been handed to a waiter and not taken from since)
+    bool out_listed = false;  // the handle sits in the pipeline's OutQueue (or has been handed to a waiter and not taken from since)
     std::deque<std::vector<uint8_t>> in;
     std::deque<Output> out;
     sk_decode_options opt{};
@@ -115,8 +115,22 @@ struct Batch {
 
 }  // namespace
 
-struct sk_pipeline {
+// handles with something to receive (outputs or the end of the stream), for callers that serve many handles; one queue
+// for all lanes of a pipeline, holding public handles
+struct OutQueue {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<uint32_t> ready;
+    bool stop = false;
+};
+
+// One lane = one engine + the threads and batches that feed it.  A pipeline is one or more lanes behind one handle
+// space: ticks of different engines overlap on the device (a tick is a chain of dependent launches with a
+// synchronisation at its end), which one lane's submission thread cannot do by itself.
+struct sk_lane {
     sk_engine *engine = nullptr;
+    OutQueue *oq = nullptr;
+    uint32_t lane_index = 0, n_lanes = 1;  // public handle = handle * n_lanes + lane_index
     sk_pipeline_config cfg{};
     std::vector<std::unique_ptr<PStream>> streams;
     std::mutex handles_mu;
@@ -136,11 +150,6 @@ struct sk_pipeline {
     std::condition_variable deliver_cv;
     bool stop = false;
 
-    // handles with something to receive (outputs or the end of the stream), for callers that serve many handles
-    std::mutex oq_mu;
-    std::condition_variable oq_cv;
-    std::deque<uint32_t> out_ready;
-
     std::vector<std::thread> workers;
     std::thread submitter;
     std::vector<std::thread> deliverers;
@@ -157,7 +166,7 @@ uint64_t ns_since(Clock::time_point t0) {
 }
 
 // call with s.mu held: true = the stream has work, is free and is not in the ready queue yet (now marked as queued)
-bool mark_schedulable(sk_pipeline *p, PStream &s) {
+bool mark_schedulable(sk_lane *p, PStream &s) {
     if (!s.open || s.busy || s.queued || s.finished || s.cancelled) return false;
     if ((s.in.empty() && !s.more) || s.out.size() >= p->cfg.output_buffer) return false;
     s.queued = true;
@@ -165,7 +174,7 @@ bool mark_schedulable(sk_pipeline *p, PStream &s) {
 }
 
 // call with s.mu held
-void maybe_schedule(sk_pipeline *p, PStream &s, uint32_t handle) {
+void maybe_schedule(sk_lane *p, PStream &s, uint32_t handle) {
     if (!mark_schedulable(p, s)) return;
     {
         std::lock_guard<std::mutex> lk(p->rq_mu);
@@ -174,7 +183,7 @@ void maybe_schedule(sk_pipeline *p, PStream &s, uint32_t handle) {
     p->rq_cv.notify_one();
 }
 
-void release_device_side(sk_pipeline *p, PStream &s) {
+void release_device_side(sk_lane *p, PStream &s) {
     if (s.engine_stream != kNoStream) {
         (void)sk_stream_close(p->engine, s.engine_stream);  // also drops its resampler
         s.engine_stream = kNoStream;
@@ -198,7 +207,7 @@ struct Parsed {  // what one worker pass produced for one stream
 };
 
 // Pulls ADTS frames out of the stream's byte queue and runs the front-end on them, at most `limit` frames.
-void parse_some(sk_pipeline *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_frame_desc *descs, std::vector<uint8_t> &au_stage,
+void parse_some(sk_lane *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_frame_desc *descs, std::vector<uint8_t> &au_stage,
                 sk_au_item *au_items, Parsed &r) {
     const bool gpu_entropy = p->cfg.gpu_entropy != 0;
     auto fail = [&](int32_t st, const std::string &msg) {
@@ -300,7 +309,7 @@ void parse_some(sk_pipeline *p, PStream &s, uint32_t limit, float *coeffs, sk_aa
     }
 }
 
-void worker_main(sk_pipeline *p) {
+void worker_main(sk_lane *p) {
     const uint32_t per_stream = p->cfg.max_stream_frames_per_tick;
     const bool gpu_entropy = p->cfg.gpu_entropy != 0;
     std::vector<float> coeffs(gpu_entropy ? 0 : (size_t)per_stream * 2 * 1024);
@@ -328,7 +337,9 @@ void worker_main(sk_pipeline *p) {
         }
         Parsed r;
         const Clock::time_point t0 = Clock::now();
-        const uint32_t limit = std::min(per_stream, room);
+        // room in the output queue bounds the access units of this pass: one AudioData per unit, or -- through the
+        // streaming resampler -- one per completed chunk of 4096 source frames = 4 units (lib.rs:1970-2003)
+        const uint32_t limit = std::min(per_stream, s.resample ? (room > per_stream / 4 ? per_stream : 4 * room) : room);
         parse_some(p, s, limit, coeffs.data(), descs.data(), au_stage, au_items.data(), r);
         s.more = r.n_frames == limit && !r.eof && !r.failed;
         p->parse_ns.fetch_add(ns_since(t0));
@@ -411,7 +422,7 @@ void push_error(PStream &s, int32_t status, const std::string &msg) {
     s.out.push_back(std::move(o));
 }
 
-void submit_main(sk_pipeline *p) {
+void submit_main(sk_lane *p) {
     std::vector<sk_tick_stream> ts;
     for (;;) {
         Batch *b;
@@ -493,7 +504,7 @@ void submit_main(sk_pipeline *p) {
 
 // Hands a finished tick's outputs to the streams' queues: outputs first (in order), then the end-of-stream /
 // error notes, then the stream is free to be parsed again.
-void deliver_main(sk_pipeline *p) {
+void deliver_main(sk_lane *p) {
     std::vector<uint32_t> wake;  // streams that can be parsed again: queued in one go, one wake-up
     std::vector<uint32_t> listed;  // handles that now have something to receive
     for (;;) {
@@ -610,10 +621,10 @@ void deliver_main(sk_pipeline *p) {
         }
         if (!listed.empty()) {
             {
-                std::lock_guard<std::mutex> lk(p->oq_mu);
-                p->out_ready.insert(p->out_ready.end(), listed.begin(), listed.end());
+                std::lock_guard<std::mutex> lk(p->oq->mu);
+                for (uint32_t h : listed) p->oq->ready.push_back(h * p->n_lanes + p->lane_index);
             }
-            p->oq_cv.notify_all();
+            p->oq->cv.notify_all();
         }
         bool last;
         {
@@ -654,21 +665,24 @@ unsigned usable_cpus() {
     return n ? n : 1;
 }
 
-PStream *stream_of(sk_pipeline *p, uint32_t handle) {
+PStream *stream_of(sk_lane *p, uint32_t handle) {
     if (!p || handle >= p->streams.size()) return nullptr;
     return p->streams[handle].get();
 }
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline **out) {
+int lane_create(sk_engine *e, const sk_pipeline_config *cfg, OutQueue *oq, uint32_t lane_index, uint32_t n_lanes, sk_lane **out) {
     if (!e || !out) return SK_ERR_INVALID_ARG;
     *out = nullptr;
-    sk_pipeline *p = new (std::nothrow) sk_pipeline();
+    sk_lane *p = new (std::nothrow) sk_lane();
     if (!p) return SK_ERR_OOM;
     p->engine = e;
+    p->oq = oq;
+    p->lane_index = lane_index;
+    p->n_lanes = n_lanes;
     if (cfg) p->cfg = *cfg;
     if (!p->cfg.entropy_threads) {
         const unsigned cpus = usable_cpus();  // leave room for the submission + delivery threads and the callers' own
@@ -714,7 +728,7 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
         p->streams[i].reset(new PStream());
         p->free_handles.push_back(p->cfg.max_streams - 1 - i);
     }
-    for (int i = 1; i < sk_pipeline::kBatches; ++i) p->free_batches.push_back(i);
+    for (int i = 1; i < sk_lane::kBatches; ++i) p->free_batches.push_back(i);
     for (uint32_t i = 0; i < p->cfg.entropy_threads; ++i) p->workers.emplace_back(worker_main, p);
     p->submitter = std::thread(submit_main, p);
     // with the front-end on the GPU the entropy threads have little to do and delivery is the busiest host stage
@@ -728,7 +742,7 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
     return SK_OK;
 }
 
-void sk_pipeline_destroy(sk_pipeline *p) {
+void lane_destroy(sk_lane *p) {
     if (!p) return;
     {
         std::lock_guard<std::mutex> a(p->rq_mu);
@@ -739,7 +753,6 @@ void sk_pipeline_destroy(sk_pipeline *p) {
     p->batch_cv.notify_all();
     p->room_cv.notify_all();
     p->deliver_cv.notify_all();
-    p->oq_cv.notify_all();
     for (std::thread &t : p->workers) t.join();
     if (p->submitter.joinable()) p->submitter.join();
     for (std::thread &t : p->deliverers) t.join();
@@ -752,7 +765,7 @@ void sk_pipeline_destroy(sk_pipeline *p) {
     delete p;
 }
 
-int sk_pipeline_spawn(sk_pipeline *p, const sk_decode_options *opt, uint32_t *handle) {
+int lane_spawn(sk_lane *p, const sk_decode_options *opt, uint32_t *handle) {
     if (!p || !handle) return SK_ERR_INVALID_ARG;
     sk_decode_options o{};
     if (opt) o = *opt;
@@ -786,7 +799,7 @@ int sk_pipeline_spawn(sk_pipeline *p, const sk_decode_options *opt, uint32_t *ha
     return SK_OK;
 }
 
-int sk_pipeline_send(sk_pipeline *p, uint32_t handle, const uint8_t *data, size_t len) {
+int lane_send(sk_lane *p, uint32_t handle, const uint8_t *data, size_t len) {
     PStream *s = stream_of(p, handle);
     if (!s || (len && !data)) return SK_ERR_INVALID_ARG;
     if (len > kMaxInputChunkBytes) return SK_PIPE_CHUNK_TOO_LARGE;  // lib.rs:2796-2798
@@ -801,9 +814,7 @@ int sk_pipeline_send(sk_pipeline *p, uint32_t handle, const uint8_t *data, size_
     return SK_OK;
 }
 
-int sk_pipeline_finish(sk_pipeline *p, uint32_t handle) { return sk_pipeline_send(p, handle, nullptr, 0); }  // lib.rs:2838-2840
-
-static int take_output(sk_pipeline *p, PStream &s, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info) {
+int take_output(sk_lane *p, PStream &s, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info) {
     // s.mu held
     if (s.out.empty()) return s.finished ? SK_PIPE_CLOSED : 0;
     Output &o = s.out.front();
@@ -822,15 +833,15 @@ static int take_output(sk_pipeline *p, PStream &s, uint32_t handle, uint8_t *dat
     if (!s.out_listed && (!s.out.empty() || s.finished)) {  // a waiter that stops early hears about the rest again
         s.out_listed = true;
         {
-            std::lock_guard<std::mutex> lk(p->oq_mu);
-            p->out_ready.push_back(handle);
+            std::lock_guard<std::mutex> lk(p->oq->mu);
+            p->oq->ready.push_back(handle * p->n_lanes + p->lane_index);
         }
-        p->oq_cv.notify_one();
+        p->oq->cv.notify_one();
     }
     return 1;
 }
 
-int sk_pipeline_try_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info) {
+int lane_try_recv(sk_lane *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info) {
     PStream *s = stream_of(p, handle);
     if (!s || !info || (cap && !data)) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(s->mu);
@@ -838,7 +849,7 @@ int sk_pipeline_try_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t 
     return take_output(p, *s, handle, data, cap, info);
 }
 
-int sk_pipeline_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info, uint32_t timeout_ms) {
+int lane_recv(sk_lane *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info, uint32_t timeout_ms) {
     PStream *s = stream_of(p, handle);
     if (!s || !info || (cap && !data)) return SK_ERR_INVALID_ARG;
     std::unique_lock<std::mutex> lk(s->mu);
@@ -849,7 +860,7 @@ int sk_pipeline_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap,
     return take_output(p, *s, handle, data, cap, info);
 }
 
-int sk_pipeline_cancel(sk_pipeline *p, uint32_t handle) {  // shutdown(), lib.rs:2868-2881: also what Drop does
+int lane_cancel(sk_lane *p, uint32_t handle) {  // shutdown(), lib.rs:2868-2881: also what Drop does
     PStream *s = stream_of(p, handle);
     if (!s) return SK_ERR_INVALID_ARG;
     bool release_now = false;
@@ -872,32 +883,12 @@ int sk_pipeline_cancel(sk_pipeline *p, uint32_t handle) {  // shutdown(), lib.rs
     return SK_OK;
 }
 
-int sk_pipeline_wait_outputs(sk_pipeline *p, uint32_t *handles, uint32_t cap, uint32_t timeout_ms) {
-    if (!p || !handles || !cap) return SK_ERR_INVALID_ARG;
-    uint32_t n = 0;
-    {
-        std::unique_lock<std::mutex> lk(p->oq_mu);
-        p->oq_cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(timeout_ms),
-                            [&] { return p->stop || !p->out_ready.empty(); });
-        while (n < cap && !p->out_ready.empty()) {
-            handles[n++] = p->out_ready.front();
-            p->out_ready.pop_front();
-        }
-    }
-    for (uint32_t i = 0; i < n; ++i) {  // handed out: the next delivery (or a partial drain) lists the handle again
-        PStream &s = *p->streams[handles[i]];
-        std::lock_guard<std::mutex> lk(s.mu);
-        s.out_listed = false;
-    }
-    return (int)n;
-}
-
-size_t sk_pipeline_queued_input_bytes(sk_pipeline *p, uint32_t handle) {  // lib.rs:2863-2866
+size_t lane_queued_input_bytes(sk_lane *p, uint32_t handle) {  // lib.rs:2863-2866
     PStream *s = stream_of(p, handle);
     return s ? s->queued_bytes.load() : 0;
 }
 
-int sk_pipeline_get_stats(sk_pipeline *p, sk_pipeline_stats *out) {
+int lane_get_stats(sk_lane *p, sk_pipeline_stats *out) {
     if (!p || !out) return SK_ERR_INVALID_ARG;
     out->ticks = p->n_ticks.load();
     out->frames = p->n_frames.load();
@@ -908,7 +899,209 @@ int sk_pipeline_get_stats(sk_pipeline *p, sk_pipeline_stats *out) {
     out->idle_ns = p->idle_ns.load();
     out->deliver_ns = p->deliver_ns.load();
     out->entropy_threads = p->cfg.entropy_threads;
-    out->reserved = 0;
+    out->lanes = 1;
+    return SK_OK;
+}
+
+}  // namespace
+
+// ---- the pipeline: lanes behind one handle space ---------------------------------------------------------------
+struct sk_pipeline {
+    std::vector<sk_lane *> lanes;
+    std::vector<sk_engine *> owned_engines;  // lanes 1.. run on engines of their own, on the device of the caller's engine
+    // one completion queue per lane: a thread in sk_pipeline_wait_outputs waits on "its" lane's queue (threads are dealt
+    // out over the lanes as they first call) and sweeps the others, so consumer threads do not meet on one mutex; one
+    // consumer alone still serves every lane, at worst a millisecond late
+    std::vector<std::unique_ptr<OutQueue>> oqs;
+    std::atomic<uint32_t> next_lane{0}, next_waiter{0};
+};
+
+namespace {
+inline sk_lane *lane_of(sk_pipeline *p, uint32_t handle, uint32_t *inner) {
+    if (!p || p->lanes.empty()) return nullptr;
+    const uint32_t n = (uint32_t)p->lanes.size();
+    *inner = handle / n;
+    return p->lanes[handle % n];
+}
+}  // namespace
+
+extern "C" {
+
+int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline **out) {
+    if (!e || !out) return SK_ERR_INVALID_ARG;
+    *out = nullptr;
+    sk_pipeline_config c{};
+    if (cfg) c = *cfg;
+    // Two lanes when the front-end runs on the GPU and there are streams enough to fill two ticks at a time: a tick is then
+    // ~7 ms of dependent launches whatever its size, and the second engine's tick fills the device while the first
+    // one's drains.  Measured with 16 384 streams: 6.2-8.3 M access units/s on two lanes against 5.5-6.9 M on one; with
+    // 8192 streams two lanes run half-empty ticks and lose (3.5-6.3 M against 5.5-6.8 M), so one lane stays the default
+    // there.  With the host front-end the host threads are the limit and a second lane only splits them.
+    if (!c.max_streams) c.max_streams = 1024;
+    const uint32_t tick_frames = c.max_frames_per_tick ? c.max_frames_per_tick : (c.gpu_entropy ? 65536u : 16384u);
+    const uint32_t stream_frames = c.max_stream_frames_per_tick ? c.max_stream_frames_per_tick : (c.gpu_entropy ? 16u : 8u);
+    const uint32_t streams_per_tick = std::max(1u, tick_frames / std::max(1u, stream_frames));
+    uint32_t n_lanes = c.lanes ? c.lanes : ((c.gpu_entropy && c.max_streams >= 4 * streams_per_tick) ? 2u : 1u);
+    if (n_lanes > 8) return SK_ERR_INVALID_ARG;
+    if (n_lanes > c.max_streams) n_lanes = c.max_streams;
+    if (!c.entropy_threads) {
+        const unsigned cpus = usable_cpus();  // leave room for the submission + delivery threads and the callers' own
+        c.entropy_threads = cpus > 5 ? std::min(cpus - 5, 64u) : 1;
+    }
+    sk_pipeline *p = new (std::nothrow) sk_pipeline();
+    if (!p) return SK_ERR_OOM;
+    sk_pipeline_config lane_cfg = c;
+    lane_cfg.lanes = 1;
+    lane_cfg.max_streams = (c.max_streams + n_lanes - 1) / n_lanes;
+    lane_cfg.entropy_threads = std::max(1u, c.entropy_threads / n_lanes);
+    int rc = SK_OK;
+    for (uint32_t i = 0; i < n_lanes && rc == SK_OK; ++i) {
+        sk_engine *le = e;
+        if (i > 0) {
+            rc = sk_engine_create(sk_engine_device(e), std::max(lane_cfg.max_streams, 16u), &le);
+            if (rc != SK_OK) break;
+            p->owned_engines.push_back(le);
+        }
+        sk_lane *lane = nullptr;
+        p->oqs.emplace_back(new OutQueue());
+        rc = lane_create(le, &lane_cfg, p->oqs.back().get(), i, n_lanes, &lane);
+        if (rc == SK_OK) p->lanes.push_back(lane);
+    }
+    if (rc != SK_OK) {
+        sk_pipeline_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return SK_OK;
+}
+
+void sk_pipeline_destroy(sk_pipeline *p) {
+    if (!p) return;
+    for (auto &q : p->oqs) {
+        {
+            std::lock_guard<std::mutex> lk(q->mu);
+            q->stop = true;
+        }
+        q->cv.notify_all();
+    }
+    if (std::getenv("SK_PIPELINE_TRACE"))
+        for (sk_lane *l : p->lanes)
+            std::fprintf(stderr, "[sk_pipeline] lane %u: ticks %llu frames %llu tick_ms %.1f idle_ms %.1f deliver_ms %.1f parse_ms %.1f\n", l->lane_index,
+                         (unsigned long long)l->n_ticks.load(), (unsigned long long)l->n_frames.load(), l->tick_ns.load() / 1e6,
+                         l->idle_ns.load() / 1e6, l->deliver_ns.load() / 1e6, l->parse_ns.load() / 1e6);
+    for (sk_lane *l : p->lanes) lane_destroy(l);
+    for (sk_engine *e : p->owned_engines) sk_engine_destroy(e);
+    delete p;
+}
+
+int sk_pipeline_spawn(sk_pipeline *p, const sk_decode_options *opt, uint32_t *handle) {
+    if (!p || !handle || p->lanes.empty()) return SK_ERR_INVALID_ARG;
+    const uint32_t n = (uint32_t)p->lanes.size();
+    const uint32_t first = p->next_lane.fetch_add(1) % n;
+    int rc = SK_ERR_CAPACITY;
+    for (uint32_t k = 0; k < n; ++k) {  // round robin; a full lane passes the stream on
+        const uint32_t li = (first + k) % n;
+        uint32_t inner = 0;
+        rc = lane_spawn(p->lanes[li], opt, &inner);
+        if (rc == SK_OK) {
+            *handle = inner * n + li;
+            return SK_OK;
+        }
+        if (rc != SK_ERR_CAPACITY) return rc;
+    }
+    return rc;
+}
+
+int sk_pipeline_send(sk_pipeline *p, uint32_t handle, const uint8_t *data, size_t len) {
+    uint32_t inner;
+    sk_lane *l = lane_of(p, handle, &inner);
+    return l ? lane_send(l, inner, data, len) : SK_ERR_INVALID_ARG;
+}
+
+int sk_pipeline_finish(sk_pipeline *p, uint32_t handle) { return sk_pipeline_send(p, handle, nullptr, 0); }  // lib.rs:2838-2840
+
+int sk_pipeline_try_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info) {
+    uint32_t inner;
+    sk_lane *l = lane_of(p, handle, &inner);
+    return l ? lane_try_recv(l, inner, data, cap, info) : SK_ERR_INVALID_ARG;
+}
+
+int sk_pipeline_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info, uint32_t timeout_ms) {
+    uint32_t inner;
+    sk_lane *l = lane_of(p, handle, &inner);
+    return l ? lane_recv(l, inner, data, cap, info, timeout_ms) : SK_ERR_INVALID_ARG;
+}
+
+int sk_pipeline_cancel(sk_pipeline *p, uint32_t handle) {
+    uint32_t inner;
+    sk_lane *l = lane_of(p, handle, &inner);
+    return l ? lane_cancel(l, inner) : SK_ERR_INVALID_ARG;
+}
+
+int sk_pipeline_wait_outputs(sk_pipeline *p, uint32_t *handles, uint32_t cap, uint32_t timeout_ms) {
+    if (!p || !handles || !cap || p->oqs.empty()) return SK_ERR_INVALID_ARG;
+    const uint32_t n_q = (uint32_t)p->oqs.size();
+    thread_local uint32_t waiter_id = 0xffffffffu;
+    if (waiter_id == 0xffffffffu) waiter_id = p->next_waiter.fetch_add(1);
+    const uint32_t home = waiter_id % n_q;
+    const auto deadline = std::chrono::system_clock::now() + std::chrono::milliseconds(timeout_ms);
+    uint32_t n = 0;
+    for (;;) {
+        bool stopped = false;
+        for (uint32_t k = 0; k < n_q && n < cap; ++k) {  // the home queue first, then whatever the others hold
+            OutQueue &q = *p->oqs[(home + k) % n_q];
+            std::unique_lock<std::mutex> lk(q.mu, std::defer_lock);
+            if (k == 0) lk.lock();
+            else if (!lk.try_lock()) continue;
+            stopped = stopped || q.stop;
+            while (n < cap && !q.ready.empty()) {
+                handles[n++] = q.ready.front();
+                q.ready.pop_front();
+            }
+        }
+        if (n || stopped) break;
+        const auto now = std::chrono::system_clock::now();
+        if (now >= deadline) break;
+        OutQueue &q = *p->oqs[home];
+        std::unique_lock<std::mutex> lk(q.mu);
+        // with several lanes the wait is cut into millisecond slices so that a lone consumer also sees the other lanes
+        const auto until = n_q > 1 ? std::min(deadline, now + std::chrono::milliseconds(1)) : deadline;
+        q.cv.wait_until(lk, until, [&] { return q.stop || !q.ready.empty(); });
+    }
+    for (uint32_t i = 0; i < n; ++i) {  // handed out: the next delivery (or a partial drain) lists the handle again
+        uint32_t inner;
+        sk_lane *l = lane_of(p, handles[i], &inner);
+        PStream *s = stream_of(l, inner);
+        if (!s) continue;
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->out_listed = false;
+    }
+    return (int)n;
+}
+
+size_t sk_pipeline_queued_input_bytes(sk_pipeline *p, uint32_t handle) {  // lib.rs:2863-2866
+    uint32_t inner;
+    sk_lane *l = lane_of(p, handle, &inner);
+    return l ? lane_queued_input_bytes(l, inner) : 0;
+}
+
+int sk_pipeline_get_stats(sk_pipeline *p, sk_pipeline_stats *out) {
+    if (!p || !out) return SK_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof(*out));
+    for (sk_lane *l : p->lanes) {
+        sk_pipeline_stats s{};
+        (void)lane_get_stats(l, &s);
+        out->ticks += s.ticks;
+        out->frames += s.frames;
+        out->outputs += s.outputs;
+        out->errors += s.errors;
+        out->parse_ns += s.parse_ns;
+        out->tick_ns += s.tick_ns;
+        out->idle_ns += s.idle_ns;
+        out->deliver_ns += s.deliver_ns;
+        out->entropy_threads += s.entropy_threads;
+    }
+    out->lanes = (uint32_t)p->lanes.size();
     return SK_OK;
 }
 

@@ -24,6 +24,16 @@ struct sk_engine {
 };
 extern "C" {
 int sk_engine_device(const sk_engine *) { return 0; }
+uint32_t sk_engine_max_streams(const sk_engine *e) { return (uint32_t)e->open.size(); }
+int sk_engine_create(int, uint32_t max_streams, sk_engine **out) {  // lanes 1.. of a pipeline make their own
+    sk_engine *e = new sk_engine();
+    e->open.assign(max_streams, 0);
+    e->channels.assign(max_streams, 0);
+    e->next_unit.assign(max_streams, 0);
+    *out = e;
+    return SK_OK;
+}
+void sk_engine_destroy(sk_engine *e) { delete e; }
 const char *sk_strerror(int) { return "stub"; }
 int sk_stream_open(sk_engine *e, uint32_t, uint8_t ch, uint32_t *out) {
     std::lock_guard<std::mutex> lk(e->mu);
@@ -89,6 +99,7 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
 
 // ---- scenarios -------------------------------------------------------------------------------------------
 static std::vector<uint8_t> clip;
+static uint32_t g_lanes = 0;  // sk_pipeline_config::lanes of every scenario
 static uint64_t rng_state = 88172645463325252ull;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
 
@@ -133,6 +144,7 @@ static int scenario_many_streams(sk_engine *e) {
     cfg.max_frames_per_tick = 96;
     cfg.max_stream_frames_per_tick = 5;
     cfg.tick_wait_us = 50;
+    cfg.lanes = g_lanes;
     sk_pipeline *p = nullptr;
     CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
     const uint32_t n = 32, loops = 3;
@@ -183,6 +195,7 @@ static int scenario_wait_outputs(sk_engine *e) {
     cfg.entropy_threads = 3;
     cfg.max_streams = 24;
     cfg.max_stream_frames_per_tick = 3;
+    cfg.lanes = g_lanes;
     sk_pipeline *p = nullptr;
     CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
     const uint32_t n = 24;
@@ -239,6 +252,7 @@ static int scenario_backpressure_and_errors(sk_engine *e) {
     sk_pipeline_config cfg{};
     cfg.entropy_threads = 2;
     cfg.max_streams = 8;
+    cfg.lanes = g_lanes;
     sk_pipeline *p = nullptr;
     CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
     uint32_t h = 0;
@@ -301,6 +315,7 @@ static int scenario_cancel_churn(sk_engine *e) {
     sk_pipeline_config cfg{};
     cfg.entropy_threads = 3;
     cfg.max_streams = 6;
+    cfg.lanes = g_lanes;
     sk_pipeline *p = nullptr;
     CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
     for (int round = 0; round < 60; ++round) {
@@ -314,10 +329,12 @@ static int scenario_cancel_churn(sk_engine *e) {
         // cancelled handles come back once their in-flight work has been delivered
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
-            {
-                std::lock_guard<std::mutex> lk(p->handles_mu);
-                if (p->free_handles.size() == 6) break;
+            size_t free_now = 0;
+            for (sk_lane *l : p->lanes) {
+                std::lock_guard<std::mutex> lk(l->handles_mu);
+                free_now += l->free_handles.size();
             }
+            if (free_now == 6) break;
             CHECK(std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20));
             std::this_thread::sleep_for(std::chrono::microseconds(100));
         }
@@ -347,6 +364,13 @@ int main(int argc, char **argv) {
     if (int rc = scenario_wait_outputs(&e)) return rc;
     if (int rc = scenario_backpressure_and_errors(&e)) return rc;
     if (int rc = scenario_cancel_churn(&e)) return rc;
+    g_lanes = 2;  // the same scenarios over two engines behind one handle space
+    if (int rc = scenario_many_streams(&e)) return rc;
+    if (int rc = scenario_wait_outputs(&e)) return rc;
+    if (int rc = scenario_backpressure_and_errors(&e)) return rc;
+    if (int rc = scenario_cancel_churn(&e)) return rc;
+    g_lanes = 3;
+    if (int rc = scenario_many_streams(&e)) return rc;
     std::puts("scheduler scenarios ok");
     return 0;
 }
