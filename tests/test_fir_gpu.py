@@ -278,3 +278,32 @@ def test_full_size_dc_gain_and_linearity(engine, oracle):
     engine.downsample_48k_16k_dev(half, frames, rows, frames, yb, n_out)
     engine.synchronize()
     assert (ya * 0.5 - yb).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("amplitude", [1.0, 1e-6])
+def test_bf16_split_fir_is_f32_accurate(engine, oracle, amplitude):
+    """fir_bf16.hip computes the f32 filter from three bf16 pieces per operand (six products).  Measured against the
+    filter evaluated in f64 it stays at f32 level -- 2.2e-7 relative RMS on MI355X, the oracle's f32 chain 1.15e-7, the
+    bound 1e-6 -- at full scale and on a quiet signal alike (bf16 keeps the f32 exponent range, so relative accuracy
+    does not depend on level)."""
+    rng = np.random.default_rng(2024)
+    x = (amplitude * rng.uniform(-1, 1, (16, 6000))).astype(np.float32)
+    got = engine.downsample_48k_16k(x)
+    want32 = oracle.downsample_planar(x, 48000, 16000)
+    taps = oracle.resampler_taps(16000 / 48000).astype(np.float64)
+    n_out = got.shape[1]
+    # y[m] = sum_p h[p] x[3m - 125 + p], zero outside the signal (rubato's 128-frame delay already trimmed by the wrapper:
+    # locate the alignment from the f32 result rather than restating the trimming rule)
+    padded = np.concatenate([np.zeros((16, 512)), x.astype(np.float64), np.zeros((16, 1024))], axis=1)
+    best = None
+    for shift in range(0, 400):
+        idx = 3 * np.arange(8)[:, None] + np.arange(256)[None, :] + shift
+        trial = padded[0][idx] @ taps
+        if np.abs(trial - want32[0, :8]).max() < 1e-5 * amplitude:
+            best = shift
+            break
+    assert best is not None
+    idx = 3 * np.arange(n_out)[:, None] + np.arange(256)[None, :] + best
+    exact = np.stack([padded[r][idx] @ taps for r in range(16)])
+    err_gpu, err_f32 = rel_rms(got, exact), rel_rms(want32, exact)
+    assert err_f32 < 2e-7 and err_gpu < 3e-7, (err_gpu, err_f32)
