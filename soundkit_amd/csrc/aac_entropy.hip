@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void k_aac_entropy(EntropyArgs a) {
     t.tuples = reinterpret_cast<const uint64_t *>(lds + a.lds_tuple_off);
     t.sf_mult = reinterpret_cast<const float *>(lds + a.lds_sf_off);
     t.swb = reinterpret_cast<const uint16_t *>(lds + a.lds_swb_off);
+    t.pow43_lo = reinterpret_cast<const float *>(lds + a.lds_pow_off);
     const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
     if (task >= a.n_tasks) return;
     const EntropyTask tk = a.tasks[task];
@@ -67,14 +68,26 @@ __device__ __forceinline__ sk_ec::Tables lds_tables(const EntropyArgs &a, uint4 
     t.tuples = reinterpret_cast<const uint64_t *>(lds + a.lds_tuple_off);
     t.sf_mult = reinterpret_cast<const float *>(lds + a.lds_sf_off);
     t.swb = reinterpret_cast<const uint16_t *>(lds + a.lds_swb_off);
+    t.pow43_lo = reinterpret_cast<const float *>(lds + a.lds_pow_off);
     return t;
 }
 
-__global__ __launch_bounds__(256) void k_aac_entropy_parse(EntropyArgs a) {
+// Lanes per wave that carry a unit: a wave executes the union of its lanes' paths (codebooks, sign and escape branches
+// differ from unit to unit), and a tick of 65 536 units on 64 lanes per wave is one wave per SIMD, every latency in
+// the open.  Fewer units per wave (the first 64 >> lane_shift lanes) means shorter unions and more waves to hide
+// latency behind, for more wave-instructions in total on SIMDs that were mostly waiting (profiles/r01_pmc_entropy.md).
+__device__ __forceinline__ bool unit_of_lane(const EntropyArgs &a, uint32_t &k) {
+    const uint32_t per_wave = 64u >> a.lane_shift;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    k = wave * per_wave + lane;
+    return lane < per_wave && k < a.n_units;
+}
+
+__global__ __launch_bounds__(512) void k_aac_entropy_parse(EntropyArgs a) {
     extern __shared__ uint4 lds_raw[];
     const sk_ec::Tables t = lds_tables(a, lds_raw);
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.n_units) return;
+    uint32_t k;
+    if (!unit_of_lane(a, k)) return;
     const EntropyUnit u = a.units[k];
     const EntropyTask tk = a.tasks[u.task];
     sk_ec::Stream st{tk.sf_index, (int)tk.channels, 0u};
@@ -108,11 +121,11 @@ __global__ __launch_bounds__(64) void k_aac_entropy_link(EntropyArgs a) {
     a.pns_state[tk.stream] = state;
 }
 
-__global__ __launch_bounds__(256) void k_aac_entropy_finish(EntropyArgs a) {
+__global__ __launch_bounds__(512) void k_aac_entropy_finish(EntropyArgs a) {
     extern __shared__ uint4 lds_raw[];
     const sk_ec::Tables t = lds_tables(a, lds_raw);
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.n_units) return;
+    uint32_t k;
+    if (!unit_of_lane(a, k)) return;
     const EntropyUnit u = a.units[k];
     const EntropyTask tk = a.tasks[u.task];
     float *coef = a.coeffs + (size_t)u.off1024 * 1024;
@@ -133,9 +146,12 @@ __global__ __launch_bounds__(256) void k_aac_entropy_finish(EntropyArgs a) {
 
 hipError_t launch_aac_entropy_parallel(const EntropyArgs &a, hipStream_t s) {
     if (a.n_units == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_aac_entropy_parse, dim3((a.n_units + 255) / 256), dim3(256), a.lds_bytes, s, a);
+    if (a.lane_shift > 4) return hipErrorInvalidValue;
+    // workgroups of eight waves share one copy of the tables in LDS (~60 KB): two per CU, four waves per SIMD
+    const uint32_t per_wave = 64u >> a.lane_shift, waves = (a.n_units + per_wave - 1) / per_wave, blocks = (waves + 7) / 8;
+    hipLaunchKernelGGL(k_aac_entropy_parse, dim3(blocks), dim3(512), a.lds_bytes, s, a);
     hipLaunchKernelGGL(k_aac_entropy_link, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_aac_entropy_finish, dim3((a.n_units + 255) / 256), dim3(256), a.lds_bytes, s, a);
+    hipLaunchKernelGGL(k_aac_entropy_finish, dim3(blocks), dim3(512), a.lds_bytes, s, a);
     return hipGetLastError();
 }
 

@@ -61,12 +61,15 @@ struct Tables {
     const uint64_t *tuples;   // per spectral symbol: bytes 0-3 the values (int8), byte 4 sign-bit count, byte 5 escape flag
     const uint16_t *swb;      // every band-offset table back to back
     const float *pow43;       // [8192]
+    const float *pow43_lo;    // its first kPow43Lo entries again (device: a copy in LDS; all but escape values end here)
     const float *sf_mult;     // [768]: scale factor -256..511
     const float *is_mult;     // [512]: 2^(-position / 4) for intensity positions -256..255 (scalefactor.rs:208-210)
     const float *tns_sin;     // [2][17]: sin(signed * pi / divisor) for coef_res 3 / 4 bits, signed -8..8 (tns.rs:208-235)
 };
 
 // ---- bit reader over 32-bit big-endian-packed words (the buffer is 4-byte aligned and zero-padded by >= 8 bytes) ----
+constexpr uint32_t kPow43Lo = 32;
+
 struct Bits {
     const uint32_t *words;
     uint32_t total, pos;
@@ -74,18 +77,24 @@ struct Bits {
     // uncoalesced, dependent round trip -- one per 32 bits consumed instead of two per peek
     uint32_t cached;  // index of the first cached word (0xffffffff: nothing cached yet)
     uint64_t window;  // bswap(words[cached]) << 32 | bswap(words[cached + 1])
+    // the word after the window, requested when the window moves and not needed before it moves again: the load's
+    // latency overlaps the decoding of 32 bits instead of standing in front of it
+    uint32_t ahead, last_word;  // last_word: last index inside the unit's 8 bytes of zero padding
 };
 
-SKE Bits make_bits(const uint32_t *words, uint32_t len_bytes) { return Bits{words, len_bytes * 8, 0, 0xffffffffu, 0}; }
+SKE Bits make_bits(const uint32_t *words, uint32_t len_bytes) {
+    return Bits{words, len_bytes * 8, 0, 0xffffffffu, 0, 0, (len_bytes + 8) / 4 - 1};
+}
 
 SKE uint32_t ec_bswap(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
 
 SKE uint32_t peek32(Bits &b) {  // next 32 bits, left-aligned; bits past the end read as the padding (zero)
     const uint32_t i = b.pos >> 5, s = b.pos & 31;
     if (i != b.cached) {
-        if (b.cached != 0xffffffffu && i == b.cached + 1) b.window = (b.window << 32) | ec_bswap(b.words[i + 1]);
+        if (b.cached != 0xffffffffu && i == b.cached + 1) b.window = (b.window << 32) | ec_bswap(b.ahead);
         else b.window = ((uint64_t)ec_bswap(b.words[i]) << 32) | ec_bswap(b.words[i + 1]);
         b.cached = i;
+        b.ahead = b.words[i + 2 < b.last_word ? i + 2 : b.last_word];
     }
     return (uint32_t)((b.window << s) >> 32);
 }
@@ -346,7 +355,7 @@ SKE float dequantize(const Tables &t, int q, float scale) {  // dsp.rs:397-405
     if (q == 0) return 0.0f;
     const float sign = q < 0 ? -1.0f : 1.0f;
     const uint32_t mag = q < 0 ? (uint32_t)(-(int64_t)q) : (uint32_t)q;
-    const float m = mag < 8192 ? t.pow43[mag] : ec_powf((float)mag, 4.0f / 3.0f);
+    const float m = mag < kPow43Lo ? t.pow43_lo[mag] : (mag < 8192 ? t.pow43[mag] : ec_powf((float)mag, 4.0f / 3.0f));
     return sign * m * scale;
 }
 

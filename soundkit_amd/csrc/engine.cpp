@@ -1667,13 +1667,14 @@ int ensure_entropy_tables(sk_engine *e) {
     // global memory
     const size_t b_meta = 0, b_lut = b_meta + pad(h.meta.size() * 4), b_tup = b_lut + pad(h.lut.size() * 4),
                  b_sf = b_tup + pad(h.tuples.size() * 8), b_swb = b_sf + pad(h.sf_mult.size() * 4),
-                 lds_end = b_swb + pad(h.swb.size() * 2), b_pow = lds_end, b_is = b_pow + pad(h.pow43.size() * 4),
+                 b_plo = b_swb + pad(h.swb.size() * 2), lds_end = b_plo + pad(sk_ec::kPow43Lo * 4), b_pow = lds_end, b_is = b_pow + pad(h.pow43.size() * 4),
                  b_tns = b_is + pad(h.is_mult.size() * 4), total = b_tns + pad(h.tns_sin.size() * 4);
     std::vector<uint8_t> blob(total, 0);
     std::memcpy(blob.data() + b_meta, h.meta.data(), h.meta.size() * 4);
     std::memcpy(blob.data() + b_lut, h.lut.data(), h.lut.size() * 4);
     std::memcpy(blob.data() + b_tup, h.tuples.data(), h.tuples.size() * 8);
     std::memcpy(blob.data() + b_pow, h.pow43.data(), h.pow43.size() * 4);
+    std::memcpy(blob.data() + b_plo, h.pow43.data(), sk_ec::kPow43Lo * 4);
     std::memcpy(blob.data() + b_sf, h.sf_mult.data(), h.sf_mult.size() * 4);
     std::memcpy(blob.data() + b_is, h.is_mult.data(), h.is_mult.size() * 4);
     std::memcpy(blob.data() + b_tns, h.tns_sin.data(), h.tns_sin.size() * 4);
@@ -1687,6 +1688,7 @@ int ensure_entropy_tables(sk_engine *e) {
     t.tuples = (const uint64_t *)(base + b_tup);
     t.swb = (const uint16_t *)(base + b_swb);
     t.pow43 = (const float *)(base + b_pow);
+    t.pow43_lo = (const float *)(base + b_plo);
     t.sf_mult = (const float *)(base + b_sf);
     t.is_mult = (const float *)(base + b_is);
     t.tns_sin = (const float *)(base + b_tns);
@@ -1699,6 +1701,7 @@ int ensure_entropy_tables(sk_engine *e) {
     ea.lds_tuple_off = (uint32_t)b_tup;
     ea.lds_sf_off = (uint32_t)b_sf;
     ea.lds_swb_off = (uint32_t)b_swb;
+    ea.lds_pow_off = (uint32_t)b_plo;
     e->ec_ready = true;
     return SK_OK;
 }
@@ -1855,6 +1858,14 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 SK_HIP(e->tick_side.reserve((size_t)n_frames * (sizeof(sk_ec::Scratch) + sizeof(uint32_t)) + 128),
                        "alloc entropy side information");
                 ea.n_units = n_frames;
+                // units per wave: 16 while that still fits four waves per SIMD (4096 waves), then 32, then 64 -- a wave runs
+                // the union of its lanes' paths and a SIMD with one wave has every latency in the open; measured on
+                // ~22 000-unit ticks: parse 2.0 -> 1.7 ms, finish 0.80 -> 0.61 ms (SK_ENTROPY_LANE_SHIFT forces a value)
+                static const int forced_shift = [] {
+                    const char *v = std::getenv("SK_ENTROPY_LANE_SHIFT");
+                    return v && v[0] >= '0' && v[0] <= '4' ? (int)(v[0] - '0') : -1;
+                }();
+                ea.lane_shift = forced_shift >= 0 ? (uint32_t)forced_shift : (n_frames <= 65536 ? 2u : (n_frames <= 131072 ? 1u : 0u));
                 ea.side = (sk_ec::Scratch *)e->tick_side.p;
                 ea.pns_start = (uint32_t *)((uint8_t *)e->tick_side.p + (((size_t)n_frames * sizeof(sk_ec::Scratch) + 15) & ~(size_t)15));
                 SK_HIP(sk::launch_aac_entropy_parallel(ea, e->stream), "launch entropy decode");

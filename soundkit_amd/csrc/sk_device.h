@@ -177,7 +177,7 @@ struct EntropyArgs {
     // tuple table, scale-factor multipliers, band offsets (byte offsets from lds_blob)
     const uint8_t *lds_blob;
     uint32_t lds_bytes;
-    uint32_t lds_meta_off, lds_lut_off, lds_tuple_off, lds_sf_off, lds_swb_off;
+    uint32_t lds_meta_off, lds_lut_off, lds_tuple_off, lds_sf_off, lds_swb_off, lds_pow_off;
     const uint32_t *words;
     const EntropyUnit *units;
     const EntropyTask *tasks;
@@ -190,6 +190,7 @@ struct EntropyArgs {
     uint32_t n_units;
     sk_ec::Scratch *side;  // [n_units] side information handed from the first phase to the third
     uint32_t *pns_start;   // [n_units] generator state each unit starts from
+    uint32_t lane_shift;   // the first 64 >> lane_shift lanes of a wave carry a unit each (0..4)
 };
 hipError_t launch_aac_entropy(const EntropyArgs &a, hipStream_t s);           // one lane per stream, units in sequence
 hipError_t launch_aac_entropy_parallel(const EntropyArgs &a, hipStream_t s);  // parse | link | finish

@@ -22,6 +22,7 @@ static sk_ec::Tables make_tables() {
     t.tuples = h.tuples.data();
     t.swb = h.swb.data();
     t.pow43 = h.pow43.data();
+    t.pow43_lo = h.pow43.data();
     t.sf_mult = h.sf_mult.data();
     t.is_mult = h.is_mult.data();
     t.tns_sin = h.tns_sin.data();
