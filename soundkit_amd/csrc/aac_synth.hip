@@ -19,6 +19,23 @@
 // post-twiddled spectrum crosses LDS once (8 x ds_write_b64, 4 x ds_read_b128 per lane).
 #include "sk_device.h"
 
+// streaming accesses of the main path: spectra are read once, PCM written once.  SK_SYNTH_NT_LOAD / SK_SYNTH_NT_STORE
+// build the non-temporal forms for A/B runs (tools/build_ab.sh aac_synth SK_SYNTH_NT_LOAD ...).
+#ifdef SK_SYNTH_NT_BOTH
+#define SK_SYNTH_NT_LOAD
+#define SK_SYNTH_NT_STORE
+#endif
+#ifdef SK_SYNTH_NT_LOAD
+#define SK_SYNTH_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define SK_SYNTH_LOAD(p) (*(p))
+#endif
+#ifdef SK_SYNTH_NT_STORE
+#define SK_SYNTH_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define SK_SYNTH_STORE(v, p) (*(p) = (v))
+#endif
+
 namespace sk {
 
 namespace {
@@ -350,7 +367,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
     auto load_spectrum = [&](f2 (&xin)[8], uint32_t e) {
         const float *src = a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e].off1024) * 1024 + 2 * lane;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) xin[r] = *reinterpret_cast<const f2 *>(src + 128 * r);
+        for (int r = 0; r < 8; ++r) xin[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
     };
     auto frame = [&](f2 (&xin)[8], uint32_t e) __attribute__((always_inline)) {
         const SynthEntry ent = entries[e];
@@ -400,7 +417,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
                 const float *src =
                     a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e + kDepth].off1024) * 1024 + 2 * lane;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) xin[r] = *reinterpret_cast<const f2 *>(src + 128 * r);
+                for (int r = 0; r < 8; ++r) xin[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
             }
 #if !defined(SK_ABLATE_FFT)
             fft512(z, ex, t64, base2, lane);
@@ -430,8 +447,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
                 // out1[508-j..511-j] = M0.im, F1.re, M1.im, F0.re (dsp.rs:517, 529)
                 m.x = M.y * W1m.x + dly[8 * r + 4]; m.y = F.z * W1m.y + dly[8 * r + 5];
                 m.z = M.w * W1m.z + dly[8 * r + 6]; m.w = F.x * W1m.w + dly[8 * r + 7];
-                *reinterpret_cast<f4 *>(out_ptr + j) = f;
-                *reinterpret_cast<f4 *>(out_ptr + 1020 - j) = m;
+                SK_SYNTH_STORE(f, reinterpret_cast<f4 *>(out_ptr + j));
+                SK_SYNTH_STORE(m, reinterpret_cast<f4 *>(out_ptr + 1020 - j));
                 // out2[j..j+3] = F0.im, M1.re, F1.im, M0.re       (dsp.rs:518, 530)
                 dly[8 * r + 0] = F.y * W2f.x; dly[8 * r + 1] = M.z * W2f.y;
                 dly[8 * r + 2] = F.w * W2f.z; dly[8 * r + 3] = M.x * W2f.w;
@@ -454,7 +471,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
                 const float *src =
                     a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e + kDepth].off1024) * 1024 + 2 * lane;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) xin[r] = *reinterpret_cast<const f2 *>(src + 128 * r);
+                for (int r = 0; r < 8; ++r) xin[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
             }
         }
         prev_shape = shape;  // decoder.rs:371

@@ -8,6 +8,6 @@ src=$1; shift
 mkdir -p ../ab
 for X in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -ffp-contract=off -D$X -c $src.hip -o build/${src}_$X.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../ab/lib_$X.so $(ls build/*.o | grep -v "build/${src}") build/${src}_$X.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../ab/lib_$X.so $(ls build/*.o | grep -v "_SK_" | grep -v "build/${src}\.o") build/${src}_$X.o
 done
 ls ../ab
