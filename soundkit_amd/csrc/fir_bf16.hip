@@ -428,7 +428,11 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
 
 }  // namespace
 
-bool fir_bf16_supported(const FirArgs &a) { return a.afrag16 != nullptr; }
+bool fir_bf16_supported(const FirArgs &a) {
+    // tile and sample indices are 32-bit inside the kernel; longer rows (> ~2^31 / 3 outputs) stay on the f32 kernel
+    const int64_t end_pair = ((int64_t)a.out_first + a.out_count + 31) / 32;
+    return a.afrag16 != nullptr && end_pair <= 0x7ffffff0ll / 96 && a.out_count <= 0x7fffff00u;
+}
 
 hipError_t launch_fir_48k_16k_bf16(const FirArgs &a, hipStream_t s) {
     if (a.rows == 0 || a.out_count == 0) return hipSuccess;
