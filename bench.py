@@ -485,7 +485,7 @@ def main():
                     "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                     "traffic": pmc_traffic(pmc_kind + "_f32", rows=streams * ch, frames=fir_in), "avg_launch_ms": ms}
             else:
-                # fir_bf16.hip: six bf16 products per tap at 80 % useful MACs = 3840 issued flop per output, 1/16 of the time
+                # fir_bf16.hip: 41 bf16 MFMAs per 16 x 16 outputs = 2624 issued flop per output, 1/16 of the time
                 # they would take on the f32 matrix path; what bounds the launch now is its own HBM traffic:
                 # 4 B per input sample + 4 B (f32) or 2 B (s16) per output sample
                 fir_bytes = streams * ch * (fir_in * 4.0 + n_fir_out * (2.0 if fused else 4.0))
@@ -494,7 +494,7 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fir_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic": pmc_traffic(pmc_kind, rows=streams * ch, frames=fir_in), "avg_launch_ms": ms,
                     "algorithmic_tflops": flops / (ms * 1e-3) / 1e12,
-                    "issued_bf16_tflops": flops * 7.5 / (ms * 1e-3) / 1e12, "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TF}
+                    "issued_bf16_tflops": flops * 5.125 / (ms * 1e-3) / 1e12, "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TF}
         if "k_f32_planar_stereo_to_s16le_batch" in per_kernel:
             ms = per_kernel["k_f32_planar_stereo_to_s16le_batch"]
             cvt_bytes = streams * ch * eng.downsample_out_frames(frames * 1024) * 6.0  # 4 B in + 2 B out per sample

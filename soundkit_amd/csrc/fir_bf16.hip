@@ -19,8 +19,8 @@
 //
 // Tiles 48 samples apart alternate between windows aligned at 0 and at 16 modulo 32, so even and odd tiles read the
 // row through two window grids (16 samples apart) and share ONE set of A fragments: 10 steps x {h1,h2,h3} x 4 VGPRs =
-// 120 registers.  A window of one grid feeds the 3-4 tiles of that parity that are in flight (steps s, s+3, s+6, s+9),
-// six MFMAs each.  Useful MACs / issued = 256 / 320 = 80 %, times six products.
+// 120 registers at most (92 with the products that are left out, below).  A window of one grid feeds the 3-4 tiles of
+// that parity that are in flight (steps s, s+3, s+6, s+9), up to six MFMAs each.  Useful MACs / issued = 256 / 320 = 80 %.
 //
 // Input rows are loaded to registers 64 samples at a time, split into the three bf16 planes there (v_and / v_sub /
 // v_perm: the matrix instruction holds the vector issue port for only half of its 16 cycles, so this work sits in the
@@ -42,6 +42,12 @@ constexpr int kRing = 192;                   // samples of each row held in LDS
 constexpr int kRowBytes = 2 * kRing + 16;    // 400 = 16 * 25: odd multiple of 16 -> conflict-free ds_read_b128 over 16 rows
 constexpr int kPlaneBytes = 16 * kRowBytes;  // one bf16 plane of the 16 rows
 constexpr int kWindows = 10;                 // windows (K steps) per tile
+// Products kept per window, in the order x1h1 | x1h2, x2h1 | x2h2, x1h3, x3h1 (relative size 1 | 2^-8 | 2^-16).  The taps a
+// window can meet are small at both ends of the filter -- largest |h| relative to the peak tap: 2^-18.7, 2^-11.1, 2^-6.6,
+// 2^-2.4, 1, 1, 2^-4.5, 2^-8.1, 2^-13.9, 2^-24.6 for windows 0..9 -- and a product whose size times that factor is under
+// 2^-24 of the peak cannot be told from f32 rounding: 41 MFMAs per tile instead of 60, the same error against an f64
+// evaluation to three digits (tests/test_fir_gpu.py holds the bound, tools/fir_split_model.py shows the budget).
+__device__ constexpr int kProducts[kWindows] = {1, 3, 6, 6, 6, 6, 6, 3, 3, 1};
 #ifndef SK_BF_AHEAD
 #define SK_BF_AHEAD 2
 #endif
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const int s = 3 * d + wi;
-                        if (s >= kWindows) continue;
+                        if (s >= kWindows || prod >= kProducts[s]) continue;
                         f32x4 &c = acc[par][(K - d + 4) & 3];
                         if (s == 0 && prod == 0) c = mfma_bf16(af[s][hk[prod]], bcur.p[xk[prod]], (f32x4){0.f, 0.f, 0.f, 0.f});
                         else c = mfma_bf16(af[s][hk[prod]], bcur.p[xk[prod]], c);
@@ -381,8 +387,12 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
             // a matrix instruction holds the vector issue port for half of its 16 cycles: two ordinary vector
             // instructions per MFMA ride along free, a longer run between two MFMAs stalls the matrix pipe
             if (INTERIOR) {
+                int mfmas = 0;
 #pragma unroll
-                for (int g = 0; g < 40; ++g) {
+                for (int d = 0; d < 4; ++d)
+                    if (3 * d + wi < kWindows) mfmas += 2 * kProducts[3 * d + wi];
+#pragma unroll
+                for (int g = 0; g < mfmas; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
                 }
