@@ -46,7 +46,7 @@ constexpr int kWindows = 10;                 // windows (K steps) per tile
 // window can meet are small at both ends of the filter -- largest |h| relative to the peak tap: 2^-18.7, 2^-11.1, 2^-6.6,
 // 2^-2.4, 1, 1, 2^-4.5, 2^-8.1, 2^-13.9, 2^-24.6 for windows 0..9 -- and a product whose size times that factor is under
 // 2^-24 of the peak cannot be told from f32 rounding: 41 MFMAs per tile instead of 60, the same error against an f64
-// evaluation to three digits (tests/test_fir_gpu.py holds the bound, tools/fir_split_model.py shows the budget).
+// evaluation to three digits (tests/test_fir_gpu.py holds the bound, tests/fir_split_model.py shows the budget).
 __device__ constexpr int kProducts[kWindows] = {1, 3, 6, 6, 6, 6, 6, 3, 3, 1};
 #ifndef SK_BF_AHEAD
 #define SK_BF_AHEAD 2

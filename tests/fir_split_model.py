@@ -2,14 +2,14 @@
 """Host model of fir_bf16.hip's arithmetic: three-way bf16 split of samples and taps by truncation, the products kept
 per 32-sample window, f32 accumulation after every window (the matrix instruction's internal sum taken as exact).
 Prints the error against an f64 evaluation of the same filter for several product sets -- the budget behind kProducts.
-No GPU needed:  python tools/fir_split_model.py"""
+No GPU needed:  python tests/fir_split_model.py  (test infrastructure: it uses the oracle's taps)"""
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from oracle import oracle  # noqa: E402  (test infrastructure: this tool is not part of the product)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))  # the repository root: oracle/
+from oracle import oracle  # noqa: E402
 
 
 def trunc_bf16(v):
@@ -23,21 +23,25 @@ def split3(v):
     return a, b, (r - b).astype(np.float32)
 
 
-def main():
+SETS = {
+    "60 MFMAs per tile (all six products everywhere)": [6] * 10,
+    "41 (kProducts)": [1, 3, 6, 6, 6, 6, 6, 3, 3, 1],
+    "39": [1, 3, 4, 6, 6, 6, 6, 3, 3, 1],
+    "35": [1, 3, 4, 6, 6, 6, 4, 3, 1, 1],
+}
+
+
+def errors(sets=SETS, n=40000, verbose=False):
+    """{label: (relative RMS error, max abs error)} of the split arithmetic against an f64 evaluation."""
     h = oracle.resampler_taps(16000 / 48000).astype(np.float32)
     peak = np.abs(h).max()
-    for s in range(10):
-        lo, hi = max(0, 32 * s - 48), min(255, 32 * s + 28)
-        print("window %d meets taps %3d..%3d, largest |h| / peak = 2^%.1f" % (s, lo, hi, np.log2(np.abs(h[lo:hi + 1]).max() / peak)))
+    if verbose:
+        for s in range(10):
+            lo, hi = max(0, 32 * s - 48), min(255, 32 * s + 28)
+            print("window %d meets taps %3d..%3d, largest |h| / peak = 2^%.1f" % (s, lo, hi, np.log2(np.abs(h[lo:hi + 1]).max() / peak)))
     p6 = [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (0, 2)]  # (tap piece, sample piece): x1h1 | x1h2 x2h1 | x2h2 x1h3 x3h1
-    sets = {
-        "60 MFMAs per tile (all six products everywhere)": [6] * 10,
-        "41 (kProducts)": [1, 3, 6, 6, 6, 6, 6, 3, 3, 1],
-        "39": [1, 3, 4, 6, 6, 6, 6, 3, 3, 1],
-        "35": [1, 3, 4, 6, 6, 6, 4, 3, 1, 1],
-    }
     rng = np.random.default_rng(1)
-    n = 40000
+    result = {}
     x = rng.uniform(-1, 1, n).astype(np.float32)
     hs, xs = split3(h), split3(x)
     tiles = (n - 600) // 48
@@ -61,9 +65,11 @@ def main():
             out[:, i] = acc
         if exact is None:
             exact = ex
-        print("%-50s relative RMS error %.3e, max abs %.3e" % (label, np.sqrt(np.mean((out - exact) ** 2) / np.mean(exact ** 2)),
-                                                              np.abs(out - exact).max()))
+        result[label] = (float(np.sqrt(np.mean((out - exact) ** 2) / np.mean(exact ** 2))), float(np.abs(out - exact).max()))
+        if verbose:
+            print("%-50s relative RMS error %.3e, max abs %.3e" % ((label,) + result[label]))
+    return result
 
 
 if __name__ == "__main__":
-    main()
+    errors(verbose=True)
