@@ -93,3 +93,53 @@ def test_fused_s16_epilogue_equals_fir_then_convert(engine, ch, n_streams, n_fra
     assert got == n_out
     assert torch.equal(fused[:, :n_out], sep)
     assert not fused[:, n_out:].any()  # nothing written past the end
+
+
+def test_full_size_default_chain_spot_checked_against_oracle(oracle):
+    """The bench's default workload at its full size (4096 streams x 64 stereo frames, frame-major, the reference's seeded
+    spectra scaled to audible level, s16 in the FIR epilogue): three streams out of the batch are restated on the CPU.  The FIR sums in another
+    order than the oracle, so an s16 value may differ by one LSB on a small fraction of samples."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    n_streams, n_frames, ch = 4096, 64, 2
+    eng = soundkit_amd.Engine(0, n_streams)
+    try:
+        # the reference's test spectrum is in +-12, which synthesises to well under one 16-bit step: scaled up as in the
+        # small-batch test above so that the s16 comparison has something to compare
+        coeffs = bench.seeded_spectra(torch, torch.device("cuda:0"), n_streams, n_frames, ch) * 2500.0  # [stream][frame]
+        picked = [0, 1777, 4095]
+        host = {s: coeffs.view(n_streams, n_frames, ch, 1024)[s].cpu().numpy() for s in picked}
+        packed = coeffs.view(n_streams, n_frames, ch, 1024).transpose(0, 1).contiguous().view(-1, ch, 1024)
+        del coeffs
+        sids = np.array([eng.open_stream(48000, ch) for _ in range(n_streams)], np.uint32)
+        shape_of_frame = (np.arange(n_frames) & 1).astype(np.uint8)
+        descs, n = soundkit_amd.descs_from_arrays(np.tile(sids, n_frames), ch, np.zeros((n_streams * n_frames, 2), np.uint8),
+                                                  np.repeat(shape_of_frame, n_streams)[:, None].repeat(2, 1))
+        plan = eng.plan(descs, n)
+        assert plan.frames_ok == n
+        pcm = torch.empty_like(packed)
+        n_out = eng.downsample_out_frames(n_frames * 1024)
+        stride = (n_out + 7) // 8 * 8
+        out = torch.zeros((n_streams, stride, ch), dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        plan.run_f32(packed, pcm)
+        got = eng.downsample_48k_16k_frames_s16_dev(pcm, ch * 1024, n_streams * ch * 1024, ch, n_streams, n_frames, out, stride)
+        eng.synchronize()
+        assert got == n_out
+        seqs = np.zeros((n_frames, 2), np.uint8)
+        shapes = np.repeat(shape_of_frame[:, None], 2, 1)
+        for s in picked:
+            ref_pcm, _ = oracle.synthesize_stream(host[s], seqs, shapes)
+            planar = np.ascontiguousarray(ref_pcm.transpose(1, 0, 2).reshape(ch, n_frames * 1024))
+            want = oracle.planar_f32_to_s16_interleaved(oracle.downsample_planar(planar, 48000, 16000)).reshape(n_out, ch)
+            mine = out[s, :n_out].cpu().numpy()
+            d = np.abs(mine.astype(np.int32) - want.astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 0.01, (s, int(d.max()), float((d > 0).mean()))
+            assert np.abs(mine).max() > 100  # not silence
+        assert not out[:, n_out:].any()
+        plan.destroy()
+    finally:
+        eng.close()
