@@ -42,6 +42,10 @@ def pmc_traffic(kind, **config):
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak
 SEED0 = 0x12345678
+# the reference's test spectrum (+-12) synthesises to well under one 16-bit step; at this gain the 16 kHz s16 output peaks at
+# a few hundred steps (tests/test_pipeline_gpu.py checks the same data against the oracle).  Not a performance knob:
+# nothing on the path is data-dependent.
+SPECTRUM_GAIN = 2500.0
 
 
 def lcg_tables(n=1024):
@@ -100,6 +104,7 @@ def cpu_baseline_pipeline(target_s=15.0):
     from oracle import oracle as O
     n_frames = 64
     spectra = np.stack([[O.seeded_spectrum(1024, (SEED0 + f * 2 + c) & 0xFFFFFFFF) for c in range(2)] for f in range(n_frames)])
+    spectra = (spectra * np.float32(SPECTRUM_GAIN)).astype(np.float32)
     chans = [O.Channel(), O.Channel()]
     shapes = [[f & 1, f & 1] for f in range(n_frames)]
     done, t0 = 0, time.perf_counter()
@@ -361,7 +366,7 @@ def main():
         kernel_ms.setdefault(name, []).append((a, b))
 
     if args.workload in ("aac_synth", "pipeline"):
-        coeffs = seeded_spectra(torch, device, streams, frames, ch, stream0=rank * streams)  # [stream][frame]
+        coeffs = seeded_spectra(torch, device, streams, frames, ch, stream0=rank * streams) * SPECTRUM_GAIN  # [stream][frame]
         sids = np.array([eng.open_stream(48000, ch) for _ in range(streams)], np.uint32)
         shape_of_frame = (np.arange(frames) & 1).astype(np.uint8)  # Sine / KBD alternate
         if args.layout == "frame":
@@ -454,7 +459,7 @@ def main():
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "streams_per_gpu": streams, "frames_per_stream": frames,
-                       "sample_rate": 48000, "channels": ch, "seed": "0x12345678 + stream*0x9e3779b9 + frame*2 + ch",
+                       "sample_rate": 48000, "channels": ch, "seed": "0x12345678 + stream*0x9e3779b9 + frame*2 + ch", "spectrum": "dsp.rs:725-738 seeded_spectrum x %g" % SPECTRUM_GAIN,
                        "parallelism": "streams sharded, %d rank(s), no collective" % world},
         }
         rl = {}
