@@ -367,7 +367,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
     auto load_spectrum = [&](f2 (&xin)[8], uint32_t e) {
         const float *src = a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e].off1024) * 1024 + 2 * lane;
 #pragma unroll
+#ifdef SK_SYNTH_ABLATE_F4LOAD  // timing experiment only (wrong data order): the same bytes as four 16-byte loads per lane
+        for (int r = 0; r < 4; ++r) {
+            const f4 v = *reinterpret_cast<const f4 *>(src + 2 * lane + 256 * r);
+            xin[2 * r] = (f2){v.x, v.y};
+            xin[2 * r + 1] = (f2){v.z, v.w};
+        }
+#else
         for (int r = 0; r < 8; ++r) xin[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
+#endif
     };
     auto frame = [&](f2 (&xin)[8], uint32_t e) __attribute__((always_inline)) {
         const SynthEntry ent = entries[e];
@@ -417,7 +425,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
                 const float *src =
                     a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e + kDepth].off1024) * 1024 + 2 * lane;
 #pragma unroll
+#ifdef SK_SYNTH_ABLATE_F4LOAD
+                for (int r = 0; r < 4; ++r) {
+                    const f4 v = *reinterpret_cast<const f4 *>(src + 2 * lane + 256 * r);
+                    xin[2 * r] = (f2){v.x, v.y};
+                    xin[2 * r + 1] = (f2){v.z, v.w};
+                }
+#else
                 for (int r = 0; r < 8; ++r) xin[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
+#endif
             }
 #if !defined(SK_ABLATE_FFT)
             fft512(z, ex, t64, base2, lane);
@@ -471,7 +487,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
                 const float *src =
                     a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e + kDepth].off1024) * 1024 + 2 * lane;
 #pragma unroll
+#ifdef SK_SYNTH_ABLATE_F4LOAD
+                for (int r = 0; r < 4; ++r) {
+                    const f4 v = *reinterpret_cast<const f4 *>(src + 2 * lane + 256 * r);
+                    xin[2 * r] = (f2){v.x, v.y};
+                    xin[2 * r + 1] = (f2){v.z, v.w};
+                }
+#else
                 for (int r = 0; r < 8; ++r) xin[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
+#endif
             }
         }
         prev_shape = shape;  // decoder.rs:371
