@@ -180,9 +180,11 @@ template <int OP>
 hipError_t launch_convert_op(const void *in, void *out, size_t n, hipStream_t s) {
     const bool vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
     size_t groups = n / 4;
+    // one group of four samples per thread, blocks in address order: short-lived waves that each touch one piece of
+    // memory stream at 6.3 TB/s on this part, a grid-stride loop over a capped grid at 5.5-5.7 (tools/probe/stream_probe.hip)
     size_t blocks = (groups + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 16384) blocks = 16384;
+    if (blocks > 0x7fffffffu) blocks = 0x7fffffffu;
     if (vec)
         hipLaunchKernelGGL((k_convert<OP, true>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)in,
                            (uint8_t *)out, n);
@@ -393,9 +395,9 @@ __global__ __launch_bounds__(256) void k_exact_to_i16(int fmt, const uint8_t *in
 }
 
 inline unsigned grid_for(size_t items) {
-    size_t blocks = (items + 255) / 256;
+    size_t blocks = (items + 255) / 256;  // one item per thread (the kernels keep their grid-stride loops for larger inputs)
     if (blocks < 1) blocks = 1;
-    if (blocks > 16384) blocks = 16384;
+    if (blocks > 0x7fffffffu) blocks = 0x7fffffffu;
     return (unsigned)blocks;
 }
 

@@ -1,0 +1,96 @@
+// stream_probe.hip -- what shape of kernel streams fastest on this box?  y[i] = x[i] + 1 over 2.18 GB each way.
+//   hipcc --offload-arch=gfx950 -O3 -o stream_probe stream_probe.hip && ./stream_probe
+// Variants: tile-per-block (U float4 loads in flight per thread, no loop) with block sizes 256/512/1024, and a
+// grid-stride loop sized to fill the chip k waves per SIMD deep.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int U>
+__global__ void k_tile(const f4 *__restrict__ x, f4 *__restrict__ y, size_t n4) {
+    const size_t base = (size_t)blockIdx.x * blockDim.x * U + threadIdx.x;
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = base + (size_t)u * blockDim.x < n4 ? x[base + (size_t)u * blockDim.x] : (f4){0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (base + (size_t)u * blockDim.x < n4) y[base + (size_t)u * blockDim.x] = v[u] + 1.0f;
+}
+
+template <int U>
+__global__ void k_stride(const f4 *__restrict__ x, f4 *__restrict__ y, size_t n4) {
+    const size_t step = (size_t)gridDim.x * blockDim.x * U;
+    for (size_t base = (size_t)blockIdx.x * blockDim.x * U + threadIdx.x; base < n4; base += step) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = base + (size_t)u * blockDim.x < n4 ? x[base + (size_t)u * blockDim.x] : (f4){0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (base + (size_t)u * blockDim.x < n4) y[base + (size_t)u * blockDim.x] = v[u] + 1.0f;
+    }
+}
+
+// one wave walks a contiguous span of 4 KiB pieces in order (the synthesis kernel's shape): D pieces in flight
+template <int D>
+__global__ void k_walk(const f4 *__restrict__ x, f4 *__restrict__ y, size_t pieces_per_wave, size_t n_pieces, size_t piece_stride) {
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    // piece p of wave w sits at (p * n_waves + w): frame-major batch, every wave reads its own 4 KiB of each "frame"
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    f4 v[D][4];
+    for (size_t p0 = 0; p0 < pieces_per_wave; p0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const size_t piece = (p0 + d) * n_waves + wave;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[d][r] = x[piece * 256 + 64 * r + lane];
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const size_t piece = (p0 + d) * n_waves + wave;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[piece * 256 + 64 * r + lane] = v[d][r] + 1.0f;
+        }
+    }
+}
+
+#define CHECK(e) do { hipError_t err_ = (e); if (err_ != hipSuccess) { std::printf("%s: %s\n", #e, hipGetErrorString(err_)); return 1; } } while (0)
+
+int main() {
+    const size_t n = (size_t)4096 * 64 * 2 * 1024, n4 = n / 4;
+    f4 *x, *y;
+    CHECK(hipMalloc(&x, n * 4));
+    CHECK(hipMalloc(&y, n * 4));
+    CHECK(hipMemset(x, 0, n * 4));
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    auto time = [&](const char *name, auto launch) {
+        for (int i = 0; i < 3; ++i) launch();
+        hipEventRecord(a);
+        for (int i = 0; i < 20; ++i) launch();
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        ms /= 20;
+        std::printf("%-44s %.3f ms  %.2f TB/s\n", name, ms, 2.0 * n * 4 / ms / 1e9);
+    };
+    time("tile, 256 threads x 4 loads", [&] { hipLaunchKernelGGL(k_tile<4>, dim3((n4 + 1023) / 1024), dim3(256), 0, 0, x, y, n4); });
+    time("tile, 256 threads x 8 loads", [&] { hipLaunchKernelGGL(k_tile<8>, dim3((n4 + 2047) / 2048), dim3(256), 0, 0, x, y, n4); });
+    time("tile, 256 threads x 1 load", [&] { hipLaunchKernelGGL(k_tile<1>, dim3((n4 + 255) / 256), dim3(256), 0, 0, x, y, n4); });
+    time("tile, 1024 threads x 4 loads", [&] { hipLaunchKernelGGL(k_tile<4>, dim3((n4 + 4095) / 4096), dim3(1024), 0, 0, x, y, n4); });
+    time("grid-stride, 2048 blocks x 256 x 4 loads", [&] { hipLaunchKernelGGL(k_stride<4>, dim3(2048), dim3(256), 0, 0, x, y, n4); });
+    time("grid-stride, 8192 blocks x 256 x 4 loads", [&] { hipLaunchKernelGGL(k_stride<4>, dim3(8192), dim3(256), 0, 0, x, y, n4); });
+    time("grid-stride, 1024 blocks x 256 x 1 load", [&] { hipLaunchKernelGGL(k_stride<1>, dim3(1024), dim3(256), 0, 0, x, y, n4); });
+    const size_t pieces = n4 / 256;
+    time("walk, 8192 waves (4/block), 1 piece in flight", [&] { hipLaunchKernelGGL(k_walk<1>, dim3(2048), dim3(256), 0, 0, x, y, pieces / 8192, pieces, 0); });
+    time("walk, 8192 waves, 2 pieces in flight", [&] { hipLaunchKernelGGL(k_walk<2>, dim3(2048), dim3(256), 0, 0, x, y, pieces / 8192, pieces, 0); });
+    time("walk, 8192 waves, 4 pieces in flight", [&] { hipLaunchKernelGGL(k_walk<4>, dim3(2048), dim3(256), 0, 0, x, y, pieces / 8192, pieces, 0); });
+    time("walk, 16384 waves, 1 piece in flight", [&] { hipLaunchKernelGGL(k_walk<1>, dim3(4096), dim3(256), 0, 0, x, y, pieces / 16384, pieces, 0); });
+    time("walk, 4096 waves, 2 pieces in flight", [&] { hipLaunchKernelGGL(k_walk<2>, dim3(1024), dim3(256), 0, 0, x, y, pieces / 4096, pieces, 0); });
+    return 0;
+}
