@@ -57,6 +57,22 @@ __global__ void k_walk(const f4 *__restrict__ x, f4 *__restrict__ y, size_t piec
     }
 }
 
+// the same walk with pieces of L KiB (L 16-byte loads per lane in flight)
+template <int L>
+__global__ void k_walk_small(const f4 *__restrict__ x, f4 *__restrict__ y, size_t pieces_per_wave) {
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t p = 0; p < pieces_per_wave; ++p) {
+        const size_t piece = p * n_waves + wave;
+        f4 v[L];
+#pragma unroll
+        for (int r = 0; r < L; ++r) v[r] = x[piece * (64 * L) + 64 * r + lane];
+#pragma unroll
+        for (int r = 0; r < L; ++r) y[piece * (64 * L) + 64 * r + lane] = v[r] + 1.0f;
+    }
+}
+
 #define CHECK(e) do { hipError_t err_ = (e); if (err_ != hipSuccess) { std::printf("%s: %s\n", #e, hipGetErrorString(err_)); return 1; } } while (0)
 
 int main() {
@@ -92,5 +108,14 @@ int main() {
     time("walk, 8192 waves, 4 pieces in flight", [&] { hipLaunchKernelGGL(k_walk<4>, dim3(2048), dim3(256), 0, 0, x, y, pieces / 8192, pieces, 0); });
     time("walk, 16384 waves, 1 piece in flight", [&] { hipLaunchKernelGGL(k_walk<1>, dim3(4096), dim3(256), 0, 0, x, y, pieces / 16384, pieces, 0); });
     time("walk, 4096 waves, 2 pieces in flight", [&] { hipLaunchKernelGGL(k_walk<2>, dim3(1024), dim3(256), 0, 0, x, y, pieces / 4096, pieces, 0); });
+    for (int waves : {1024, 2048, 4096, 8192, 16384, 32768}) {
+        char name[96];
+        std::snprintf(name, sizeof name, "walk, %d waves, 4 KiB pieces", waves);
+        time(name, [&] { hipLaunchKernelGGL(k_walk_small<4>, dim3(waves / 4), dim3(256), 0, 0, x, y, n4 / 256 / waves); });
+        std::snprintf(name, sizeof name, "walk, %d waves, 1 KiB pieces", waves);
+        time(name, [&] { hipLaunchKernelGGL(k_walk_small<1>, dim3(waves / 4), dim3(256), 0, 0, x, y, n4 / 64 / waves); });
+        std::snprintf(name, sizeof name, "walk, %d waves, 2 KiB pieces", waves);
+        time(name, [&] { hipLaunchKernelGGL(k_walk_small<2>, dim3(waves / 4), dim3(256), 0, 0, x, y, n4 / 128 / waves); });
+    }
     return 0;
 }
