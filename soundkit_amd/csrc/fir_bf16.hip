@@ -206,7 +206,14 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
 
     const int lane = threadIdx.x;
     const int j = lane & 15, q = lane >> 4;
+    // SK_FIR_TIME_MAJOR experiment: blocks ordered by time segment first, so that short-lived blocks sweep the
+    // frame-packed PCM in address order
+#ifdef SK_FIR_TIME_MAJOR
+    const uint32_t n_groups = gridDim.x / n_segs;
+    const uint32_t group = blockIdx.x % n_groups, seg = blockIdx.x / n_groups;
+#else
     const uint32_t group = blockIdx.x / n_segs, seg = blockIdx.x % n_segs;
+#endif
     const uint32_t row0 = group * 16;
     // tile pair u = absolute outputs 32 u .. 32 u + 31 (even tile 2u, odd tile 2u + 1); segments start at multiples of 4
     const int32_t p_begin = pair0 + (int32_t)seg * pairs_per_seg;
@@ -458,6 +465,9 @@ hipError_t launch_fir_48k_16k_bf16(const FirArgs &a, hipStream_t s) {
     if (n_segs > max_segs) n_segs = max_segs;
     uint32_t pps = (pairs + n_segs - 1) / n_segs;
     pps = (pps + 3) & ~3u;
+#ifdef SK_FIR_PPS
+    pps = SK_FIR_PPS;  // experiment: short segments (many short-lived blocks)
+#endif
     n_segs = (pairs + pps - 1) / pps;
 
     const bool strides_ok = a.in_block ? (a.in_block % 4 == 0 && a.in_block_stride % 4 == 0 && a.in_group_stride % 4 == 0)
