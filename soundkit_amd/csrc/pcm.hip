@@ -531,7 +531,7 @@ hipError_t launch_f32_planar_to_bytes_batch(int fmt, const float *planar, size_t
     const int bps = sk_pcm_fmt_bytes(fmt);
     if (fmt == SK_FMT_S16LE && ch == 2 && (((uintptr_t)out & 15) == 0)) {
         size_t blocks = ((batch * frames + 3) / 4 + 255) / 256;
-        if (blocks > 16384) blocks = 16384;
+        if (blocks > 0x7fffffffu) blocks = 0x7fffffffu;  // one group per thread, blocks in address order (see launch_convert_op)
         hipLaunchKernelGGL(k_f32_planar_stereo_to_s16le_batch, dim3((unsigned)blocks), dim3(256), 0, s, planar,
                            plane_stride, frames, batch, out);
     } else {
