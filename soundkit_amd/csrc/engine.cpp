@@ -464,9 +464,9 @@ int sk_engine_synchronize(sk_engine *e) {
 // ---- streams --------------------------------------------------------------------------------
 
 static int reset_stream_state(sk_engine *e, uint32_t id) {
-    SK_HIP(hipMemsetAsync(e->d_delay + (size_t)id * 2048, 0, 2048 * sizeof(float), e->stream), "reset delay");
-    SK_HIP(hipMemsetAsync(e->d_prev_shape + (size_t)id * 2, 0, 2, e->stream), "reset shape");
-    SK_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->d_pns + id), 0x1f2e3d4c, 1, e->stream), "reset pns state");  // spectral.rs:2459
+    // overlap delay, previous window shape and PNS generator (spectral.rs:2459) in one small launch
+    SK_HIP(sk::launch_reset_stream(e->d_delay + (size_t)id * 2048, e->d_prev_shape + (size_t)id * 2, e->d_pns + id, e->stream),
+           "reset stream state");
     return SK_OK;
 }
 

@@ -47,6 +47,7 @@ struct FrameSpan {
 };
 
 hipError_t launch_aac_synth(const SynthArgs &a, hipStream_t s);
+hipError_t launch_reset_stream(float *delay2048, uint8_t *shape2, uint32_t *pns, hipStream_t s);
 hipError_t launch_frames_to_s16(const float *planar, int16_t *out, const FrameSpan *frames, uint32_t n, hipStream_t s);
 hipError_t launch_dequantize(const int16_t *q, const int16_t *sf, float *out, size_t n, const float *pow43,
                              const float *sftab, hipStream_t s);
