@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of the FIR variants built by tools/build_ab.sh, alternated on one box: bash tools/ab_fir_bf16.sh "<bench args>" variant...
+# A/B of library variants built by tools/build_ab.sh (soundkit_amd/ab/lib_<variant>.so), alternated on one box around the default build:
+#   bash tools/ab_bench.sh "<bench args>" variant...   -> frames/s and the per-kernel launch times of each
 ARGS=$1; shift
 for v in base "$@" base; do
   if [ $v = base ]; then unset SOUNDKIT_AMD_LIB; else export SOUNDKIT_AMD_LIB=$PWD/soundkit_amd/ab/lib_$v.so; fi
