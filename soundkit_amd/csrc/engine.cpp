@@ -1749,6 +1749,7 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     using TClock = std::chrono::steady_clock;
     TClock::time_point t_mark = TClock::now();
     double t_sec[6] = {0, 0, 0, 0, 0, 0};
+    double t_au[3] = {0, 0, 0};  // au mode, inside section 1: host work until the launches are queued | waiting for them | reading the statuses
     auto lap = [&](int k) {
         const TClock::time_point now = TClock::now();
         t_sec[k] += std::chrono::duration<double, std::milli>(now - t_mark).count();
@@ -1875,7 +1876,10 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
         }
         SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth");
         if (au_mode) {  // which units failed decides what the later stages may use
+            const TClock::time_point q0 = TClock::now();
+            t_au[0] = std::chrono::duration<double, std::milli>(q0 - t_mark).count();
             SK_HIP(hipStreamSynchronize(e->stream), "entropy sync");
+            t_au[1] = std::chrono::duration<double, std::milli>(TClock::now() - q0).count();
             for (uint32_t i = 0; i < n_streams; ++i) {
                 tc[i].good = ts[i].n_frames;
                 tc[i].bad_status = 0;
@@ -2074,8 +2078,8 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     SK_HIP(hipStreamSynchronize(e->stream), "tick sync");
     lap(4);
     if (trace)
-        std::fprintf(stderr, "sk_tick_run: %u streams %u frames | plan %.2f  h2d+synth %.2f  resample %.2f  pack %.2f  sync %.2f ms\n",
-                     n_streams, n_frames, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4]);
+        std::fprintf(stderr, "sk_tick_run: %u streams %u frames | plan %.2f  h2d+synth %.2f  resample %.2f  pack %.2f  sync %.2f ms | au: queue %.2f wait %.2f\n",
+                     n_streams, n_frames, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4], t_au[0], t_au[1]);
     *n_outs = n_rec;
     if (out_bytes) *out_bytes = cursor;
     return SK_OK;
