@@ -162,7 +162,21 @@ def cpu_baseline_fir(target_s=10.0):
             "sample": "oracle sko_downsample_planar, %d x 1 s of 48 kHz stereo in %.1f s" % (done, dt)}
 
 
-CPU_BASELINES = {"fir": cpu_baseline_fir, "aac_synth": cpu_baseline_synth, "pipeline": cpu_baseline_pipeline}
+def cpu_baseline_pcm(target_s=10.0):
+    """Oracle ('port'), single thread: float_sample_to_i16 (soundkit-decoder lib.rs:1815-1827) over 16 Mi samples, looped."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(SEED0)
+    x = (rng.random(1 << 24, dtype=np.float32) * 2.2 - 1.1).astype(np.float32)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < target_s:
+        O.pcm_convert("FLOAT_TO_I16_ROUND", x)
+        done += x.size
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": "sko_pcm_convert FLOAT_TO_I16_ROUND, %d samples (16 Mi looped) in %.1f s" % (done, dt)}
+
+
+CPU_BASELINES = {"pcm": cpu_baseline_pcm, "fir": cpu_baseline_fir, "aac_synth": cpu_baseline_synth, "pipeline": cpu_baseline_pipeline}
 
 
 def end_to_end(args, eng, torch, dist, world, rank, device):
@@ -295,7 +309,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "aac_synth", "fir", "end_to_end"])
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "aac_synth", "fir", "pcm", "end_to_end"])
     ap.add_argument("--streams", type=int, default=4096)
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--layout", default="frame", choices=["frame", "stream"],
@@ -416,6 +430,19 @@ def main():
             def step():
                 timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
             workload = "aac_lc_synth: %d streams x %d frames, 48 kHz stereo, IMDCT+window+OLA, f32 planar out, %s-major batch" % (streams, frames, args.layout)
+    elif args.workload == "pcm":
+        # soundkit::audio_bytes / the worker's output stage as one elementwise pass: f32 -> s16 with the reference's
+        # float_sample_to_i16 rounding, 512 Mi samples (2 GiB in, 1 GiB out)
+        n_samples = 1 << 29
+        g = torch.Generator(device=device).manual_seed(SEED0 + rank)
+        x = torch.rand(n_samples, generator=g, device=device) * 2.2 - 1.1
+        y = torch.empty(n_samples, dtype=torch.int16, device=device)
+        units_per_step = n_samples
+        unit = "samples/s"
+
+        def step():
+            timed("k_convert", lambda: eng.pcm_convert_dev("FLOAT_TO_I16_ROUND", x, y, n_samples))
+        workload = "audio_bytes conversion FLOAT_TO_I16_ROUND: %d f32 samples -> s16" % n_samples
     else:
         frames_in = 48000
         rows = streams * ch
@@ -500,6 +527,15 @@ def main():
                     "traffic": pmc_traffic(pmc_kind, rows=streams * ch, frames=fir_in), "avg_launch_ms": ms,
                     "algorithmic_tflops": flops / (ms * 1e-3) / 1e12,
                     "issued_bf16_tflops": flops * 5.125 / (ms * 1e-3) / 1e12, "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TF}
+        if "k_convert" in per_kernel:
+            ms = per_kernel["k_convert"]
+            cvt = units_per_step * 6.0  # 4 B in + 2 B out per sample (sk_pcm_op_in_bytes / _out_bytes)
+            rl["k_convert"] = {"kernel": "k_convert<SK_PCM_FLOAT_TO_I16_ROUND>", "bound": "hbm", "achieved": cvt / (ms * 1e-3) / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cvt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "avg_launch_ms": ms}
+            out["metric"] = "PCM samples/s through soundkit::audio_bytes-style conversion (f32 -> s16, reference rounding)"
+            out["config"] = {"workload": workload, "samples_per_gpu": units_per_step,
+                             "parallelism": "independent buffers, %d rank(s), no collective" % world}
         if "k_f32_planar_stereo_to_s16le_batch" in per_kernel:
             ms = per_kernel["k_f32_planar_stereo_to_s16le_batch"]
             cvt_bytes = streams * ch * eng.downsample_out_frames(frames * 1024) * 6.0  # 4 B in + 2 B out per sample
