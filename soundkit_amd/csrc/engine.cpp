@@ -1859,14 +1859,16 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 SK_HIP(e->tick_side.reserve((size_t)n_frames * (sizeof(sk_ec::Scratch) + sizeof(uint32_t)) + 128),
                        "alloc entropy side information");
                 ea.n_units = n_frames;
-                // units per wave: 16 while that still fits four waves per SIMD (4096 waves), then 32, then 64 -- a wave runs
-                // the union of its lanes' paths and a SIMD with one wave has every latency in the open; measured on
-                // ~22 000-unit ticks: parse 2.0 -> 1.7 ms, finish 0.80 -> 0.61 ms (SK_ENTROPY_LANE_SHIFT forces a value)
+                // units per wave: 16 up to two waves per SIMD (2048 waves), then 32, then 64 -- a wave runs the union of its
+                // lanes' paths, a SIMD with one wave has every latency in the open, and past a couple of waves per SIMD the
+                // vector issue rate is the limit (a wave instruction costs the same with 16 lanes populated as with 64).
+                // tools/prof_entropy_tick.sh, parse + finish: 22 400 units 4.17 / 3.26 / 3.03 ms at 64 / 32 / 16 per wave,
+                // 54 400 units 4.17 / 3.37 / 3.62 ms (SK_ENTROPY_LANE_SHIFT forces a value)
                 static const int forced_shift = [] {
                     const char *v = std::getenv("SK_ENTROPY_LANE_SHIFT");
                     return v && v[0] >= '0' && v[0] <= '4' ? (int)(v[0] - '0') : -1;
                 }();
-                ea.lane_shift = forced_shift >= 0 ? (uint32_t)forced_shift : (n_frames <= 65536 ? 2u : (n_frames <= 131072 ? 1u : 0u));
+                ea.lane_shift = forced_shift >= 0 ? (uint32_t)forced_shift : (n_frames <= 32768 ? 2u : (n_frames <= 131072 ? 1u : 0u));
                 ea.side = (sk_ec::Scratch *)e->tick_side.p;
                 ea.pns_start = (uint32_t *)((uint8_t *)e->tick_side.p + (((size_t)n_frames * sizeof(sk_ec::Scratch) + 15) & ~(size_t)15));
                 SK_HIP(sk::launch_aac_entropy_parallel(ea, e->stream), "launch entropy decode");
