@@ -13,7 +13,7 @@ for s in "$@"; do
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     if "k_aac_entropy_parse" in r["Name"] or "k_aac_entropy_finish" in r["Name"]:
-        print("   %-24s calls %s avg_us %.1f" % (r["Name"].split("::")[-1].split("(")[0], r["Calls"], float(r["AverageNs"]) / 1e3))
+        print("   %-24s calls %s avg_us %.1f" % ("parse" if "parse" in r["Name"] else "finish", r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
   rm -rf "$OUT"
 done
