@@ -191,7 +191,9 @@ def parse_asc(asc):
 class Ics:
     """ics.rs:57-110"""
 
-    def __init__(self, r):
+    def __init__(self, r=None):
+        if r is None:  # filled in by make()
+            return
         if r.flag():
             raise AacError("InvalidConfig", "ICS reserved bit is set")
         self.sequence = r.read(2)
@@ -213,19 +215,39 @@ class Ics:
             self.num_windows, self.group_len = 1, [1]
         self.groups = len(self.group_len)
 
+    @classmethod
+    def make(cls, sequence, shape, max_sfb, group_len=(1,)):
+        """an IcsInfo given field by field, as the reference's unit tests build theirs"""
+        ics = cls()
+        ics.sequence, ics.shape, ics.max_sfb = sequence, shape, max_sfb
+        ics.group_len = list(group_len)
+        ics.num_windows = 8 if sequence == EIGHT_SHORT else 1
+        ics.groups = len(ics.group_len)
+        return ics
+
 
 class Channel:
     """IndividualChannelStream::read, channel.rs:36-75"""
 
-    def __init__(self, r, common):
+    def __init__(self, r, common, read_delta=None):
         self.global_gain = r.read(8)
         self.ics = common if common is not None else Ics(r)
         self.books = self.read_sections(r)                 # section.rs:60-120
-        self.scale = self.read_scalefactors(r)             # scalefactor.rs:80-153
+        self.scale = self.read_scalefactors(r, read_delta)  # scalefactor.rs:80-153
         self.pulse = self.read_pulse(r) if r.flag() else None
         self.tns = self.read_tns(r) if r.flag() else None
         if r.flag():
             raise AacError("UnsupportedFeature", "gain control")
+
+    @classmethod
+    def prefix(cls, global_gain, ics, section_bits):
+        """IndividualChannelStreamPrefix {global_gain, ics_info, section_data} read from section bits alone (the
+        reference tests' prefix_with_sections helpers, e.g. spectral.rs:3232-3283)"""
+        ch = cls.__new__(cls)
+        ch.global_gain, ch.ics = global_gain, ics
+        ch.books = ch.read_sections(Bits(section_bits))
+        ch.scale, ch.values, ch.pulse, ch.tns = None, None, None, None
+        return ch
 
     def read_sections(self, r):
         ics = self.ics
@@ -254,7 +276,10 @@ class Channel:
             books.append(row)
         return books
 
-    def read_scalefactors(self, r):
+    def read_scalefactors(self, r, read_delta=None):
+        """ScaleFactorData::read (scalefactor.rs:80-153).  `read_delta` stands in for the reference's injectable
+        ScaleFactorDecoder (its tests pass mini tables and fixed sequences); the default is the standard codebook.
+        Also keeps the transmitted values as (kind, value) in self.values, the reference's ScaleFactorValue."""
         def checked(a, b, what):  # i16::checked_add
             s = a + b
             if not -32768 <= s <= 32767:
@@ -262,15 +287,18 @@ class Channel:
             return s
 
         def delta():
+            if read_delta is not None:
+                return read_delta(r)
             return huffman(r, "sf", "invalid AAC scalefactor codeword") - 60   # index - LAV, scalefactor.rs:212-214
         spectral, noise, intensity, first_noise = self.global_gain, self.global_gain - 90, 0, True
-        scale = []
+        scale, values = [], []
         for g in range(self.ics.groups):
-            row = []
+            row, vrow = [], []
             for sfb in range(self.ics.max_sfb):
                 book = self.books[g][sfb]
                 if book == 0:
                     row.append(F(0.0))
+                    vrow.append(("Zero", 0))
                 elif book == NOISE:
                     if first_noise:
                         noise = checked(noise, r.read(9) - 256, "noise scalefactor overflow")
@@ -278,13 +306,18 @@ class Channel:
                     else:
                         noise = checked(noise, delta(), "noise scalefactor overflow")
                     row.append(scalefactor_multiplier(noise))
+                    vrow.append(("Noise", noise))
                 elif book in (INTENSITY, INTENSITY_NEG):
                     intensity = checked(intensity, delta(), "intensity scalefactor overflow")
                     row.append(powf(F(2.0), F(-0.25) * F(intensity)))          # scalefactor.rs:208-210
+                    vrow.append(("Intensity", intensity))
                 else:
                     spectral = checked(spectral, delta(), "spectral scalefactor overflow")
                     row.append(scalefactor_multiplier(spectral))
+                    vrow.append(("Spectral", spectral))
             scale.append(row)
+            values.append(vrow)
+        self.values = values
         return scale
 
     @staticmethod
@@ -346,6 +379,14 @@ def read_escape(r):  # spectral.rs:214-230
 
 def read_band(r, book, count):
     """quantised values of `count` coefficients coded with spectral codebook `book` (spectral.rs:117-212, 327-423)"""
+    if book == 0:   # SpectralCodebookKind::from_codebook_id, spectral.rs:22-42
+        raise AacError("InvalidConfig", "zero codebook has no spectral Huffman data")
+    if book == 12:
+        raise AacError("InvalidBitstream", "reserved AAC spectral codebook")
+    if 13 <= book <= 15:
+        raise AacError("InvalidConfig", "non-spectral codebook cannot decode coefficients")
+    if book > 15:
+        raise AacError("InvalidBitstream", "invalid AAC spectral codebook id")
     out = []
     what = "invalid AAC spectral codeword"
     if book <= 4:
@@ -372,6 +413,103 @@ def read_band(r, book, count):
                 v = [-x if s else x for x, s in zip(v, signs)]
             out += v
     return out
+
+
+def _ms_selected(mask, g, sfb):
+    """mid_side_selected (stereo.rs:431-448); mask = (mode, used) with mode 0 none / 1 some / 2 all"""
+    mode, used = mask
+    if mode == 2:
+        return True
+    if mode != 1:
+        return False
+    if g >= len(used) or sfb >= len(used[g]):
+        raise AacError("InvalidConfig", "mid/side mask does not cover intensity band")
+    return bool(used[g][sfb])
+
+
+def _group_windows(ics):
+    """(group, first window, windows) of a short frame with the reference's coverage checks (stereo.rs:181-194, 231-235)"""
+    w0 = 0
+    for g, glen in enumerate(ics.group_len):
+        if glen == 0:
+            raise AacError("InvalidBitstream", "short-window group has zero length")
+        if w0 + glen > 8:
+            raise AacError("InvalidBitstream", "short-window groups exceed eight windows")
+        yield g, w0, glen
+        w0 += glen
+    if w0 != 8:
+        raise AacError("InvalidBitstream", "short-window groups do not cover eight windows")
+
+
+def apply_intensity(mask, ics, off, right_books, right_scale, left, right):
+    """apply_intensity_stereo_long / _short (stereo.rs:114-241): right = left * 2^(-position/4) * sign, sign +1 for
+    codebook 14 and -1 for 15 (intensity_codebook_sign, :419-425), flipped where the mid/side mask selects the band
+    (:145-149, :215-219)"""
+    if len(left) != len(right):
+        raise AacError("InvalidConfig", "intensity stereo channel buffers have different lengths")
+    short = ics.sequence == EIGHT_SHORT
+    for g, w0, glen in (_group_windows(ics) if short else [(0, 0, 1)]):
+        for sfb in range(ics.max_sfb):
+            book = right_books[g][sfb]
+            if book not in (INTENSITY, INTENSITY_NEG):
+                continue
+            if sfb + 1 >= len(off):
+                raise AacError("InvalidConfig", "missing scale-factor band offset")
+            s, e = off[sfb], off[sfb + 1]
+            if short and e > 128:
+                raise AacError("InvalidConfig", "short intensity scale-factor band exceeds window length")
+            if not short and e > len(left):
+                raise AacError("InvalidConfig", "intensity scale-factor band exceeds channel buffer")
+            sign = F(1.0) if book == INTENSITY else F(-1.0)
+            if _ms_selected(mask, g, sfb):
+                sign = -sign
+            scale = right_scale[g][sfb]
+            for w in range(w0, w0 + glen):
+                a, b = w * 128 * short + s, w * 128 * short + e
+                if b > len(left):
+                    raise AacError("InvalidConfig", "short intensity scale-factor band exceeds channel buffer")
+                right[a:b] = left[a:b] * scale * sign
+
+
+def apply_mid_side(mask, ics, off, left, right, left_books=None, right_books=None):
+    """apply_mid_side_long / _short and their _excluding_intensity forms (stereo.rs:8-112, 243-405): with the
+    section codebooks given, a band is left alone when the right channel codes it as intensity or either channel
+    as noise (mid_side_allowed, :410-417)"""
+    if len(left) != len(right):
+        raise AacError("InvalidConfig", "mid/side channel buffers have different lengths")
+    mode, used = mask
+    short = ics.sequence == EIGHT_SHORT
+    if mode == 0:
+        return
+    if mode == 1:
+        if not short and len(used) != 1:
+            raise AacError("NotImplemented", "grouped mid/side stereo reconstruction")
+        if short and (ics.max_sfb > len(used[0]) or ics.groups > len(used)):
+            raise AacError("InvalidConfig", "mid/side mask does not cover requested short-window groups/bands")
+        if not short and ics.max_sfb > len(used[0]):
+            raise AacError("InvalidConfig", "mid/side mask does not cover requested scale-factor bands")
+    for g, w0, glen in (_group_windows(ics) if short else [(0, 0, 1)]):
+        for sfb in range(ics.max_sfb):
+            if sfb + 1 >= len(off):
+                raise AacError("InvalidConfig", "missing scale-factor band offset")
+            s, e = off[sfb], off[sfb + 1]
+            if short and e > 128:
+                raise AacError("InvalidConfig", "short mid/side scale-factor band exceeds window length")
+            if not short and e > len(left):
+                raise AacError("InvalidConfig", "mid/side scale-factor band exceeds channel buffer")
+            if mode == 1 and not used[g][sfb]:
+                continue
+            if left_books is not None:
+                lb, rb = left_books[g][sfb], right_books[g][sfb]
+                if rb in (INTENSITY, INTENSITY_NEG) or lb == NOISE or rb == NOISE:
+                    continue
+            for w in range(w0, w0 + glen):
+                a, b = w * 128 * short + s, w * 128 * short + e
+                if b > len(left):
+                    raise AacError("InvalidConfig", "mid/side scale-factor band exceeds channel buffer")
+                mid, side = left[a:b].copy(), right[a:b].copy()
+                left[a:b] = mid + side
+                right[a:b] = mid - side
 
 
 class Decoder:
@@ -401,13 +539,19 @@ class Decoder:
         norm = scale / np.sqrt(energy)
         return [v * norm for v in vals]
 
-    def spectrum(self, r, ch, allow_intensity):
-        """decode_channel_spectrum (decoder.rs:220-244) + decode_standard_with_pulse_and_pns (spectral.rs:1907-2294)"""
+    def spectrum(self, r, ch, allow_intensity, off=None, band_reader=None, length=1024):
+        """decode_channel_spectrum (decoder.rs:220-244) + decode_standard_with_pulse_and_pns (spectral.rs:1907-2294).
+        `off` (a BandLayout), `band_reader` (the reference's injectable SpectralDecoder::read_quantized) and `length`
+        (SpectralCoefficients::new(n)) default to what the decoder uses; the reference's unit tests pass their own.
+        The quantised values, pulses included, stay in self.quant (SpectralCoefficients::quantized())."""
         ics = ch.ics
         if not allow_intensity and any(b in (INTENSITY, INTENSITY_NEG) for row in ch.books for b in row):
             raise AacError("InvalidBitstream", "intensity stereo is only valid in the right channel of a channel pair")
-        off = self.offsets(ics)
-        coef = np.zeros(1024, np.float32)
+        if off is None:
+            off = self.offsets(ics)
+        read = band_reader if band_reader is not None else read_band
+        coef = np.zeros(length, np.float32)
+        self.quant = quant = [0] * length
 
         def band(sfb, limit, what):
             if sfb + 1 >= len(off):
@@ -427,7 +571,8 @@ class Decoder:
                     book = ch.books[g][sfb]
                     for w in range(w0, w0 + glen):
                         if 1 <= book <= 11:
-                            q = read_band(r, book, e - s)
+                            q = read(r, book, e - s)
+                            quant[w * 128 + s:w * 128 + e] = q
                             coef[w * 128 + s:w * 128 + e] = [dequantize(x, ch.scale[g][sfb]) for x in q]
                         elif book == NOISE:
                             coef[w * 128 + s:w * 128 + e] = self.noise(ch.scale[g][sfb], e - s)
@@ -435,22 +580,21 @@ class Decoder:
             if w0 != 8:
                 raise AacError("InvalidBitstream", "short-window groups do not cover eight windows")
             return coef
-        quant = [0] * 1024
         for sfb in range(ics.max_sfb):  # noiseless coding first ...
-            s, e = band(sfb, 1024, "scale-factor band exceeds coefficient buffer")
+            s, e = band(sfb, length, "scale-factor band exceeds coefficient buffer")
             book = ch.books[0][sfb]
             if 1 <= book <= 11:
-                quant[s:e] = read_band(r, book, e - s)
+                quant[s:e] = read(r, book, e - s)
             elif book == NOISE and ch.pulse is None:  # without pulse data the reference synthesises noise in band order
                 coef[s:e] = self.noise(ch.scale[0][sfb], e - s)
         if ch.pulse is not None:  # ... apply_pulse_data, spectral.rs:2198-2247
             start_sfb, pulses = ch.pulse
             if start_sfb >= ics.max_sfb:
                 raise AacError("InvalidBitstream", "pulse start scale-factor band exceeds max_sfb")
-            index = band(start_sfb, 1024, "scale-factor band exceeds coefficient buffer")[0]
+            index = band(start_sfb, length, "scale-factor band exceeds coefficient buffer")[0]
             for offset, amp in pulses:
                 index += offset
-                if index >= 1024:
+                if index >= length:
                     raise AacError("InvalidBitstream", "pulse target exceeds spectral coefficient buffer")
                 target = next((b for b in range(ics.max_sfb) if off[b] <= index < off[b + 1]), None)
                 if target is None:
@@ -468,48 +612,27 @@ class Decoder:
         return coef
 
     def stereo(self, mask, ics, left_ch, right_ch, left, right):
-        """apply_common_stereo_tools (decoder.rs:268-334): intensity (stereo.rs:114-241), then mid/side on the bands
-        that are neither intensity-coded on the right nor noise on either side (stereo.rs:44-112, 410-417)"""
+        """apply_common_stereo_tools (decoder.rs:268-334): intensity first, then mid/side on the bands that are
+        neither intensity-coded on the right nor noise on either side (stereo.rs:410-417)"""
         off = self.offsets(ics)
-        short = ics.sequence == EIGHT_SHORT
-        wlen = 128 if short else 1024
-        mode, used = mask
-
-        def selected(g, sfb):
-            return mode == 2 or (mode == 1 and used[g][sfb])
-        for tool in ("intensity", "mid_side"):
-            w0 = 0
-            for g, glen in enumerate(ics.group_len if short else [1]):
-                for sfb in range(ics.max_sfb):
-                    s, e = off[sfb], off[sfb + 1]
-                    if e > wlen:
-                        raise AacError("InvalidConfig", "scale-factor band exceeds window length")
-                    rb, lb = right_ch.books[g][sfb], left_ch.books[g][sfb]
-                    for w in range(w0, w0 + glen):
-                        a, b = w * wlen + s, w * wlen + e
-                        if tool == "intensity" and rb in (INTENSITY, INTENSITY_NEG):
-                            sign = F(1.0) if rb == INTENSITY else F(-1.0)   # stereo.rs:431-437
-                            if selected(g, sfb):
-                                sign = -sign                               # stereo.rs:145-149
-                            right[a:b] = left[a:b] * right_ch.scale[g][sfb] * sign
-                        elif tool == "mid_side" and selected(g, sfb) and rb not in (INTENSITY, INTENSITY_NEG) \
-                                and lb != NOISE and rb != NOISE:
-                            mid, side = left[a:b].copy(), right[a:b].copy()
-                            left[a:b] = mid + side
-                            right[a:b] = mid - side
-                w0 += glen
+        apply_intensity(mask, ics, off, right_ch.books, right_ch.scale, left, right)
+        apply_mid_side(mask, ics, off, left, right, left_ch.books, right_ch.books)
 
     def tns(self, ch, coef):
-        """apply_tns (tns.rs:103-276)"""
-        ics = ch.ics
+        """apply_channel_tns (decoder.rs:246-266): the rate's band layout and TNS_MAX_BANDS (tns.rs:85-101, 284-285)"""
         if self.sf_index < 0:
             raise AacError("UnsupportedFeature", "explicit sample-rate TNS max bands")
+        short = ch.ics.sequence == EIGHT_SHORT
+        apply_tns(ch.tns, ch.ics, self.offsets(ch.ics), _TNS_MAX[1 if short else 0][self.sf_index], coef)
+
+    @staticmethod
+    def _apply_tns(tns, ics, off, max_bands, coef):
+        """apply_tns (tns.rs:103-276)"""
         short = ics.sequence == EIGHT_SHORT
-        off = self.offsets(ics)
         bands = len(off) - 1
         wlen = 128 if short else 1024
-        limit = min(_TNS_MAX[1 if short else 0][self.sf_index], ics.max_sfb, bands)
-        for w, (res, filters) in enumerate(ch.tns):
+        limit = min(max_bands, ics.max_sfb, bands)
+        for w, (res, filters) in enumerate(tns):
             res_bits = 4 if res else 3
             bottom = bands
             for length, order, direction, bits, coeffs in filters:
@@ -522,7 +645,7 @@ class Decoder:
                     continue
                 lpc, prev = [F(0.0)] * 20, [F(0.0)] * 20   # tns_lpc_coefficients, tns.rs:176-206
                 for i in range(order):
-                    refl = -self.tns_coefficient(coeffs[i], bits, res_bits)
+                    refl = -Decoder.tns_coefficient(coeffs[i], bits, res_bits)
                     lpc[i] = refl
                     for k in range((i + 1) >> 1):
                         fwd, bwd = prev[k], prev[i - 1 - k]
@@ -610,13 +733,7 @@ class Decoder:
         common_window = r.flag()
         if common_window:
             common = Ics(r)
-            mode = r.read(2)  # read_mid_side_mask, channel.rs:222-251
-            if mode == 3:
-                raise AacError("InvalidBitstream", "reserved mid/side mask mode")
-            used = None
-            if mode == 1:
-                used = [[r.flag() for _ in range(common.max_sfb)] for _ in range(common.groups)]
-            mask = (mode, used)
+            mask = read_ms_mask(r, common)
         left_ch = Channel(r, common)
         left = self.spectrum(r, left_ch, False)
         right_ch = Channel(r, common)
@@ -647,3 +764,36 @@ def split_adts(data):
         out.append((asc, data[pos + header:pos + length]))
         pos += length
     return out
+
+
+def apply_tns(tns, ics, off, max_bands, coef):
+    """tns.rs:103-174 with the caller's BandLayout and max-bands value"""
+    Decoder._apply_tns(tns, ics, off, max_bands, coef)
+
+
+def tns_max_bands(sf_index, short):
+    """lc_tns_max_bands (tns.rs:85-101)"""
+    return _TNS_MAX[1 if short else 0][sf_index]
+
+
+def read_tns(r, ics):
+    """TnsData::read (tns.rs:34-83) -> [(coef_res, [(length, order, direction, coef_bits, coeffs)])] per window"""
+    ch = Channel.__new__(Channel)
+    ch.ics = ics
+    return ch.read_tns(r)
+
+
+def read_pulse(r):
+    """PulseData::read (pulse.rs:20-35) -> (pulse_start_sfb, [(offset, amp)])"""
+    return Channel.read_pulse(r)
+
+
+def read_ms_mask(r, ics):
+    """read_mid_side_mask (channel.rs:222-251) -> (mode, used[group][sfb] or None)"""
+    mode = r.read(2)
+    if mode == 3:
+        raise AacError("InvalidBitstream", "reserved mid/side mask mode")
+    used = None
+    if mode == 1:
+        used = [[r.flag() for _ in range(ics.max_sfb)] for _ in range(ics.groups)]
+    return mode, used
