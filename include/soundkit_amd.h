@@ -348,7 +348,8 @@ int sk_tick_run(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, 
  * stream in the order of `streams`, byte_offset is a multiple of 4 and every unit is followed by >= 8 zero bytes.
  * The streams must have been opened with the AudioSpecificConfig's sample rate and channel count.  A unit the
  * front-end rejects yields an output record with its sk_aac_status in `status` and ends that stream's tick, exactly
- * like a unit sk_aac_decoder_parse would have rejected on the host (same codes; the message text is host-only). */
+ * like a unit sk_aac_decoder_parse would have rejected on the host (same codes; the message text is host-only).
+ * byte_len is at most 8192 (an ADTS frame cannot exceed 8191 bytes) and au_bytes_len at most 4 GiB - 1. */
 typedef struct sk_au_item {
     uint32_t byte_offset;
     uint32_t byte_len;
@@ -356,6 +357,18 @@ typedef struct sk_au_item {
 int sk_tick_run_au(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, const sk_au_item *units, uint32_t n_units,
                    const uint8_t *au_bytes, size_t au_bytes_len, uint8_t *out_bytes, size_t out_cap, sk_tick_output *outputs,
                    uint32_t outputs_cap, uint32_t *n_outputs, size_t *out_bytes_used);
+
+/* The front-end alone, batched on the GPU: AacLcDecoder::decode_access_unit (soundkit-aac-lc/src/decoder.rs:104-164) up to
+ * the hand-over to synthesis (decoder.rs:336) for every listed unit -- the device counterpart of sk_aac_decoder_parse.
+ * Units are listed stream by stream (units_per_stream[i] of streams[i], in order), laid out as for sk_tick_run_au.
+ * coeffs_out receives channels * 1024 f32 per unit, packed in unit order; descs_out[k] the stream, channel count and
+ * the window_sequence / window_shape of unit k -- ready to be passed to sk_aac_synthesize_*; status_out[k] is 0 or the
+ * unit's sk_aac_status (a failed unit has zero spectra; the units after it in its stream are not decoded: -199).
+ * Advances each stream's PNS generator (spectral.rs:2416-2459) exactly as decoding those units does; the synthesis
+ * state is untouched. */
+int sk_aac_entropy_decode(sk_engine *, const uint32_t *streams, const uint32_t *units_per_stream, uint32_t n_streams,
+                          const sk_au_item *units, uint32_t n_units, const uint8_t *au_bytes, size_t au_bytes_len,
+                          float *coeffs_out, sk_aac_frame_desc *descs_out, int32_t *status_out);
 
 /* ---- batch scheduler: N streams -> one submission loop per GPU ------------------------------------- */
 /* Replaces one pipeline_worker thread per stream (soundkit-decoder lib.rs:2891-3038) for ADTS AAC-LC input and keeps

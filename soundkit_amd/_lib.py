@@ -182,6 +182,7 @@ _sig = {
     "sk_pipeline_queued_input_bytes": (_sz, [_vp, _u32]),
     "sk_pipeline_get_stats": (_i, [_vp, _vp]),
     "sk_tick_run_au": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _sz, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
+    "sk_aac_entropy_decode": (_i, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _sz, _vp, _vp, _vp]),
     "sk_tick_out_bound": (_sz, [_vp, _u32, C.POINTER(_u32)]),
     "sk_tick_run": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
 }

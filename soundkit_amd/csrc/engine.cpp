@@ -1715,9 +1715,17 @@ int sf_index_of(uint32_t rate) {
 
 // Both tick entry points.  units == nullptr: the spectra come from the host (descs / coeffs).  Otherwise the access
 // units themselves do, and the front-end runs on the device before the synthesis.
+constexpr uint32_t kMaxAccessUnitBytes = 8192;
+
+struct EntropyProbe {  // sk_aac_entropy_decode: stop after the front-end and hand its results to the caller
+    float *spectra;
+    sk_aac_frame_desc *descs;
+    int32_t *status;
+};
+
 int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
               const sk_au_item *units, const uint8_t *au_bytes, size_t au_len, uint32_t n_frames, uint8_t *out, size_t out_cap,
-              sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) {
+              sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes, const EntropyProbe *probe = nullptr) {
     const bool au_mode = units != nullptr;
     std::vector<sk_aac_frame_desc> au_descs;
     if (!e || !n_outs || (n_streams && !ts)) return SK_ERR_INVALID_ARG;
@@ -1732,6 +1740,7 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
         uint64_t total = 0;
         for (uint32_t i = 0; i < n_streams; ++i) total += ts[i].n_frames;
         if (total != n_frames) return SK_ERR_INVALID_ARG;
+        if (au_len > 0xffffffffull) return SK_ERR_INVALID_ARG;  // unit offsets and the bit reader count in 32 bits
         au_descs.resize(n_frames);
         uint32_t k = 0;
         for (uint32_t i = 0; i < n_streams; ++i) {
@@ -1740,6 +1749,8 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 au_descs[k] = sk_aac_frame_desc{};
                 au_descs[k].stream = ts[i].stream;
                 au_descs[k].channels = e->streams[ts[i].stream].channels;
+                // an ADTS frame is at most 8191 bytes (13-bit frame_length); nothing longer can be an access unit
+                if (units[k].byte_len > kMaxAccessUnitBytes) return SK_ERR_INVALID_ARG;
                 if (units[k].byte_offset % 4 || (size_t)units[k].byte_offset + units[k].byte_len + 8 > au_len) return SK_ERR_INVALID_ARG;
             }
         }
@@ -1875,6 +1886,23 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             }
             SK_HIP(hipMemcpyAsync(status.data(), d_status, (size_t)n_frames * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream),
                    "D2H entropy status");
+        }
+        if (probe) {  // the front-end alone: spectra, window fields and statuses back to the caller, nothing synthesised
+            std::vector<sk::SynthEntry> got(hp.entries.size());
+            SK_HIP(hipMemcpyAsync(got.data(), a.entries, got.size() * sizeof(sk::SynthEntry), hipMemcpyDeviceToHost, e->stream),
+                   "D2H entropy window fields");
+            SK_HIP(hipMemcpyAsync(probe->spectra, e->in_buf.p, elems * 4, hipMemcpyDeviceToHost, e->stream), "D2H entropy spectra");
+            SK_HIP(hipStreamSynchronize(e->stream), "entropy sync");
+            for (uint32_t k = 0; k < n_frames; ++k) {
+                probe->status[k] = status[k];
+                probe->descs[k] = descs[k];
+                for (uint32_t c = 0; c < descs[k].channels; ++c) {
+                    const uint32_t win = got[hp.entry_of[(size_t)k * 2 + c]].win;
+                    probe->descs[k].window_sequence[c] = (uint8_t)(win & 3u);
+                    probe->descs[k].window_shape[c] = (uint8_t)((win >> 2) & 1u);
+                }
+            }
+            return SK_OK;
         }
         SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth");
         if (au_mode) {  // which units failed decides what the later stages may use
@@ -2095,6 +2123,20 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
                 const float *coeffs, uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs,
                 uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) {
     return tick_impl(e, ts, n_streams, descs, coeffs, nullptr, nullptr, 0, n_frames, out, out_cap, outs, outs_cap, n_outs, out_bytes);
+}
+
+int sk_aac_entropy_decode(sk_engine *e, const uint32_t *streams, const uint32_t *units_per_stream, uint32_t n_streams,
+                          const sk_au_item *units, uint32_t n_units, const uint8_t *au_bytes, size_t au_bytes_len, float *coeffs_out,
+                          sk_aac_frame_desc *descs_out, int32_t *status_out) {
+    if (!e || (n_streams && (!streams || !units_per_stream)) || (n_units && (!units || !coeffs_out || !descs_out || !status_out)))
+        return SK_ERR_INVALID_ARG;
+    if (n_units == 0) return SK_OK;
+    std::vector<sk_tick_stream> ts(n_streams);
+    for (uint32_t i = 0; i < n_streams; ++i) ts[i] = sk_tick_stream{streams[i], units_per_stream[i], 16, 1, 0, 0};
+    const EntropyProbe probe{coeffs_out, descs_out, status_out};
+    uint32_t n_outs = 0;
+    return tick_impl(e, ts.data(), n_streams, nullptr, nullptr, units, au_bytes, au_bytes_len, n_units, nullptr, 0, nullptr, 0, &n_outs,
+                     nullptr, &probe);
 }
 
 int sk_tick_run_au(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_au_item *units, uint32_t n_units,

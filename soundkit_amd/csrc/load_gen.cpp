@@ -8,6 +8,8 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -18,11 +20,36 @@ typedef struct sk_load_result {
     uint64_t access_units, outputs, pcm_frames, pcm_bytes, errors, input_full;
 } sk_load_result;
 
+// Optional per-stream bookkeeping for the parity tests (stream i = the i-th spawned handle): what each stream
+// delivered, in delivery order -- FNV-1a over (frames, channels, bits, rate, bytes) of every AudioData, counts, and the
+// raw bytes of a few chosen streams for comparison with the oracle.
+typedef struct sk_load_check {
+    uint64_t *hash;      /* [n_streams] */
+    uint32_t *outputs;   /* [n_streams] AudioData delivered */
+    uint64_t *bytes;     /* [n_streams] */
+    uint32_t *errors;    /* [n_streams] error records delivered */
+    const uint32_t *capture;  /* [n_capture] stream indices whose bytes are kept */
+    uint32_t n_capture;
+    uint8_t *capture_buf;     /* [n_capture][capture_cap] */
+    size_t capture_cap;
+    size_t *capture_len;      /* [n_capture] */
+} sk_load_check;
+
+int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len, uint32_t clip_units, uint32_t n_streams,
+                           uint32_t loops, const sk_decode_options *opt, uint32_t feeder_threads, uint32_t chunk_bytes,
+                           sk_load_result *res, const sk_load_check *chk);
+
 // Every stream receives `loops` copies of the clip in chunks of chunk_bytes, then finish().  Returns when every
 // stream has ended and is drained.
 int sk_loadgen_run(sk_pipeline *p, const uint8_t *clip, size_t clip_len, uint32_t clip_units, uint32_t n_streams,
                    uint32_t loops, const sk_decode_options *opt, uint32_t feeder_threads, uint32_t chunk_bytes,
                    sk_load_result *res) {
+    return sk_loadgen_run_checked(p, clip, clip_len, clip_units, n_streams, loops, opt, feeder_threads, chunk_bytes, res, nullptr);
+}
+
+int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len, uint32_t clip_units, uint32_t n_streams,
+                           uint32_t loops, const sk_decode_options *opt, uint32_t feeder_threads, uint32_t chunk_bytes,
+                           sk_load_result *res, const sk_load_check *chk) {
     if (!p || !clip || !clip_len || !n_streams || !loops || !res) return SK_ERR_INVALID_ARG;
     if (!feeder_threads) feeder_threads = 2;
     if (!chunk_bytes || chunk_bytes > clip_len) chunk_bytes = (uint32_t)clip_len;
@@ -40,6 +67,22 @@ int sk_loadgen_run(sk_pipeline *p, const uint8_t *clip, size_t clip_len, uint32_
     for (uint32_t h : handles) max_handle = std::max(max_handle, h);
     std::vector<std::atomic<char>> ended(max_handle + 1);
     for (auto &e : ended) e.store(0);
+    std::vector<uint32_t> index_of(chk ? max_handle + 1 : 0, 0);
+    std::vector<int32_t> capture_slot(chk ? n_streams : 0, -1);
+    std::unique_ptr<std::mutex[]> locks(chk ? new std::mutex[n_streams] : nullptr);
+    if (chk) {
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            index_of[handles[i]] = i;
+            chk->hash[i] = 0xcbf29ce484222325ull;
+            chk->outputs[i] = 0;
+            chk->bytes[i] = 0;
+            chk->errors[i] = 0;
+        }
+        for (uint32_t c = 0; c < chk->n_capture; ++c) {
+            if (chk->capture[c] < n_streams) capture_slot[chk->capture[c]] = (int32_t)c;
+            chk->capture_len[c] = 0;
+        }
+    }
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> threads;
     // producers: each owns a slice of the streams and keeps their input queues fed (send never blocks: back off when full)
@@ -116,6 +159,29 @@ int sk_loadgen_run(sk_pipeline *p, const uint8_t *clip, size_t clip_len, uint32_
                                 ++o;
                                 f += info.frames;
                                 b += info.bytes;
+                            }
+                            if (chk) {
+                                const uint32_t i = index_of[h];
+                                std::lock_guard<std::mutex> g(locks[i]);
+                                if (info.is_error) {
+                                    ++chk->errors[i];
+                                    continue;
+                                }
+                                uint64_t hsh = chk->hash[i];
+                                auto mix = [&](const uint8_t *d, size_t n) {
+                                    for (size_t q = 0; q < n; ++q) hsh = (hsh ^ d[q]) * 0x100000001b3ull;
+                                };
+                                const uint32_t head[4] = {info.frames, info.channel_count, info.bits_per_sample, info.sampling_rate};
+                                mix(reinterpret_cast<const uint8_t *>(head), sizeof head);
+                                mix(buf.data(), info.bytes);
+                                chk->hash[i] = hsh;
+                                ++chk->outputs[i];
+                                chk->bytes[i] += info.bytes;
+                                const int32_t slot = capture_slot[i];
+                                if (slot >= 0 && chk->capture_len[slot] + info.bytes <= chk->capture_cap) {
+                                    std::memcpy(chk->capture_buf + (size_t)slot * chk->capture_cap + chk->capture_len[slot], buf.data(), info.bytes);
+                                    chk->capture_len[slot] += info.bytes;
+                                }
                             }
                             continue;
                         }

@@ -110,6 +110,7 @@ class Engine:
         self._h = h
         self.device = device
         self.max_streams = max_streams
+        self._channels = {}
 
     # ---- lifetime ---------------------------------------------------------------------
     def close(self):
@@ -140,6 +141,7 @@ class Engine:
     def open_stream(self, sample_rate=48000, channels=2):
         sid = C.c_uint32()
         check(lib.sk_stream_open(self._h, sample_rate, channels, C.byref(sid)), "sk_stream_open", self._h)
+        self._channels[sid.value] = channels
         return sid.value
 
     def close_stream(self, sid):
@@ -412,6 +414,36 @@ class Engine:
                                  max_out.value, C.byref(n_out), C.byref(used)), "sk_tick_run_au", self._h)
         return [(r.stream_index, r.status, r.frames, r.channels, r.bits, out[r.byte_offset:r.byte_offset + r.bytes].tobytes())
                 for r in recs[:n_out.value]]
+
+
+    def entropy_decode(self, streams, access_units):
+        """sk_aac_entropy_decode: the AAC-LC front-end alone, on the GPU.  streams: [(stream id, unit count)];
+        access_units: the raw units of all streams, stream by stream.  -> [(status, coeffs [ch][1024] f32,
+        window_sequence[ch], window_shape[ch])] per unit."""
+        import ctypes as C
+        n = len(access_units)
+        ids = np.array([s for s, _ in streams], np.uint32)
+        counts = np.array([c for _, c in streams], np.uint32)
+        assert int(counts.sum()) == n
+        items = np.zeros((max(n, 1), 2), np.uint32)
+        blob = bytearray()
+        for k, au in enumerate(access_units):
+            items[k] = (len(blob), len(au))
+            blob += bytes(au) + b"\0" * (8 + (-len(au)) % 4)
+        blob = np.frombuffer(bytes(blob) + b"\0" * 8, np.uint8)
+        ch = np.repeat(np.array([self._channels[int(s)] for s in ids], np.uint32), counts) if n else np.zeros(0, np.uint32)
+        coeffs = np.zeros(max(int(ch.sum()) * 1024, 1), np.float32)
+        descs = (FrameDesc * max(n, 1))()
+        status = np.zeros(max(n, 1), np.int32)
+        check(lib.sk_aac_entropy_decode(self._h, _ptr(ids), _ptr(counts), len(streams), _ptr(items), n, _ptr(blob), blob.size,
+                                        _ptr(coeffs), descs, _ptr(status)), "sk_aac_entropy_decode", self._h)
+        out, off = [], 0
+        for k in range(n):
+            c = int(ch[k])
+            out.append((int(status[k]), coeffs[off:off + c * 1024].reshape(c, 1024).copy(),
+                        [int(descs[k].window_sequence[i]) for i in range(c)], [int(descs[k].window_shape[i]) for i in range(c)]))
+            off += c * 1024
+        return out
 
 
 _default = None

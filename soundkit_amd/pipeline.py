@@ -89,6 +89,8 @@ class DecodePipelineHandle:
         self._info = AudioInfo()
 
     def send(self, data):
+        if self._id is None:
+            raise DecodeError("PipelineClosed")
         data = bytes(data)
         rc = lib.sk_pipeline_send(self._s._h, self._id, data if data else None, len(data))
         if rc == SK_PIPE_INPUT_FULL:
@@ -103,14 +105,20 @@ class DecodePipelineHandle:
     def finish(self):
         self.send(b"")
 
-    def _take(self, call):
+    def _take(self, call, on_empty=None):
+        if self._id is None:
+            raise DecodeError("PipelineClosed")
         for _ in range(2):
             rc = call()
             if rc == SK_ERR_CAPACITY:
                 self._buf = np.empty(int(self._info.bytes) * 2, np.uint8)
                 continue
             break
-        if rc == 0 or rc == SK_PIPE_CLOSED:
+        if rc == SK_PIPE_CLOSED:
+            return None
+        if rc == 0:
+            if on_empty is not None:
+                raise on_empty
             return None
         if rc != 1:
             raise SoundkitError(rc, "sk_pipeline_recv")
@@ -126,11 +134,16 @@ class DecodePipelineHandle:
                                                            C.byref(self._info)))
 
     def recv(self, timeout_ms=10000):
+        """Blocks for the next output: AudioData or a DecodeError value; None only when the stream has ended and is
+        drained.  A wait that runs out raises TimeoutError -- it never looks like the end of the stream."""
         return self._take(lambda: lib.sk_pipeline_recv(self._s._h, self._id, self._buf.ctypes.data, self._buf.size,
-                                                       C.byref(self._info), timeout_ms))
+                                                       C.byref(self._info), timeout_ms),
+                          TimeoutError("no output within %d ms" % timeout_ms))
 
     def ended(self):
         """True once the worker side has ended and every output has been taken."""
+        if self._id is None:
+            return True
         rc = lib.sk_pipeline_try_recv(self._s._h, self._id, self._buf.ctypes.data, 0, C.byref(self._info))
         return rc == SK_PIPE_CLOSED
 
@@ -140,6 +153,8 @@ class DecodePipelineHandle:
         self._id = None
 
     def queued_input_bytes(self):
+        if self._id is None:
+            raise DecodeError("PipelineClosed")
         return lib.sk_pipeline_queued_input_bytes(self._s._h, self._id)
 
     def __del__(self):  # Drop, lib.rs:2884-2888

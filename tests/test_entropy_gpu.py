@@ -1,6 +1,7 @@
-"""The AAC-LC front-end on the GPU (csrc/aac_entropy.hip over csrc/aac_entropy_core.h, sk_tick_run_au): the whole
-worker path from raw access units to output bytes without the host touching the bitstream, checked against the same
-tick fed by the host front-end (bit-identical bytes) and for error behaviour."""
+"""The AAC-LC front-end on the GPU (csrc/aac_entropy.hip over csrc/aac_entropy_core.h): first against the ORACLE
+(oracle/aac_frontend.py) through sk_aac_entropy_decode -- spectra bit for bit, window fields and error kinds on every
+fixture access unit and on damaged ones -- then the whole worker path (sk_tick_run_au: raw access units to output
+bytes without the host touching the bitstream) against the same tick fed by the host front-end."""
 import os
 
 import numpy as np
@@ -77,6 +78,88 @@ def run(engine, mode, specs, per_tick):
     for sid in sids:
         engine.close_stream(sid)
     return outs
+
+
+def test_gpu_front_end_equals_oracle_on_every_fixture_unit(engine):
+    """All 273 access units of the four ADTS fixtures, every file its own stream, decoded by the gfx950 front-end in
+    two calls (the PNS generator is carried in the engine between them): bit-identical to the oracle's spectra."""
+    from oracle import aac_frontend as OF
+    loaded = []
+    for name in FILES:
+        frames = OF.split_adts(open(os.path.join(GOLD, name), "rb").read())
+        dec = OF.Decoder(frames[0][0])
+        want = [dec.decode_access_unit(au) for _, au in frames]
+        loaded.append((engine.open_stream(dec.sample_rate, dec.channels), [au for _, au in frames], want))
+    try:
+        total = 0
+        done = [0] * len(loaded)
+        for part in (0, 1):
+            spans = [(0, len(u) // 3) if part == 0 else (len(u) // 3, len(u)) for _, u, _ in loaded]
+            got = engine.entropy_decode([(sid, b - a) for (sid, _, _), (a, b) in zip(loaded, spans)],
+                                        [au for (_, u, _), (a, b) in zip(loaded, spans) for au in u[a:b]])
+            pos = 0
+            for (sid, units, want), (a, b) in zip(loaded, spans):
+                for i in range(a, b):
+                    status, coeffs, seq, shape = got[pos]
+                    pos += 1
+                    assert status == 0, (sid, i, status)
+                    assert (seq, shape) == (want[i][1], want[i][2]), (sid, i)
+                    assert np.array_equal(coeffs.view(np.uint32), want[i][0].view(np.uint32)), (sid, i, np.abs(coeffs - want[i][0]).max())
+                    total += 1
+        assert total == 273
+    finally:
+        for sid, _, _ in loaded:
+            engine.close_stream(sid)
+
+
+def test_gpu_front_end_rejects_what_the_oracle_rejects(engine):
+    """1200 damaged access units (the mutations of tests/test_oracle_frontend.py), each on a fresh stream so that the
+    PNS generator starts from the reference's seed on both sides, all in one launch: the same verdict as the oracle --
+    identical spectra when it accepts, the same AacLcError kind when it rejects."""
+    from oracle import aac_frontend as OF
+    from soundkit_amd._lib import ERR_NAMES
+    state = 0x2545F4914F6CDD1D
+    cases = []
+    for name in ("aac-stereo-48k.adts", "mono16k_A_Tusk.aac", "stereo-music-44100-192k.aac"):
+        frames = OF.split_adts(open(os.path.join(GOLD, name), "rb").read())
+        for trial in range(400):
+            state ^= (state << 13) & 0xFFFFFFFFFFFFFFFF
+            state ^= state >> 7
+            state ^= (state << 17) & 0xFFFFFFFFFFFFFFFF
+            au = bytearray(frames[(state >> 8) % len(frames)][1])
+            for k in range(1 + (state >> 20) % 3):
+                r = (state >> (24 + 9 * k)) & 0xFFFFFF
+                if r % 3 == 0:
+                    au[(r >> 4) % len(au)] ^= 1 << (r & 7)
+                elif r % 3 == 1:
+                    au[(r >> 4) % len(au)] = (r >> 12) & 0xFF
+                else:
+                    del au[(r >> 4) % len(au):]
+                    if not au:
+                        au = bytearray(b"\0")
+            oracle = OF.Decoder(frames[0][0])
+            try:
+                want = oracle.decode_access_unit(bytes(au))
+            except OF.AacError as e:
+                want = e
+            cases.append((engine.open_stream(oracle.sample_rate, oracle.channels), bytes(au), want))
+    try:
+        got = engine.entropy_decode([(sid, 1) for sid, _, _ in cases], [au for _, au, _ in cases])
+        accepted = rejected = 0
+        for k, ((sid, au, want), (status, coeffs, seq, shape)) in enumerate(zip(cases, got)):
+            if isinstance(want, OF.AacError):
+                assert status != 0 and ERR_NAMES[status] == want.kind, (k, status, want.kind, str(want))
+                assert not coeffs.any()
+                rejected += 1
+            else:
+                assert status == 0, (k, status)
+                assert (seq, shape) == (want[1], want[2]), k
+                assert np.array_equal(coeffs.view(np.uint32), want[0].view(np.uint32)), k
+                accepted += 1
+        assert accepted > 50 and rejected > 300
+    finally:
+        for sid, _, _ in cases:
+            engine.close_stream(sid)
 
 
 def sf_index(rate):
