@@ -131,22 +131,34 @@ def usable_cores():
 
 
 def cpu_baseline_all_cores(workload, target_s=8.0):
-    """The same single-thread oracle loop in one process per usable core (affinity and cgroup quota), started as
-    child processes before this process touches the GPU; the sum of their rates."""
+    """The oracle loop in one process per usable core (affinity and cgroup quota), started as child processes before
+    this process touches the GPU; the sum of their rates.  The children load a build of oracle/sk_oracle.c made here,
+    for this host's cores (-O3 -march=native, -ffp-contract=off kept: same results, tests/test_oracle_pins.py), when a
+    compiler is present; else the portable -O2 library."""
     import subprocess
+    import tempfile
+    from oracle import oracle as O
     cores = usable_cores()
+    tmp = tempfile.mkdtemp(prefix="sk_oracle_native_")
+    native = O.build_native(tmp)
+    env = dict(os.environ)
+    if native:
+        env["SK_ORACLE_LIB"] = native
     code = ("import json, sys; sys.path.insert(0, %r); import bench; "
             "print(json.dumps(bench.CPU_BASELINES[%r](%f)))" % (ROOT, workload, target_s))
-    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
              for _ in range(cores)]
     results = []
     for p in procs:
         out, _ = p.communicate()
         if p.returncode == 0 and out.strip():
             results.append(json.loads(out.strip().splitlines()[-1]))
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     if not results:
         return None
     return {"value": sum(r["value"] for r in results), "unit": results[0]["unit"], "cores": len(results), "kind": "port",
+            "build": "-O3 -march=native -ffp-contract=off" if native else "-O2 -ffp-contract=off (no compiler on this host)",
             "sample": "%d processes, each: %s" % (len(results), results[0]["sample"])}
 
 
@@ -304,6 +316,54 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     print(json.dumps(out))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N copies of this command as ranks 0..N-1 (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set),
+    relay rank 0's JSON line, fail if any rank fails.  The parent never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
+    if any(codes) or not lines:
+        sys.stderr.write("bench.py --gpus %d: rank exit codes %s\n" % (n, codes))
+        return next((c for c in codes if c), 1)
+    line = json.loads(lines[-1])
+    if line.get("n_gpus") != n:
+        sys.stderr.write("bench.py: rank 0 reported n_gpus=%r for --gpus %d\n" % (line.get("n_gpus"), n))
+        return 1
+    print(lines[-1])
+    return 0
+
+
+def dry_run(args, world, rank):
+    """SK_BENCH_DRY_RUN=1: the launch / rendezvous / reduction skeleton of the bench on gloo without a GPU (the CPU test
+    of `--gpus N`): every rank joins, the timed region is reduced with max, rank 0 prints who it saw."""
+    import torch.distributed as dist
+    from soundkit_amd import sharding
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    elapsed = sharding.reduce_elapsed(0.001 * (rank + 1))
+    ranks = sharding.sum_units(1)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(ranks), "steps": args.steps, "warmup": args.warmup,
+                          "elapsed_max_s": elapsed}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,8 +375,9 @@ def main():
     ap.add_argument("--layout", default="frame", choices=["frame", "stream"],
                     help="packing of the batch: frame-major [frame][stream] (one tick of every stream after another) or stream-major")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-all-cores", action="store_true",
-                    help="also time the oracle in one process per usable core (adds ~10 s; cpu_baseline_all_cores in the JSON)")
+    ap.add_argument("--cpu-baseline-all-cores", action="store_true", help="(default now; kept so that older command lines still run)")
+    ap.add_argument("--cpu-baseline-single-core-only", action="store_true",
+                    help="skip the one-process-per-core leg of the CPU baseline (saves ~10 s)")
     ap.add_argument("--separate-s16", action="store_true",
                     help="pipeline: f32 FIR output and a separate f32 -> interleaved s16 kernel instead of the conversion in the FIR's "
                          "epilogue (same bytes out, tests/test_pipeline_gpu.py; the chain measured before the bf16 FIR, DESIGN.md 4.2)")
@@ -336,20 +397,25 @@ def main():
     ap.add_argument("--out-channels", type=int, default=1, help="end_to_end: DecodeOptions.output_channels (0 = source)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` on its own: become the launcher of N ranks (before anything here touches the GPU)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:  # never print a line whose n_gpus is not what was asked for
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("SK_BENCH_DRY_RUN") == "1":
+        return dry_run(args, world, rank)
+
     # child processes are started before anything here initialises the GPU
     all_cores = None
-    if (args.cpu_baseline_all_cores and not args.no_cpu_baseline and args.workload in CPU_BASELINES
-            and int(os.environ.get("WORLD_SIZE", "1")) == 1):
+    if not args.no_cpu_baseline and args.workload in CPU_BASELINES and world == 1 and not args.cpu_baseline_single_core_only:
         all_cores = cpu_baseline_all_cores(args.workload)
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -484,7 +550,9 @@ def main():
             "metric": "AAC-LC 1024-sample frames/s (whole node) + xrealtime, batch=4096 48 kHz stereo",
             "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32 (FIR: exact 3 x bf16 split of both operands, f32 accumulate; 2.2e-7 rel. RMS vs f64)" if args.workload in ("pipeline", "fir") and os.environ.get("SK_FIR_F32") != "1" else "f32",
+            "data": "synthetic",
             "config": {"workload": workload, "streams_per_gpu": streams, "frames_per_stream": frames,
                        "sample_rate": 48000, "channels": ch, "seed": "0x12345678 + stream*0x9e3779b9 + frame*2 + ch", "spectrum": "dsp.rs:725-738 seeded_spectrum x %g" % SPECTRUM_GAIN,
                        "parallelism": "streams sharded, %d rank(s), no collective" % world},
@@ -543,15 +611,24 @@ def main():
                 "kernel": "k_f32_planar_stereo_to_s16le_batch", "bound": "hbm", "achieved": cvt_bytes / (ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cvt_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": None, "avg_launch_ms": ms}
+        for entry in rl.values():
+            entry["traffic_source"] = ("stored PMC pass of this workload (%s), not a counter read of this run" % os.path.relpath(PMC_SUMMARY, ROOT)
+                                       if entry.get("traffic") is not None else None)
         dominant = max(rl, key=lambda k: rl[k]["avg_launch_ms"])
         out["roofline"] = dict(rl[dominant])
         if len(rl) > 1:
             out["roofline"]["note"] = "dominant kernel of the step (largest launch time); every kernel of the chain is in `kernels`"
             out["kernels"] = rl
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = CPU_BASELINES[args.workload]()
-            if all_cores:
-                out["cpu_baseline_all_cores"] = all_cores
+            single = CPU_BASELINES[args.workload](6.0 if all_cores else 15.0)
+            single["build"] = "-O2 -ffp-contract=off (portable oracle/libsk_oracle.so)"
+            # the stated baseline is the host's cores all busy; the single-thread figure sits beside it, as does the
+            # reference's own published single-thread rate (whole AAC-LC decode, hardware unstated)
+            out["cpu_baseline"] = all_cores or single
+            out["cpu_baseline_single_core"] = single
+            out["cpu_reference_published"] = {"value": 31278.3, "unit": "frames/s", "cores": 1, "kind": "reference-published",
+                                              "sample": "soundkit-aac-lc README.md:105, soundkit-lc-reuse: whole AAC-LC decode (entropy + "
+                                                        "synthesis), hardware unstated; not measured here"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libsk_oracle.so")
+# SK_ORACLE_LIB: another build of the same sk_oracle.c (bench.py's cpu_baseline uses one compiled for the host it runs on)
+_LIB_PATH = os.environ.get("SK_ORACLE_LIB") or os.path.join(_HERE, "libsk_oracle.so")
 
 ONLY_LONG, LONG_START, EIGHT_SHORT, LONG_STOP = 0, 1, 2, 3
 SINE, KBD = 0, 1
@@ -28,7 +29,22 @@ OPS = [
 OP = {name: i for i, name in enumerate(OPS)}
 
 
+def build_native(out_dir):
+    """sk_oracle.c compiled for the cores of THIS host (-O3 -march=native; -ffp-contract=off stays, so every f32 result
+    is the portable build's) into out_dir; returns the path, or None when no compiler is available."""
+    out = os.path.join(out_dir, "libsk_oracle_native.so")
+    cmd = [os.environ.get("CC", "gcc"), "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+           "-D_GNU_SOURCE", "-shared", "-o", out, os.path.join(_HERE, "sk_oracle.c"), "-lm"]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return out
+
+
 def build(force=False):
+    if os.environ.get("SK_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(
             os.path.join(_HERE, "sk_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
