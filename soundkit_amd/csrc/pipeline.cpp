@@ -143,6 +143,7 @@ struct sk_lane {
     std::mutex batch_mu;
     std::condition_variable batch_cv;   // submission thread: work arrived / writers done
     std::condition_variable room_cv;    // workers: the filling batch has room again
+    size_t au_pass_budget = 0;          // gpu_entropy: access-unit bytes one worker pass may stage (= what an empty batch holds)
     static constexpr int kBatches = 3;  // one filling, one on the GPU, one being delivered
     Batch batches[kBatches];
     int filling = 0;
@@ -183,18 +184,24 @@ void maybe_schedule(sk_lane *p, PStream &s, uint32_t handle) {
     p->rq_cv.notify_one();
 }
 
+// Gives back what a stream holds outside the scheduler.  Two threads can get here for the same stream -- the delivery
+// thread for a stream that has just finished, and a caller cancelling that same handle the moment it saw the end -- so the
+// resources are taken over under the stream's lock and released once.
 void release_device_side(sk_lane *p, PStream &s) {
-    if (s.engine_stream != kNoStream) {
-        (void)sk_stream_close(p->engine, s.engine_stream);  // also drops its resampler
+    uint32_t engine_stream;
+    sk_aac_decoder *fe;
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        engine_stream = s.engine_stream;
         s.engine_stream = kNoStream;
-    }
-    if (s.fe) {
-        sk_aac_decoder_destroy(s.fe);
+        fe = s.fe;
         s.fe = nullptr;
+        s.pending.clear();
+        s.pending.shrink_to_fit();
+        s.pending_pos = 0;
     }
-    s.pending.clear();
-    s.pending.shrink_to_fit();
-    s.pending_pos = 0;
+    if (engine_stream != kNoStream) (void)sk_stream_close(p->engine, engine_stream);  // also drops its resampler
+    if (fe) sk_aac_decoder_destroy(fe);
 }
 
 struct Parsed {  // what one worker pass produced for one stream
@@ -202,6 +209,7 @@ struct Parsed {  // what one worker pass produced for one stream
     size_t n_floats = 0;
     size_t n_au_bytes = 0;  // gpu_entropy: bytes staged (units padded as the device wants them)
     bool eof = false, failed = false;
+    bool budget_stop = false;  // stopped early because the staged bytes reached what one batch can take
     int32_t fail_status = 0;
     std::string fail_msg;
 };
@@ -289,6 +297,12 @@ void parse_some(sk_lane *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_fr
         }
         if (gpu_entropy) {  // framing only: the access unit itself goes to the device
             const size_t padded = (pay_len + 8 + 3) & ~(size_t)3;
+            // one pass never stages more than an empty batch holds (a stream of maximum-length ADTS frames would otherwise
+            // wait for room that cannot come); the rest of the stream's frames go into the next tick
+            if (r.n_frames > 0 && r.n_au_bytes + padded > p->au_pass_budget) {
+                r.budget_stop = true;
+                break;
+            }
             if (au_stage.size() < r.n_au_bytes + padded) au_stage.resize(r.n_au_bytes + padded + 4096);
             std::memcpy(au_stage.data() + r.n_au_bytes, frame + pay_off, pay_len);
             std::memset(au_stage.data() + r.n_au_bytes + pay_len, 0, padded - pay_len);
@@ -341,7 +355,7 @@ void worker_main(sk_lane *p) {
         // streaming resampler -- one per completed chunk of 4096 source frames = 4 units (lib.rs:1970-2003)
         const uint32_t limit = std::min(per_stream, s.resample ? (room > per_stream / 4 ? per_stream : 4 * room) : room);
         parse_some(p, s, limit, coeffs.data(), descs.data(), au_stage, au_items.data(), r);
-        s.more = r.n_frames == limit && !r.eof && !r.failed;
+        s.more = (r.n_frames == limit || r.budget_stop) && !r.eof && !r.failed;
         p->parse_ns.fetch_add(ns_since(t0));
         if (r.n_frames == 0 && !r.eof && !r.failed) {  // nothing complete yet
             bool dropped;
@@ -707,7 +721,9 @@ int lane_create(sk_engine *e, const sk_pipeline_config *cfg, OutQueue *oq, uint3
         b.units.resize(p->cfg.max_frames_per_tick);
         hipError_t he;
         if (p->cfg.gpu_entropy) {  // access units are ~0.4-0.8 KiB; 2 KiB each on average leaves room for any legal mix
-            b.au_cap = (size_t)p->cfg.max_frames_per_tick * 2048 + 16384;
+            // ... and never less than one maximum-length ADTS frame (8191 bytes, padded) so that any single unit fits
+            b.au_cap = std::max<size_t>((size_t)p->cfg.max_frames_per_tick * 2048, 8192 + 16) + 16384;
+            p->au_pass_budget = b.au_cap;
             he = hipHostMalloc((void **)&b.au_bytes, b.au_cap + 64, hipHostMallocPortable);
         } else {
             b.coeff_cap = (size_t)p->cfg.max_frames_per_tick * 2 * 1024;

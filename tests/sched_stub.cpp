@@ -64,9 +64,35 @@ size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n, uint32_t *max_out
     *max_outputs = outs;
     return bytes;
 }
-int sk_tick_run_au(sk_engine *, const sk_tick_stream *, uint32_t, const sk_au_item *, uint32_t, const uint8_t *, size_t, uint8_t *, size_t,
-                   sk_tick_output *, uint32_t, uint32_t *, size_t *) {
-    return SK_ERR_UNSUPPORTED;  // the stand-in engine has no device front-end: the scenarios run with gpu_entropy = 0
+// the device front-end's stand-in: checks the unit table the way engine.cpp does and answers one record per unit
+// (stream, running unit number, byte checksum)
+int sk_tick_run_au(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_au_item *units, uint32_t n_units,
+                   const uint8_t *au, size_t au_len, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap,
+                   uint32_t *n_outs, size_t *used) {
+    std::lock_guard<std::mutex> lk(e->mu);
+    std::map<uint32_t, int> seen;
+    uint32_t f = 0, k = 0;
+    size_t cursor = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (seen[ts[i].stream]++) return SK_ERR_INVALID_ARG;
+        if (ts[i].stream >= e->open.size() || !e->open[ts[i].stream]) return SK_ERR_BAD_STREAM;
+        for (uint32_t j = 0; j < ts[i].n_frames; ++j, ++f) {
+            if (f >= n_units || k >= outs_cap || cursor + 64 > out_cap) return SK_ERR_INVALID_ARG;
+            if (units[f].byte_len > 8192 || units[f].byte_offset % 4 || (size_t)units[f].byte_offset + units[f].byte_len + 8 > au_len)
+                return SK_ERR_INVALID_ARG;
+            uint32_t sum = 0;
+            for (uint32_t c = 0; c < units[f].byte_len + 8; ++c)  // the 8 bytes after a unit must be there (and zero)
+                sum = sum * 31u + au[units[f].byte_offset + c];
+            uint32_t words[4] = {ts[i].stream, e->next_unit[ts[i].stream]++, sum, 0xabcd1234u};
+            std::memcpy(out + cursor, words, 16);
+            outs[k++] = sk_tick_output{i, 1024, cursor, 16, 0, e->channels[ts[i].stream], 16, 0};
+            cursor += 64;
+        }
+    }
+    if (f != n_units) return SK_ERR_INVALID_ARG;
+    *n_outs = k;
+    if (used) *used = cursor;
+    return SK_OK;
 }
 int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
                 uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs,
@@ -310,6 +336,64 @@ static int scenario_backpressure_and_errors(sk_engine *e) {
     return 0;
 }
 
+// gpu_entropy with maximum-length ADTS frames (8191 bytes: a real access unit followed by zero bytes, which the
+// bitstream allows) and a tick far smaller than one worker pass of them: every unit must still arrive, in order --
+// a pass that staged more bytes than an empty batch holds used to wait for room that never came.
+static int scenario_max_length_frames(sk_engine *e) {
+    sk_pipeline_config cfg{};
+    cfg.entropy_threads = 3;
+    cfg.max_streams = 8;
+    cfg.max_frames_per_tick = 3;
+    cfg.max_stream_frames_per_tick = 16;   // clamped to 3 by create; the byte budget is what must hold
+    cfg.tick_wait_us = 50;
+    cfg.gpu_entropy = 1;
+    cfg.lanes = g_lanes;
+    sk_pipeline *p = nullptr;
+    CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
+    std::vector<uint8_t> big;
+    uint32_t units = 0;
+    for (size_t pos = 0; pos + 7 <= clip.size() && units < 12;) {
+        const size_t len = ((clip[pos + 3] & 3u) << 11) | (clip[pos + 4] << 3) | (clip[pos + 5] >> 5);
+        std::vector<uint8_t> frame(8191, 0);
+        std::memcpy(frame.data(), clip.data() + pos, len);
+        frame[3] = (uint8_t)((frame[3] & ~3u) | ((8191 >> 11) & 3u));
+        frame[4] = (uint8_t)((8191 >> 3) & 0xff);
+        frame[5] = (uint8_t)((frame[5] & 0x1f) | ((8191 & 7u) << 5));
+        big.insert(big.end(), frame.begin(), frame.end());
+        pos += len;
+        ++units;
+    }
+    const uint32_t n = 5;
+    std::vector<uint32_t> handles(n);
+    for (uint32_t i = 0; i < n; ++i) CHECK(sk_pipeline_spawn(p, nullptr, &handles[i]) == SK_OK);
+    std::thread feeder([&] {
+        for (uint32_t i = 0; i < n; ++i) {
+            size_t sent = 0;
+            while (sent < big.size()) {
+                const size_t len = std::min<size_t>(big.size() - sent, 30000 + 1000 * i);
+                if (sk_pipeline_send(p, handles[i], big.data() + sent, len) == SK_OK) sent += len;
+                else std::this_thread::sleep_for(std::chrono::microseconds(100));
+            }
+            while (sk_pipeline_finish(p, handles[i]) != SK_OK) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+    });
+    std::vector<std::vector<Got>> got(n);
+    std::vector<int> errors(n, 0);
+    CHECK(drain_all(p, handles, got, errors) == 0);
+    feeder.join();
+    for (uint32_t i = 0; i < n; ++i) {
+        CHECK(errors[i] == 0);
+        CHECK(got[i].size() == units);
+        for (size_t k = 0; k < got[i].size(); ++k) {
+            CHECK(got[i][k].unit == k);
+            CHECK(got[i][k].sum == got[0][k].sum);
+        }
+    }
+    for (uint32_t h : handles) CHECK(sk_pipeline_cancel(p, h) == SK_OK);
+    sk_pipeline_destroy(p);
+    return 0;
+}
+
 static int scenario_cancel_churn(sk_engine *e);
 static int scenario_cancel_churn(sk_engine *e) {
     sk_pipeline_config cfg{};
@@ -371,6 +455,10 @@ int main(int argc, char **argv) {
     if (int rc = scenario_cancel_churn(&e)) return rc;
     g_lanes = 3;
     if (int rc = scenario_many_streams(&e)) return rc;
+    g_lanes = 1;
+    if (int rc = scenario_max_length_frames(&e)) return rc;
+    g_lanes = 2;
+    if (int rc = scenario_max_length_frames(&e)) return rc;
     std::puts("scheduler scenarios ok");
     return 0;
 }
