@@ -111,14 +111,36 @@ __global__ __launch_bounds__(64) void k_aac_entropy_link(EntropyArgs a) {
             a.status[k] = EC_SKIPPED;
             continue;
         }
-        if (a.status[k] != sk_ec::EC_OK) {
-            dead = true;
-            continue;
-        }
         a.pns_start[k] = state;
+        // a unit that failed while parsing still consumed the noise it had counted up to that point (the sequential
+        // decoder's generator has advanced that far when it returns the error)
         state = sk_ec::pns_advance(state, a.side[k].noise_samples);
+        if (a.status[k] != sk_ec::EC_OK) dead = true;
     }
     a.pns_state[tk.stream] = state;
+}
+
+// After the third phase: a unit can also fail there (stereo tools, TNS, trailing bits, an all-zero noise band), when the
+// units behind it in its stream have long been linked and finished.  The sequential decoder would not have touched
+// them: mark them skipped, silence them, and put the stream's generator where the failed unit left it (all of its
+// noise is generated before any of those checks).  One lane per stream; streams without such a failure only read
+// their statuses.
+__global__ __launch_bounds__(64) void k_aac_entropy_seal(EntropyArgs a) {
+    const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
+    if (task >= a.n_tasks) return;
+    const EntropyTask tk = a.tasks[task];
+    uint32_t k = tk.first;
+    const uint32_t end = tk.first + tk.count;
+    while (k < end && a.status[k] == sk_ec::EC_OK) ++k;
+    if (k >= end || k + 1 >= end || a.status[k + 1] == EC_SKIPPED) return;  // no failure, or one the link phase already handled
+    a.pns_state[tk.stream] = sk_ec::pns_advance(a.pns_start[k], a.side[k].noise_samples);
+    for (uint32_t j = k + 1; j < end; ++j) {
+        const EntropyUnit u = a.units[j];
+        a.status[j] = EC_SKIPPED;
+        float *coef = a.coeffs + (size_t)u.off1024 * 1024;
+        for (uint32_t i = 0; i < tk.channels * 1024u; ++i) coef[i] = 0.0f;
+        for (uint32_t c = 0; c < tk.channels; ++c) a.entries[u.entry[c]].win = 0;
+    }
 }
 
 __global__ __launch_bounds__(512) void k_aac_entropy_finish(EntropyArgs a) {
@@ -152,6 +174,7 @@ hipError_t launch_aac_entropy_parallel(const EntropyArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_aac_entropy_parse, dim3(blocks), dim3(512), a.lds_bytes, s, a);
     hipLaunchKernelGGL(k_aac_entropy_link, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_aac_entropy_finish, dim3(blocks), dim3(512), a.lds_bytes, s, a);
+    hipLaunchKernelGGL(k_aac_entropy_seal, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

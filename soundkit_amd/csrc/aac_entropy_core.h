@@ -60,7 +60,9 @@ struct Tables {
     const uint32_t *lut;      // the twelve two-level Huffman tables as aac_frontend.cpp builds them, back to back
     const uint64_t *tuples;   // per spectral symbol: bytes 0-3 the values (int8), byte 4 sign-bit count, byte 5 escape flag
     const uint16_t *swb;      // every band-offset table back to back
-    const float *pow43;       // [8192]
+    const float *pow43;       // [kPow43Len]: v^(4/3) from the host's powf for every magnitude the syntax can produce
+    const float *sf_wide;     // [65536]: 2^((sf - 100) / 4) for every i16 scale factor, host powf (dsp.rs:407-413)
+    const float *is_wide;     // [65536]: 2^(-position / 4) for every i16 intensity position, host powf
     const float *pow43_lo;    // its first kPow43Lo entries again (device: a copy in LDS; all but escape values end here)
     const float *sf_mult;     // [768]: scale factor -256..511
     const float *is_mult;     // [512]: 2^(-position / 4) for intensity positions -256..255 (scalefactor.rs:208-210)
@@ -69,6 +71,10 @@ struct Tables {
 
 // ---- bit reader over 32-bit big-endian-packed words (the buffer is 4-byte aligned and zero-padded by >= 8 bytes) ----
 constexpr uint32_t kPow43Lo = 32;
+// The largest quantised magnitude: an escape of 16 extra bits (spectral.rs:214-230) is 2^17 - 1, four pulses add at most
+// 4 * 15 (pulse.rs:20-35).  The reference computes powf beyond its 8192-entry table; a device powf is not the host's,
+// so every reachable value is tabulated (host libm, once) and the device never evaluates a transcendental.
+constexpr uint32_t kPow43Len = (1u << 17) + 64;
 
 struct Bits {
     const uint32_t *words;
@@ -240,9 +246,9 @@ SKE float ec_sinf(float a) { return sinf(a); }
 SKE float ec_sqrtf(float a) { return sqrtf(a); }
 #endif
 
-SKE float sf_multiplier(const Tables &t, int sf) {  // dsp.rs:407-413
+SKE float sf_multiplier(const Tables &t, int sf) {  // dsp.rs:407-413; sf is an i16 (checked_add above)
     if (sf >= -256 && sf <= 511) return t.sf_mult[sf + 256];
-    return ec_powf(2.0f, ((float)sf - 100.0f) * 0.25f);
+    return t.sf_wide[sf + 32768];
 }
 
 SKE int read_scalefactors(const Tables &t, Bits &b, Channel &ch) {  // scalefactor.rs:80-153
@@ -270,8 +276,7 @@ SKE int read_scalefactors(const Tables &t, Bits &b, Channel &ch) {  // scalefact
                 EC_TRY(huffman(t, 0, b, &sym));
                 if (!i16_add(intensity, (int)sym - 60, &intensity)) return EC_INVALID_BITSTREAM;
                 // scalefactor.rs:208-210; tabulated with the host's powf so that the device build agrees to the bit
-                ch.mult[g * stride + sfb] = (intensity >= -256 && intensity <= 255) ? t.is_mult[intensity + 256]
-                                                                                   : ec_powf(2.0f, -0.25f * (float)intensity);
+                ch.mult[g * stride + sfb] = (intensity >= -256 && intensity <= 255) ? t.is_mult[intensity + 256] : t.is_wide[intensity + 32768];
             } else {
                 EC_TRY(huffman(t, 0, b, &sym));
                 if (!i16_add(spectral, (int)sym - 60, &spectral)) return EC_INVALID_BITSTREAM;
@@ -355,7 +360,7 @@ SKE float dequantize(const Tables &t, int q, float scale) {  // dsp.rs:397-405
     if (q == 0) return 0.0f;
     const float sign = q < 0 ? -1.0f : 1.0f;
     const uint32_t mag = q < 0 ? (uint32_t)(-(int64_t)q) : (uint32_t)q;
-    const float m = mag < kPow43Lo ? t.pow43_lo[mag] : (mag < 8192 ? t.pow43[mag] : ec_powf((float)mag, 4.0f / 3.0f));
+    const float m = mag < kPow43Lo ? t.pow43_lo[mag] : (mag < kPow43Len ? t.pow43[mag] : ec_powf((float)mag, 4.0f / 3.0f));
     return sign * m * scale;
 }
 

@@ -7,13 +7,17 @@
 
 namespace sk_ec {
 
+constexpr uint32_t kHostPow43Len = (1u << 17) + 64;  // = kPow43Len of aac_entropy_core.h (engine.cpp asserts it)
+
 struct HostTables {
     std::vector<uint32_t> lut;      // all twelve two-level Huffman tables back to back
     uint32_t lut_offset[12];        // [0] scalefactors, [1..11] spectral books
     uint32_t primary_bits[12];
     std::vector<uint64_t> tuples;   // per spectral symbol: bytes 0-3 values, byte 4 sign-bit count, byte 5 escape flag
     uint32_t tuple_offset[12];
-    std::vector<float> pow43;       // 8192
+    std::vector<float> pow43;       // kPow43Len: every magnitude an escape sequence (+ pulses) can reach
+    std::vector<float> sf_wide;     // 65536: scale factors -32768..32767 (the i16 the reference accumulates in)
+    std::vector<float> is_wide;     // 65536: intensity positions -32768..32767
     std::vector<float> sf_mult;     // 768
     std::vector<float> is_mult;     // 512: intensity positions -256..255
     std::vector<float> tns_sin;     // 2 x 17

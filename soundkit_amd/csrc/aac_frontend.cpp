@@ -1000,6 +1000,9 @@ const HostTables &host_tables() {
             }
         }
         h.pow43.assign(t.pow43, t.pow43 + 8192);
+        for (uint32_t v = 8192; v < kHostPow43Len; ++v) h.pow43.push_back(std::pow((float)v, 4.0f / 3.0f));  // as dequantize() above
+        for (int sf = -32768; sf <= 32767; ++sf) h.sf_wide.push_back(std::pow(2.0f, ((float)sf - 100.0f) * 0.25f));
+        for (int pos = -32768; pos <= 32767; ++pos) h.is_wide.push_back(std::pow(2.0f, -0.25f * (float)pos));
         h.sf_mult.assign(t.sf_mult, t.sf_mult + 768);
         for (int pos = -256; pos <= 255; ++pos) h.is_mult.push_back(std::pow(2.0f, -0.25f * (float)pos));
         for (int res_bits = 3; res_bits <= 4; ++res_bits)

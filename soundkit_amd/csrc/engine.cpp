@@ -1658,6 +1658,7 @@ namespace {
 
 // the front-end's tables, flattened and uploaded once
 int ensure_entropy_tables(sk_engine *e) {
+    static_assert(sk_ec::kHostPow43Len == sk_ec::kPow43Len, "host table and device bound must agree");
     if (e->ec_ready) return SK_OK;
     const sk_ec::HostTables &h = sk_ec::host_tables();
     auto pad = [](size_t n) { return (n + 255) & ~(size_t)255; };
@@ -1668,7 +1669,8 @@ int ensure_entropy_tables(sk_engine *e) {
     const size_t b_meta = 0, b_lut = b_meta + pad(h.meta.size() * 4), b_tup = b_lut + pad(h.lut.size() * 4),
                  b_sf = b_tup + pad(h.tuples.size() * 8), b_swb = b_sf + pad(h.sf_mult.size() * 4),
                  b_plo = b_swb + pad(h.swb.size() * 2), lds_end = b_plo + pad(sk_ec::kPow43Lo * 4), b_pow = lds_end, b_is = b_pow + pad(h.pow43.size() * 4),
-                 b_tns = b_is + pad(h.is_mult.size() * 4), total = b_tns + pad(h.tns_sin.size() * 4);
+                 b_tns = b_is + pad(h.is_mult.size() * 4), b_sfw = b_tns + pad(h.tns_sin.size() * 4), b_isw = b_sfw + pad(h.sf_wide.size() * 4),
+                 total = b_isw + pad(h.is_wide.size() * 4);
     std::vector<uint8_t> blob(total, 0);
     std::memcpy(blob.data() + b_meta, h.meta.data(), h.meta.size() * 4);
     std::memcpy(blob.data() + b_lut, h.lut.data(), h.lut.size() * 4);
@@ -1679,6 +1681,8 @@ int ensure_entropy_tables(sk_engine *e) {
     std::memcpy(blob.data() + b_is, h.is_mult.data(), h.is_mult.size() * 4);
     std::memcpy(blob.data() + b_tns, h.tns_sin.data(), h.tns_sin.size() * 4);
     std::memcpy(blob.data() + b_swb, h.swb.data(), h.swb.size() * 2);
+    std::memcpy(blob.data() + b_sfw, h.sf_wide.data(), h.sf_wide.size() * 4);
+    std::memcpy(blob.data() + b_isw, h.is_wide.data(), h.is_wide.size() * 4);
     SK_HIP(hipMalloc(&e->d_ec_blob, total), "alloc entropy tables");
     SK_HIP(hipMemcpy(e->d_ec_blob, blob.data(), total, hipMemcpyHostToDevice), "upload entropy tables");
     const uint8_t *base = (const uint8_t *)e->d_ec_blob;
@@ -1692,6 +1696,8 @@ int ensure_entropy_tables(sk_engine *e) {
     t.sf_mult = (const float *)(base + b_sf);
     t.is_mult = (const float *)(base + b_is);
     t.tns_sin = (const float *)(base + b_tns);
+    t.sf_wide = (const float *)(base + b_sfw);
+    t.is_wide = (const float *)(base + b_isw);
     sk::EntropyArgs &ea = e->ec_args;
     ea.t = t;
     ea.lds_blob = base;

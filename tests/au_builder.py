@@ -257,3 +257,51 @@ def random_access_unit(rng, sf_index, channels, dense=True):
 
 def asc_for(sf_index, channels):
     return bytes([(2 << 3) | (sf_index >> 1), ((sf_index & 1) << 7) | (channels << 3)])
+
+
+def adts_frame(au, sf_index, channels):
+    """the access unit behind a 7-byte ADTS header (protection absent), as parse_adts_access_unit expects it
+    (soundkit-decoder lib.rs:1007-1027)"""
+    n = len(au) + 7
+    assert n < 8192
+    return bytes([0xFF, 0xF1, (1 << 6) | (sf_index << 2) | (channels >> 2), ((channels & 3) << 6) | (n >> 11),
+                  (n >> 3) & 0xFF, ((n & 7) << 5) | 0x1F, 0xFC]) + au
+
+
+def extreme_scalefactor_units():
+    """Scale factors and intensity positions outside the reference's tables (dsp.rs:407-413 falls back to powf beyond
+    -256..511; scalefactor.rs:208-210 always computes): [(sf_index, channels, access unit)] with small quantised
+    values so that nothing overflows.  44.1 kHz: the first bands are 4 wide, one codebook-1 quad each."""
+    out = []
+    for gain, step in ((255, 60), (0, -60)):           # spectral scale factor walks to 255 + 300 / 0 - 300
+        w = Writer()
+        w.put(0, 3), w.put(0, 4), w.put(gain, 8)
+        w.put(0, 1), w.put(0, 2), w.put(0, 1), w.put(8, 6), w.put(0, 1)      # OnlyLong, sine, max_sfb 8, no prediction
+        w.put(1, 4), w.put(8, 5)                                             # one section: codebook 1, 8 bands
+        for k in range(8):
+            w.code("sf", 60 + (step if k < 5 else 0))
+        w.put(0, 1), w.put(0, 1), w.put(0, 1)
+        for k in range(8):
+            v = [(k + j) % 3 - 1 for j in range(4)]
+            w.code(1, (v[0] + 1) * 27 + (v[1] + 1) * 9 + (v[2] + 1) * 3 + v[3] + 1)
+        w.put(7, 3)
+        out.append((4, 1, w.bytes()))
+    for step in (60, -60):                             # intensity position walks to +-300 on the right channel
+        w = Writer()
+        w.put(1, 3), w.put(0, 4), w.put(1, 1)
+        w.put(0, 1), w.put(0, 2), w.put(1, 1), w.put(8, 6), w.put(0, 1)
+        w.put(0, 2)                                                          # no mid/side
+        w.put(100, 8), w.put(1, 4), w.put(8, 5)
+        for _ in range(8):
+            w.code("sf", 60)
+        w.put(0, 1), w.put(0, 1), w.put(0, 1)
+        for k in range(8):
+            v = [(k + j) % 3 - 1 for j in range(4)]
+            w.code(1, (v[0] + 1) * 27 + (v[1] + 1) * 9 + (v[2] + 1) * 3 + v[3] + 1)
+        w.put(100, 8), w.put(15 if step > 0 else 14, 4), w.put(8, 5)
+        for k in range(8):
+            w.code("sf", 60 + (step if k < 5 else 0))
+        w.put(0, 1), w.put(0, 1), w.put(0, 1)
+        w.put(7, 3)
+        out.append((4, 2, w.bytes()))
+    return out

@@ -26,6 +26,8 @@ static sk_ec::Tables make_tables() {
     t.sf_mult = h.sf_mult.data();
     t.is_mult = h.is_mult.data();
     t.tns_sin = h.tns_sin.data();
+    t.sf_wide = h.sf_wide.data();
+    t.is_wide = h.is_wide.data();
     return t;
 }
 

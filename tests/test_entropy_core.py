@@ -18,3 +18,27 @@ def test_entropy_core_equals_host_front_end_under_sanitizers(tmp_path):
     out = subprocess.run([exe, "6000"] + [os.path.join(HERE, "golden", "aac", f) for f in FILES], capture_output=True, text=True)
     assert out.returncode == 0 and "identical" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
     assert "checked 24273 access units" in out.stdout
+
+
+def test_entropy_core_equals_host_front_end_on_generated_units(tmp_path):
+    """the same harness on units from tests/au_builder.py (pulse data, escapes up to the 16-bit limit, every codebook and
+    window grouping, values beyond the reference's tables) and on 300 mutants of each generated stream"""
+    import numpy as np
+
+    from au_builder import adts_frame, extreme_scalefactor_units, random_access_unit
+    exe = str(tmp_path / "entropy_core_check")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-ffp-contract=off", "-Wno-subobject-linkage", "-o", exe, os.path.join(HERE, "entropy_core_check.cpp")],
+                          cwd=HERE)
+    files, units = [], 0
+    for k, (sf_index, channels) in enumerate([(3, 2), (4, 1), (8, 2), (11, 1), (0, 2)]):
+        rng = np.random.default_rng(900 + k)
+        aus = [random_access_unit(rng, sf_index, channels) for _ in range(60)]
+        aus += [au for sf, ch, au in extreme_scalefactor_units() if (sf, ch) == (sf_index, channels)]
+        path = str(tmp_path / ("gen%d.adts" % k))
+        open(path, "wb").write(b"".join(adts_frame(au, sf_index, channels) for au in aus))
+        files.append(path)
+        units += len(aus) + 300
+    out = subprocess.run([exe, "300"] + files, capture_output=True, text=True)
+    assert out.returncode == 0 and "identical" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+    assert "checked %d access units" % units in out.stdout

@@ -5,7 +5,7 @@ from unit to unit of a stream."""
 import numpy as np
 import pytest
 
-from au_builder import asc_for, random_access_unit
+from au_builder import asc_for, extreme_scalefactor_units, random_access_unit
 from oracle import aac_frontend as OF
 from soundkit_amd import aac_lc
 
@@ -78,6 +78,46 @@ def test_host_front_end_equals_oracle_on_random_units(k):
     assert accepted >= 100
 
 
+def test_values_beyond_the_reference_tables_host():
+    """scale factors past -256..511, intensity positions past +-256: the reference leaves its tables for powf there"""
+    for sf_index, channels, au in extreme_scalefactor_units():
+        want, seq, shape = OF.Decoder(asc_for(sf_index, channels)).decode_access_unit(au)
+        got, gseq, gshape = aac_lc.AacLcFrontEnd(asc_for(sf_index, channels)).parse(au)
+        assert np.isfinite(want).all() and np.count_nonzero(want[-1]) >= 16
+        assert (gseq, gshape) == (seq, shape) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_values_beyond_the_reference_tables_gpu(engine):
+    """the same on the device, which evaluates no powf: every reachable value is tabulated from the host's libm.
+    Also an escape sequence of the largest size the reference accepts (16 extra bits, magnitude >= 65536)."""
+    cases = list(extreme_scalefactor_units())
+    from au_builder import Writer
+    w = Writer()
+    w.put(0, 3), w.put(0, 4), w.put(60, 8)
+    w.put(0, 1), w.put(0, 2), w.put(0, 1), w.put(1, 6), w.put(0, 1)
+    w.put(11, 4), w.put(1, 5), w.code("sf", 60), w.put(0, 1), w.put(0, 1), w.put(0, 1)
+    w.code(11, 16 * 17 + 16), w.put(1, 1), w.put(0, 1)                 # pair (16, 16), signs -, +
+    for n, tail in ((12, 0x1234), (9, 0x0ABC)):                         # escapes of 16 and 13 bits
+        for _ in range(n):
+            w.put(1, 1)
+        w.put(0, 1), w.put(tail, n + 4)
+    w.code(11, 0)
+    w.put(7, 3)
+    cases.append((4, 1, w.bytes()))
+    sids = [engine.open_stream(OF.RATES[sf], ch) for sf, ch, _ in cases]
+    try:
+        got = engine.entropy_decode([(sid, 1) for sid in sids], [au for _, _, au in cases])
+        for (sf_index, channels, au), (status, coeffs, seq, shape) in zip(cases, got):
+            want, wseq, wshape = OF.Decoder(asc_for(sf_index, channels)).decode_access_unit(au)
+            assert status == 0 and (seq, shape) == (wseq, wshape)
+            assert np.array_equal(coeffs.view(np.uint32), want.view(np.uint32)), np.abs(coeffs - want).max()
+        assert abs(got[-1][1][0, 0]) > 1e5   # the 16-bit escape really is there: (2^16 + 0x1234)^(4/3) * 2^-10
+    finally:
+        for sid in sids:
+            engine.close_stream(sid)
+
+
 @pytest.mark.gpu
 def test_gpu_front_end_equals_oracle_on_random_units(engine):
     """every configuration as its own stream in ONE sk_aac_entropy_decode call, then a second call on the same
@@ -110,3 +150,63 @@ def test_gpu_front_end_equals_oracle_on_random_units(engine):
     finally:
         for sid, _, _, _ in streams:
             engine.close_stream(sid)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("damage", ["trailing_bits", "truncated"])
+def test_a_failed_unit_leaves_the_stream_where_the_sequential_decoder_does(engine, damage):
+    """A unit that fails late (non-zero trailing bits: found after everything else has been decoded) or while parsing
+    (cut short), in the middle of a launch: the units behind it are not decoded (status -199, zero spectra) and the
+    stream's PNS generator stands where the oracle's stands when it raises -- the next launch on the stream continues
+    bit-identically with the oracle decoder that saw the same error."""
+    from soundkit_amd._lib import ERR_NAMES
+    sf_index, channels = 3, 2
+    u = make_stream(7100, sf_index, channels, 14)
+    asc = asc_for(sf_index, channels)
+
+    def attempt(bad):
+        """oracle on u[:5] + bad -> (decoder, results, error, generator before / after the bad unit)"""
+        dec = OF.Decoder(asc)
+        res = [dec.decode_access_unit(au) for au in u[:5]]
+        before = dec.pns_state
+        try:
+            dec.decode_access_unit(bad)
+        except OF.AacError as e:
+            return dec, res, e, before, dec.pns_state
+        return dec, res, None, before, dec.pns_state
+    # a damaged unit 5 whose failure comes AFTER it has drawn noise, so that the generator's position is part of the test
+    bad = None
+    for donor in u[5:]:
+        full = attempt(donor)
+        if full[2] is not None or full[3] == full[4]:
+            continue                                     # this unit draws no noise
+        if damage == "trailing_bits":
+            cands = [donor + b"\x00\x80"]
+        else:
+            cands = [donor[:cut] for cut in range(len(donor) - 1, len(donor) // 2, -1)]
+        for cand in cands:
+            dec, want, err, before, after = attempt(cand)
+            if err is not None and after != before and (damage == "trailing_bits" or after != full[4]):
+                bad = cand
+                break
+        if bad is not None:
+            break
+    assert bad is not None, "the generator never produced a suitable unit"
+    if damage == "trailing_bits":
+        assert "trailing bits" in str(err)
+    later = [dec.decode_access_unit(au) for au in u[9:14]]        # the oracle decoder carries on from where it stopped
+    exc = type("E", (), {"value": err})
+    sid = engine.open_stream(OF.RATES[sf_index], channels)
+    try:
+        got = engine.entropy_decode([(sid, 9)], u[:5] + [bad] + u[6:9])
+        for i in range(5):
+            assert got[i][0] == 0 and np.array_equal(got[i][1].view(np.uint32), want[i][0].view(np.uint32)), i
+        assert ERR_NAMES[got[5][0]] == exc.value.kind and not got[5][1].any()
+        for i in range(6, 9):
+            assert got[i][0] == -199 and not got[i][1].any() and got[i][2] == [0, 0], (i, got[i][0])
+        got = engine.entropy_decode([(sid, 5)], u[9:14])
+        for i in range(5):
+            assert got[i][0] == 0 and (got[i][2], got[i][3]) == (later[i][1], later[i][2])
+            assert np.array_equal(got[i][1].view(np.uint32), later[i][0].view(np.uint32)), (damage, i)
+    finally:
+        engine.close_stream(sid)
