@@ -151,6 +151,10 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
                 const int n = sk_pipeline_wait_outputs(p, ready.data(), (uint32_t)ready.size(), 20);
                 for (int k = 0; k < n; ++k) {
                     const uint32_t h = ready[(size_t)k];
+                    // with per-stream checks a stream is drained by one consumer at a time: receive-then-hash must not
+                    // interleave with another thread's, or the order-sensitive hash would see outputs out of order
+                    std::unique_lock<std::mutex> drain_lock;
+                    if (chk && h <= max_handle) drain_lock = std::unique_lock<std::mutex>(locks[index_of[h]]);
                     for (;;) {
                         const int rc = sk_pipeline_try_recv(p, h, buf.data(), buf.size(), &info);
                         if (rc == 1) {
@@ -162,7 +166,6 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
                             }
                             if (chk) {
                                 const uint32_t i = index_of[h];
-                                std::lock_guard<std::mutex> g(locks[i]);
                                 if (info.is_error) {
                                     ++chk->errors[i];
                                     continue;

@@ -112,7 +112,7 @@ def test_values_beyond_the_reference_tables_gpu(engine):
             want, wseq, wshape = OF.Decoder(asc_for(sf_index, channels)).decode_access_unit(au)
             assert status == 0 and (seq, shape) == (wseq, wshape)
             assert np.array_equal(coeffs.view(np.uint32), want.view(np.uint32)), np.abs(coeffs - want).max()
-        assert abs(got[-1][1][0, 0]) > 1e5   # the 16-bit escape really is there: (2^16 + 0x1234)^(4/3) * 2^-10
+        assert abs(got[-1][1][0, 0]) > 2000   # the 16-bit escape really is there: (2^16 + 0x1234)^(4/3) * 2^-10
     finally:
         for sid in sids:
             engine.close_stream(sid)
