@@ -382,6 +382,9 @@ def main():
                     help="pipeline: f32 FIR output and a separate f32 -> interleaved s16 kernel instead of the conversion in the FIR's "
                          "epilogue (same bytes out, tests/test_pipeline_gpu.py; the chain measured before the bf16 FIR, DESIGN.md 4.2)")
     ap.add_argument("--fused-s16", action="store_true", help="(default now; kept so that older command lines still run)")
+    ap.add_argument("--chain", default="s16", choices=["s16", "f32"],
+                    help="pipeline: what crosses HBM between synthesis and FIR -- s16 as in the reference worker (default), or the f32 "
+                         "PCM (round 1's chain)")
     ap.add_argument("--entropy-threads", type=int, default=0, help="end_to_end: host threads for the AAC front-end (0 = cores - 1, split over ranks)")
     ap.add_argument("--tick-wait-us", type=int, default=0, help="end_to_end: how long a non-empty batch waits for more frames (0 = library default 200)")
     ap.add_argument("--tick-frames", type=int, default=0, help="end_to_end: access units per GPU tick, whole batch (0 = library default)")
@@ -482,7 +485,7 @@ def main():
                                                                                      streams, frames, fir_out, out_stride))
                     timed("k_f32_planar_stereo_to_s16le_batch",
                           lambda: eng.f32_planar_to_bytes_batch_dev(fmt_s16, fir_out, streams, out_stride, n_out, ch, s16_out))
-            else:  # the s16 output stage runs in the FIR's epilogue (same bytes, tests/test_pipeline_gpu.py)
+            elif args.chain == "f32":  # f32 PCM between the kernels; the s16 output stage runs in the FIR's epilogue
                 s16_stride = (n_out + 7) // 8 * 8
                 s16_out = torch.empty((streams, s16_stride, ch), dtype=torch.int16, device=device)
 
@@ -490,8 +493,23 @@ def main():
                     timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
                     timed("k_fir_48k_16k", lambda: eng.downsample_48k_16k_frames_s16_dev(pcm, stream_stride, frame_stride, ch,
                                                                                          streams, frames, s16_out, s16_stride))
+            else:
+                # the worker's own data flow (soundkit-decoder lib.rs:1793-1813, 3324-3456): the decoder's output is s16, the
+                # resampler is fed s / 32768.  The synthesis kernel writes the s16 itself (planar), the FIR reads it in place.
+                s16_stride = (n_out + 7) // 8 * 8
+                s16_out = torch.empty((streams, s16_stride, ch), dtype=torch.int16, device=device)
+                del pcm
+                pcm16 = torch.empty(coeffs.shape, dtype=torch.int16, device=device)
+
+                def step():
+                    timed("k_aac_synth", lambda: plan.run_s16_planar(coeffs, pcm16))
+                    timed("k_fir_48k_16k", lambda: eng.downsample_48k_16k_frames_s16_to_s16_dev(pcm16, stream_stride, frame_stride, ch,
+                                                                                                streams, frames, s16_out, s16_stride))
+            chain_note = {"f32": "f32 PCM between the kernels (not the reference's data flow: it narrows to s16 before resampling)",
+                          "s16": "s16 PCM between the kernels as in the reference worker (decode_aac_access_unit -> "
+                                 "audio_data_to_f32_channels: s / 32768)"}["f32" if args.separate_s16 else args.chain]
             workload = ("aac_lc decode tail: %d streams x %d frames, 48 kHz stereo: IMDCT+window+OLA -> 48k->16k MFMA FIR -> "
-                        "interleaved s16 (%s), %s-major batch" % (streams, frames, "separate kernel" if args.separate_s16 else "in the FIR epilogue", args.layout))
+                        "interleaved s16 (%s), %s-major batch; %s" % (streams, frames, "separate kernel" if args.separate_s16 else "in the FIR epilogue", args.layout, chain_note))
         else:
             def step():
                 timed("k_aac_synth", lambda: plan.run_f32(coeffs, pcm))
@@ -551,7 +569,10 @@ def main():
             "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (FIR: exact 3 x bf16 split of both operands, f32 accumulate; 2.2e-7 rel. RMS vs f64)" if args.workload in ("pipeline", "fir") and os.environ.get("SK_FIR_F32") != "1" else "f32",
+            "dtype": ("f32 (synthesis f32; s16 between the kernels as in the reference; FIR: taps split exactly into 3 x bf16, the 16-bit "
+                      "samples into 2 x bf16, f32 accumulate)" if args.workload == "pipeline" and args.chain == "s16" and not args.separate_s16
+                      else "f32 (FIR: exact 3 x bf16 split of both operands, f32 accumulate; 2.2e-7 rel. RMS vs f64)"
+                      if args.workload in ("pipeline", "fir") and os.environ.get("SK_FIR_F32") != "1" else "f32"),
             "data": "synthetic",
             "config": {"workload": workload, "streams_per_gpu": streams, "frames_per_stream": frames,
                        "sample_rate": 48000, "channels": ch, "seed": "0x12345678 + stream*0x9e3779b9 + frame*2 + ch", "spectrum": "dsp.rs:725-738 seeded_spectrum x %g" % SPECTRUM_GAIN,
@@ -563,13 +584,15 @@ def main():
             ms = per_kernel["k_aac_synth"]
             # algorithmic bytes of this variant: 4 KiB in + 4 KiB out per channel-frame, the overlap delay
             # crosses HBM once per channel per launch (in + out); canonical figure charges it every frame
-            variant_bytes = streams * frames * ch * 8192 + streams * ch * 8192
-            canonical_bytes = streams * frames * 32768
+            s16_between = args.workload == "pipeline" and args.chain == "s16" and not args.separate_s16
+            out_b = 2048 if s16_between else 4096  # planar s16 or f32 PCM out per channel-frame
+            variant_bytes = streams * frames * ch * (4096 + out_b) + streams * ch * 8192
+            canonical_bytes = streams * frames * (32768 - (4096 if s16_between else 0))  # minus 2048 B per channel-frame for s16 out
             rl["k_aac_synth"] = {
                 "kernel": "k_aac_synth", "bound": "hbm", "achieved": variant_bytes / (ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": variant_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("aac_synth", streams=streams, frames=frames, channels=ch), "avg_launch_ms": ms,
-                "variant": "delay on-chip: 8192 B per channel-frame + 8192 B per channel per launch",
+                "variant": "delay on-chip: %d B per channel-frame (4096 in + %d out) + 8192 B per channel per launch" % (4096 + out_b, out_b),
                 "achieved_canonical_32768B_per_stereo_frame": canonical_bytes / (ms * 1e-3) / 1e9,
             }
         if "k_fir_48k_16k" in per_kernel:
@@ -588,13 +611,15 @@ def main():
                 # fir_bf16.hip: 41 bf16 MFMAs per 16 x 16 outputs = 2624 issued flop per output, 1/16 of the time
                 # they would take on the f32 matrix path; what bounds the launch now is its own HBM traffic:
                 # 4 B per input sample + 4 B (f32) or 2 B (s16) per output sample
-                fir_bytes = streams * ch * (fir_in * 4.0 + n_fir_out * (2.0 if fused else 4.0))
+                in_b = 2.0 if (fused and args.chain == "s16") else 4.0
+                fir_bytes = streams * ch * (fir_in * in_b + n_fir_out * (2.0 if fused else 4.0))
                 rl["k_fir_48k_16k"] = {
                     "kernel": "k_fir_48k_16k_bf16", "bound": "hbm", "achieved": fir_bytes / (ms * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fir_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic": pmc_traffic(pmc_kind, rows=streams * ch, frames=fir_in), "avg_launch_ms": ms,
                     "algorithmic_tflops": flops / (ms * 1e-3) / 1e12,
-                    "issued_bf16_tflops": flops * 5.125 / (ms * 1e-3) / 1e12, "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TF}
+                    "issued_bf16_tflops": flops * (4.5 if in_b == 2.0 else 5.125) / (ms * 1e-3) / 1e12, "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TF,
+                    "bytes_per_output_sample": 3 * in_b + (2.0 if fused else 4.0)}
         if "k_convert" in per_kernel:
             ms = per_kernel["k_convert"]
             cvt = units_per_step * 6.0  # 4 B in + 2 B out per sample (sk_pcm_op_in_bytes / _out_bytes)

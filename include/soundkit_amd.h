@@ -120,6 +120,12 @@ uint64_t sk_aac_plan_elements(const sk_aac_plan *); /* total f32 elements of coe
 uint32_t sk_aac_plan_frames_ok(const sk_aac_plan *);
 int sk_aac_plan_run_f32_dev(sk_engine *, const sk_aac_plan *, const float *d_coeffs, float *d_pcm);
 int sk_aac_plan_run_s16_dev(sk_engine *, const sk_aac_plan *, const float *d_coeffs, int16_t *d_pcm);
+/* The s16 of decode_aac_access_unit (soundkit-decoder lib.rs:1793-1813: float_sample_to_i16 of every sample) written by
+ * the synthesis kernel itself, PLANAR: the packing of the f32 form with two bytes per sample (channel c of frame i at
+ * element (off_i + c) * 1024).  This is the intermediate of the worker's decode -> resample path -- the resampler is fed
+ * these integers / 32768 (lib.rs:3563-3617) -- kept on the device at half the bytes of the f32 PCM;
+ * sk_downsample_48k_16k_frames_s16_to_s16_dev reads it in place.  d_pcm16 is 8-byte aligned. */
+int sk_aac_plan_run_s16_planar_dev(sk_engine *, const sk_aac_plan *, const float *d_coeffs, int16_t *d_pcm16);
 
 /* ---- AAC-LC access-unit front-end (host cores) ------------------------------------------------
  * The entropy / side-information half of AacLcDecoder::decode_access_unit (soundkit-aac-lc/src/
@@ -297,6 +303,19 @@ int sk_downsample_48k_16k_frames_dev(sk_engine *, const float *d_pcm, size_t str
 int sk_downsample_48k_16k_frames_s16_dev(sk_engine *, const float *d_pcm, size_t stream_stride, size_t frame_stride,
                                          uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream,
                                          int16_t *d_out, size_t out_stride, uint32_t *out_frames);
+
+/* apply_output_options' resample step on the worker's own data (lib.rs:3324-3456): audio_data_to_f32_channels
+ * (s16 / 32768, lib.rs:3563-3617) -> 48k->16k sinc FIR -> f32_channels_to_bytes (float_sample_to_i16), over the planar s16
+ * PCM of sk_aac_plan_run_s16_planar_dev, indexed like sk_downsample_48k_16k_frames_dev's input (strides in samples,
+ * multiples of 4).  A 16-bit sample is exactly two bf16 values, so the matrix-core FIR needs two input planes and
+ * 36 instead of 41 products per tile.  d_out[s][m][c] interleaved s16, out_stride frames per stream. */
+int sk_downsample_48k_16k_frames_s16_to_s16_dev(sk_engine *, const int16_t *d_pcm16, size_t stream_stride, size_t frame_stride,
+                                                uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream,
+                                                int16_t *d_out, size_t out_stride, uint32_t *out_frames);
+/* the same filter output before the 16-bit stage: row s * channels + c of d_out (f32, out_stride per row) */
+int sk_downsample_48k_16k_frames_s16_to_f32_dev(sk_engine *, const int16_t *d_pcm16, size_t stream_stride, size_t frame_stride,
+                                                uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream,
+                                                float *d_out, size_t out_stride, uint32_t *out_frames);
 
 /* StreamingResampler (soundkit-decoder lib.rs:1917-2060), any pair of COMMON_SAMPLE_RATES, fixed 4096-frame
  * chunks, history kept per stream on the device.  in: n_streams x channels x frames planar

@@ -128,6 +128,9 @@ _sig = {
     "sk_aac_plan_frames_ok": (_u32, [_vp]),
     "sk_aac_plan_run_f32_dev": (_i, [_vp, _vp, _vp, _vp]),
     "sk_aac_plan_run_s16_dev": (_i, [_vp, _vp, _vp, _vp]),
+    "sk_aac_plan_run_s16_planar_dev": (_i, [_vp, _vp, _vp, _vp]),
+    "sk_downsample_48k_16k_frames_s16_to_f32_dev": (_i, [_vp, _vp, _sz, _sz, _u32, _u32, _u32, _vp, _sz, C.POINTER(_u32)]),
+    "sk_downsample_48k_16k_frames_s16_to_s16_dev": (_i, [_vp, _vp, _sz, _sz, _u32, _u32, _u32, _vp, _sz, C.POINTER(_u32)]),
     "sk_aac_decoder_create": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "sk_aac_decoder_destroy": (None, [_vp]),
     "sk_aac_decoder_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(C.c_uint8)]),

@@ -94,6 +94,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+// four PCM samples as the s16 the worker emits (float_sample_to_i16, soundkit-decoder lib.rs:1815-1827), packed
+__device__ __forceinline__ u2 pack4_s16(const f4 &v) {
+    const uint32_t a = (uint32_t)dev_float_sample_to_i16_f32(v.x) & 0xffffu, b = (uint32_t)dev_float_sample_to_i16_f32(v.y);
+    const uint32_t c = (uint32_t)dev_float_sample_to_i16_f32(v.z) & 0xffffu, d = (uint32_t)dev_float_sample_to_i16_f32(v.w);
+    return (u2){a | (b << 16), c | (d << 16)};
+}
+
 typedef __attribute__((address_space(3))) f2 lds_f2;
 typedef __attribute__((address_space(3))) f4 lds_f4;
 typedef __attribute__((address_space(3))) float lds_f;
@@ -207,8 +215,8 @@ __device__ __forceinline__ void fft512(f2 (&z)[8], lds_f2 *ex, const lds_f2 *t64
 __device__ __attribute__((noinline)) void synth_rare_frame(lds_f2 *ex, lds_f *stage, const lds_f2 *tw_lds,
                                                             const lds_f2 *t64, float base2_re, float base2_im,
                                                             const float *win, const f2 *w64, const f2 *tw_short,
-                                                            float *out_ptr, int seq, int prev_shape, int shape,
-                                                            int lane) {
+                                                            float *out_ptr, int16_t *out16_ptr, int seq, int prev_shape,
+                                                            int shape, int lane) {
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const f2 base2 = (f2){base2_re, base2_im};
     const float *prev_long = win + 2048 * prev_shape;
@@ -307,13 +315,21 @@ __device__ __attribute__((noinline)) void synth_rare_frame(lds_f2 *ex, lds_f *st
         f.z = o[8 * r + 2] + dly[8 * r + 2]; f.w = o[8 * r + 3] + dly[8 * r + 3];
         m.x = o[8 * r + 4] + dly[8 * r + 4]; m.y = o[8 * r + 5] + dly[8 * r + 5];
         m.z = o[8 * r + 6] + dly[8 * r + 6]; m.w = o[8 * r + 7] + dly[8 * r + 7];
-        *reinterpret_cast<f4 *>(out_ptr + j) = f;
-        *reinterpret_cast<f4 *>(out_ptr + 1020 - j) = m;
+        if (out16_ptr) {  // wave-uniform
+            *reinterpret_cast<u2 *>(out16_ptr + j) = pack4_s16(f);
+            *reinterpret_cast<u2 *>(out16_ptr + 1020 - j) = pack4_s16(m);
+        } else {
+            *reinterpret_cast<f4 *>(out_ptr + j) = f;
+            *reinterpret_cast<f4 *>(out_ptr + 1020 - j) = m;
+        }
     }
     write_positions(stage, lane, d);
     wave_sync();
 }
 
+// OUT16: the PCM leaves as planar s16 (float_sample_to_i16 of every sample; same [off1024][1024] packing, two bytes
+// per sample) -- what decode_aac_access_unit hands on (soundkit-decoder lib.rs:1793-1813) before interleaving
+template <bool OUT16>
 __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synth(SynthArgs a) {
     __shared__ f2 lds[kWavesPerBlock][kExchange];
     __shared__ float stage_lds[kWavesPerBlock][kStage];
@@ -382,7 +398,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
         const uint32_t win = __builtin_amdgcn_readfirstlane(ent.win);
         const int seq = win & 3;
         const int shape = (win >> 2) & 1;
-        float *out_ptr = a.pcm + (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024;
+        float *out_ptr = OUT16 ? nullptr : a.pcm + (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024;
+        int16_t *out16_ptr = OUT16 ? a.pcm16 + (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024 : nullptr;
 
         // ---- pre-twiddle (dsp.rs:495-503): consumes xin so the next spectrum can land in it ----
         f2 z[8];
@@ -463,8 +480,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
                 // out1[508-j..511-j] = M0.im, F1.re, M1.im, F0.re (dsp.rs:517, 529)
                 m.x = M.y * W1m.x + dly[8 * r + 4]; m.y = F.z * W1m.y + dly[8 * r + 5];
                 m.z = M.w * W1m.z + dly[8 * r + 6]; m.w = F.x * W1m.w + dly[8 * r + 7];
-                SK_SYNTH_STORE(f, reinterpret_cast<f4 *>(out_ptr + j));
-                SK_SYNTH_STORE(m, reinterpret_cast<f4 *>(out_ptr + 1020 - j));
+                if (OUT16) {
+                    SK_SYNTH_STORE(pack4_s16(f), reinterpret_cast<u2 *>(out16_ptr + j));
+                    SK_SYNTH_STORE(pack4_s16(m), reinterpret_cast<u2 *>(out16_ptr + 1020 - j));
+                } else {
+                    SK_SYNTH_STORE(f, reinterpret_cast<f4 *>(out_ptr + j));
+                    SK_SYNTH_STORE(m, reinterpret_cast<f4 *>(out_ptr + 1020 - j));
+                }
                 // out2[j..j+3] = F0.im, M1.re, F1.im, M0.re       (dsp.rs:518, 530)
                 dly[8 * r + 0] = F.y * W2f.x; dly[8 * r + 1] = M.z * W2f.y;
                 dly[8 * r + 2] = F.w * W2f.z; dly[8 * r + 3] = M.x * W2f.w;
@@ -480,7 +502,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
             write_positions(stage, lane, dly);
             wave_sync();
             synth_rare_frame(ex, stage, tw_lds, t64, base2.x, base2.y, a.t.win, reinterpret_cast<const f2 *>(a.t.w64),
-                             reinterpret_cast<const f2 *>(a.t.tw_short), out_ptr, seq, prev_shape, shape, lane);
+                             reinterpret_cast<const f2 *>(a.t.tw_short), out_ptr, out16_ptr, seq, prev_shape, shape, lane);
             read_positions(stage, lane, dly);
             wave_sync();
             if (e + kDepth < count) {
@@ -594,7 +616,8 @@ hipError_t launch_reset_stream(float *delay2048, uint8_t *shape2, uint32_t *pns,
 hipError_t launch_aac_synth(const SynthArgs &a, hipStream_t s) {
     if (a.n_tasks == 0) return hipSuccess;
     const uint32_t blocks = (a.n_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(k_aac_synth, dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
+    if (a.pcm16) hipLaunchKernelGGL(k_aac_synth<true>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
+    else hipLaunchKernelGGL(k_aac_synth<false>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -671,10 +671,11 @@ int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n,
     return SK_OK;
 }
 
-static int run_plan(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, float *d_pcm) {
+static int run_plan(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, float *d_pcm, int16_t *d_pcm16 = nullptr) {
     sk::SynthArgs a{};
     a.coeffs = d_coeffs;
     a.pcm = d_pcm;
+    a.pcm16 = d_pcm16;
     a.delay = e->d_delay;
     a.prev_shape = e->d_prev_shape;
     a.tasks = p->d_tasks;
@@ -692,6 +693,15 @@ int sk_aac_plan_run_f32_dev(sk_engine *e, const sk_aac_plan *p, const float *d_c
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e->device);
     return run_plan(e, p, d_coeffs, d_pcm);
+}
+
+int sk_aac_plan_run_s16_planar_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, int16_t *d_pcm16) {
+    if (!e || !p || p->eng != e) return SK_ERR_INVALID_ARG;
+    if (p->n_tasks == 0) return SK_OK;
+    if (!d_coeffs || !d_pcm16 || ((uintptr_t)d_pcm16 & 7)) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    return run_plan(e, p, d_coeffs, nullptr, d_pcm16);
 }
 
 int sk_aac_plan_run_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, int16_t *d_pcm) {
@@ -1053,6 +1063,59 @@ int sk_downsample_48k_16k_frames_s16_dev(sk_engine *e, const float *d_pcm, size_
     a.out_first = 0;
     a.out_count = n_out;
     SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch fir (frame-packed input, s16 output)");
+    return SK_OK;
+}
+
+static int fir_from_s16(sk_engine *e, const int16_t *d_pcm16, size_t stream_stride, size_t frame_stride, uint32_t channels,
+                        uint32_t n_streams, uint32_t frames_per_stream, int16_t *d_out16, float *d_out32, size_t out_stride,
+                        uint32_t *out_frames);
+
+int sk_downsample_48k_16k_frames_s16_to_s16_dev(sk_engine *e, const int16_t *d_pcm16, size_t stream_stride, size_t frame_stride,
+                                                uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream, int16_t *d_out,
+                                                size_t out_stride, uint32_t *out_frames) {
+    return fir_from_s16(e, d_pcm16, stream_stride, frame_stride, channels, n_streams, frames_per_stream, d_out, nullptr, out_stride,
+                        out_frames);
+}
+
+int sk_downsample_48k_16k_frames_s16_to_f32_dev(sk_engine *e, const int16_t *d_pcm16, size_t stream_stride, size_t frame_stride,
+                                                uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream, float *d_out,
+                                                size_t out_stride, uint32_t *out_frames) {
+    return fir_from_s16(e, d_pcm16, stream_stride, frame_stride, channels, n_streams, frames_per_stream, nullptr, d_out, out_stride,
+                        out_frames);
+}
+
+static int fir_from_s16(sk_engine *e, const int16_t *d_pcm16, size_t stream_stride, size_t frame_stride, uint32_t channels,
+                        uint32_t n_streams, uint32_t frames_per_stream, int16_t *d_out, float *d_out32, size_t out_stride,
+                        uint32_t *out_frames) {
+    if (!e || channels < 1 || channels > SK_MAX_CHANNELS) return SK_ERR_INVALID_ARG;
+    const uint64_t samples = (uint64_t)frames_per_stream * SK_AAC_FRAME_LEN;
+    if (samples > 0xfffffffcull) return SK_ERR_INVALID_ARG;
+    const uint32_t n_out = sk_downsample_48k_16k_out_frames((uint32_t)samples);
+    if (out_frames) *out_frames = n_out;
+    if (n_streams == 0 || n_out == 0) return SK_OK;
+    if (!d_pcm16 || (!d_out && !d_out32) || out_stride < n_out || frame_stride < (size_t)channels * SK_AAC_FRAME_LEN ||
+        stream_stride % 4 || frame_stride % 4 || ((uintptr_t)d_pcm16 & 7))
+        return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    sk::FirArgs a = fir_base(e);
+    a.in16 = d_pcm16;
+    if (d_out) {
+        a.out16 = d_out;
+        a.out16_stride = out_stride;
+        a.out16_ch = channels;
+    } else {
+        a.out = d_out32;
+        a.out_stride = out_stride;
+    }
+    a.in_block = SK_AAC_FRAME_LEN;
+    a.in_ch = channels;
+    a.in_block_stride = frame_stride;
+    a.in_group_stride = stream_stride;
+    a.rows = n_streams * channels;
+    a.in_frames = (uint32_t)samples;
+    a.out_count = n_out;
+    SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch fir (s16 frame-packed input, s16 output)");
     return SK_OK;
 }
 

@@ -325,6 +325,7 @@ hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s) {
     if (a.rows == 0 || a.out_count == 0) return hipSuccess;
     // SK_FIR_F32=1 keeps the f32-MFMA kernel below (A/B runs, profiles/r01_ab_fir.md)
     static const bool force_f32 = [] { const char *v = std::getenv("SK_FIR_F32"); return v && v[0] == '1'; }();
+    if (a.in16) return fir_bf16_supported(a) ? launch_fir_48k_16k_bf16(a, s) : hipErrorInvalidValue;  // s16 rows: bf16 kernel only
     if (!force_f32 && fir_bf16_supported(a)) return launch_fir_48k_16k_bf16(a, s);
     const uint32_t total_blocks = (a.out_count + 15) / 16;
     const uint32_t groups = (a.rows + 15) / 16;

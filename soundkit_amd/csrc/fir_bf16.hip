@@ -48,6 +48,11 @@ constexpr int kWindows = 10;                 // windows (K steps) per tile
 // 2^-24 of the peak cannot be told from f32 rounding: 41 MFMAs per tile instead of 60, the same error against an f64
 // evaluation to three digits (tests/test_fir_gpu.py holds the bound, tests/fir_split_model.py shows the budget).
 __device__ constexpr int kProducts[kWindows] = {1, 3, 6, 6, 6, 6, 6, 3, 3, 1};
+// s16 input (the worker's path: the resampler is fed float_sample_to_i16(x) / 32768, soundkit-decoder lib.rs:1793-1813,
+// 3563-3617): a 16-bit sample is exactly TWO bf16 values, x * 32768 = 256 a + b with a = s >> 8, b = s & 255, so the third
+// input plane and the product x3h1 do not exist -- 36 MFMAs per tile, two LDS planes, half the input bytes.  The factor
+// 2^-15 is applied to the accumulated sums (a power of two: it commutes with every rounding).
+__host__ __device__ constexpr int products_of(int s, bool in16) { return in16 && kProducts[s] > 5 ? 5 : kProducts[s]; }
 #ifndef SK_BF_AHEAD
 #define SK_BF_AHEAD 2
 #endif
@@ -80,17 +85,29 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &p1, uin
     p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
+// two s16 samples in one dword (the earlier one low) -> their two bf16 planes: p1 = 256 * (s >> 8), p2 = s & 255
+__device__ __forceinline__ void split_pair16(uint32_t u, uint32_t &p1, uint32_t &p2) {
+    const uint32_t m = u & 0xff00ff00u;
+    const float a0 = (float)(int)(int16_t)(m & 0xffffu), a1 = (float)((int)m >> 16);
+    const float b0 = (float)(u & 0xffu), b1 = (float)((u >> 16) & 0xffu);
+    p1 = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
+    p2 = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(b0), 0x07060302u);
+}
+
+template <bool IN16>
 struct Stage {
     // ALIGNED: load ld (0..3) of a chunk holds samples 4 (lane & 15) .. + 3 of row 4 ld + (lane >> 4)
     // otherwise: its word e holds sample `lane` of row 4 ld + e
     // a half-chunk = loads 2 half, 2 half + 1 (eight rows); it sits in slot pair v[2 slot], v[2 slot + 1]
-    const float *base[4];
+    using Elem = std::conditional_t<IN16, int16_t, float>;
+    using Vec = std::conditional_t<IN16, u32x2, f32x4>;  // four samples of a row
+    const Elem *base[4];
     uint32_t ok_mask;
-    f32x4 v[2 * kAhead];  // kAhead half-chunks (two loads each) in flight
+    Vec v[2 * kAhead];  // kAhead half-chunks (two loads each) in flight
 };
 
-template <bool ALIGNED, bool PACKED>
-__device__ __forceinline__ void stage_init(const FirArgs &a, int lane, uint32_t row0, Stage &st) {
+template <bool ALIGNED, bool PACKED, bool IN16>
+__device__ __forceinline__ void stage_init(const FirArgs &a, int lane, uint32_t row0, Stage<IN16> &st) {
     st.ok_mask = 0;
     if (ALIGNED) {
 #pragma unroll
@@ -98,15 +115,18 @@ __device__ __forceinline__ void stage_init(const FirArgs &a, int lane, uint32_t 
             const uint32_t r = row0 + 4 * ld + (lane >> 4);
             const bool ok = r < a.rows;  // rows past the end alias row 0: their results are never stored
             const uint32_t phys = a.row_map ? a.row_map[ok ? r : 0] : (ok ? r : 0);
-            st.base[ld] = a.in + row_base_offset<PACKED>(a, phys) + 4 * (lane & 15);
+            if constexpr (IN16) st.base[ld] = a.in16 + row_base_offset<PACKED>(a, phys) + 4 * (lane & 15);
+            else st.base[ld] = a.in + row_base_offset<PACKED>(a, phys) + 4 * (lane & 15);
             if (ok) st.ok_mask |= 1u << ld;
         }
     }
 }
 
 // issue the global loads of loads [ld0, ld1) of the chunk that starts at stream sample n (wave-uniform)
-template <bool ALIGNED, bool PACKED, bool INTERIOR = false>
-__device__ __forceinline__ void stage_issue(const FirArgs &a, int lane, uint32_t row0, int64_t n, Stage &st, int half, int slot) {
+template <bool ALIGNED, bool PACKED, bool INTERIOR = false, bool IN16 = false>
+__device__ __forceinline__ void stage_issue(const FirArgs &a, int lane, uint32_t row0, int64_t n, Stage<IN16> &st, int half, int slot) {
+    using Vec = typename Stage<IN16>::Vec;
+    using Elem = typename Stage<IN16>::Elem;
 #ifdef SK_BF_ABLATE_LOAD
 #pragma unroll
     for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(st.v[2 * slot + e]));
@@ -124,7 +144,7 @@ __device__ __forceinline__ void stage_issue(const FirArgs &a, int lane, uint32_t
 #pragma unroll
             for (int e2 = 0; e2 < 2; ++e2) {
                 const int ld = 2 * half + e2, sl = 2 * slot + e2;
-                st.v[sl] = *reinterpret_cast<const f32x4 *>(st.base[ld] + off);
+                st.v[sl] = *reinterpret_cast<const Vec *>(st.base[ld] + off);
             }
         } else {
             asm volatile("; chunk at an edge of the row" ::: "memory");  // a real branch: not if-converted into the loads above
@@ -135,11 +155,11 @@ __device__ __forceinline__ void stage_issue(const FirArgs &a, int lane, uint32_t
 #pragma unroll
             for (int e2 = 0; e2 < 2; ++e2) {
                 const int ld = 2 * half + e2, sl = 2 * slot + e2;
-                const float *src = ((sel >> ld) & 1u) ? st.base[ld] + off : a.zeros + 4 * lane;
-                st.v[sl] = *reinterpret_cast<const f32x4 *>(src);
+                const Elem *src = ((sel >> ld) & 1u) ? st.base[ld] + off : reinterpret_cast<const Elem *>(a.zeros) + 4 * lane;
+                st.v[sl] = *reinterpret_cast<const Vec *>(src);
             }
         }
-    } else {
+    } else if constexpr (!IN16) {  // s16 rows are only taken aligned (launch_fir_48k_16k_bf16 checks)
         const int64_t idx = n + lane - a.in_origin;
         const bool in_range = idx >= 0 && idx < (int64_t)a.in_frames;
         const size_t off = time_offset<PACKED>(a, (uint32_t)idx);
@@ -158,12 +178,19 @@ __device__ __forceinline__ void stage_issue(const FirArgs &a, int lane, uint32_t
 }
 
 // split loads [ld0, ld1) and write them to the ring at sample position `ring_at` (of the chunk's first sample)
-template <bool ALIGNED>
-__device__ __forceinline__ void stage_commit(unsigned char *lds, int lane, int ring_at, const Stage &st, int half, int slot) {
+template <bool ALIGNED, bool IN16>
+__device__ __forceinline__ void stage_commit(unsigned char *lds, int lane, int ring_at, const Stage<IN16> &st, int half, int slot) {
 #pragma unroll
     for (int e2 = 0; e2 < 2; ++e2) {
         const int ld = 2 * half + e2, sl = 2 * slot + e2;
-        if (ALIGNED) {
+        if constexpr (IN16) {
+            uint32_t p1a, p2a, p1b, p2b;
+            split_pair16(st.v[sl][0], p1a, p2a);
+            split_pair16(st.v[sl][1], p1b, p2b);
+            unsigned char *dst = lds + (4 * ld + (lane >> 4)) * kRowBytes + 2 * (ring_at + 4 * (lane & 15));
+            *reinterpret_cast<u32x2 *>(dst) = (u32x2){p1a, p1b};
+            *reinterpret_cast<u32x2 *>(dst + kPlaneBytes) = (u32x2){p2a, p2b};
+        } else if (ALIGNED) {
             uint32_t p1a, p2a, p3a, p1b, p2b, p3b;
 #ifdef SK_BF_ABLATE_SPLIT
             p1a = p2a = p3a = __float_as_uint(st.v[sl][0]) ^ __float_as_uint(st.v[sl][1]);
@@ -199,10 +226,12 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 &av, const u32x4 &bv, con
 }
 
 // OUT16: 0 = f32 rows out
-template <bool ALIGNED, bool PACKED, int OUT16>
+template <bool ALIGNED, bool PACKED, int OUT16, bool IN16 = false>
 __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t pair0, int32_t pair_end, int32_t pairs_per_seg,
                                                             uint32_t n_segs, int out_vec) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * kPlaneBytes];
+    static_assert(!IN16 || ALIGNED, "s16 rows are read four samples at a time");
+    constexpr int kPlanes = IN16 ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kPlanes * kPlaneBytes];
 
     const int lane = threadIdx.x;
     const int j = lane & 15, q = lane >> 4;
@@ -230,8 +259,8 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
             for (int k = 0; k < 3; ++k) af[s][k] = src[(s * 3 + k) * 64 + lane];
     }
 
-    Stage st;
-    stage_init<ALIGNED, PACKED>(a, lane, row0, st);
+    Stage<IN16> st;
+    stage_init<ALIGNED, PACKED, IN16>(a, lane, row0, st);
 
     // body-relative time rho = n - 96 P0 (P0 = first period of an unrolled body of four): the ring index of rho is
     // static because 4 periods = 384 samples = 2 ring revolutions
@@ -239,13 +268,13 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
     // the ring starts with rho in [-128, 0) in place and the half-chunks that the first kAhead steps commit in flight
 #pragma unroll
     for (int c = -2; c < 0; ++c) {
-        stage_issue<ALIGNED, PACKED>(a, lane, row0, n_begin + 64 * c, st, 0, 0);
-        stage_issue<ALIGNED, PACKED>(a, lane, row0, n_begin + 64 * c, st, 1, 1);
-        stage_commit<ALIGNED>(lds, lane, ring_index(64 * c), st, 0, 0);
-        stage_commit<ALIGNED>(lds, lane, ring_index(64 * c), st, 1, 1);
+        stage_issue<ALIGNED, PACKED, false, IN16>(a, lane, row0, n_begin + 64 * c, st, 0, 0);
+        stage_issue<ALIGNED, PACKED, false, IN16>(a, lane, row0, n_begin + 64 * c, st, 1, 1);
+        stage_commit<ALIGNED, IN16>(lds, lane, ring_index(64 * c), st, 0, 0);
+        stage_commit<ALIGNED, IN16>(lds, lane, ring_index(64 * c), st, 1, 1);
     }
 #pragma unroll
-    for (int i = 0; i < kAhead; ++i) stage_issue<ALIGNED, PACKED>(a, lane, row0, n_begin + 64 * (i >> 1), st, i & 1, i % kAhead);
+    for (int i = 0; i < kAhead; ++i) stage_issue<ALIGNED, PACKED, false, IN16>(a, lane, row0, n_begin + 64 * (i >> 1), st, i & 1, i % kAhead);
 
     const uint32_t out_row = row0 + j;
     float *out_ptr = OUT16 ? nullptr
@@ -259,7 +288,7 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
         BFrag f;
         const unsigned char *src = (ring_index(rho) + 32 > kRing ? b_base_wrap : b_base) + 2 * ring_index(rho);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) f.p[p] = *reinterpret_cast<const u32x4 *>(src + p * kPlaneBytes);
+        for (int p = 0; p < kPlanes; ++p) f.p[p] = *reinterpret_cast<const u32x4 *>(src + p * kPlaneBytes);
         return f;
     };
 
@@ -268,7 +297,8 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
     float *out_lane = to_s16 ? nullptr : out_ptr + 4 * q;
     // s16: the lane of a stream's first channel writes the interleaved frames of all its channels
     int16_t *out16_ptr = to_s16 ? a.out16 + (size_t)((row_exists ? out_row : 0) / (OUT16 ? OUT16 : 1)) * a.out16_stride * OUT16 : nullptr;
-    auto store_tile = [&](auto itag, const f32x4 &v, int32_t pair, int parity) __attribute__((always_inline)) {
+    auto store_tile = [&](auto itag, const f32x4 &vraw, int32_t pair, int parity) __attribute__((always_inline)) {
+        const f32x4 v = IN16 ? vraw * (1.0f / 32768.0f) : vraw;  // the samples went in as integers
         // INTERIOR: every tile of the body lies inside the segment and the output range, all 16 rows exist, stores are
         // vector stores -- no branch, so a whole body is one scheduling region
         constexpr bool INTERIOR = decltype(itag)::value;
@@ -353,9 +383,9 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
                 // the scheduler works on one step at a time: across a whole branch-free body it hoists loads and LDS reads
                 // far enough to spill
                 __builtin_amdgcn_sched_barrier(0);
-                stage_commit<ALIGNED>(lds, lane, ring_index(64 * (step >> 1)), st, step & 1, step % kAhead);
-                stage_issue<ALIGNED, PACKED, INTERIOR>(a, lane, row0, n_body + 64 * ((step + kAhead) >> 1), st,
-                                                       (step + kAhead) & 1, step % kAhead);
+                stage_commit<ALIGNED, IN16>(lds, lane, ring_index(64 * (step >> 1)), st, step & 1, step % kAhead);
+                stage_issue<ALIGNED, PACKED, INTERIOR, IN16>(a, lane, row0, n_body + 64 * ((step + kAhead) >> 1), st,
+                                                             (step + kAhead) & 1, step % kAhead);
             }
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
@@ -371,7 +401,7 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const int s = 3 * d + wi;
-                        if (s >= kWindows || prod >= kProducts[s]) continue;
+                        if (s >= kWindows || prod >= products_of(s, IN16)) continue;
                         f32x4 &c = acc[par][(K - d + 4) & 3];
                         if (s == 0 && prod == 0) c = mfma_bf16(af[s][hk[prod]], bcur.p[xk[prod]], (f32x4){0.f, 0.f, 0.f, 0.f});
                         else c = mfma_bf16(af[s][hk[prod]], bcur.p[xk[prod]], c);
@@ -397,7 +427,7 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
                 int mfmas = 0;
 #pragma unroll
                 for (int d = 0; d < 4; ++d)
-                    if (3 * d + wi < kWindows) mfmas += 2 * kProducts[3 * d + wi];
+                    if (3 * d + wi < kWindows) mfmas += 2 * products_of(3 * d + wi, IN16);
 #pragma unroll
                 for (int g = 0; g < mfmas; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
@@ -472,7 +502,8 @@ hipError_t launch_fir_48k_16k_bf16(const FirArgs &a, hipStream_t s) {
 
     const bool strides_ok = a.in_block ? (a.in_block % 4 == 0 && a.in_block_stride % 4 == 0 && a.in_group_stride % 4 == 0)
                                        : (a.in_stride % 4 == 0);
-    const bool aligned = ((a.in_origin & 3) == 0) && strides_ok && (a.in_frames % 4 == 0) && (((uintptr_t)a.in & 15) == 0);
+    const bool aligned = ((a.in_origin & 3) == 0) && strides_ok && (a.in_frames % 4 == 0) &&
+                         (a.in16 ? (((uintptr_t)a.in16 & 7) == 0) : (((uintptr_t)a.in & 15) == 0));
     if (a.out16 && (a.out16_ch < 1 || a.out16_ch > 2 || a.out_off || a.rows % a.out16_ch)) return hipErrorInvalidValue;
     const int out_vec = a.out16 ? ((a.out_first % 4 == 0) && (a.out16_stride * a.out16_ch) % 8 == 0 && (((uintptr_t)a.out16 & 15) == 0))
                                 : ((a.out_first % 4 == 0) && (a.out_stride % 4 == 0) && (((uintptr_t)a.out & 15) == 0) &&
@@ -483,7 +514,15 @@ hipError_t launch_fir_48k_16k_bf16(const FirArgs &a, hipStream_t s) {
 #define SK_FIR_LAUNCH(AL, PK, O16)                                                                                 \
     hipLaunchKernelGGL((k_fir_48k_16k_bf16<AL, PK, O16>), grid, block, 0, s, a, (int32_t)first_pair, (int32_t)end_pair, \
                        (int32_t)pps, n_segs, out_vec)
-    if (a.out16) {  // the fused 16-bit output exists for the frame-packed input of the synthesis kernel
+    if (a.in16) {  // planar s16 from the synthesis kernel: frame-packed, aligned
+        if (!packed || !aligned) return hipErrorInvalidValue;
+        if (!a.out16) hipLaunchKernelGGL((k_fir_48k_16k_bf16<true, true, 0, true>), grid, block, 0, s, a, (int32_t)first_pair,
+                                         (int32_t)end_pair, (int32_t)pps, n_segs, out_vec);
+        else if (a.out16_ch == 2) hipLaunchKernelGGL((k_fir_48k_16k_bf16<true, true, 2, true>), grid, block, 0, s, a, (int32_t)first_pair,
+                                                (int32_t)end_pair, (int32_t)pps, n_segs, out_vec);
+        else hipLaunchKernelGGL((k_fir_48k_16k_bf16<true, true, 1, true>), grid, block, 0, s, a, (int32_t)first_pair, (int32_t)end_pair,
+                                (int32_t)pps, n_segs, out_vec);
+    } else if (a.out16) {  // the fused 16-bit output exists for the frame-packed input of the synthesis kernel
         if (!packed) return hipErrorInvalidValue;
         if (aligned && a.out16_ch == 2) SK_FIR_LAUNCH(true, true, 2);
         else if (aligned) SK_FIR_LAUNCH(true, true, 1);

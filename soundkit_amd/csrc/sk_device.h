@@ -32,6 +32,7 @@ struct SynthTables {
 struct SynthArgs {
     const float *coeffs;
     float *pcm;
+    int16_t *pcm16;       // non-null: planar s16 out instead of `pcm` (same off1024 packing, 1024 i16 per channel-frame)
     float *delay;         // [states][1024]
     uint8_t *prev_shape;  // [states]
     const SynthTask *tasks;
@@ -96,6 +97,7 @@ __device__ __forceinline__ int dev_float_sample_to_i16_f32(float x) {
 
 struct FirArgs {
     const float *in;      // [rows][in_stride]
+    const int16_t *in16;  // non-null (fir_bf16.hip only): the rows are s16, sample value s / 32768 -- same indexing as `in`
     float *out;           // [rows][out_stride]
     // fused s16 output (out == nullptr): the worker's f32_channels_to_bytes for 16 bits, interleaved over out16_ch
     // adjacent rows (1: each row its own mono stream; 2: rows 2k / 2k+1 are L / R of stream k)

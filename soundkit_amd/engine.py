@@ -87,6 +87,11 @@ class Plan:
         check(lib.sk_aac_plan_run_f32_dev(self.engine._h, self._h, _ptr(d_coeffs), _ptr(d_pcm)),
               "sk_aac_plan_run_f32_dev", self.engine._h)
 
+    def run_s16_planar(self, d_coeffs, d_pcm16):
+        """planar s16 PCM (float_sample_to_i16 of every sample), same packing as run_f32's output"""
+        check(lib.sk_aac_plan_run_s16_planar_dev(self.engine._h, self._h, _ptr(d_coeffs), _ptr(d_pcm16)),
+              "sk_aac_plan_run_s16_planar_dev", self.engine._h)
+
     def run_s16(self, d_coeffs, d_pcm):
         check(lib.sk_aac_plan_run_s16_dev(self.engine._h, self._h, _ptr(d_coeffs), _ptr(d_pcm)),
               "sk_aac_plan_run_s16_dev", self.engine._h)
@@ -316,6 +321,23 @@ class Engine:
         check(lib.sk_downsample_48k_16k_frames_s16_dev(self._h, _ptr(d_pcm), stream_stride, frame_stride, channels, n_streams,
                                                        frames_per_stream, _ptr(d_out), out_stride, C.byref(got)),
               "sk_downsample_48k_16k_frames_s16_dev", self._h)
+        return got.value
+
+    def downsample_48k_16k_frames_s16_to_s16_dev(self, d_pcm16, stream_stride, frame_stride, channels, n_streams, frames_per_stream,
+                                                 d_out, out_stride):
+        """the worker's resample step on planar s16 PCM (Plan.run_s16_planar): d_out [n_streams][out_stride][channels] int16"""
+        got = C.c_uint32()
+        check(lib.sk_downsample_48k_16k_frames_s16_to_s16_dev(self._h, _ptr(d_pcm16), stream_stride, frame_stride, channels,
+                                                              n_streams, frames_per_stream, _ptr(d_out), out_stride, C.byref(got)),
+              "sk_downsample_48k_16k_frames_s16_to_s16_dev", self._h)
+        return got.value
+
+    def downsample_48k_16k_frames_s16_to_f32_dev(self, d_pcm16, stream_stride, frame_stride, channels, n_streams, frames_per_stream,
+                                                 d_out, out_stride):
+        got = C.c_uint32()
+        check(lib.sk_downsample_48k_16k_frames_s16_to_f32_dev(self._h, _ptr(d_pcm16), stream_stride, frame_stride, channels,
+                                                              n_streams, frames_per_stream, _ptr(d_out), out_stride, C.byref(got)),
+              "sk_downsample_48k_16k_frames_s16_to_f32_dev", self._h)
         return got.value
 
     def downsample_48k_16k_frames_dev(self, d_pcm, stream_stride, frame_stride, channels, n_streams, frames_per_stream,

@@ -1,0 +1,194 @@
+"""The worker's decode -> resample data flow kept in 16 bits on the device, as the reference has it: the AAC decoder's
+output is s16 (decode_aac_access_unit, soundkit-decoder lib.rs:1793-1813), apply_output_options turns it back into
+f32 = s / 32768 (audio_data_to_f32_channels, lib.rs:3563-3617), resamples and narrows again (lib.rs:3619-3647).
+
+  sk_aac_plan_run_s16_planar_dev           synthesis kernel writing float_sample_to_i16(x), planar
+  sk_downsample_48k_16k_frames_s16_to_*    the bf16-matrix FIR reading those integers (two bf16 planes, 36 products)
+"""
+import numpy as np
+import pytest
+
+import soundkit_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def make_batch(engine, oracle, layout, ch, n_streams, n_frames, gain=2500.0):
+    coeffs = np.empty((n_streams, n_frames, ch, 1024), np.float32)
+    for s in range(n_streams):
+        for f in range(n_frames):
+            for c in range(ch):
+                coeffs[s, f, c] = oracle.seeded_spectrum(1024, 0x12345678 + 977 * s + 2 * f + c) * np.float32(gain)
+    seq_chain = [0, 1, 2, 3, 0, 0]
+    seqs = np.zeros((n_streams, n_frames, 2), np.uint8)
+    shapes = np.zeros((n_streams, n_frames, 2), np.uint8)
+    for s in range(n_streams):
+        for f in range(n_frames):
+            seqs[s, f] = seq_chain[(f + s) % 6] if s % 2 else 0
+            shapes[s, f] = (f + s) & 1
+    sids = np.array([engine.open_stream(48000, ch) for _ in range(n_streams)], np.uint32)
+    if layout == "frame":
+        order = [(s, f) for f in range(n_frames) for s in range(n_streams)]
+        strides = (ch * 1024, n_streams * ch * 1024)
+    else:
+        order = [(s, f) for s in range(n_streams) for f in range(n_frames)]
+        strides = (n_frames * ch * 1024, ch * 1024)
+    packed = np.stack([coeffs[s, f] for s, f in order])
+    descs, n = soundkit_amd.descs_from_arrays([sids[s] for s, f in order], ch, [seqs[s, f] for s, f in order],
+                                              [shapes[s, f] for s, f in order])
+    return coeffs, seqs, shapes, sids, order, strides, packed, descs, n
+
+
+@pytest.mark.parametrize("layout", ["frame", "stream"])
+@pytest.mark.parametrize("ch", [1, 2])
+def test_planar_s16_synthesis_is_the_rounded_f32_synthesis(engine, oracle, layout, ch):
+    """every window sequence and shape pair; the s16 kernel output equals float_sample_to_i16 applied (by the oracle) to
+    the f32 kernel's output of the same frames, bit for bit, and the carried state is the same afterwards"""
+    import torch
+    n_streams, n_frames = 6, 6
+    coeffs, seqs, shapes, sids, order, strides, packed, descs, n = make_batch(engine, oracle, layout, ch, n_streams, n_frames, 9000.0)
+    plan = engine.plan(descs, n)
+    d_coeffs = torch.from_numpy(packed).cuda()
+    d_f32 = torch.empty_like(d_coeffs)
+    d_s16 = torch.zeros(d_coeffs.shape, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    plan.run_f32(d_coeffs, d_f32)
+    engine.synchronize()
+    state_f32 = [engine.get_state(int(sid), ch) for sid in sids]
+    for sid in sids:
+        engine.reset_stream(int(sid))
+    plan.run_s16_planar(d_coeffs, d_s16)
+    engine.synchronize()
+    f32 = d_f32.cpu().numpy()
+    want = oracle.pcm_convert("FLOAT_TO_I16_ROUND", f32.ravel()).reshape(f32.shape)
+    got = d_s16.cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.abs(got).max() == 32767 or np.abs(got.astype(np.int32)).max() > 20000   # loud enough to reach the clamp region
+    for sid, (delay, shape) in zip(sids, state_f32):
+        d2, s2 = engine.get_state(int(sid), ch)
+        assert np.array_equal(d2, delay) and np.array_equal(s2, shape)
+    plan.destroy()
+    for sid in sids:
+        engine.close_stream(int(sid))
+
+
+@pytest.mark.parametrize("ch,n_streams,n_frames,layout", [(2, 37, 5, "stream"), (1, 21, 3, "frame"), (2, 16, 7, "frame"), (1, 33, 4, "stream")])
+def test_fir_on_s16_rows(engine, oracle, ch, n_streams, n_frames, layout):
+    """random full-range s16 rows (extremes included): the f32 result against the filter evaluated in f64 on s / 32768
+    (<= 1e-6 relative RMS, north_star), against the oracle's f32 chain, and the s16 result = float_sample_to_i16 of it"""
+    import torch
+    rng = np.random.default_rng(11 + ch + n_streams)
+    x = rng.integers(-32768, 32768, (n_streams, n_frames, ch, 1024), dtype=np.int64).astype(np.int16)
+    x[0, 0, 0, :6] = [32767, -32768, 0, 1, -1, 255]
+    if layout == "frame":
+        packed = np.ascontiguousarray(x.transpose(1, 0, 2, 3))
+        strides = (ch * 1024, n_streams * ch * 1024)
+    else:
+        packed = x
+        strides = (n_frames * ch * 1024, ch * 1024)
+    d_in = torch.from_numpy(packed).cuda()
+    n_out = engine.downsample_out_frames(n_frames * 1024)
+    f_stride = (n_out + 3) // 4 * 4
+    o_stride = (n_out + 7) // 8 * 8
+    d_f32 = torch.zeros((n_streams * ch, f_stride), device="cuda")
+    d_s16 = torch.zeros((n_streams, o_stride, ch), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    assert engine.downsample_48k_16k_frames_s16_to_f32_dev(d_in, strides[0], strides[1], ch, n_streams, n_frames, d_f32, f_stride) == n_out
+    assert engine.downsample_48k_16k_frames_s16_to_s16_dev(d_in, strides[0], strides[1], ch, n_streams, n_frames, d_s16, o_stride) == n_out
+    engine.synchronize()
+    taps = engine.taps().astype(np.float64)
+    got = d_f32.cpu().numpy()[:, :n_out].reshape(n_streams, ch, n_out)
+    s16 = d_s16.cpu().numpy()
+    assert not s16[:, n_out:].any()
+    worst64 = worst32 = 0.0
+    for s in range(n_streams):
+        rows = x[s].transpose(1, 0, 2).reshape(ch, n_frames * 1024).astype(np.float32) / np.float32(32768.0)
+        want32 = oracle.downsample_planar(rows, 48000, 16000)
+        padded = np.concatenate([np.zeros((ch, 125)), rows.astype(np.float64), np.zeros((ch, 256))], axis=1)
+        want64 = np.stack([[np.dot(taps, padded[c, 3 * m:3 * m + 256]) for m in range(n_out)] for c in range(ch)])
+        rms = np.sqrt(np.mean(want64 ** 2))
+        worst64 = max(worst64, np.sqrt(np.mean((got[s] - want64) ** 2)) / rms)
+        worst32 = max(worst32, np.sqrt(np.mean((got[s] - want32.astype(np.float64)) ** 2)) / rms)
+        assert np.array_equal(s16[s, :n_out], oracle.planar_f32_to_s16_interleaved(got[s]).reshape(n_out, ch))
+        d = np.abs(s16[s, :n_out].astype(np.int32) - oracle.planar_f32_to_s16_interleaved(want32).reshape(n_out, ch))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01
+    assert worst64 < 1e-6 and worst32 < 1e-6, (worst64, worst32)
+
+
+@pytest.mark.parametrize("layout", ["frame", "stream"])
+@pytest.mark.parametrize("ch", [1, 2])
+def test_s16_chain_matches_the_oracle_chain(engine, oracle, layout, ch):
+    import torch
+    n_streams, n_frames = 5, 6
+    coeffs, seqs, shapes, sids, order, strides, packed, descs, n = make_batch(engine, oracle, layout, ch, n_streams, n_frames)
+    plan = engine.plan(descs, n)
+    d_coeffs = torch.from_numpy(packed).cuda()
+    d_pcm16 = torch.zeros(d_coeffs.shape, dtype=torch.int16, device="cuda")
+    n_out = engine.downsample_out_frames(n_frames * 1024)
+    o_stride = (n_out + 7) // 8 * 8
+    d_out = torch.zeros((n_streams, o_stride, ch), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    plan.run_s16_planar(d_coeffs, d_pcm16)
+    assert engine.downsample_48k_16k_frames_s16_to_s16_dev(d_pcm16, strides[0], strides[1], ch, n_streams, n_frames, d_out, o_stride) == n_out
+    engine.synchronize()
+    out = d_out.cpu().numpy()
+    differing = total = 0
+    for s in range(n_streams):
+        pcm, _ = oracle.synthesize_stream(coeffs[s], seqs[s], shapes[s])
+        planar = np.ascontiguousarray(pcm.transpose(1, 0, 2).reshape(ch, n_frames * 1024))
+        q = oracle.pcm_convert("FLOAT_TO_I16_ROUND", planar.ravel()).reshape(planar.shape).astype(np.float32) / np.float32(32768.0)
+        want = oracle.planar_f32_to_s16_interleaved(oracle.downsample_planar(q, 48000, 16000)).reshape(n_out, ch)
+        d = np.abs(out[s, :n_out].astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1, (s, int(d.max()))
+        differing, total = differing + int((d > 0).sum()), total + d.size
+        assert np.abs(want).max() > 100
+    assert differing <= 0.01 * total
+    plan.destroy()
+    for sid in sids:
+        engine.close_stream(int(sid))
+
+
+def test_full_size_s16_chain_spot_checked_against_oracle(oracle):
+    """bench.py's default workload at full size (4096 streams x 64 stereo frames, frame-major): three streams restated on the CPU"""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    n_streams, n_frames, ch = 4096, 64, 2
+    eng = soundkit_amd.Engine(0, n_streams)
+    try:
+        coeffs = bench.seeded_spectra(torch, torch.device("cuda:0"), n_streams, n_frames, ch) * bench.SPECTRUM_GAIN
+        picked = [0, 2049, 4095]
+        host = {s: coeffs.view(n_streams, n_frames, ch, 1024)[s].cpu().numpy() for s in picked}
+        packed = coeffs.view(n_streams, n_frames, ch, 1024).transpose(0, 1).contiguous().view(-1, ch, 1024)
+        del coeffs
+        sids = np.array([eng.open_stream(48000, ch) for _ in range(n_streams)], np.uint32)
+        shape_of_frame = (np.arange(n_frames) & 1).astype(np.uint8)
+        descs, n = soundkit_amd.descs_from_arrays(np.tile(sids, n_frames), ch, np.zeros((n_streams * n_frames, 2), np.uint8),
+                                                  np.repeat(shape_of_frame, n_streams)[:, None].repeat(2, 1))
+        plan = eng.plan(descs, n)
+        pcm16 = torch.zeros(packed.shape, dtype=torch.int16, device="cuda")
+        n_out = eng.downsample_out_frames(n_frames * 1024)
+        stride = (n_out + 7) // 8 * 8
+        out = torch.zeros((n_streams, stride, ch), dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        plan.run_s16_planar(packed, pcm16)
+        got = eng.downsample_48k_16k_frames_s16_to_s16_dev(pcm16, ch * 1024, n_streams * ch * 1024, ch, n_streams, n_frames, out, stride)
+        eng.synchronize()
+        assert got == n_out
+        seqs = np.zeros((n_frames, 2), np.uint8)
+        shapes = np.repeat(shape_of_frame[:, None], 2, 1)
+        for s in picked:
+            ref_pcm, _ = oracle.synthesize_stream(host[s], seqs, shapes)
+            planar = np.ascontiguousarray(ref_pcm.transpose(1, 0, 2).reshape(ch, n_frames * 1024))
+            q = oracle.pcm_convert("FLOAT_TO_I16_ROUND", planar.ravel()).reshape(planar.shape).astype(np.float32) / np.float32(32768.0)
+            want = oracle.planar_f32_to_s16_interleaved(oracle.downsample_planar(q, 48000, 16000)).reshape(n_out, ch)
+            mine = out[s, :n_out].cpu().numpy()
+            d = np.abs(mine.astype(np.int32) - want.astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 0.01, (s, int(d.max()), float((d > 0).mean()))
+            assert np.abs(mine).max() > 100
+        assert not out[:, n_out:].any()
+        plan.destroy()
+    finally:
+        eng.close()
