@@ -544,6 +544,184 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
     if (lane == 0) a.prev_shape[state] = (uint8_t)prev_shape;
 }
 
+// ---- OnlyLong channels, frames in parallel -------------------------------------------------------------------------------
+// The walking kernel above keeps a channel's overlap in registers by giving the whole channel to one long-lived wave;
+// what it pays is the shape: thousands of waves each creeping through their own 4 KiB pieces stream at ~5.1 TB/s on this
+// part where a grid of short-lived blocks sweeping memory in address order reaches 6.2 (tools/probe/stream_probe.hip).
+// The overlap is not a recurrence -- delay_e depends on X_e alone (dsp.rs:267-279) -- so a channel can be cut anywhere at
+// the price of transforming the frame before the cut once more.  Here a workgroup of kGroupWaves waves takes
+// kGroupFrames = 2 kGroupWaves - 1 consecutive OnlyLong frames of one channel: wave w transforms the frames A = 2w - 1
+// and B = 2w of the group (A of wave 0 is the frame BEFORE the group, kept only for its second half -- or the channel's
+// carried state when the group opens the launch).  B's overlap is A's second half, in registers; A's is the second half
+// of the previous wave's B, handed over through LDS behind the block's one barrier.  The wave that holds the channel's
+// last frame writes the new state to `delay_next` / `shape_next` (another group of the same channel may not have read the
+// old state yet); k_commit_state moves it over.
+#ifndef SK_GROUP_MINW
+#define SK_GROUP_MINW 3
+#endif
+constexpr int kGroupWaves = 8;
+constexpr int kGroupFrames = 2 * kGroupWaves - 1;
+
+template <bool OUT16>
+__global__ __launch_bounds__(kGroupWaves * 64, SK_GROUP_MINW) void k_aac_synth_group(SynthArgs a, const SynthGroup *groups, float *delay_next,
+                                                                          uint8_t *shape_next) {
+    __shared__ f2 lds[kGroupWaves][kExchange];
+    __shared__ f2 tw_tab[512];
+    __shared__ f2 t64_tab[64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 512; i += kGroupWaves * 64) tw_tab[i] = reinterpret_cast<const f2 *>(a.t.tw_long)[i];
+    if (threadIdx.x < 64) t64_tab[threadIdx.x] = reinterpret_cast<const f2 *>(a.t.w64)[((threadIdx.x >> 3) * (threadIdx.x & 7)) & 63];
+
+    const SynthGroup g = groups[blockIdx.x];
+    const SynthTask task = a.tasks[g.task];
+    const uint32_t first = __builtin_amdgcn_readfirstlane(g.first), n_out = __builtin_amdgcn_readfirstlane(g.count);
+    const uint32_t state = __builtin_amdgcn_readfirstlane(task.state), t_count = __builtin_amdgcn_readfirstlane(task.count);
+    const SynthEntry *entries = a.entries + __builtin_amdgcn_readfirstlane(task.begin);
+    lds_f2 *ex = (lds_f2 *)lds[wave];
+    const lds_f2 *tw_lds = (const lds_f2 *)tw_tab;
+    const lds_f2 *t64 = (const lds_f2 *)t64_tab;
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+
+    // frame A: output 2w - 1 of the group (wave 0: the frame before it, or the carried state); frame B: output 2w
+    const bool from_state = wave == 0 && first == 0;
+    const bool a_active = wave == 0 ? first > 0 : (uint32_t)(2 * wave - 1) < n_out;
+    const bool b_active = (uint32_t)(2 * wave) < n_out;
+    const uint32_t ea = first + 2u * (uint32_t)wave - 1u, eb = ea + 1u;  // entries of A and B (when active)
+    f2 xa[8], xb[8];
+    uint32_t win_a = 0, win_b = 0;
+    size_t off_a = 0, off_b = 0;
+    if (a_active) {
+        const SynthEntry ent = entries[ea];
+        win_a = __builtin_amdgcn_readfirstlane(ent.win);
+        off_a = (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024;
+        const float *src = a.coeffs + off_a + 2 * lane;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xa[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
+    }
+    if (b_active) {
+        const SynthEntry ent = entries[eb];
+        win_b = __builtin_amdgcn_readfirstlane(ent.win);
+        off_b = (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024;
+        const float *src = a.coeffs + off_b + 2 * lane;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xb[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
+    }
+    const int shape_a = (win_a >> 2) & 1, shape_b = (win_b >> 2) & 1;
+    // the window shape before A: the entry before it, or the carried shape at the start of the launch
+    int shape_before_a = 0;
+    if (a_active && wave >= 1)
+        shape_before_a = ea > 0 ? (int)((__builtin_amdgcn_readfirstlane(entries[ea - 1].win) >> 2) & 1u)
+                                : __builtin_amdgcn_readfirstlane((int)a.prev_shape[state]);
+    const int shape_before_b = from_state ? __builtin_amdgcn_readfirstlane((int)a.prev_shape[state]) : shape_a;
+    float da[16];  // A's windowed second half (or the carried state): B's overlap
+    if (from_state) {
+        const float *delay_ptr = a.delay + (size_t)state * 1024;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 4 * lane + 256 * r;
+            const f4 f = *reinterpret_cast<const f4 *>(delay_ptr + j);
+            const f4 m = *reinterpret_cast<const f4 *>(delay_ptr + 1020 - j);
+            da[8 * r + 0] = f.x; da[8 * r + 1] = f.y; da[8 * r + 2] = f.z; da[8 * r + 3] = f.w;
+            da[8 * r + 4] = m.x; da[8 * r + 5] = m.y; da[8 * r + 6] = m.z; da[8 * r + 7] = m.w;
+        }
+    }
+    __syncthreads();  // twiddles in place
+    const f2 base2 = reinterpret_cast<const f2 *>(a.t.w512)[hi3 * lo3];
+
+    // one frame: first half x W1 -> o, second half x W2 -> d, at this lane's 16 positions (the walking kernel's products,
+    // in its order: dsp.rs:516-531)
+    auto transform = [&](const f2 (&xin)[8], int prev_shape, int shape, float (&o)[16], float (&d)[16]) __attribute__((always_inline)) {
+        const float *w1 = a.t.win + 2048 * prev_shape, *w2 = a.t.win + 2048 * shape + 1024;
+        f4 w1f[2], w1m[2], w2f[2], w2m[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 4 * lane + 256 * r;
+            w1f[r] = *reinterpret_cast<const f4 *>(w1 + j);
+            w1m[r] = *reinterpret_cast<const f4 *>(w1 + 1020 - j);
+            w2f[r] = *reinterpret_cast<const f4 *>(w2 + j);
+            w2m[r] = *reinterpret_cast<const f4 *>(w2 + 1020 - j);
+        }
+        f2 z[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {  // pre-twiddle (dsp.rs:495-503)
+            const float even = xin[r].x;
+            const float odd = -__shfl(xin[7 - r].y, 63 - lane);
+            const f2 t = tw_lds[lane + 64 * r];
+            z[r] = (f2){odd * t.y - even * t.x, odd * t.x + even * t.y};
+        }
+        fft512(z, ex, t64, base2, lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ex[lane + 64 * j] = cmul(tw_lds[lane + 64 * j], (f2){z[j].x, -z[j].y});
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int q = 2 * lane + 128 * r;
+            const f4 F = *reinterpret_cast<const lds_f4 *>(&ex[256 + q]);
+            const f4 M = *reinterpret_cast<const lds_f4 *>(&ex[254 - q]);
+            const f4 W1f = w1f[r], W1m = w1m[r], W2f = w2f[r], W2m = w2m[r];
+            o[8 * r + 0] = -F.x * W1f.x; o[8 * r + 1] = -M.w * W1f.y; o[8 * r + 2] = -F.z * W1f.z; o[8 * r + 3] = -M.y * W1f.w;
+            o[8 * r + 4] = M.y * W1m.x; o[8 * r + 5] = F.z * W1m.y; o[8 * r + 6] = M.w * W1m.z; o[8 * r + 7] = F.x * W1m.w;
+            d[8 * r + 0] = F.y * W2f.x; d[8 * r + 1] = M.z * W2f.y; d[8 * r + 2] = F.w * W2f.z; d[8 * r + 3] = M.x * W2f.w;
+            d[8 * r + 4] = M.x * W2m.x; d[8 * r + 5] = F.w * W2m.y; d[8 * r + 6] = M.z * W2m.z; d[8 * r + 7] = F.y * W2m.w;
+        }
+        wave_sync();
+    };
+    auto store_pcm = [&](size_t off, const float (&o)[16], const float (&p)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 4 * lane + 256 * r;
+            const f4 f = (f4){o[8 * r + 0] + p[8 * r + 0], o[8 * r + 1] + p[8 * r + 1], o[8 * r + 2] + p[8 * r + 2], o[8 * r + 3] + p[8 * r + 3]};
+            const f4 m = (f4){o[8 * r + 4] + p[8 * r + 4], o[8 * r + 5] + p[8 * r + 5], o[8 * r + 6] + p[8 * r + 6], o[8 * r + 7] + p[8 * r + 7]};
+            if (OUT16) {
+                SK_SYNTH_STORE(pack4_s16(f), reinterpret_cast<u2 *>(a.pcm16 + off + j));
+                SK_SYNTH_STORE(pack4_s16(m), reinterpret_cast<u2 *>(a.pcm16 + off + 1020 - j));
+            } else {
+                SK_SYNTH_STORE(f, reinterpret_cast<f4 *>(a.pcm + off + j));
+                SK_SYNTH_STORE(m, reinterpret_cast<f4 *>(a.pcm + off + 1020 - j));
+            }
+        }
+    };
+    auto store_state = [&](const float (&d)[16], int shape) __attribute__((always_inline)) {
+        float *dst = delay_next + (size_t)state * 1024;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 4 * lane + 256 * r;
+            *reinterpret_cast<f4 *>(dst + j) = (f4){d[8 * r + 0], d[8 * r + 1], d[8 * r + 2], d[8 * r + 3]};
+            *reinterpret_cast<f4 *>(dst + 1020 - j) = (f4){d[8 * r + 4], d[8 * r + 5], d[8 * r + 6], d[8 * r + 7]};
+        }
+        if (lane == 0) shape_next[state] = (uint8_t)shape;
+    };
+
+    float oa[16], ob[16], db[16];
+    if (a_active) {
+        transform(xa, shape_before_a, shape_a, oa, da);
+        if (ea + 1 == t_count) store_state(da, shape_a);
+    }
+    if (b_active) {
+        transform(xb, shape_before_b, shape_b, ob, db);
+        store_pcm(off_b, ob, da);
+        if (eb + 1 == t_count) store_state(db, shape_b);
+        write_positions((lds_f *)ex, lane, db);  // the next wave's A overlaps with this
+    }
+    __syncthreads();
+    if (!a_active || wave == 0) return;
+    float prev[16];
+    read_positions((const lds_f *)lds[wave - 1], lane, prev);
+    store_pcm(off_a, oa, prev);
+}
+
+// the states the group kernel left in delay_next / shape_next become the channels' carried states
+__global__ __launch_bounds__(256) void k_commit_state(const SynthTask *tasks, const uint32_t *task_ids, uint32_t n, float *delay,
+                                                      const float *delay_next, uint8_t *shape, const uint8_t *shape_next) {
+    const uint32_t k = blockIdx.x;
+    if (k >= n) return;
+    const uint32_t state = tasks[task_ids[k]].state;
+    reinterpret_cast<f4 *>(delay + (size_t)state * 1024)[threadIdx.x] = reinterpret_cast<const f4 *>(delay_next + (size_t)state * 1024)[threadIdx.x];
+    if (threadIdx.x == 0) shape[state] = shape_next[state];
+}
+
 // planar f32 [ch][1024] -> interleaved i16 [1024][ch] with float_sample_to_i16
 // (soundkit-decoder/src/lib.rs:1793-1827): non-finite -> 0, clamp +-1, f64 scale by 32768
 // (negative) or 32767, round half away from zero, clamp.
@@ -620,6 +798,18 @@ hipError_t launch_aac_synth(const SynthArgs &a, hipStream_t s) {
     else hipLaunchKernelGGL(k_aac_synth<false>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
     return hipGetLastError();
 }
+
+hipError_t launch_aac_synth_groups(const SynthArgs &a, const SynthGroup *groups, uint32_t n_groups, const uint32_t *task_ids,
+                                   uint32_t n_group_tasks, float *delay_next, uint8_t *shape_next, hipStream_t s) {
+    if (n_groups == 0) return hipSuccess;
+    if (a.pcm16) hipLaunchKernelGGL(k_aac_synth_group<true>, dim3(n_groups), dim3(kGroupWaves * 64), 0, s, a, groups, delay_next, shape_next);
+    else hipLaunchKernelGGL(k_aac_synth_group<false>, dim3(n_groups), dim3(kGroupWaves * 64), 0, s, a, groups, delay_next, shape_next);
+    hipLaunchKernelGGL(k_commit_state, dim3(n_group_tasks), dim3(256), 0, s, a.tasks, task_ids, n_group_tasks, a.delay, delay_next,
+                       a.prev_shape, shape_next);
+    return hipGetLastError();
+}
+
+uint32_t synth_group_frames() { return kGroupFrames; }
 
 hipError_t launch_frames_to_s16(const float *planar, int16_t *out, const FrameSpan *frames, uint32_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;

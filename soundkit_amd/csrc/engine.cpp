@@ -204,6 +204,8 @@ struct sk_engine {
 
     float *d_delay = nullptr;
     uint8_t *d_prev_shape = nullptr;
+    float *d_delay_next = nullptr;      // where the OnlyLong group kernel leaves new states until k_commit_state moves them
+    uint8_t *d_shape_next = nullptr;
     float *d_rs = nullptr;  // [max_streams * 2][kRsRow], allocated on first sk_resampler_open
 
     // tables
@@ -241,6 +243,11 @@ struct sk_aac_plan {
     sk::SynthTask *d_tasks = nullptr;
     sk::SynthEntry *d_entries = nullptr;
     sk::FrameSpan *d_spans = nullptr;
+    // tasks whose frames are all OnlyLong run as groups of frames (k_aac_synth_group), the others walk (k_aac_synth)
+    sk::SynthTask *d_walk_tasks = nullptr;
+    sk::SynthGroup *d_groups = nullptr;
+    uint32_t *d_group_tasks = nullptr;
+    uint32_t n_walk_tasks = 0, n_groups = 0, n_group_tasks = 0;
 };
 
 #define SK_HIP(expr, what)                               \
@@ -401,6 +408,8 @@ int sk_engine_create(int device, uint32_t max_streams, sk_engine **out) {
         he = hipMalloc((void **)&e->d_delay, states * 1024 * sizeof(float));
         if (he != hipSuccess) { rc = e->hip_fail(he, "alloc delay"); break; }
         he = hipMalloc((void **)&e->d_prev_shape, states);
+        if (he == hipSuccess) he = hipMalloc((void **)&e->d_delay_next, states * 1024 * sizeof(float));
+        if (he == hipSuccess) he = hipMalloc((void **)&e->d_shape_next, states);
         if (he != hipSuccess) { rc = e->hip_fail(he, "alloc prev_shape"); break; }
         (void)hipMemset(e->d_delay, 0, states * 1024 * sizeof(float));
         (void)hipMemset(e->d_prev_shape, 0, states);
@@ -427,7 +436,7 @@ void sk_engine_destroy(sk_engine *e) {
     {
         DeviceGuard guard(e->device);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
-        for (void *p : {(void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
+        for (void *p : {(void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_delay_next, (void *)e->d_shape_next, (void *)e->d_rs, (void *)e->d_tables,
                         (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag, (void *)e->d_afrag16,
                         (void *)e->d_zeros})
             if (p) (void)hipFree(p);
@@ -550,6 +559,9 @@ void sk_aac_plan_destroy(sk_aac_plan *p) {
         if (p->d_tasks) (void)hipFree(p->d_tasks);
         if (p->d_entries) (void)hipFree(p->d_entries);
         if (p->d_spans) (void)hipFree(p->d_spans);
+        if (p->d_walk_tasks) (void)hipFree(p->d_walk_tasks);
+        if (p->d_groups) (void)hipFree(p->d_groups);
+        if (p->d_group_tasks) (void)hipFree(p->d_group_tasks);
     }
     delete p;
 }
@@ -566,13 +578,17 @@ struct HostPlan {
     std::vector<sk::SynthEntry> entries;
     std::vector<sk::FrameSpan> spans;
     std::vector<uint32_t> entry_of;  // [frame * 2 + channel] -> index into entries (valid frames only)
+    // split of `tasks` by kernel: all-OnlyLong tasks cut into groups of frames, the rest for the walking kernel
+    std::vector<sk::SynthTask> walk_tasks;
+    std::vector<sk::SynthGroup> groups;
+    std::vector<uint32_t> group_tasks;
     uint32_t frames_ok = 0;
     uint64_t off1024 = 0;  // total packed size in units of 1024 f32
 };
 
 // Validates the descs and lays the batch out as one task per (stream, channel) state, frames of a state in
 // array order.  Caller holds e->mu.
-int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, int32_t *status, HostPlan &hp) {
+int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, int32_t *status, HostPlan &hp, bool windows_known = true) {
     // pass 1: validate, count entries per (stream, channel) state, in first-touch order
     std::vector<uint32_t> touched;
     std::vector<uint8_t> ok(n, 0);
@@ -635,6 +651,25 @@ int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, in
     if (bad_desc_channels || off > 0xffffffffull) return SK_ERR_INVALID_ARG;
     hp.frames_ok = frames_ok;
     hp.off1024 = off;
+    // which kernel runs which task.  The frames-in-parallel kernel (k_aac_synth_group) is correct and tested but slower than
+    // the walking one on this part (profiles/r02_ab_synth_groups.md: 1.02 against 0.93 ms), so it runs only on request:
+    // SK_SYNTH_GROUPS=1
+    static const bool use_groups = [] { const char *v = std::getenv("SK_SYNTH_GROUPS"); return v && v[0] == '1'; }();
+    hp.walk_tasks.clear();
+    hp.groups.clear();
+    hp.group_tasks.clear();
+    const uint32_t per_group = sk::synth_group_frames();
+    for (uint32_t t = 0; t < tasks.size(); ++t) {
+        bool only_long = windows_known && use_groups;
+        for (uint32_t k = 0; only_long && k < tasks[t].count; ++k) only_long = (entries[tasks[t].begin + k].win & 3u) == 0;
+        if (!only_long) {
+            hp.walk_tasks.push_back(tasks[t]);
+            continue;
+        }
+        hp.group_tasks.push_back(t);
+        for (uint32_t first = 0; first < tasks[t].count; first += per_group)
+            hp.groups.push_back(sk::SynthGroup{t, first, std::min(per_group, tasks[t].count - first), 0});
+    }
     return SK_OK;
 }
 
@@ -662,6 +697,12 @@ int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n,
         hipError_t he = upload(&p->d_tasks, hp.tasks);
         if (he == hipSuccess) he = upload(&p->d_entries, hp.entries);
         if (he == hipSuccess) he = upload(&p->d_spans, hp.spans);
+        if (he == hipSuccess && !hp.walk_tasks.empty()) he = upload(&p->d_walk_tasks, hp.walk_tasks);
+        if (he == hipSuccess && !hp.groups.empty()) he = upload(&p->d_groups, hp.groups);
+        if (he == hipSuccess && !hp.group_tasks.empty()) he = upload(&p->d_group_tasks, hp.group_tasks);
+        p->n_walk_tasks = (uint32_t)hp.walk_tasks.size();
+        p->n_groups = (uint32_t)hp.groups.size();
+        p->n_group_tasks = (uint32_t)hp.group_tasks.size();
         if (he != hipSuccess) {
             sk_aac_plan_destroy(p);
             return e->hip_fail(he, "upload plan");
@@ -678,10 +719,13 @@ static int run_plan(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, f
     a.pcm16 = d_pcm16;
     a.delay = e->d_delay;
     a.prev_shape = e->d_prev_shape;
-    a.tasks = p->d_tasks;
     a.entries = p->d_entries;
-    a.n_tasks = p->n_tasks;
     a.t = e->synth_tables;
+    a.tasks = p->d_tasks;
+    SK_HIP(sk::launch_aac_synth_groups(a, p->d_groups, p->n_groups, p->d_group_tasks, p->n_group_tasks, e->d_delay_next,
+                                       e->d_shape_next, e->stream), "launch aac synth (groups)");
+    a.tasks = p->d_walk_tasks;
+    a.n_tasks = p->n_walk_tasks;
     SK_HIP(sk::launch_aac_synth(a, e->stream), "launch aac synth");
     return SK_OK;
 }
@@ -1861,7 +1905,7 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     // ---- synthesis of the whole batch ----
     std::vector<int32_t> status(n_frames, 0);
     HostPlan hp;
-    int rc = build_plan_host(e, descs, n_frames, status.data(), hp);
+    int rc = build_plan_host(e, descs, n_frames, status.data(), hp, !au_mode);  // au mode: the windows are not known yet
     if (rc != SK_OK) return rc;
     std::vector<uint64_t> off1024(n_frames + 1, 0);
     for (uint32_t i = 0; i < n_frames; ++i) off1024[i + 1] = off1024[i] + descs[i].channels;
@@ -1973,7 +2017,19 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             }
             return SK_OK;
         }
-        SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth");
+        if (!hp.groups.empty()) {  // channels that are OnlyLong throughout this tick: frames in parallel
+            const sk::SynthGroup *d_groups = nullptr;
+            const uint32_t *d_group_tasks = nullptr;
+            SK_HIP(aux.put(hp.groups, e->stream, &d_groups), "upload tick groups");
+            SK_HIP(aux.put(hp.group_tasks, e->stream, &d_group_tasks), "upload tick group tasks");
+            SK_HIP(sk::launch_aac_synth_groups(a, d_groups, (uint32_t)hp.groups.size(), d_group_tasks, (uint32_t)hp.group_tasks.size(),
+                                               e->d_delay_next, e->d_shape_next, e->stream), "launch tick synth (groups)");
+        }
+        if (!hp.walk_tasks.empty()) {
+            SK_HIP(aux.put(hp.walk_tasks, e->stream, &a.tasks), "upload tick walk tasks");
+            a.n_tasks = (uint32_t)hp.walk_tasks.size();
+            SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth");
+        }
         if (au_mode) {  // which units failed decides what the later stages may use
             const TClock::time_point q0 = TClock::now();
             t_au[0] = std::chrono::duration<double, std::milli>(q0 - t_mark).count();

@@ -73,6 +73,45 @@ __global__ void k_walk_small(const f4 *__restrict__ x, f4 *__restrict__ y, size_
     }
 }
 
+// The shape proposed for the synthesis kernel: a workgroup = FR consecutive 4 KiB pieces ("frames") of one channel, one
+// wave per piece, plus one wave that re-reads the piece before the group (the overlap it needs); every wave hands 4 KiB to
+// its neighbour through LDS behind one barrier and stores its own piece -- single touch, blocks in address order.
+// WORK: dependent FMAs per loaded value (stands in for the FFT); OUT_HALF: store 2 KiB instead of 4 (s16 output).
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int FR, int WORK, bool OUT_HALF>
+__global__ __launch_bounds__((FR + 1) * 64) void k_group(const float *__restrict__ x, float *__restrict__ y, size_t n_pieces) {
+    __shared__ f4 hand[FR + 1][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t first = (size_t)blockIdx.x * FR;
+    const long piece = (long)first + wave - 1;  // wave 0 reads the piece before the group
+    f2v v[8];
+    if (piece >= 0 && (size_t)piece < n_pieces) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = *reinterpret_cast<const f2v *>(x + (size_t)piece * 1024 + 2 * lane + 128 * r);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = (f2v){0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < WORK; ++k)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] * 1.0001f + v[(r + 1) & 7];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hand[wave][64 * r + lane] = (f4){v[2 * r].x, v[2 * r].y, v[2 * r + 1].x, v[2 * r + 1].y};
+    __syncthreads();
+    if (wave == 0 || piece < 0 || (size_t)piece >= n_pieces) return;  // nothing is stored outside the arrays
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const f4 prev = hand[wave - 1][64 * r + lane];
+        const f4 out = (f4){v[2 * r].x, v[2 * r].y, v[2 * r + 1].x, v[2 * r + 1].y} + prev;
+        if (OUT_HALF) {
+            if (r < 2) reinterpret_cast<f4 *>(y + (size_t)piece * 512)[64 * r + lane] = out;
+        } else {
+            reinterpret_cast<f4 *>(y + (size_t)piece * 1024)[64 * r + lane] = out;
+        }
+    }
+}
+
 #define CHECK(e) do { hipError_t err_ = (e); if (err_ != hipSuccess) { std::printf("%s: %s\n", #e, hipGetErrorString(err_)); return 1; } } while (0)
 
 int main() {
@@ -108,7 +147,27 @@ int main() {
     time("walk, 8192 waves, 4 pieces in flight", [&] { hipLaunchKernelGGL(k_walk<4>, dim3(2048), dim3(256), 0, 0, x, y, pieces / 8192, pieces, 0); });
     time("walk, 16384 waves, 1 piece in flight", [&] { hipLaunchKernelGGL(k_walk<1>, dim3(4096), dim3(256), 0, 0, x, y, pieces / 16384, pieces, 0); });
     time("walk, 4096 waves, 2 pieces in flight", [&] { hipLaunchKernelGGL(k_walk<2>, dim3(1024), dim3(256), 0, 0, x, y, pieces / 4096, pieces, 0); });
-    for (int waves : {1024, 2048, 4096, 8192, 16384, 32768}) {
+    {
+        const size_t np = n / 1024;
+        auto rate = [&](const char *name, double bytes, auto launch) {
+            for (int i = 0; i < 3; ++i) launch();
+            hipEventRecord(a);
+            for (int i = 0; i < 20; ++i) launch();
+            hipEventRecord(b);
+            hipEventSynchronize(b);
+            float ms;
+            hipEventElapsedTime(&ms, a, b);
+            ms /= 20;
+            std::printf("%-60s %.3f ms  %.2f TB/s useful (%.2f incl. re-read)\n", name, ms, bytes / ms / 1e9, (bytes + n * 4.0 / 8) / ms / 1e9);
+        };
+        rate("group: 8 frames + 1 / block, no work, 4 KiB out", 2.0 * n * 4, [&] { hipLaunchKernelGGL((k_group<8, 0, false>), dim3(np / 8), dim3(576), 0, 0, (const float *)x, (float *)y, np); });
+        rate("group: 8 frames + 1 / block, 40 FMA rounds, 4 KiB out", 2.0 * n * 4, [&] { hipLaunchKernelGGL((k_group<8, 40, false>), dim3(np / 8), dim3(576), 0, 0, (const float *)x, (float *)y, np); });
+        rate("group: 8 frames + 1 / block, 40 FMA rounds, 2 KiB out", 1.5 * n * 4, [&] { hipLaunchKernelGGL((k_group<8, 40, true>), dim3(np / 8), dim3(576), 0, 0, (const float *)x, (float *)y, np); });
+        rate("group: 15 frames + 1 / block, 40 FMA rounds, 4 KiB out", 2.0 * n * 4, [&] { hipLaunchKernelGGL((k_group<15, 40, false>), dim3((np + 14) / 15), dim3(1024), 0, 0, (const float *)x, (float *)y, np); });
+        rate("group: 4 frames + 1 / block, 40 FMA rounds, 4 KiB out", 2.0 * n * 4, [&] { hipLaunchKernelGGL((k_group<4, 40, false>), dim3(np / 4), dim3(320), 0, 0, (const float *)x, (float *)y, np); });
+        rate("group: 8 frames + 1 / block, 80 FMA rounds, 4 KiB out", 2.0 * n * 4, [&] { hipLaunchKernelGGL((k_group<8, 80, false>), dim3(np / 8), dim3(576), 0, 0, (const float *)x, (float *)y, np); });
+    }
+    for (int waves : {1024, 8192}) {
         char name[96];
         std::snprintf(name, sizeof name, "walk, %d waves, 4 KiB pieces", waves);
         time(name, [&] { hipLaunchKernelGGL(k_walk_small<4>, dim3(waves / 4), dim3(256), 0, 0, x, y, n4 / 256 / waves); });
