@@ -182,6 +182,33 @@ const char *sk_adts_decoder_last_error(const sk_adts_decoder *);
 int sk_aac_dequantize_dev(sk_engine *, const int16_t *d_quant, const int16_t *d_scalefactor, float *d_out, size_t n);
 int sk_aac_dequantize(sk_engine *, const int16_t *quant, const int16_t *scalefactor, float *out, size_t n);
 
+/* ---- MPEG-1/2 Layer III hybrid synthesis ----------------------------------------------------------------
+ * The transform half of what Mp3Decoder gets from nanomp3::Decoder::decode (soundkit-mp3/src/lib.rs:279-305, :284): for
+ * every granule and channel, 576 requantised / stereo-processed / reordered frequency lines -> alias reduction ->
+ * IMDCT 36 or 3 x 12 with the block-type windows -> overlap-add -> frequency inversion -> 32-band polyphase synthesis
+ * (ISO/IEC 11172-3 2.4.3.4), 576 PCM samples out, float in +-1.0 interleaved as nanomp3 emits them, or s16 through
+ * f32_to_i16 (lib.rs:376-385).  Carried state (overlap, polyphase FIFO) is per engine stream, reset by sk_stream_open /
+ * sk_stream_reset.  NOT here, because the data exists nowhere in this tree or container: the bitstream side (Huffman
+ * tables, ISO 11172-3 Table B.7) and the synthesis window D (Table B.3), which the caller supplies once per engine --
+ * until then the synthesis entry points return SK_ERR_UNSUPPORTED.  Parity of this row is unpinned.
+ * Lines of a short block (block_type 2) are window-interleaved: X_w[m] = xr[18 sb + 3 m + w]. */
+typedef struct sk_mp3_granule_desc {
+    uint32_t stream;
+    uint8_t channels;            /* 1 or 2; must equal the stream's */
+    uint8_t block_type[2];       /* per channel: 0 normal, 1 start, 2 short, 3 stop */
+    uint8_t mixed_block_flag[2]; /* per channel, meaningful with block_type 2 */
+    uint8_t reserved[3];
+} sk_mp3_granule_desc;
+int sk_mp3_set_synthesis_window(sk_engine *, const float *d512);
+/* xr: granule i holds channels x 576 f32, granules packed back to back; pcm_out: granule i holds 576 x channels
+ * interleaved samples at the same packing.  A granule whose status != 0 leaves silence. */
+int sk_mp3_hybrid_synthesize_f32(sk_engine *, const sk_mp3_granule_desc *descs, const float *xr, float *pcm_out, uint32_t n,
+                                 int32_t *status_per_granule);
+int sk_mp3_hybrid_synthesize_s16(sk_engine *, const sk_mp3_granule_desc *descs, const float *xr, int16_t *pcm_out, uint32_t n,
+                                 int32_t *status_per_granule);
+int sk_mp3_hybrid_synthesize_f32_dev(sk_engine *, const sk_mp3_granule_desc *descs, const float *d_xr, float *d_pcm, uint32_t n,
+                                     int32_t *status_per_granule);
+
 /* ---- sample-width / interleave conversion: soundkit::audio_bytes -------- */
 /* Elementwise ops; n = number of OUTPUT samples.  Citations: soundkit/src/audio_bytes.rs
  * unless noted. */

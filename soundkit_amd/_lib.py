@@ -26,6 +26,12 @@ class FrameDesc(C.Structure):
                 ("window_shape", C.c_uint8 * 2), ("reserved", C.c_uint8 * 3)]
 
 
+class Mp3GranuleDesc(C.Structure):
+    """sk_mp3_granule_desc"""
+    _fields_ = [("stream", C.c_uint32), ("channels", C.c_uint8), ("block_type", C.c_uint8 * 2), ("mixed_block_flag", C.c_uint8 * 2),
+                ("reserved", C.c_uint8 * 3)]
+
+
 class TickStream(C.Structure):
     """sk_tick_stream"""
     _fields_ = [("stream", C.c_uint32), ("n_frames", C.c_uint32), ("out_bits", C.c_uint8), ("out_channels", C.c_uint8),
@@ -185,6 +191,10 @@ _sig = {
     "sk_pipeline_queued_input_bytes": (_sz, [_vp, _u32]),
     "sk_pipeline_get_stats": (_i, [_vp, _vp]),
     "sk_tick_run_au": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _sz, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
+    "sk_mp3_set_synthesis_window": (_i, [_vp, _vp]),
+    "sk_mp3_hybrid_synthesize_f32": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    "sk_mp3_hybrid_synthesize_s16": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    "sk_mp3_hybrid_synthesize_f32_dev": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "sk_aac_entropy_decode": (_i, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _sz, _vp, _vp, _vp]),
     "sk_tick_out_bound": (_sz, [_vp, _u32, C.POINTER(_u32)]),
     "sk_tick_run": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),

@@ -207,6 +207,9 @@ struct sk_engine {
     float *d_delay_next = nullptr;      // where the OnlyLong group kernel leaves new states until k_commit_state moves them
     uint8_t *d_shape_next = nullptr;
     float *d_rs = nullptr;  // [max_streams * 2][kRsRow], allocated on first sk_resampler_open
+    // MP3 hybrid synthesis (mp3_hybrid.hip): tables and per-(stream, channel) state, allocated on first use
+    float *d_mp3_tables = nullptr, *d_mp3_state = nullptr;
+    bool mp3_window_set = false;
 
     // tables
     float *d_tables = nullptr;
@@ -436,7 +439,7 @@ void sk_engine_destroy(sk_engine *e) {
     {
         DeviceGuard guard(e->device);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
-        for (void *p : {(void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_delay_next, (void *)e->d_shape_next, (void *)e->d_rs, (void *)e->d_tables,
+        for (void *p : {(void *)e->d_mp3_tables, (void *)e->d_mp3_state, (void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_delay_next, (void *)e->d_shape_next, (void *)e->d_rs, (void *)e->d_tables,
                         (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag, (void *)e->d_afrag16,
                         (void *)e->d_zeros})
             if (p) (void)hipFree(p);
@@ -476,6 +479,9 @@ static int reset_stream_state(sk_engine *e, uint32_t id) {
     // overlap delay, previous window shape and PNS generator (spectral.rs:2459) in one small launch
     SK_HIP(sk::launch_reset_stream(e->d_delay + (size_t)id * 2048, e->d_prev_shape + (size_t)id * 2, e->d_pns + id, e->stream),
            "reset stream state");
+    if (e->d_mp3_state)  // the Layer III overlap and polyphase FIFO of both channels
+        SK_HIP(hipMemsetAsync(e->d_mp3_state + (size_t)id * 2 * sk::kMp3StateFloats, 0, 2 * sk::kMp3StateFloats * sizeof(float), e->stream),
+               "reset mp3 state");
     return SK_OK;
 }
 
@@ -1338,6 +1344,166 @@ int sk_downsample_f32(sk_engine *e, const float *in, uint32_t rows, uint32_t fra
                             hipMemcpyDeviceToHost, e->stream), "D2H resample output");
     SK_HIP(hipStreamSynchronize(e->stream), "resample sync");
     return SK_OK;
+}
+
+// ---- MPEG Layer III hybrid synthesis (mp3_hybrid.hip) -------------------------------------------------------------------
+namespace {
+
+constexpr size_t kMp3Imdct = 4 * 36 * 20, kMp3Matrix = 64 * 32, kMp3Window = 512;
+
+// ISO/IEC 11172-3 2.4.3.4.10.2-3: the IMDCT of each block type with its window folded in, as a 36 x 18 matrix (rows
+// padded to 20); block type 2 = three 12-point transforms of the window-interleaved lines, placed at 6 w + 6
+void mp3_imdct_matrices(std::vector<float> &out) {
+    const double pi = 3.14159265358979323846;
+    out.assign(kMp3Imdct, 0.0f);
+    for (int bt = 0; bt < 4; ++bt)
+        for (int i = 0; i < 36; ++i)
+            for (int k = 0; k < 18; ++k) {
+                double v = 0.0;
+                if (bt != 2) {
+                    double w;
+                    if (bt == 0) w = std::sin(pi / 36 * (i + 0.5));
+                    else if (bt == 1) w = i < 18 ? std::sin(pi / 36 * (i + 0.5)) : (i < 24 ? 1.0 : (i < 30 ? std::sin(pi / 12 * (i - 18 + 0.5)) : 0.0));
+                    else w = i < 6 ? 0.0 : (i < 12 ? std::sin(pi / 12 * (i - 6 + 0.5)) : (i < 18 ? 1.0 : std::sin(pi / 36 * (i + 0.5))));
+                    v = std::cos(pi / 72 * (2 * i + 1 + 18) * (2 * k + 1)) * w;
+                } else {
+                    const int w = k % 3, m = k / 3, p = i - 6 * w - 6;
+                    if (p >= 0 && p < 12) v = std::cos(pi / 24 * (2 * p + 1 + 6) * (2 * m + 1)) * std::sin(pi / 12 * (p + 0.5));
+                }
+                out[((size_t)bt * 36 + i) * 20 + k] = (float)v;
+            }
+}
+
+int ensure_mp3(sk_engine *e) {
+    if (e->d_mp3_tables) return SK_OK;
+    const double pi = 3.14159265358979323846;
+    std::vector<float> t;
+    mp3_imdct_matrices(t);
+    for (int i = 0; i < 64; ++i)
+        for (int k = 0; k < 32; ++k) t.push_back((float)std::cos((16 + i) * (2 * k + 1) * pi / 64));
+    t.resize(kMp3Imdct + kMp3Matrix + kMp3Window, 0.0f);  // the window stays zero until the caller sets it
+    static const double c[8] = {-0.6, -0.535, -0.33, -0.185, -0.095, -0.041, -0.0142, -0.0037};  // ISO 11172-3 Table B.9
+    for (int i = 0; i < 8; ++i) t.push_back((float)(1.0 / std::sqrt(1.0 + c[i] * c[i])));
+    for (int i = 0; i < 8; ++i) t.push_back((float)(c[i] / std::sqrt(1.0 + c[i] * c[i])));
+    SK_HIP(hipMalloc((void **)&e->d_mp3_tables, t.size() * sizeof(float)), "alloc mp3 tables");
+    SK_HIP(hipMemcpy(e->d_mp3_tables, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice), "upload mp3 tables");
+    const size_t state_bytes = (size_t)e->max_streams * 2 * sk::kMp3StateFloats * sizeof(float);
+    SK_HIP(hipMalloc((void **)&e->d_mp3_state, state_bytes), "alloc mp3 state");
+    SK_HIP(hipMemset(e->d_mp3_state, 0, state_bytes), "clear mp3 state");
+    return SK_OK;
+}
+
+int mp3_synthesize(sk_engine *e, const sk_mp3_granule_desc *descs, const float *xr, void *pcm_out, uint32_t n, int32_t *status,
+                   bool s16, bool device_ptrs) {
+    if (!e || (n && (!descs || !xr || !pcm_out))) return SK_ERR_INVALID_ARG;
+    if (n == 0) return SK_OK;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    int rc = ensure_mp3(e);
+    if (rc != SK_OK) return rc;
+    if (!e->mp3_window_set) return SK_ERR_UNSUPPORTED;  // no synthesis window: sk_mp3_set_synthesis_window first
+    // one task per (stream, channel), granules in array order (the AAC plan's layout with 576-line units)
+    std::vector<uint32_t> touched;
+    std::vector<uint8_t> ok(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const sk_mp3_granule_desc &d = descs[i];
+        int32_t st = SK_FRAME_OK;
+        if (!stream_ok(e, d.stream)) st = SK_FRAME_BAD_STREAM;
+        else if (d.channels != e->streams[d.stream].channels) st = SK_FRAME_BAD_CHANNELS;
+        else
+            for (uint32_t c = 0; c < d.channels; ++c)
+                if (d.block_type[c] > 3 || d.mixed_block_flag[c] > 1) st = SK_FRAME_BAD_WINDOW;
+        if (d.channels < 1 || d.channels > SK_MAX_CHANNELS) return SK_ERR_INVALID_ARG;
+        if (status) status[i] = st;
+        if (st != SK_FRAME_OK) continue;
+        ok[i] = 1;
+        for (uint32_t c = 0; c < d.channels; ++c)
+            if (e->state_count[d.stream * 2 + c]++ == 0) touched.push_back(d.stream * 2 + c);
+    }
+    std::vector<sk::SynthTask> tasks(touched.size());
+    uint32_t n_entries = 0;
+    for (size_t t = 0; t < touched.size(); ++t) {
+        tasks[t] = sk::SynthTask{touched[t], n_entries, 0, 0};
+        n_entries += e->state_count[touched[t]];
+        e->state_task[touched[t]] = (uint32_t)t;
+    }
+    std::vector<sk::SynthEntry> entries(n_entries);
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const sk_mp3_granule_desc &d = descs[i];
+        if (ok[i])
+            for (uint32_t c = 0; c < d.channels; ++c) {
+                sk::SynthTask &t = tasks[e->state_task[d.stream * 2 + c]];
+                entries[t.begin + t.count++] = sk::SynthEntry{(uint32_t)(off + c), (uint32_t)d.block_type[c] | ((uint32_t)d.mixed_block_flag[c] << 2) |
+                                                                                       ((uint32_t)(d.channels - 1) << 3) | (c << 4)};
+            }
+        off += d.channels;
+    }
+    for (uint32_t state : touched) e->state_count[state] = 0;
+    if (off * 576 > 0xffffffffull) return SK_ERR_INVALID_ARG;
+    const size_t elems = (size_t)off * 576, out_bytes = elems * (s16 ? sizeof(int16_t) : sizeof(float));
+    sk::Mp3Args a{};
+    a.state = e->d_mp3_state;
+    a.n_tasks = (uint32_t)tasks.size();
+    a.imdct = e->d_mp3_tables;
+    a.matrix = a.imdct + kMp3Imdct;
+    a.window = a.matrix + kMp3Matrix;
+    a.cs_ca = a.window + kMp3Window;
+    SK_HIP(e->aux2_buf.reserve(tasks.size() * sizeof(sk::SynthTask) + entries.size() * sizeof(sk::SynthEntry) + 512), "alloc mp3 schedule");
+    sk::SynthTask *d_tasks = (sk::SynthTask *)e->aux2_buf.p;
+    sk::SynthEntry *d_entries = (sk::SynthEntry *)((uint8_t *)e->aux2_buf.p + ((tasks.size() * sizeof(sk::SynthTask) + 255) & ~(size_t)255));
+    SK_HIP(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(sk::SynthTask), hipMemcpyHostToDevice, e->stream), "H2D mp3 tasks");
+    SK_HIP(hipMemcpyAsync(d_entries, entries.data(), entries.size() * sizeof(sk::SynthEntry), hipMemcpyHostToDevice, e->stream),
+           "H2D mp3 entries");
+    SK_HIP(hipStreamSynchronize(e->stream), "mp3 schedule sync");  // the vectors go out of scope
+    a.tasks = d_tasks;
+    a.entries = d_entries;
+    if (device_ptrs) {
+        a.xr = xr;
+        if (s16) a.pcm16 = (int16_t *)pcm_out;
+        else a.pcm = (float *)pcm_out;
+        if (!tasks.empty()) SK_HIP(sk::launch_mp3_hybrid(a, e->stream), "launch mp3 hybrid synthesis");
+        return SK_OK;
+    }
+    SK_HIP(e->in_buf.reserve(elems * sizeof(float) + 16), "alloc mp3 input");
+    SK_HIP(e->out_buf.reserve(elems * sizeof(float) + 16), "alloc mp3 output");
+    SK_HIP(hipMemcpyAsync(e->in_buf.p, xr, elems * sizeof(float), hipMemcpyHostToDevice, e->stream), "H2D mp3 lines");
+    SK_HIP(hipMemsetAsync(e->out_buf.p, 0, out_bytes, e->stream), "clear mp3 output");  // rejected granules stay silent
+    a.xr = (const float *)e->in_buf.p;
+    if (s16) a.pcm16 = (int16_t *)e->out_buf.p;
+    else a.pcm = (float *)e->out_buf.p;
+    if (!tasks.empty()) SK_HIP(sk::launch_mp3_hybrid(a, e->stream), "launch mp3 hybrid synthesis");
+    SK_HIP(hipMemcpyAsync(pcm_out, e->out_buf.p, out_bytes, hipMemcpyDeviceToHost, e->stream), "D2H mp3 pcm");
+    SK_HIP(hipStreamSynchronize(e->stream), "mp3 sync");
+    return SK_OK;
+}
+
+}  // namespace
+
+int sk_mp3_set_synthesis_window(sk_engine *e, const float *d512) {
+    if (!e || !d512) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    const int rc = ensure_mp3(e);
+    if (rc != SK_OK) return rc;
+    SK_HIP(hipMemcpy(e->d_mp3_tables + kMp3Imdct + kMp3Matrix, d512, kMp3Window * sizeof(float), hipMemcpyHostToDevice), "upload mp3 window");
+    e->mp3_window_set = true;
+    return SK_OK;
+}
+
+int sk_mp3_hybrid_synthesize_f32(sk_engine *e, const sk_mp3_granule_desc *descs, const float *xr, float *pcm_out, uint32_t n,
+                                 int32_t *status) {
+    return mp3_synthesize(e, descs, xr, pcm_out, n, status, false, false);
+}
+
+int sk_mp3_hybrid_synthesize_s16(sk_engine *e, const sk_mp3_granule_desc *descs, const float *xr, int16_t *pcm_out, uint32_t n,
+                                 int32_t *status) {
+    return mp3_synthesize(e, descs, xr, pcm_out, n, status, true, false);
+}
+
+int sk_mp3_hybrid_synthesize_f32_dev(sk_engine *e, const sk_mp3_granule_desc *descs, const float *d_xr, float *d_pcm, uint32_t n,
+                                     int32_t *status) {
+    return mp3_synthesize(e, descs, d_xr, d_pcm, n, status, false, true);
 }
 
 int sk_resampler_open(sk_engine *e, uint32_t id, uint32_t in_hz, uint32_t out_hz) {

@@ -166,6 +166,23 @@ struct RowCopy {
 };
 hipError_t launch_row_copies(const float *src_base, float *dst_base, const RowCopy *jobs, uint32_t n_jobs, hipStream_t s);
 
+// mp3_hybrid.hip -- Layer III hybrid synthesis (ISO/IEC 11172-3 2.4.3.4), one wave per (stream, channel)
+constexpr uint32_t kMp3StateFloats = 1664;  // overlap[576] | ring[1024] | ring position | padding
+struct Mp3Args {
+    const float *xr;       // [granule-channels][576] requantised, stereo-processed, reordered frequency lines
+    float *pcm;            // interleaved f32 out ...
+    int16_t *pcm16;        // ... or s16 (f32_to_i16, soundkit-mp3 lib.rs:376-385); one of the two
+    float *state;          // [states][kMp3StateFloats]
+    const SynthTask *tasks;      // state = stream * 2 + channel
+    const SynthEntry *entries;   // off1024 = index of the channel's 576 lines; win = block_type | mixed << 2 | (channels - 1) << 3 | channel << 4
+    uint32_t n_tasks;
+    const float *imdct;    // [4][36][20]: IMDCT x window matrices of block types 0..3 (rows padded to 20)
+    const float *matrix;   // [64][32]: cos((16 + i)(2k + 1) pi / 64)
+    const float *window;   // [512]: the synthesis window D (caller-supplied)
+    const float *cs_ca;    // [16]: alias-reduction cs[8] | ca[8]
+};
+hipError_t launch_mp3_hybrid(const Mp3Args &a, hipStream_t s);
+
 // aac_entropy.hip -- the AAC-LC front-end on the device, one stream per lane
 }  // namespace sk
 #include "aac_entropy_core.h"

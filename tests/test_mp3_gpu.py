@@ -1,0 +1,135 @@
+"""csrc/mp3_hybrid.hip (Layer III hybrid synthesis on gfx950, behind sk_mp3_hybrid_synthesize_*) against
+oracle/mp3_hybrid.py (ISO/IEC 11172-3 2.4.3.4 in f64; tests/test_mp3_oracle.py checks its transform pair): float
+output within 1e-6 relative RMS (north_star's float tolerance), the s16 tail bit-exact on the kernel's own floats
+(soundkit-mp3/src/lib.rs:376-385).  The synthesis window is a synthetic prototype -- Table B.3 is not in this tree -- so
+these tests pin the arithmetic, not the table ("parity unpinned")."""
+import numpy as np
+import pytest
+
+from oracle import mp3_hybrid as M
+from soundkit_amd import mp3
+from soundkit_amd._lib import SoundkitError
+
+pytestmark = pytest.mark.gpu
+D = M.synthetic_window(7)
+
+
+def rel_rms(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2))
+
+
+def test_needs_the_synthesis_window_first():
+    import soundkit_amd
+    eng = soundkit_amd.Engine(0, 4)
+    try:
+        sid = eng.open_stream(44100, 1)
+        with pytest.raises(SoundkitError) as exc:
+            mp3.hybrid_synthesize([(sid, 1, [0], [0])], np.zeros((1, 1, 576), np.float32), eng)
+        assert exc.value.status == -6   # SK_ERR_UNSUPPORTED
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_every_block_type_against_the_oracle(engine, oracle, channels):
+    """six streams with their own block-type sequences (normal, start, short, mixed short, stop), three calls of uneven
+    length: the overlap and the polyphase FIFO are carried in the engine from call to call"""
+    mp3.set_synthesis_window(D, engine)
+    rng = np.random.default_rng(20 + channels)
+    n_streams, n_gran = 6, 11
+    seqs = [[(0, 0)] * n_gran, [(0, 0), (1, 0), (2, 0), (2, 0), (3, 0), (0, 0), (1, 0), (2, 1), (3, 0), (0, 0), (0, 0)],
+            [(2, 1)] * n_gran, [(2, 0)] * n_gran, [(1, 0), (3, 0)] * 5 + [(0, 0)], [(3, 0), (2, 1), (1, 0), (0, 0)] * 2 + [(2, 0)] * 3]
+    xr = rng.standard_normal((n_streams, n_gran, channels, 576)).astype(np.float32) * np.float32(0.05)
+    xr[:, :, :, 400:] *= np.float32(0.1)
+    sids = [engine.open_stream(44100, channels) for _ in range(n_streams)]
+    got = [[] for _ in range(n_streams)]
+    try:
+        for first, last in ((0, 4), (4, 5), (5, 11)):
+            granules, lines = [], []
+            for g in range(first, last):          # granule-major: the streams advance together
+                for s in range(n_streams):
+                    bts = [seqs[s][g][0] if c == 0 else seqs[(s + 1) % n_streams][g][0] for c in range(channels)]
+                    mix = [seqs[s][g][1] if c == 0 else seqs[(s + 1) % n_streams][g][1] for c in range(channels)]
+                    granules.append((sids[s], channels, bts, mix))
+                    lines.append(xr[s, g])
+            pcm, status = mp3.hybrid_synthesize(granules, np.stack(lines), engine)
+            assert not status.any()
+            k = 0
+            for g in range(first, last):
+                for s in range(n_streams):
+                    got[s].append(pcm[k])
+                    k += 1
+        worst = 0.0
+        for s in range(n_streams):
+            chans = [M.Channel() for _ in range(channels)]
+            want = np.zeros((n_gran, 576, channels))
+            for g in range(n_gran):
+                for c in range(channels):
+                    bt, mixed = seqs[s][g] if c == 0 else seqs[(s + 1) % n_streams][g]
+                    want[g, :, c] = chans[c].granule(xr[s, g, c].astype(np.float64), bt, mixed, D.astype(np.float32).astype(np.float64))
+            mine = np.stack(got[s])
+            worst = max(worst, rel_rms(mine, want))
+            assert np.abs(mine - want).max() < 2e-6 * np.abs(want).max()
+        assert worst < 1e-6, worst
+    finally:
+        for sid in sids:
+            engine.close_stream(sid)
+
+
+def test_s16_tail_and_rejected_granules(engine, oracle):
+    mp3.set_synthesis_window(D, engine)
+    rng = np.random.default_rng(9)
+    xr = (rng.standard_normal((5, 2, 576)) * 0.3).astype(np.float32)   # loud: reaches the saturation of f32_to_i16
+    a, b = engine.open_stream(16000, 2), engine.open_stream(16000, 2)
+    try:
+        granules = [(a, 2, [0, 2], [0, 0]), (b, 2, [1, 1], [0, 0]), (a, 2, [2, 3], [1, 0]), (b, 1, [0, 0], [0, 0]), (b, 2, [3, 0], [0, 0])]
+        f32, status = mp3.hybrid_synthesize(granules, xr, engine)
+        assert status.tolist() == [0, 0, 0, 2, 0] and not f32[3].any()   # SK_FRAME_BAD_CHANNELS: silence, the rest decoded
+        engine.reset_stream(a), engine.reset_stream(b)
+        s16, status = mp3.hybrid_synthesize(granules, xr, engine, s16=True)
+        assert status.tolist() == [0, 0, 0, 2, 0]
+        assert np.array_equal(s16, oracle.pcm_convert("MP3_F32_TO_I16", f32.ravel()).reshape(f32.shape))
+        assert np.abs(s16.astype(np.int32)).max() == 32767 or (np.abs(f32) > 1.0).any()
+    finally:
+        engine.close_stream(a), engine.close_stream(b)
+
+
+def test_full_batch_properties():
+    """4096 stereo streams x 2 granules (one MPEG-1 frame each) in one launch: every stream that gets the same lines gives
+    the same PCM, the transform is linear, and two calls of one granule equal one call of two (state carried exactly)"""
+    import soundkit_amd
+    n_streams = 4096
+    eng = soundkit_amd.Engine(0, n_streams)
+    try:
+        mp3.set_synthesis_window(D, eng)
+        rng = np.random.default_rng(1)
+        base = (rng.standard_normal((2, 2, 2, 576)) * 0.05).astype(np.float32)   # two different inputs x [granule][ch][576]
+        sids = [eng.open_stream(44100, 2) for _ in range(n_streams)]
+        types = [[0, 2], [1, 3]]
+
+        def run(lines_of_stream, granule_range):
+            granules, lines = [], []
+            for g in granule_range:
+                for s in range(n_streams):
+                    granules.append((sids[s], 2, types[g], [0, 0]))
+                    lines.append(lines_of_stream(s)[g])
+            pcm, status = mp3.hybrid_synthesize(granules, np.stack(lines), eng)
+            assert not status.any()
+            return pcm.reshape(len(list(granule_range)), n_streams, 576, 2)
+        one = run(lambda s: base[s & 1], range(2))
+        for k in (0, 1):
+            assert (one[:, k::2] == one[:, k:k + 1]).all()                      # same lines -> same samples, all 2048 of them
+        assert not np.array_equal(one[:, 0], one[:, 1])
+        for sid in sids:
+            eng.reset_stream(sid)
+        first = run(lambda s: base[s & 1], range(1))
+        second = run(lambda s: base[s & 1], range(1, 2))
+        assert np.array_equal(first[0], one[0]) and np.array_equal(second[0], one[1])   # call boundaries do not show
+        for sid in sids:
+            eng.reset_stream(sid)
+        combo = run(lambda s: (np.float32(0.5) * base[0] + np.float32(0.25) * base[1]) if s & 1 else base[0], range(2))
+        want = 0.5 * one[:, 0].astype(np.float64) + 0.25 * one[:, 1].astype(np.float64)
+        assert rel_rms(combo[:, 1], want) < 1e-6
+    finally:
+        eng.close()
