@@ -80,15 +80,15 @@ def test_every_block_type_against_the_oracle(engine, oracle, channels):
 def test_s16_tail_and_rejected_granules(engine, oracle):
     mp3.set_synthesis_window(D, engine)
     rng = np.random.default_rng(9)
-    xr = (rng.standard_normal((5, 2, 576)) * 0.3).astype(np.float32)   # loud: reaches the saturation of f32_to_i16
+    xr = (rng.standard_normal((5, 2, 576)) * 2.5).astype(np.float32)   # loud: reaches the saturation of f32_to_i16
     a, b = engine.open_stream(16000, 2), engine.open_stream(16000, 2)
     try:
-        granules = [(a, 2, [0, 2], [0, 0]), (b, 2, [1, 1], [0, 0]), (a, 2, [2, 3], [1, 0]), (b, 1, [0, 0], [0, 0]), (b, 2, [3, 0], [0, 0])]
+        granules = [(a, 2, [0, 2], [0, 0]), (b, 2, [1, 1], [0, 0]), (a, 2, [2, 3], [1, 0]), (b, 2, [0, 7], [0, 0]), (b, 2, [3, 0], [0, 0])]
         f32, status = mp3.hybrid_synthesize(granules, xr, engine)
-        assert status.tolist() == [0, 0, 0, 2, 0] and not f32[3].any()   # SK_FRAME_BAD_CHANNELS: silence, the rest decoded
+        assert status.tolist() == [0, 0, 0, 3, 0] and not f32[3].any()   # SK_FRAME_BAD_WINDOW (block type 7): silence, the rest decoded
         engine.reset_stream(a), engine.reset_stream(b)
         s16, status = mp3.hybrid_synthesize(granules, xr, engine, s16=True)
-        assert status.tolist() == [0, 0, 0, 2, 0]
+        assert status.tolist() == [0, 0, 0, 3, 0]
         assert np.array_equal(s16, oracle.pcm_convert("MP3_F32_TO_I16", f32.ravel()).reshape(f32.shape))
         assert np.abs(s16.astype(np.int32)).max() == 32767 or (np.abs(f32) > 1.0).any()
     finally:
