@@ -382,6 +382,9 @@ def main():
                     help="pipeline: f32 FIR output and a separate f32 -> interleaved s16 kernel instead of the conversion in the FIR's "
                          "epilogue (same bytes out, tests/test_pipeline_gpu.py; the chain measured before the bf16 FIR, DESIGN.md 4.2)")
     ap.add_argument("--fused-s16", action="store_true", help="(default now; kept so that older command lines still run)")
+    ap.add_argument("--mix", action="store_true",
+                    help="aac_synth / pipeline: SURVEY 8d's mixed-sequence batch (10 %% EightShort, each bracketed by LongStart / LongStop) "
+                         "instead of OnlyLong; adds `mix` to the JSON: launch time per frame class from three timed batches")
     ap.add_argument("--chain", default="s16", choices=["s16", "f32"],
                     help="pipeline: what crosses HBM between synthesis and FIR -- s16 as in the reference worker (default), or the f32 "
                          "PCM (round 1's chain)")
@@ -459,7 +462,28 @@ def main():
         else:
             ids = np.repeat(sids, frames)
             shapes = np.tile(shape_of_frame, streams)[:, None].repeat(2, 1)
-        seqs = np.zeros((streams * frames, 2), np.uint8)  # OnlyLong
+        def sequences(shorts_per_bracket):
+            """window sequence of every (stream, frame): OnlyLong, or -- SURVEY 8d's mixed variant -- per ten frames one
+            LongStart, `shorts_per_bracket` EightShort, one LongStop (dsp.rs:230-338), each stream shifted by its index"""
+            pattern = np.zeros(10, np.uint8)
+            if shorts_per_bracket:
+                pattern[1] = 1
+                pattern[2:2 + shorts_per_bracket] = 2
+                pattern[2 + shorts_per_bracket] = 3
+            sf = pattern[(np.arange(frames)[None, :] + np.arange(streams)[:, None]) % 10]  # [stream][frame]
+            if frames >= 10:  # brackets cut by the batch's edges fall back to OnlyLong (a stream starts and ends long)
+                for srow in sf:
+                    k = 0
+                    while k < frames and srow[k] in (2, 3):
+                        srow[k] = 0
+                        k += 1
+                    k = frames - 1
+                    while k >= 0 and srow[k] in (1, 2):
+                        srow[k] = 0
+                        k -= 1
+            flat = sf.T.reshape(-1) if args.layout == "frame" else sf.reshape(-1)
+            return np.repeat(flat[:, None], 2, 1)
+        seqs = sequences(1 if args.mix else 0)
         descs, n = soundkit_amd.descs_from_arrays(ids, ch, seqs, shapes)
         plan = eng.plan(descs, n)
         assert plan.frames_ok == n
@@ -560,6 +584,41 @@ def main():
     torch.cuda.synchronize()
     from soundkit_amd import sharding
     elapsed = sharding.reduce_elapsed(time.perf_counter() - t0, device)  # max over ranks
+    mix_report = None
+    if args.mix and args.workload in ("aac_synth", "pipeline") and rank == 0:
+        # k_aac_synth alone on three batches of the same spectra: OnlyLong; one EightShort per bracket; three per bracket.
+        # Two unknowns (a transition frame, a short frame) from the two differences.
+        def synth_ms(shorts):
+            d2, n2 = soundkit_amd.descs_from_arrays(ids, ch, sequences(shorts), shapes)
+            p2 = eng.plan(d2, n2)
+            scratch = torch.empty_like(coeffs)
+            for _ in range(3):
+                p2.run_f32(coeffs, scratch)
+            eng.synchronize()
+            a0, b0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(ext)
+            for _ in range(10):
+                p2.run_f32(coeffs, scratch)
+            b0.record(ext)
+            eng.synchronize()
+            p2.destroy()
+            seq0 = sequences(shorts)[:, 0]
+            return a0.elapsed_time(b0) / 10, int((seq0 == 2).sum()) * ch, int(((seq0 == 1) | (seq0 == 3)).sum()) * ch
+        t_long, _, _ = synth_ms(0)
+        t1, n_short1, n_trans1 = synth_ms(1)
+        t3, n_short3, n_trans3 = synth_ms(3)
+        total_cf = streams * frames * ch
+        c_long = t_long / total_cf
+        # t = c_long * (total - n_short - n_trans) + c_short * n_short + c_trans * n_trans
+        A = np.array([[n_short1, n_trans1], [n_short3, n_trans3]], np.float64)
+        rhs = np.array([t1 - c_long * (total_cf - n_short1 - n_trans1), t3 - c_long * (total_cf - n_short3 - n_trans3)])
+        c_short, c_trans = np.linalg.solve(A, rhs)
+        mix_report = {"k_aac_synth_ms": {"only_long": t_long, "one_short_per_bracket (10 % EightShort)": t1, "three_shorts_per_bracket": t3},
+                      "channel_frames": total_cf, "short_frames_in_mix": n_short1, "transition_frames_in_mix": n_trans1,
+                      "ns_per_channel_frame": {"OnlyLong": c_long * 1e6, "EightShort": c_short * 1e6, "LongStart/LongStop": c_trans * 1e6},
+                      "cost_relative_to_only_long": {"EightShort": c_short / c_long, "LongStart/LongStop": c_trans / c_long},
+                      "note": "launch time attributed per frame class (chip-wide average, f32 output); a wave that meets a rare frame "
+                              "runs synth_rare_frame for it (aac_synth.hip)"}
 
     if rank == 0:
         per_kernel = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in kernel_ms.items()}
@@ -644,6 +703,8 @@ def main():
         if len(rl) > 1:
             out["roofline"]["note"] = "dominant kernel of the step (largest launch time); every kernel of the chain is in `kernels`"
             out["kernels"] = rl
+        if mix_report:
+            out["mix"] = mix_report
         if world == 1 and not args.no_cpu_baseline:
             single = CPU_BASELINES[args.workload](6.0 if all_cores else 15.0)
             single["build"] = "-O2 -ffp-contract=off (portable oracle/libsk_oracle.so)"

@@ -94,6 +94,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// The schedule is read through the constant address space: a wave-uniform load from it is a SCALAR load (s_load, counted
+// in lgkmcnt).  As a plain global pointer the compiler cannot rule out that the kernel's own stores alias it, so it
+// issued a vector load plus s_waitcnt vmcnt(0) at the top of every frame -- which also waits for the PCM stores of the
+// frame before to be acknowledged by memory: the wave drained its whole memory pipeline once (twice, with the look-up
+// for the prefetch address) per frame, and that, not bandwidth, set the launch time (profiles/r02_ab_synth_groups.md).
+typedef const __attribute__((address_space(4))) SynthEntry *const_entries;
+__device__ __forceinline__ const_entries as_constant(const SynthEntry *p) {
+    return reinterpret_cast<const_entries>(reinterpret_cast<uintptr_t>(p));
+}
+
 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 // four PCM samples as the s16 the worker emits (float_sample_to_i16, soundkit-decoder lib.rs:1815-1827), packed
 __device__ __forceinline__ u2 pack4_s16(const f4 &v) {
@@ -329,7 +339,9 @@ __device__ __attribute__((noinline)) void synth_rare_frame(lds_f2 *ex, lds_f *st
 
 // OUT16: the PCM leaves as planar s16 (float_sample_to_i16 of every sample; same [off1024][1024] packing, two bytes
 // per sample) -- what decode_aac_access_unit hands on (soundkit-decoder lib.rs:1793-1813) before interleaving
-template <bool OUT16>
+// ONLY_LONG: every frame of every task is OnlyLong (the host knows the windows and sorts the tasks): the loop is one
+// straight line, so the compiler can count its memory operations exactly instead of draining them at a join.
+template <bool OUT16, bool ONLY_LONG>
 __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synth(SynthArgs a) {
     __shared__ f2 lds[kWavesPerBlock][kExchange];
     __shared__ float stage_lds[kWavesPerBlock][kStage];
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
     const uint32_t count = __builtin_amdgcn_readfirstlane(task_v.count);
     const uint32_t state = __builtin_amdgcn_readfirstlane(task_v.state);
     if (count == 0) return;
-    const SynthEntry *entries = a.entries + __builtin_amdgcn_readfirstlane(task_v.begin);
+    const const_entries entries = as_constant(a.entries + __builtin_amdgcn_readfirstlane(task_v.begin));
 
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const f2 base2 = reinterpret_cast<const f2 *>(a.t.w512)[hi3 * lo3];
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
     auto frame = [&](f2 (&xin)[8], uint32_t e) __attribute__((always_inline)) {
         const SynthEntry ent = entries[e];
         const uint32_t win = __builtin_amdgcn_readfirstlane(ent.win);
-        const int seq = win & 3;
+        const int seq = ONLY_LONG ? 0 : (int)(win & 3);
         const int shape = (win >> 2) & 1;
         float *out_ptr = OUT16 ? nullptr : a.pcm + (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024;
         int16_t *out16_ptr = OUT16 ? a.pcm16 + (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024 : nullptr;
@@ -438,9 +450,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
                 w2m[r] = *reinterpret_cast<const f4 *>(cur_long + 2044 - j);
             }
 #endif
-            if (e + kDepth < count) {  // next spectrum in flight while this one is transformed
-                const float *src =
-                    a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e + kDepth].off1024) * 1024 + 2 * lane;
+            // next spectrum in flight while this one is transformed.  Unconditional (the last frames re-read the task's
+            // last spectrum): with a branch around these loads the compiler can no longer count what is outstanding when
+            // the epilogue needs its windows, and waits for the prefetch itself before every store.
+            {
+                const uint32_t ahead = e + kDepth < count ? e + kDepth : count - 1;
+                const float *src = a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[ahead].off1024) * 1024 + 2 * lane;
 #pragma unroll
 #ifdef SK_SYNTH_ABLATE_F4LOAD
                 for (int r = 0; r < 4; ++r) {
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
                 dly[8 * r + 6] = M.z * W2m.z; dly[8 * r + 7] = F.y * W2m.w;
             }
             wave_sync();
-        } else {
+        } else if constexpr (!ONLY_LONG) {
             // hand the frame over through LDS (see synth_rare_frame), then restart the prefetch
 #pragma unroll
             for (int r = 0; r < 8; ++r) ex[64 * r + lane] = z[r];
@@ -578,7 +593,7 @@ __global__ __launch_bounds__(kGroupWaves * 64, SK_GROUP_MINW) void k_aac_synth_g
     const SynthTask task = a.tasks[g.task];
     const uint32_t first = __builtin_amdgcn_readfirstlane(g.first), n_out = __builtin_amdgcn_readfirstlane(g.count);
     const uint32_t state = __builtin_amdgcn_readfirstlane(task.state), t_count = __builtin_amdgcn_readfirstlane(task.count);
-    const SynthEntry *entries = a.entries + __builtin_amdgcn_readfirstlane(task.begin);
+    const const_entries entries = as_constant(a.entries + __builtin_amdgcn_readfirstlane(task.begin));
     lds_f2 *ex = (lds_f2 *)lds[wave];
     const lds_f2 *tw_lds = (const lds_f2 *)tw_tab;
     const lds_f2 *t64 = (const lds_f2 *)t64_tab;
@@ -794,8 +809,13 @@ hipError_t launch_reset_stream(float *delay2048, uint8_t *shape2, uint32_t *pns,
 hipError_t launch_aac_synth(const SynthArgs &a, hipStream_t s) {
     if (a.n_tasks == 0) return hipSuccess;
     const uint32_t blocks = (a.n_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (a.pcm16) hipLaunchKernelGGL(k_aac_synth<true>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
-    else hipLaunchKernelGGL(k_aac_synth<false>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
+    if (a.only_long) {
+        if (a.pcm16) hipLaunchKernelGGL((k_aac_synth<true, true>), dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
+        else hipLaunchKernelGGL((k_aac_synth<false, true>), dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
+    } else {
+        if (a.pcm16) hipLaunchKernelGGL((k_aac_synth<true, false>), dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
+        else hipLaunchKernelGGL((k_aac_synth<false, false>), dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -247,10 +247,10 @@ struct sk_aac_plan {
     sk::SynthEntry *d_entries = nullptr;
     sk::FrameSpan *d_spans = nullptr;
     // tasks whose frames are all OnlyLong run as groups of frames (k_aac_synth_group), the others walk (k_aac_synth)
-    sk::SynthTask *d_walk_tasks = nullptr;
+    sk::SynthTask *d_walk_tasks = nullptr, *d_long_tasks = nullptr;
     sk::SynthGroup *d_groups = nullptr;
     uint32_t *d_group_tasks = nullptr;
-    uint32_t n_walk_tasks = 0, n_groups = 0, n_group_tasks = 0;
+    uint32_t n_walk_tasks = 0, n_long_tasks = 0, n_groups = 0, n_group_tasks = 0;
 };
 
 #define SK_HIP(expr, what)                               \
@@ -566,6 +566,7 @@ void sk_aac_plan_destroy(sk_aac_plan *p) {
         if (p->d_entries) (void)hipFree(p->d_entries);
         if (p->d_spans) (void)hipFree(p->d_spans);
         if (p->d_walk_tasks) (void)hipFree(p->d_walk_tasks);
+        if (p->d_long_tasks) (void)hipFree(p->d_long_tasks);
         if (p->d_groups) (void)hipFree(p->d_groups);
         if (p->d_group_tasks) (void)hipFree(p->d_group_tasks);
     }
@@ -585,7 +586,7 @@ struct HostPlan {
     std::vector<sk::FrameSpan> spans;
     std::vector<uint32_t> entry_of;  // [frame * 2 + channel] -> index into entries (valid frames only)
     // split of `tasks` by kernel: all-OnlyLong tasks cut into groups of frames, the rest for the walking kernel
-    std::vector<sk::SynthTask> walk_tasks;
+    std::vector<sk::SynthTask> walk_tasks, long_tasks;
     std::vector<sk::SynthGroup> groups;
     std::vector<uint32_t> group_tasks;
     uint32_t frames_ok = 0;
@@ -657,24 +658,28 @@ int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, in
     if (bad_desc_channels || off > 0xffffffffull) return SK_ERR_INVALID_ARG;
     hp.frames_ok = frames_ok;
     hp.off1024 = off;
-    // which kernel runs which task.  The frames-in-parallel kernel (k_aac_synth_group) is correct and tested but slower than
-    // the walking one on this part (profiles/r02_ab_synth_groups.md: 1.02 against 0.93 ms), so it runs only on request:
-    // SK_SYNTH_GROUPS=1
+    // Which kernel runs which task.  Tasks whose frames are all OnlyLong (when the host knows the windows) take the
+    // straight-line walking kernel (k_aac_synth<.., true>); the rest the general one.  SK_SYNTH_GROUPS=1 sends the OnlyLong
+    // tasks to the frames-in-parallel kernel instead (k_aac_synth_group: correct and tested but slower on this part,
+    // profiles/r02_ab_synth_groups.md).
     static const bool use_groups = [] { const char *v = std::getenv("SK_SYNTH_GROUPS"); return v && v[0] == '1'; }();
     hp.walk_tasks.clear();
+    hp.long_tasks.clear();
     hp.groups.clear();
     hp.group_tasks.clear();
     const uint32_t per_group = sk::synth_group_frames();
     for (uint32_t t = 0; t < tasks.size(); ++t) {
-        bool only_long = windows_known && use_groups;
+        bool only_long = windows_known;
         for (uint32_t k = 0; only_long && k < tasks[t].count; ++k) only_long = (entries[tasks[t].begin + k].win & 3u) == 0;
         if (!only_long) {
             hp.walk_tasks.push_back(tasks[t]);
-            continue;
+        } else if (!use_groups) {
+            hp.long_tasks.push_back(tasks[t]);
+        } else {
+            hp.group_tasks.push_back(t);
+            for (uint32_t first = 0; first < tasks[t].count; first += per_group)
+                hp.groups.push_back(sk::SynthGroup{t, first, std::min(per_group, tasks[t].count - first), 0});
         }
-        hp.group_tasks.push_back(t);
-        for (uint32_t first = 0; first < tasks[t].count; first += per_group)
-            hp.groups.push_back(sk::SynthGroup{t, first, std::min(per_group, tasks[t].count - first), 0});
     }
     return SK_OK;
 }
@@ -704,6 +709,8 @@ int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n,
         if (he == hipSuccess) he = upload(&p->d_entries, hp.entries);
         if (he == hipSuccess) he = upload(&p->d_spans, hp.spans);
         if (he == hipSuccess && !hp.walk_tasks.empty()) he = upload(&p->d_walk_tasks, hp.walk_tasks);
+        if (he == hipSuccess && !hp.long_tasks.empty()) he = upload(&p->d_long_tasks, hp.long_tasks);
+        p->n_long_tasks = (uint32_t)hp.long_tasks.size();
         if (he == hipSuccess && !hp.groups.empty()) he = upload(&p->d_groups, hp.groups);
         if (he == hipSuccess && !hp.group_tasks.empty()) he = upload(&p->d_group_tasks, hp.group_tasks);
         p->n_walk_tasks = (uint32_t)hp.walk_tasks.size();
@@ -730,8 +737,13 @@ static int run_plan(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, f
     a.tasks = p->d_tasks;
     SK_HIP(sk::launch_aac_synth_groups(a, p->d_groups, p->n_groups, p->d_group_tasks, p->n_group_tasks, e->d_delay_next,
                                        e->d_shape_next, e->stream), "launch aac synth (groups)");
+    a.tasks = p->d_long_tasks;
+    a.n_tasks = p->n_long_tasks;
+    a.only_long = 1;
+    SK_HIP(sk::launch_aac_synth(a, e->stream), "launch aac synth (OnlyLong tasks)");
     a.tasks = p->d_walk_tasks;
     a.n_tasks = p->n_walk_tasks;
+    a.only_long = 0;
     SK_HIP(sk::launch_aac_synth(a, e->stream), "launch aac synth");
     return SK_OK;
 }
@@ -2191,9 +2203,16 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             SK_HIP(sk::launch_aac_synth_groups(a, d_groups, (uint32_t)hp.groups.size(), d_group_tasks, (uint32_t)hp.group_tasks.size(),
                                                e->d_delay_next, e->d_shape_next, e->stream), "launch tick synth (groups)");
         }
+        if (!hp.long_tasks.empty()) {
+            SK_HIP(aux.put(hp.long_tasks, e->stream, &a.tasks), "upload tick OnlyLong tasks");
+            a.n_tasks = (uint32_t)hp.long_tasks.size();
+            a.only_long = 1;
+            SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth (OnlyLong tasks)");
+        }
         if (!hp.walk_tasks.empty()) {
             SK_HIP(aux.put(hp.walk_tasks, e->stream, &a.tasks), "upload tick walk tasks");
             a.n_tasks = (uint32_t)hp.walk_tasks.size();
+            a.only_long = 0;
             SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth");
         }
         if (au_mode) {  // which units failed decides what the later stages may use

@@ -43,6 +43,7 @@ struct SynthArgs {
     const SynthTask *tasks;
     const SynthEntry *entries;
     uint32_t n_tasks;
+    uint32_t only_long;   // 1: the caller vouches that every entry of every task is OnlyLong (straight-line kernel)
     SynthTables t;
 };
 
