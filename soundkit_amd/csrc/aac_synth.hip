@@ -406,12 +406,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
 #endif
     };
     auto frame = [&](f2 (&xin)[8], uint32_t e) __attribute__((always_inline)) {
-        const SynthEntry ent = entries[e];
-        const uint32_t win = __builtin_amdgcn_readfirstlane(ent.win);
+        const uint32_t ent_off = entries[e].off1024, ent_win = entries[e].win;
+        const uint32_t win = __builtin_amdgcn_readfirstlane(ent_win);
         const int seq = ONLY_LONG ? 0 : (int)(win & 3);
         const int shape = (win >> 2) & 1;
-        float *out_ptr = OUT16 ? nullptr : a.pcm + (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024;
-        int16_t *out16_ptr = OUT16 ? a.pcm16 + (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024 : nullptr;
+        float *out_ptr = OUT16 ? nullptr : a.pcm + (size_t)__builtin_amdgcn_readfirstlane(ent_off) * 1024;
+        int16_t *out16_ptr = OUT16 ? a.pcm16 + (size_t)__builtin_amdgcn_readfirstlane(ent_off) * 1024 : nullptr;
 
         // ---- pre-twiddle (dsp.rs:495-503): consumes xin so the next spectrum can land in it ----
         f2 z[8];
@@ -608,17 +608,15 @@ __global__ __launch_bounds__(kGroupWaves * 64, SK_GROUP_MINW) void k_aac_synth_g
     uint32_t win_a = 0, win_b = 0;
     size_t off_a = 0, off_b = 0;
     if (a_active) {
-        const SynthEntry ent = entries[ea];
-        win_a = __builtin_amdgcn_readfirstlane(ent.win);
-        off_a = (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024;
+        win_a = __builtin_amdgcn_readfirstlane(entries[ea].win);
+        off_a = (size_t)__builtin_amdgcn_readfirstlane(entries[ea].off1024) * 1024;
         const float *src = a.coeffs + off_a + 2 * lane;
 #pragma unroll
         for (int r = 0; r < 8; ++r) xa[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
     }
     if (b_active) {
-        const SynthEntry ent = entries[eb];
-        win_b = __builtin_amdgcn_readfirstlane(ent.win);
-        off_b = (size_t)__builtin_amdgcn_readfirstlane(ent.off1024) * 1024;
+        win_b = __builtin_amdgcn_readfirstlane(entries[eb].win);
+        off_b = (size_t)__builtin_amdgcn_readfirstlane(entries[eb].off1024) * 1024;
         const float *src = a.coeffs + off_b + 2 * lane;
 #pragma unroll
         for (int r = 0; r < 8; ++r) xb[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
