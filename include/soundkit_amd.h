@@ -157,6 +157,16 @@ int sk_aac_decoder_parse(sk_aac_decoder *, const uint8_t *access_unit, size_t le
                          sk_aac_frame_desc *desc);
 /* parse_adts_access_unit (soundkit-decoder/src/lib.rs:1007-1027): the 2-byte ASC and the raw access unit of
  * one ADTS frame; frame_len = bytes to the next frame header. */
+/* The Huffman half of the front-end alone ("GPU dequant + stereo tools + TNS fed by i16 quantized
+ * values + scalefactor bytes"): quant receives channels x 1024 i16 quantised values (pulses applied, spectral.rs:327-423,
+ * 2198-2247), side a SK_AAC_UNIT_SIDE_BYTES record (section codebooks, transmitted scale factors, grouping, mid/side mask,
+ * TNS filters, noise-sample count, and the verdict on the rest of the unit), desc the window fields.  Dequantisation
+ * (dsp.rs:397-405), PNS, intensity + mid/side and TNS then run on the device: sk_tick_run_q.  5.3 KiB per stereo
+ * access unit cross PCIe instead of 8 KiB.  A quantised magnitude beyond i16 (illegal in ISO/IEC 14496-3, which stops at
+ * 8191; the reference accepts escapes up to 2^17) is SK_AAC_ERR_UNSUPPORTED_FEATURE here. */
+#define SK_AAC_UNIT_SIDE_BYTES 1308u
+int sk_aac_decoder_parse_q(sk_aac_decoder *, const uint8_t *access_unit, size_t len, int16_t *quant /*[ch][1024]*/,
+                           void *side /*SK_AAC_UNIT_SIDE_BYTES*/, sk_aac_frame_desc *desc);
 int sk_adts_parse(const uint8_t *data, size_t len, size_t *frame_len, size_t *payload_off, size_t *payload_len,
                   uint8_t asc[2]);
 
@@ -403,6 +413,13 @@ typedef struct sk_au_item {
 int sk_tick_run_au(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, const sk_au_item *units, uint32_t n_units,
                    const uint8_t *au_bytes, size_t au_bytes_len, uint8_t *out_bytes, size_t out_cap, sk_tick_output *outputs,
                    uint32_t outputs_cap, uint32_t *n_outputs, size_t *out_bytes_used);
+
+/* The same tick fed by sk_aac_decoder_parse_q: per access unit the side record and the quantised i16 values (packed like
+ * coeffs: unit k at the running channel count x 1024); descs as for sk_tick_run.  Dequantisation, PNS (the stream's
+ * generator lives in the engine, as for sk_tick_run_au), stereo tools and TNS run on the device before the synthesis. */
+int sk_tick_run_q(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, const sk_aac_frame_desc *descs,
+                  const void *sides /*[n_units][SK_AAC_UNIT_SIDE_BYTES]*/, const int16_t *quant, uint32_t n_units, uint8_t *out_bytes,
+                  size_t out_cap, sk_tick_output *outputs, uint32_t outputs_cap, uint32_t *n_outputs, size_t *out_bytes_used);
 
 /* The front-end alone, batched on the GPU: AacLcDecoder::decode_access_unit (soundkit-aac-lc/src/decoder.rs:104-164) up to
  * the hand-over to synthesis (decoder.rs:336) for every listed unit -- the device counterpart of sk_aac_decoder_parse.

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("SOUNDKIT_AMD_LIB") or os.path.join(_HERE, "libsoundki
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "soundkit_amd.h")
 
 SK_OK = 0
+AAC_UNIT_SIDE_BYTES = 1308  # SK_AAC_UNIT_SIDE_BYTES
 ERR_NAMES = {0: "SK_OK", -1: "SK_ERR_INVALID_ARG", -2: "SK_ERR_NO_DEVICE", -3: "SK_ERR_HIP", -4: "SK_ERR_OOM",
              -5: "SK_ERR_BAD_STREAM", -6: "SK_ERR_UNSUPPORTED", -7: "SK_ERR_CAPACITY",
              -101: "UnexpectedEof", -102: "InvalidAudioObjectType", -103: "UnsupportedAudioObjectType",
@@ -143,6 +144,8 @@ _sig = {
     "sk_aac_decoder_last_error": (C.c_char_p, [_vp]),
     "sk_aac_decoder_tool_usage": (_i, [_vp, _vp]),
     "sk_aac_decoder_parse": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "sk_aac_decoder_parse_q": (_i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "sk_tick_run_q": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
     "sk_adts_parse": (_i, [_vp, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), _vp]),
     "sk_aac_dequantize_dev": (_i, [_vp, _vp, _vp, _vp, _sz]),
     "sk_aac_dequantize": (_i, [_vp, _vp, _vp, _vp, _sz]),

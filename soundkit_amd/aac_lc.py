@@ -165,6 +165,22 @@ class AacLcFrontEnd:
         return coeffs, list(desc.window_sequence)[:self.channels], list(desc.window_shape)[:self.channels]
 
 
+    def parse_q(self, access_unit):
+        """sk_aac_decoder_parse_q: the Huffman half alone -> (quant [channels][1024] i16, side record bytes,
+        window_sequence [channels], window_shape [channels]); the rest runs on the device (Engine.tick_run_q)"""
+        import ctypes as C
+        from ._lib import AAC_UNIT_SIDE_BYTES, FrameDesc
+        buf = np.frombuffer(bytes(access_unit), np.uint8)
+        quant = np.zeros((self.channels, 1024), np.int16)
+        side = np.zeros(AAC_UNIT_SIDE_BYTES, np.uint8)
+        desc = FrameDesc()
+        rc = self._lib.sk_aac_decoder_parse_q(self._h, buf.ctypes.data if buf.size else None, buf.size, quant.ctypes.data,
+                                              side.ctypes.data, C.byref(desc))
+        if rc != 0:
+            raise AacLcError(rc, self._lib.sk_aac_decoder_last_error(self._h).decode())
+        return quant, side, list(desc.window_sequence)[:self.channels], list(desc.window_shape)[:self.channels]
+
+
 class AacLcDecoder:
     """Drop-in shape of soundkit_aac_lc::AacLcDecoder: from_audio_specific_config / decode_access_unit /
     frame_info (decoder.rs:46-164).  Entropy decode on the host, IMDCT + window + overlap-add on the GPU."""

@@ -100,6 +100,28 @@ __global__ __launch_bounds__(512) void k_aac_entropy_parse(EntropyArgs a) {
     for (uint32_t c = 0; c < tk.channels; ++c) a.entries[u.entry[c]].win = (uint32_t)seq[c] | ((uint32_t)shape[c] << 2);
 }
 
+// Phase one of the quantised hand-over: the host has done the Huffman decode; a lane rebuilds its unit's side
+// information from the wire record, dequantises the integers into the synthesis input and leaves the noise bands open.
+__global__ __launch_bounds__(512) void k_aac_expand_q(EntropyArgs a) {
+    extern __shared__ uint4 lds_raw[];
+    const sk_ec::Tables t = lds_tables(a, lds_raw);
+    uint32_t k;
+    if (!unit_of_lane(a, k)) return;
+    const EntropyUnit u = a.units[k];
+    const EntropyTask tk = a.tasks[u.task];
+    const sk_ec::Stream st{tk.sf_index, (int)tk.channels, 0u};
+    sk_ec::Scratch side;
+    sk_ec::unpack_unit(t, a.wire[k], side);
+    float *coef = a.coeffs + (size_t)u.off1024 * 1024;
+    const int16_t *q = a.quant + (size_t)u.off1024 * 1024;
+    int status = (uint32_t)a.wire[k].channels == tk.channels ? sk_ec::EC_OK : sk_ec::EC_INVALID_CONFIG;
+    for (uint32_t c = 0; c < tk.channels && status == sk_ec::EC_OK; ++c) status = sk_ec::dequant_channel(t, st, side.ch[c], q + 1024 * c, coef + 1024 * c);
+    a.status[k] = status;
+    a.side[k] = side;
+    for (uint32_t c = 0; c < tk.channels; ++c)
+        a.entries[u.entry[c]].win = (uint32_t)side.ch[c].ics.sequence | ((uint32_t)side.ch[c].ics.shape << 2);
+}
+
 __global__ __launch_bounds__(64) void k_aac_entropy_link(EntropyArgs a) {
     const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
     if (task >= a.n_tasks) return;
@@ -156,6 +178,7 @@ __global__ __launch_bounds__(512) void k_aac_entropy_finish(EntropyArgs a) {
         sk_ec::Stream st{tk.sf_index, (int)tk.channels, a.pns_start[k]};
         sk_ec::Scratch side = a.side[k];
         status = sk_ec::finish_unit(t, st, a.words + u.word_offset, u.byte_len, coef, side, true);
+        if (status == sk_ec::EC_OK && a.wire) status = a.wire[k].tail_status;  // the host has looked at the rest of the unit
         a.status[k] = status;
     }
     if (status != sk_ec::EC_OK) {  // failed or skipped: silence for the synthesis launch that follows
@@ -171,7 +194,8 @@ hipError_t launch_aac_entropy_parallel(const EntropyArgs &a, hipStream_t s) {
     if (a.lane_shift > 4) return hipErrorInvalidValue;
     // workgroups of eight waves share one copy of the tables in LDS (~60 KB): two per CU, four waves per SIMD
     const uint32_t per_wave = 64u >> a.lane_shift, waves = (a.n_units + per_wave - 1) / per_wave, blocks = (waves + 7) / 8;
-    hipLaunchKernelGGL(k_aac_entropy_parse, dim3(blocks), dim3(512), a.lds_bytes, s, a);
+    if (a.wire) hipLaunchKernelGGL(k_aac_expand_q, dim3(blocks), dim3(512), a.lds_bytes, s, a);
+    else hipLaunchKernelGGL(k_aac_entropy_parse, dim3(blocks), dim3(512), a.lds_bytes, s, a);
     hipLaunchKernelGGL(k_aac_entropy_link, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_aac_entropy_finish, dim3(blocks), dim3(512), a.lds_bytes, s, a);
     hipLaunchKernelGGL(k_aac_entropy_seal, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);

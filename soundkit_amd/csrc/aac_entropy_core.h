@@ -251,11 +251,15 @@ SKE float sf_multiplier(const Tables &t, int sf) {  // dsp.rs:407-413; sf is an 
     return t.sf_wide[sf + 32768];
 }
 
-SKE int read_scalefactors(const Tables &t, Bits &b, Channel &ch) {  // scalefactor.rs:80-153
+// sf_out (optional, [128]): the transmitted values themselves -- spectral scale factor, noise energy or intensity
+// position of each band -- for the quantised hand-over to the device (WireChannel below)
+SKE int read_scalefactors(const Tables &t, Bits &b, Channel &ch, int16_t *sf_out = nullptr) {  // scalefactor.rs:80-153
     int spectral = ch.global_gain, noise = ch.global_gain - 90, intensity = 0;
     bool first_noise = true;
     const int stride = band_stride(ch.ics);
     for (int i = 0; i < 128; ++i) ch.mult[i] = 0.0f;
+    if (sf_out)
+        for (int i = 0; i < 128; ++i) sf_out[i] = 0;
     for (int g = 0; g < ch.ics.num_groups; ++g)
         for (int sfb = 0; sfb < ch.ics.max_sfb; ++sfb) {
             const int book = ch.book[g * stride + sfb];
@@ -272,15 +276,18 @@ SKE int read_scalefactors(const Tables &t, Bits &b, Channel &ch) {  // scalefact
                     if (!i16_add(noise, (int)sym - 60, &noise)) return EC_INVALID_BITSTREAM;
                 }
                 ch.mult[g * stride + sfb] = sf_multiplier(t, noise);
+                if (sf_out) sf_out[g * stride + sfb] = (int16_t)noise;
             } else if (book == BOOK_INTENSITY || book == BOOK_INTENSITY_NEG) {
                 EC_TRY(huffman(t, 0, b, &sym));
                 if (!i16_add(intensity, (int)sym - 60, &intensity)) return EC_INVALID_BITSTREAM;
                 // scalefactor.rs:208-210; tabulated with the host's powf so that the device build agrees to the bit
                 ch.mult[g * stride + sfb] = (intensity >= -256 && intensity <= 255) ? t.is_mult[intensity + 256] : t.is_wide[intensity + 32768];
+                if (sf_out) sf_out[g * stride + sfb] = (int16_t)intensity;
             } else {
                 EC_TRY(huffman(t, 0, b, &sym));
                 if (!i16_add(spectral, (int)sym - 60, &spectral)) return EC_INVALID_BITSTREAM;
                 ch.mult[g * stride + sfb] = sf_multiplier(t, spectral);
+                if (sf_out) sf_out[g * stride + sfb] = (int16_t)spectral;
             }
         }
     return EC_OK;
@@ -324,14 +331,14 @@ SKE int read_tns(Bits &b, Channel &ch) {  // tns.rs:34-83
     return EC_OK;
 }
 
-SKE int read_channel(const Tables &t, Bits &b, Channel &ch, const Ics *common) {  // channel.rs:19-75
+SKE int read_channel(const Tables &t, Bits &b, Channel &ch, const Ics *common, int16_t *sf_out = nullptr) {  // channel.rs:19-75
     uint32_t v;
     EC_TRY(read_bits(b, 8, &v));
     ch.global_gain = (uint8_t)v;
     if (common) ch.ics = *common;
     else EC_TRY(read_ics(b, ch.ics));
     EC_TRY(read_sections(b, ch));
-    EC_TRY(read_scalefactors(t, b, ch));
+    EC_TRY(read_scalefactors(t, b, ch, sf_out));
     bool flag;
     EC_TRY(read_flag(b, &flag));
     ch.pulse_present = flag;
@@ -477,8 +484,13 @@ enum PnsMode {
     PNS_COUNT,     // frame-parallel decode: only count the samples (the generator state is not known yet)
 };
 
-SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
-                        PnsMode mode, uint32_t *noise_samples) {
+// QUANT: instead of the dequantised spectrum, the quantised values themselves (pulses applied) go to `quant` as i16 --
+// what the host front-end hands to the device when dequantisation, noise, stereo tools and TNS run there (SURVEY 8f rank
+// 1).  A magnitude beyond i16 (only an escape sequence of more than 11 extra bits can produce one; ISO/IEC 14496-3 allows
+// 8191) is reported as an unsupported feature in that mode.  mode must be PNS_COUNT; coef is not touched.
+template <bool QUANT>
+SKE int decode_spectrum_t(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
+                          PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant) {
     const Ics ics = ch.ics;
     const int stride = band_stride(ics);
     const int max_sfb = ics.max_sfb, num_groups = ics.num_groups;
@@ -491,7 +503,11 @@ SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &
     const uint16_t *off;
     int bands;
     EC_TRY(layout(t, st, ics, &off, &bands));
-    for (int i = 0; i < 1024; ++i) coef[i] = 0.0f;
+    if (QUANT) {
+        for (int i = 0; i < 1024; ++i) quant[i] = 0;
+    } else {
+        for (int i = 0; i < 1024; ++i) coef[i] = 0.0f;
+    }
     Bits b = bits;  // a local copy: its fields stay in registers across the stores below
     uint32_t pns = st.pns_state;
     int q[4];
@@ -522,7 +538,15 @@ SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &
                         for (int i = s; i + dim <= e; i += dim) {
                             status = read_tuple(br, b, q);
                             if (status != EC_OK) break;
-                            for (int k = 0; k < dim; ++k) coef[w * 128 + i + k] = dequantize(t, q[k], scale);
+                            for (int k = 0; k < dim; ++k) {
+                                if (QUANT) {
+                                    if (q[k] > 32767 || q[k] < -32768) status = EC_UNSUPPORTED_FEATURE;
+                                    quant[w * 128 + i + k] = (int16_t)q[k];
+                                } else {
+                                    coef[w * 128 + i + k] = dequantize(t, q[k], scale);
+                                }
+                            }
+                            if (QUANT && status != EC_OK) break;
                         }
                 } else if (book == BOOK_NOISE) {
                     if (mode == PNS_COUNT) *noise_samples += (uint32_t)(glen * (e - s));
@@ -575,7 +599,15 @@ SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &
                     const int k = target[p] - i;
                     if (k >= 0 && k < dim) q[k] += q[k] > 0 ? amp[p] : -amp[p];
                 }
-                for (int k = 0; k < dim; ++k) coef[i + k] = dequantize(t, q[k], scale);
+                for (int k = 0; k < dim; ++k) {
+                    if (QUANT) {
+                        if (q[k] > 32767 || q[k] < -32768) status = EC_UNSUPPORTED_FEATURE;
+                        quant[i + k] = (int16_t)q[k];
+                    } else {
+                        coef[i + k] = dequantize(t, q[k], scale);
+                    }
+                }
+                if (QUANT && status != EC_OK) break;
             }
         } else if (book == BOOK_NOISE && !pulse_present) {
             if (mode == PNS_COUNT) *noise_samples += (uint32_t)(e - s);
@@ -612,6 +644,11 @@ SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &
         else EC_TRY(noise_band(ch.mult[sfb], st.pns_state, coef + s, e - s));
     }
     return EC_OK;
+}
+
+SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
+                        PnsMode mode, uint32_t *noise_samples) {
+    return decode_spectrum_t<false>(t, st, bits, ch, allow_intensity, coef, mode, noise_samples, nullptr);
 }
 
 // the noise bands of one channel, in the order decode_spectrum generates them (PNS_COUNT left them open)
@@ -813,8 +850,13 @@ struct Scratch {  // an access unit's side information: per-lane working storage
 // First phase: everything up to and including the spectral data of the channel element.  With PNS_GENERATE the noise
 // bands are filled on the way (the reference's order); with PNS_COUNT they are left open and only counted, which makes
 // the phase independent of every other access unit of the stream.
+struct QuantCapture {  // host side of the quantised hand-over: where parse_unit leaves the integers
+    int16_t *quant;    // [channels][1024] quantised spectral values, pulses applied
+    int16_t *sf[2];    // [128] each: transmitted scale factor / noise energy / intensity position per band
+};
+
 SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len_bytes, float *coef, uint8_t *sequence, uint8_t *shape,
-                   Scratch &s, PnsMode mode) {
+                   Scratch &s, PnsMode mode, const QuantCapture *qc = nullptr) {
     Bits b = make_bits(au, len_bytes);
     s.noise_samples = 0;
     while (b.total - b.pos >= 3) {  // each pass consumes >= 3 bits: bounded by the length of the access unit
@@ -824,8 +866,9 @@ SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len
         if (id == 0) {  // single channel element, decoder.rs:165-183
             if (st.channels != 1) return EC_INVALID_BITSTREAM;
             Channel &ch = s.ch[0];
-            EC_TRY(read_channel(t, b, ch, nullptr));
-            EC_TRY(decode_spectrum(t, st, b, ch, false, coef, mode, &s.noise_samples));
+            EC_TRY(read_channel(t, b, ch, nullptr, qc ? qc->sf[0] : nullptr));
+            if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, ch, false, nullptr, PNS_COUNT, &s.noise_samples, qc->quant));
+            else EC_TRY(decode_spectrum(t, st, b, ch, false, coef, mode, &s.noise_samples));
             s.is_pair = 0;
             s.common_window = 0;
             sequence[0] = ch.ics.sequence;
@@ -844,10 +887,12 @@ SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len
                 EC_TRY(read_ms_mask(b, common, s.mask));
             }
             Channel &left = s.ch[0], &right = s.ch[1];
-            EC_TRY(read_channel(t, b, left, common_window ? &common : nullptr));
-            EC_TRY(decode_spectrum(t, st, b, left, false, coef, mode, &s.noise_samples));
-            EC_TRY(read_channel(t, b, right, common_window ? &common : nullptr));
-            EC_TRY(decode_spectrum(t, st, b, right, true, coef + 1024, mode, &s.noise_samples));
+            EC_TRY(read_channel(t, b, left, common_window ? &common : nullptr, qc ? qc->sf[0] : nullptr));
+            if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, left, false, nullptr, PNS_COUNT, &s.noise_samples, qc->quant));
+            else EC_TRY(decode_spectrum(t, st, b, left, false, coef, mode, &s.noise_samples));
+            EC_TRY(read_channel(t, b, right, common_window ? &common : nullptr, qc ? qc->sf[1] : nullptr));
+            if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, right, true, nullptr, PNS_COUNT, &s.noise_samples, qc->quant + 1024));
+            else EC_TRY(decode_spectrum(t, st, b, right, true, coef + 1024, mode, &s.noise_samples));
             s.is_pair = 1;
             s.common_window = common_window;
             sequence[0] = left.ics.sequence;
@@ -879,6 +924,8 @@ SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len
     return EC_INVALID_BITSTREAM;  // "raw access unit does not contain an AAC-LC channel element"
 }
 
+SKE int unit_tail(const uint32_t *au, uint32_t len_bytes, uint32_t resume_pos);
+
 // Second phase: [the noise bands, if the first phase only counted them,] stereo tools, TNS, then the rest of the access
 // unit (fill elements, END, the trailing-zero rule) from where the first phase stopped.
 SKE int finish_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len_bytes, float *coef, Scratch &s, bool fill) {
@@ -901,8 +948,13 @@ SKE int finish_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t le
     }
     if (left.tns_present) EC_TRY(apply_tns(t, st, left, coef));
     if (s.is_pair && right.tns_present) EC_TRY(apply_tns(t, st, right, coef + 1024));
+    return unit_tail(au, len_bytes, s.resume_pos);
+}
+
+// the rest of the access unit behind the channel element: fill elements, END, the trailing-zero rule (decoder.rs:134-161)
+SKE int unit_tail(const uint32_t *au, uint32_t len_bytes, uint32_t resume_pos) {
     Bits b = make_bits(au, len_bytes);
-    b.pos = s.resume_pos;
+    b.pos = resume_pos;
     while (b.total - b.pos >= 3) {
         if (rest_is_zero(b)) break;
         uint32_t id, tag;
@@ -949,6 +1001,162 @@ SKE uint32_t pns_advance(uint32_t state, uint32_t n) {
         n >>= 1;
     }
     return state * acc_mul + acc_add;
+}
+
+// ---- quantised hand-over: host Huffman decode -> device dequantisation, noise, stereo tools, TNS -------
+// What crosses PCIe per access unit instead of channels x 1024 f32: channels x 1024 i16 quantised values plus this record
+// (section codebooks, transmitted scale factors, window / grouping, mid/side mask, TNS filters): sk_aac_unit_side in the C ABI.
+struct WireTnsFilter {
+    uint8_t window, length, order, direction, coef_bits;
+    int8_t coef[20];
+    uint8_t pad[3];
+};
+struct WireChannel {
+    uint8_t sequence, shape, max_sfb, num_windows, num_groups, tns_present, n_filters, reserved;
+    uint8_t group_len[8];
+    uint8_t tns_filter_count[8], tns_coef_res[8];
+    uint8_t book[128];
+    int16_t sf[128];
+    WireTnsFilter filter[8];  // long: <= 3 in window 0; eight-short: <= 1 per window
+};
+struct WireUnit {
+    uint8_t channels, is_pair, common_window, ms_mode;
+    int32_t tail_status;     // unit_tail's verdict (the host has the bitstream); applies if nothing fails before it
+    uint32_t noise_samples;  // PNS samples the unit consumes: the generator jump of the units behind it
+    uint8_t ms_used[16];     // bit i = MsMask::used[i]
+    WireChannel ch[2];
+};
+
+SKE void pack_unit(const Scratch &s, int channels, const int16_t *const sf[2], int32_t tail_status, WireUnit &w) {
+    for (size_t i = 0; i < sizeof w; ++i) reinterpret_cast<uint8_t *>(&w)[i] = 0;
+    w.channels = (uint8_t)channels;
+    w.is_pair = s.is_pair;
+    w.common_window = s.common_window;
+    w.ms_mode = s.is_pair && s.common_window ? s.mask.mode : 0;
+    w.tail_status = tail_status;
+    w.noise_samples = s.noise_samples;
+    if (w.ms_mode == 1)
+        for (int i = 0; i < 128; ++i)
+            if (s.mask.used[i]) w.ms_used[i >> 3] |= (uint8_t)(1u << (i & 7));
+    for (int c = 0; c < channels; ++c) {
+        const Channel &ch = s.ch[c];
+        WireChannel &wc = w.ch[c];
+        wc.sequence = ch.ics.sequence;
+        wc.shape = ch.ics.shape;
+        wc.max_sfb = ch.ics.max_sfb;
+        wc.num_windows = ch.ics.num_windows;
+        wc.num_groups = ch.ics.num_groups;
+        wc.tns_present = ch.tns_present;
+        for (int i = 0; i < 8; ++i) wc.group_len[i] = ch.ics.group_len[i];
+        for (int i = 0; i < 128; ++i) {
+            wc.book[i] = ch.book[i];
+            wc.sf[i] = sf[c][i];
+        }
+        if (ch.tns_present)
+            for (int win = 0; win < ch.ics.num_windows; ++win) {
+                wc.tns_filter_count[win] = ch.tns[win].filter_count;
+                wc.tns_coef_res[win] = ch.tns[win].coef_res;
+                for (int f = 0; f < ch.tns[win].filter_count && wc.n_filters < 8; ++f) {
+                    const TnsFilter &src = ch.tns[win].filter[f];
+                    WireTnsFilter &dst = wc.filter[wc.n_filters++];
+                    dst.window = (uint8_t)win;
+                    dst.length = src.length;
+                    dst.order = src.order;
+                    dst.direction = src.direction;
+                    dst.coef_bits = src.coef_bits;
+                    for (int i = 0; i < 20; ++i) dst.coef[i] = i < src.order ? src.coef[i] : 0;
+                }
+            }
+    }
+}
+
+// the device's side of it: the record back into the structures finish_unit works on (multipliers from the tables, as
+// read_scalefactors derives them)
+SKE void unpack_unit(const Tables &t, const WireUnit &w, Scratch &s) {
+    s.is_pair = w.is_pair;
+    s.common_window = w.common_window;
+    s.resume_pos = 0;
+    s.noise_samples = w.noise_samples;
+    s.mask.mode = w.ms_mode;
+    for (int i = 0; i < 128; ++i) s.mask.used[i] = (uint8_t)((w.ms_used[i >> 3] >> (i & 7)) & 1u);
+    for (int c = 0; c < (int)w.channels && c < 2; ++c) {
+        const WireChannel &wc = w.ch[c];
+        Channel &ch = s.ch[c];
+        ch.ics.sequence = wc.sequence;
+        ch.ics.shape = wc.shape;
+        ch.ics.max_sfb = wc.max_sfb;
+        ch.ics.num_windows = wc.num_windows;
+        ch.ics.num_groups = wc.num_groups;
+        for (int i = 0; i < 8; ++i) ch.ics.group_len[i] = wc.group_len[i];
+        ch.global_gain = 0;
+        ch.pulse_present = 0;
+        ch.pulse_start = ch.pulse_count = 0;
+        ch.tns_present = wc.tns_present;
+        for (int i = 0; i < 128; ++i) {
+            const int book = wc.book[i], sf = wc.sf[i];
+            ch.book[i] = (uint8_t)book;
+            float m = 0.0f;
+            if (book == BOOK_INTENSITY || book == BOOK_INTENSITY_NEG) m = (sf >= -256 && sf <= 255) ? t.is_mult[sf + 256] : t.is_wide[sf + 32768];
+            else if (book != BOOK_ZERO) m = sf_multiplier(t, sf);
+            ch.mult[i] = m;
+        }
+        for (int win = 0; win < 8; ++win) {
+            ch.tns[win].filter_count = wc.tns_filter_count[win];
+            ch.tns[win].coef_res = wc.tns_coef_res[win];
+        }
+        int slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < (int)wc.n_filters && k < 8; ++k) {
+            const WireTnsFilter &src = wc.filter[k];
+            const int win = src.window & 7;
+            if (slot[win] >= 4) continue;
+            TnsFilter &dst = ch.tns[win].filter[slot[win]++];
+            dst.length = src.length;
+            dst.order = src.order;
+            dst.direction = src.direction;
+            dst.coef_bits = src.coef_bits;
+            for (int i = 0; i < 20; ++i) dst.coef[i] = src.coef[i];
+        }
+    }
+}
+
+// dsp.rs:397-405 over one channel's coded bands (decode_spectrum's stores, from the integers): zero, noise and intensity
+// bands stay zero (noise is filled by fill_noise, intensity by the stereo tools)
+SKE int dequant_channel(const Tables &t, const Stream &st, const Channel &ch, const int16_t *__restrict__ quant, float *__restrict__ coef) {
+    const Ics ics = ch.ics;
+    const int stride = band_stride(ics), max_sfb = ics.max_sfb;
+    const uint16_t *off;
+    int bands;
+    EC_TRY(layout(t, st, ics, &off, &bands));
+    for (int i = 0; i < 1024; ++i) coef[i] = 0.0f;
+    if (ics.sequence == SEQ_EIGHT_SHORT) {
+        int w0 = 0;
+        for (int g = 0; g < ics.num_groups; ++g) {
+            const int glen = ics.group_len[g];
+            if (glen == 0 || w0 + glen > 8) return EC_INVALID_BITSTREAM;
+            for (int sfb = 0; sfb < max_sfb; ++sfb) {
+                const int book = ch.book[g * stride + sfb];
+                if (!(book >= 1 && book <= 11)) continue;
+                int s, e;
+                EC_TRY(band_range(off, bands, sfb, &s, &e));
+                if (e > 128) return EC_INVALID_CONFIG;
+                const float scale = ch.mult[g * stride + sfb];
+                for (int w = w0; w < w0 + glen; ++w)
+                    for (int i = s; i < e; ++i) coef[w * 128 + i] = dequantize(t, quant[w * 128 + i], scale);
+            }
+            w0 += glen;
+        }
+        return EC_OK;
+    }
+    for (int sfb = 0; sfb < max_sfb; ++sfb) {
+        const int book = ch.book[sfb];
+        if (!(book >= 1 && book <= 11)) continue;
+        int s, e;
+        EC_TRY(band_range(off, bands, sfb, &s, &e));
+        if (e > 1024) return EC_INVALID_CONFIG;
+        const float scale = ch.mult[sfb];
+        for (int i = s; i < e; ++i) coef[i] = dequantize(t, quant[i], scale);
+    }
+    return EC_OK;
 }
 
 }  // namespace sk_ec

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "aac_entropy_tables.h"
+#include "aac_entropy_core.h"
 #include "aac_tables.h"
 
 namespace {
@@ -978,7 +979,7 @@ namespace sk_ec {
 const HostTables &host_tables() {
     static const HostTables flat = [] {
         HostTables h;
-        const Tables &t = tables();
+        const auto &t = tables();  // the host parser's own tables (this file's), not sk_ec::Tables
         for (int book = 0; book < 12; ++book) {
             const Lut &lut = book == 0 ? t.sf : t.cb[book];
             h.lut_offset[book] = (uint32_t)h.lut.size();
@@ -1088,6 +1089,59 @@ int sk_aac_decoder_parse(sk_aac_decoder *dec, const uint8_t *au, size_t len, flo
     } catch (const AacError &e) {
         dec->d.last_error = e.msg;
         return e.code;
+    }
+    return SK_OK;
+}
+
+// The Huffman half alone: quantised values as i16 + the side record the device needs to dequantise,
+// fill noise, run the stereo tools and TNS (aac_entropy_core.h WireUnit).  The core's parser is used for it -- the same
+// source the device runs -- so what the device rebuilds is what this call saw.
+int sk_aac_decoder_parse_q(sk_aac_decoder *dec, const uint8_t *au, size_t len, int16_t *quant, void *side, sk_aac_frame_desc *desc) {
+    if (!dec || (!au && len) || !quant || !side || !desc || len > 8192) return SK_ERR_INVALID_ARG;
+    static_assert(sizeof(sk_ec::WireUnit) == SK_AAC_UNIT_SIDE_BYTES, "sk_aac_unit_side size");
+    static const sk_ec::Tables view = [] {
+        const sk_ec::HostTables &h = sk_ec::host_tables();
+        sk_ec::Tables t{};
+        t.meta = h.meta.data();
+        t.lut = h.lut.data();
+        t.tuples = h.tuples.data();
+        t.swb = h.swb.data();
+        t.pow43 = h.pow43.data();
+        t.pow43_lo = h.pow43.data();
+        t.sf_mult = h.sf_mult.data();
+        t.is_mult = h.is_mult.data();
+        t.tns_sin = h.tns_sin.data();
+        t.sf_wide = h.sf_wide.data();
+        t.is_wide = h.is_wide.data();
+        return t;
+    }();
+    thread_local std::vector<uint32_t> words;
+    words.assign((len + 3) / 4 + 2, 0);  // 4-byte aligned, >= 8 zero bytes behind the unit
+    if (len) std::memcpy(words.data(), au, len);
+    sk_ec::Stream st{dec->d.sf_index, dec->d.channels, 0u};
+    int16_t sf0[128], sf1[128];
+    const sk_ec::QuantCapture qc{quant, {sf0, sf1}};
+    sk_ec::Scratch scratch;
+    uint8_t seq[2] = {0, 0}, shape[2] = {0, 0};
+    int rc = sk_ec::parse_unit(view, st, words.data(), (uint32_t)len, nullptr, seq, shape, scratch, sk_ec::PNS_COUNT, &qc);
+    if (rc != sk_ec::EC_OK) {  // the reference's message: from the host parser, on the rare failing unit
+        dec->d.last_error = "AAC-LC front-end error";
+        try {
+            std::vector<float> sink(2048);
+            sk_aac_frame_desc d2;
+            parse_access_unit(dec->d, au, len, sink.data(), &d2);
+        } catch (const AacError &e) {
+            if (e.code == rc) dec->d.last_error = e.msg;
+        }
+        return rc;
+    }
+    const int32_t tail = sk_ec::unit_tail(words.data(), (uint32_t)len, scratch.resume_pos);
+    const int16_t *sfs[2] = {sf0, sf1};
+    sk_ec::pack_unit(scratch, dec->d.channels, sfs, tail, *reinterpret_cast<sk_ec::WireUnit *>(side));
+    desc->channels = (uint8_t)dec->d.channels;
+    for (int c = 0; c < 2; ++c) {
+        desc->window_sequence[c] = c < dec->d.channels ? seq[c] : 0;
+        desc->window_shape[c] = c < dec->d.channels ? shape[c] : 0;
     }
     return SK_OK;
 }

@@ -342,9 +342,9 @@ __device__ __attribute__((noinline)) void synth_rare_frame(lds_f2 *ex, lds_f *st
 // ONLY_LONG: every frame of every task is OnlyLong (the host knows the windows and sorts the tasks): the loop is one
 // straight line, so the compiler can count its memory operations exactly instead of draining them at a join.
 template <bool OUT16, bool ONLY_LONG>
-__global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synth(SynthArgs a) {
+__global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? kWavesPerSimd + 1 : kWavesPerSimd) void k_aac_synth(SynthArgs a) {
     __shared__ f2 lds[kWavesPerBlock][kExchange];
-    __shared__ float stage_lds[kWavesPerBlock][kStage];
+    __shared__ float stage_lds[ONLY_LONG ? 1 : kWavesPerBlock][ONLY_LONG ? 4 : kStage];  // rare-path staging only
     __shared__ f2 tw_tab[512];  // pre/post twiddle (dsp.rs:99-106), shared by the block's waves
     __shared__ f2 t64_tab[64];  // t64[k][n] = W64^{n k}
 
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
     const uint32_t task_id = blockIdx.x * kWavesPerBlock + wave;
     if (task_id >= a.n_tasks) return;
     lds_f2 *ex = (lds_f2 *)lds[wave];
-    lds_f *stage = (lds_f *)stage_lds[wave];
+    lds_f *stage = (lds_f *)stage_lds[ONLY_LONG ? 0 : wave];
     const lds_f2 *tw_lds = (const lds_f2 *)tw_tab;
     const lds_f2 *t64 = (const lds_f2 *)t64_tab;
 
@@ -453,6 +453,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
             // next spectrum in flight while this one is transformed.  Unconditional (the last frames re-read the task's
             // last spectrum): with a branch around these loads the compiler can no longer count what is outstanding when
             // the epilogue needs its windows, and waits for the prefetch itself before every store.
+#ifdef SK_SYNTH_ABLATE_LOAD  // timing experiment: the first spectrum is transformed over and over
+            if (e == 0x7fffffffu)
+#endif
             {
                 const uint32_t ahead = e + kDepth < count ? e + kDepth : count - 1;
                 const float *src = a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[ahead].off1024) * 1024 + 2 * lane;
@@ -495,6 +498,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kWavesPerSimd) void k_aac_synt
                 // out1[508-j..511-j] = M0.im, F1.re, M1.im, F0.re (dsp.rs:517, 529)
                 m.x = M.y * W1m.x + dly[8 * r + 4]; m.y = F.z * W1m.y + dly[8 * r + 5];
                 m.z = M.w * W1m.z + dly[8 * r + 6]; m.w = F.x * W1m.w + dly[8 * r + 7];
+#ifdef SK_SYNTH_ABLATE_STORE  // timing experiment: the PCM is computed but (almost) never stored
+                if (f.x == 1.2345e30f)
+#endif
                 if (OUT16) {
                     SK_SYNTH_STORE(pack4_s16(f), reinterpret_cast<u2 *>(out16_ptr + j));
                     SK_SYNTH_STORE(pack4_s16(m), reinterpret_cast<u2 *>(out16_ptr + 1020 - j));

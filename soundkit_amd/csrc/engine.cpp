@@ -222,7 +222,7 @@ struct sk_engine {
     // grow-only scratch
     DevBuf in_buf, out_buf, aux_buf, aux2_buf;
     // sk_tick_run: synthesis output, resampler output, packed bytes, small-array arena (+ pinned host mirror)
-    DevBuf tick_pcm, tick_res, tick_out, tick_arena, tick_au, tick_side;
+    DevBuf tick_pcm, tick_res, tick_out, tick_arena, tick_au, tick_side, tick_q;
     // entropy decode on the device (sk_tick_run_au): per-stream PNS generator state and the front-end's tables
     uint32_t *d_pns = nullptr;
     void *d_ec_blob = nullptr;
@@ -2016,11 +2016,14 @@ struct EntropyProbe {  // sk_aac_entropy_decode: stop after the front-end and ha
 
 int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
               const sk_au_item *units, const uint8_t *au_bytes, size_t au_len, uint32_t n_frames, uint8_t *out, size_t out_cap,
-              sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes, const EntropyProbe *probe = nullptr) {
+              sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes, const EntropyProbe *probe = nullptr,
+              const uint8_t *q_sides = nullptr, const int16_t *q_quant = nullptr) {
     const bool au_mode = units != nullptr;
+    const bool q_mode = q_sides != nullptr;  // quantised hand-over: descs from the host, spectra rebuilt on the device
     std::vector<sk_aac_frame_desc> au_descs;
     if (!e || !n_outs || (n_streams && !ts)) return SK_ERR_INVALID_ARG;
-    if (!au_mode && n_frames && (!descs || !coeffs)) return SK_ERR_INVALID_ARG;
+    if (!au_mode && !q_mode && n_frames && (!descs || !coeffs)) return SK_ERR_INVALID_ARG;
+    if (q_mode && n_frames && (!descs || !q_quant)) return SK_ERR_INVALID_ARG;
     if (au_mode && n_frames && !au_bytes) return SK_ERR_INVALID_ARG;
     *n_outs = 0;
     if (out_bytes) *out_bytes = 0;
@@ -2121,14 +2124,22 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
         SK_HIP(aux.put(hp.entries, e->stream, &a.entries), "upload tick entries");
         a.n_tasks = (uint32_t)hp.tasks.size();
         a.t = e->synth_tables;
-        if (!au_mode) {
+        if (!au_mode && !q_mode) {
             SK_HIP(hipMemcpyAsync(e->in_buf.p, coeffs, elems * 4, hipMemcpyHostToDevice, e->stream), "H2D tick coeffs");
         } else {
             // the front-end on the device: one lane per stream, spectra straight into the synthesis input
             rc = ensure_entropy_tables(e);
             if (rc != SK_OK) return rc;
-            SK_HIP(e->tick_au.reserve(au_len + 16), "alloc tick access units");
-            SK_HIP(hipMemcpyAsync(e->tick_au.p, au_bytes, au_len, hipMemcpyHostToDevice, e->stream), "H2D access units");
+            if (q_mode) {  // the host's integers and side records instead of the access units
+                SK_HIP(e->tick_au.reserve((size_t)n_frames * sizeof(sk_ec::WireUnit) + 16), "alloc tick side records");
+                SK_HIP(e->tick_q.reserve(elems * sizeof(int16_t) + 16), "alloc tick quantised values");
+                SK_HIP(hipMemcpyAsync(e->tick_au.p, q_sides, (size_t)n_frames * sizeof(sk_ec::WireUnit), hipMemcpyHostToDevice, e->stream),
+                       "H2D side records");
+                SK_HIP(hipMemcpyAsync(e->tick_q.p, q_quant, elems * sizeof(int16_t), hipMemcpyHostToDevice, e->stream), "H2D quantised values");
+            } else {
+                SK_HIP(e->tick_au.reserve(au_len + 16), "alloc tick access units");
+                SK_HIP(hipMemcpyAsync(e->tick_au.p, au_bytes, au_len, hipMemcpyHostToDevice, e->stream), "H2D access units");
+            }
             std::vector<sk::EntropyUnit> eu(n_frames);
             std::vector<sk::EntropyTask> et;
             for (uint32_t i = 0; i < n_streams; ++i) {
@@ -2137,14 +2148,16 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 et.push_back(sk::EntropyTask{ts[i].stream, tc[i].first, ts[i].n_frames, sf_index_of(si.sample_rate), si.channels});
                 for (uint32_t f = 0; f < ts[i].n_frames; ++f) {
                     const uint32_t k = tc[i].first + f;
-                    eu[k] = sk::EntropyUnit{units[k].byte_offset / 4, units[k].byte_len, (uint32_t)off1024[k],
+                    eu[k] = sk::EntropyUnit{q_mode ? 0u : units[k].byte_offset / 4, q_mode ? 0u : units[k].byte_len, (uint32_t)off1024[k],
                                             {hp.entry_of[(size_t)k * 2], hp.entry_of[(size_t)k * 2 + (si.channels > 1 ? 1 : 0)]},
                                             (uint32_t)et.size() - 1};
                 }
             }
             std::vector<int32_t> st_init(n_frames, 0);
             sk::EntropyArgs ea = e->ec_args;
-            ea.words = (const uint32_t *)e->tick_au.p;
+            ea.words = q_mode ? (const uint32_t *)e->d_zeros : (const uint32_t *)e->tick_au.p;
+            ea.wire = q_mode ? (const sk_ec::WireUnit *)e->tick_au.p : nullptr;
+            ea.quant = q_mode ? (const int16_t *)e->tick_q.p : nullptr;
             SK_HIP(aux.put(eu, e->stream, &ea.units), "upload entropy units");
             SK_HIP(aux.put(et, e->stream, &ea.tasks), "upload entropy tasks");
             const int32_t *d_status = nullptr;
@@ -2155,7 +2168,7 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             ea.entries = const_cast<sk::SynthEntry *>(a.entries);
             ea.status = const_cast<int32_t *>(d_status);
             static const bool serial = std::getenv("SK_ENTROPY_SERIAL") != nullptr;  // the one-lane-per-stream form, for A/B runs
-            if (serial) {
+            if (serial && !q_mode) {
                 SK_HIP(sk::launch_aac_entropy(ea, e->stream), "launch entropy decode");
             } else {
                 SK_HIP(e->tick_side.reserve((size_t)n_frames * (sizeof(sk_ec::Scratch) + sizeof(uint32_t)) + 128),
@@ -2215,7 +2228,7 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             a.only_long = 0;
             SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth");
         }
-        if (au_mode) {  // which units failed decides what the later stages may use
+        if (au_mode || q_mode) {  // which units failed decides what the later stages may use
             const TClock::time_point q0 = TClock::now();
             t_au[0] = std::chrono::duration<double, std::milli>(q0 - t_mark).count();
             SK_HIP(hipStreamSynchronize(e->stream), "entropy sync");
@@ -2433,6 +2446,15 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
                 const float *coeffs, uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs,
                 uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) {
     return tick_impl(e, ts, n_streams, descs, coeffs, nullptr, nullptr, 0, n_frames, out, out_cap, outs, outs_cap, n_outs, out_bytes);
+}
+
+int sk_tick_run_q(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const void *sides,
+                  const int16_t *quant, uint32_t n_units, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap,
+                  uint32_t *n_outs, size_t *out_bytes) {
+    if (n_units && (!sides || !quant || !descs)) return SK_ERR_INVALID_ARG;
+    static const uint8_t none[8] = {0};
+    return tick_impl(e, ts, n_streams, descs, nullptr, nullptr, nullptr, 0, n_units, out, out_cap, outs, outs_cap, n_outs, out_bytes, nullptr,
+                     sides ? (const uint8_t *)sides : none, quant);
 }
 
 int sk_aac_entropy_decode(sk_engine *e, const uint32_t *streams, const uint32_t *units_per_stream, uint32_t n_streams,

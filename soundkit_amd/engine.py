@@ -410,6 +410,28 @@ class Engine:
         return res
 
 
+    def tick_run_q(self, streams, descs, n_units, sides, quant):
+        """sk_tick_run_q: as tick_run, fed by AacLcFrontEnd.parse_q -- sides [n_units][SK_AAC_UNIT_SIDE_BYTES] u8, quant the
+        units' i16 values packed like tick_run's coeffs"""
+        import ctypes as C
+        from ._lib import TickStream, TickOutput
+        ts = (TickStream * max(len(streams), 1))()
+        for i, s in enumerate(streams):
+            ts[i].stream, ts[i].n_frames = int(s["stream"]), int(s["n_frames"])
+            ts[i].out_bits, ts[i].out_channels = int(s.get("out_bits", 16)), int(s["out_channels"])
+            ts[i].resample, ts[i].flush = int(bool(s.get("resample", 0))), int(bool(s.get("flush", 0)))
+        max_out = C.c_uint32()
+        cap = lib.sk_tick_out_bound(ts, len(streams), C.byref(max_out))
+        out = np.zeros(max(cap, 16), np.uint8)
+        recs = (TickOutput * max(max_out.value, 1))()
+        n_out, used = C.c_uint32(), C.c_size_t()
+        sides = np.ascontiguousarray(sides, np.uint8)
+        quant = np.ascontiguousarray(quant, np.int16)
+        check(lib.sk_tick_run_q(self._h, ts, len(streams), descs, _ptr(sides) if n_units else None, _ptr(quant) if n_units else None,
+                                n_units, _ptr(out), out.size, recs, max_out.value, C.byref(n_out), C.byref(used)), "sk_tick_run_q", self._h)
+        return [(r.stream_index, r.status, r.frames, r.channels, r.bits, out[r.byte_offset:r.byte_offset + r.bytes].tobytes())
+                for r in recs[:n_out.value]]
+
     def tick_run_au(self, streams, access_units):
         """sk_tick_run_au: as tick_run, but the entropy front-end runs on the GPU.  access_units: the raw access
         units (bytes) of all streams, stream by stream in the order of `streams`."""

@@ -90,6 +90,38 @@ int main(int argc, char **argv) {
                     }
                 }
             }
+            {  // the quantised hand-over: host parse to integers -> wire record -> unpack, dequantise, finish == the above
+                sk_ec::Stream st3{st.sf_index, st.channels, pns_before};
+                std::vector<int16_t> quant(2048, 0), sf0(128, 0), sf1(128, 0);
+                const sk_ec::QuantCapture qc{quant.data(), {sf0.data(), sf1.data()}};
+                uint8_t seq3[2] = {0, 0}, shape3[2] = {0, 0};
+                sk_ec::Scratch sc3;
+                int rc3 = sk_ec::parse_unit(tables, st3, words.data(), (uint32_t)au.size(), nullptr, seq3, shape3, sc3, sk_ec::PNS_COUNT, &qc);
+                const bool wide = rc3 == sk_ec::EC_UNSUPPORTED_FEATURE && rc_got != sk_ec::EC_UNSUPPORTED_FEATURE;  // |q| > 32767
+                if (rc3 == 0) {
+                    const int32_t tail = sk_ec::unit_tail(words.data(), (uint32_t)au.size(), sc3.resume_pos);
+                    const int16_t *sfs[2] = {sf0.data(), sf1.data()};
+                    sk_ec::WireUnit wire;
+                    sk_ec::pack_unit(sc3, st.channels, sfs, tail, wire);
+                    sk_ec::Scratch back;
+                    sk_ec::unpack_unit(tables, wire, back);
+                    std::vector<float> qout(2048, 0.0f);
+                    rc3 = sk_ec::dequant_channel(tables, st3, back.ch[0], quant.data(), qout.data());
+                    if (rc3 == 0 && st.channels == 2) rc3 = sk_ec::dequant_channel(tables, st3, back.ch[1], quant.data() + 1024, qout.data() + 1024);
+                    static const uint32_t no_bits[4] = {0, 0, 0, 0};
+                    if (rc3 == 0) rc3 = sk_ec::finish_unit(tables, st3, no_bits, 0, qout.data(), back, true);
+                    if (rc3 == 0) rc3 = wire.tail_status;
+                    if (rc3 != rc_got) { printf("%s %zu: quantised hand-over status %d vs %d\n", what, index, rc3, rc_got); return false; }
+                    if (rc3 == 0 && (memcmp(qout.data(), got.data(), sizeof(float) * 1024 * (size_t)st.channels) != 0 || memcmp(seq, seq3, 2) ||
+                                     memcmp(shape, shape3, 2) || st3.pns_state != st.pns_state)) {
+                        printf("%s %zu: quantised hand-over decode differs\n", what, index);
+                        return false;
+                    }
+                } else if (!wide && rc3 != rc_got) {
+                    printf("%s %zu: quantised parse status %d vs %d\n", what, index, rc3, rc_got);
+                    return false;
+                }
+            }
             if (rc_want != rc_got) {
                 printf("%s %zu: status %d vs %d (%s)\n", what, index, rc_want, rc_got, sk_aac_decoder_last_error(dec));
                 return false;

@@ -35,7 +35,7 @@ def run(engine, mode, specs, per_tick):
                                                 ((sf_index(fe.sample_rate) & 1) << 7) | (fe.channels << 3)])))
     alive = [True] * len(specs)
     while any(alive[i] and pos[i] < len(specs[i][1]) for i in range(len(specs))):
-        table, units, descs_in, coeffs, index = [], [], [], [], []
+        table, units, descs_in, coeffs, index, quants, sides = [], [], [], [], [], [], []
         for i, (fe, aus, bits, rate, ch) in enumerate(specs):
             if not alive[i] or pos[i] >= len(aus):
                 continue
@@ -44,7 +44,21 @@ def run(engine, mode, specs, per_tick):
             last = pos[i] >= len(aus)
             resample = bool(rate and rate != fe.sample_rate)
             n_ok = len(take)
-            if mode == "host":
+            if mode == "quant":
+                parsed_q = []
+                for au in take:
+                    try:
+                        parsed_q.append(fes[i].parse_q(au))
+                    except aac_lc.AacLcError as e:
+                        outs[i].append(("error", e.status))
+                        alive[i] = False
+                        break
+                n_ok = len(parsed_q)
+                for q, side, seqs, shapes in parsed_q:
+                    descs_in.append((sids[i], fe.channels, list(seqs) + [0] * (2 - fe.channels), list(shapes) + [0] * (2 - fe.channels)))
+                    quants.append(q.ravel())
+                    sides.append(side)
+            elif mode == "host":
                 parsed = []
                 for au in take:
                     try:
@@ -62,7 +76,11 @@ def run(engine, mode, specs, per_tick):
             table.append({"stream": sids[i], "n_frames": n_ok, "out_bits": bits or 16, "out_channels": ch or fe.channels,
                           "resample": resample, "flush": last and resample and alive[i]})
             index.append(i)
-        if mode == "host":
+        if mode == "quant":
+            descs, n = make_descs(descs_in)
+            res = engine.tick_run_q(table, descs, n, np.stack(sides) if sides else np.zeros((0, 8), np.uint8),
+                                    np.concatenate(quants) if quants else np.zeros(0, np.int16))
+        elif mode == "host":
             descs, n = make_descs(descs_in)
             res = engine.tick_run(table, descs, n, np.concatenate(coeffs) if coeffs else np.zeros(0, np.float32))
         else:
@@ -199,3 +217,40 @@ def test_damaged_access_units_fail_with_the_host_codes(engine):
         got = run(engine, "gpu", specs, [4, 6])
         assert want[1] == got[1] and len(got[1]) == 48
         assert want[0] == got[0], (trial, k, [x for x in want[0] if x[0] == "error"], [x for x in got[0] if x[0] == "error"])
+
+
+@pytest.mark.parametrize("bits,rate,ch", [(None, None, None), (16, 16000, 1), (24, None, 1)])
+def test_quantised_hand_over_equals_the_f32_path(engine, bits, rate, ch):
+    """the host front-end stops after the Huffman decode (sk_aac_decoder_parse_q: i16 quantised values +
+    a 1.3 KB side record per unit) and dequantisation, PNS, intensity / mid-side and TNS run on the device
+    (sk_tick_run_q) -- byte-identical AudioData to the tick fed with the host's finished f32 spectra, on every fixture
+    (PNS, IS, MS, TNS, short windows all exercised), uneven units per tick."""
+    specs = []
+    for name in FILES:
+        fe, aus = load(name)
+        specs.append((fe, aus, bits, rate, ch))
+    per_tick = [5, 3, 8, 1]
+    want = run(engine, "host", specs, per_tick)
+    got = run(engine, "quant", specs, per_tick)
+    for name, w, g in zip(FILES, want, got):
+        assert len(w) == len(g) and len(w) > 0, name
+        assert w == g, name
+
+
+def test_quantised_hand_over_on_generated_units_and_failures(engine):
+    """generated units (pulse data, escapes, every codebook) through both paths; a unit that fails on the device (TNS /
+    stereo tools / the host's verdict on its tail) ends its stream with the host path's status"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from au_builder import asc_for, random_access_unit
+    specs = []
+    for k, (sf_index, channels) in enumerate([(3, 2), (4, 1), (8, 2), (0, 2)]):
+        rng = np.random.default_rng(400 + k)
+        units = [random_access_unit(rng, sf_index, channels) for _ in range(30)]
+        if k == 0:
+            units[17] = units[17] + b"\x00\x80"     # non-zero trailing bits: found by the host, reported after the device's checks
+        specs.append((aac_lc.AacLcFrontEnd(asc_for(sf_index, channels)), units, None, None, None))
+    want = run(engine, "host", specs, [7, 4, 9, 2])
+    got = run(engine, "quant", specs, [7, 4, 9, 2])
+    assert want == got
+    assert want[0][-1][0] == "error" and len(want[0]) == 18 and all(len(w) == 30 for w in want[1:])
