@@ -450,7 +450,9 @@ typedef struct sk_pipeline_config {
     uint32_t output_buffer;              /* AudioData per output queue; 0 = DEFAULT_OUTPUT_BUFFER 16 (lib.rs:78) */
     uint32_t tick_wait_us;               /* how long a non-empty batch may wait for more frames; 0 = 200 (2000 with gpu_entropy) */
     uint32_t gpu_entropy;                /* 1: the host threads only frame the ADTS stream; Huffman decode, stereo tools and TNS
-                                          * run on the GPU too (sk_tick_run_au).  0 (default): host front-end (sk_tick_run) */
+                                          * run on the GPU too (sk_tick_run_au).  0 (default): host front-end (sk_tick_run).
+                                          * 2: the host threads do the Huffman decode only and hand over i16 quantised values +
+                                          * side records; dequantisation, PNS, stereo tools and TNS run on the GPU (sk_tick_run_q) */
     uint32_t lanes;                      /* engines the streams are spread over, each with its own batches and submission
                                           * thread, so that ticks overlap on the device; lane 0 is the caller's engine, the
                                           * others are created on the same device.  0 = 2 with gpu_entropy and max_streams >= four ticks' worth of

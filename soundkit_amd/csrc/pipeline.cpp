@@ -217,7 +217,8 @@ struct Parsed {  // what one worker pass produced for one stream
 // Pulls ADTS frames out of the stream's byte queue and runs the front-end on them, at most `limit` frames.
 void parse_some(sk_lane *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_frame_desc *descs, std::vector<uint8_t> &au_stage,
                 sk_au_item *au_items, Parsed &r) {
-    const bool gpu_entropy = p->cfg.gpu_entropy != 0;
+    const bool gpu_entropy = p->cfg.gpu_entropy == 1;
+    const bool quant = p->cfg.gpu_entropy == 2;  // host Huffman decode, the rest of the front-end on the device (sk_tick_run_q)
     auto fail = [&](int32_t st, const std::string &msg) {
         r.failed = true;
         r.fail_status = st;
@@ -308,6 +309,17 @@ void parse_some(sk_lane *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_fr
             std::memset(au_stage.data() + r.n_au_bytes + pay_len, 0, padded - pay_len);
             au_items[r.n_frames] = sk_au_item{(uint32_t)r.n_au_bytes, (uint32_t)pay_len};
             r.n_au_bytes += padded;
+        } else if (quant) {  // i16 values where the f32 spectra would go, side records staged like access units
+            sk_aac_frame_desc &d = descs[r.n_frames];
+            if (au_stage.size() < r.n_au_bytes + SK_AAC_UNIT_SIDE_BYTES) au_stage.resize(r.n_au_bytes + SK_AAC_UNIT_SIDE_BYTES + 8192);
+            const int rc = sk_aac_decoder_parse_q(s.fe, frame + pay_off, pay_len, reinterpret_cast<int16_t *>(coeffs) + r.n_floats,
+                                                  au_stage.data() + r.n_au_bytes, &d);
+            if (rc != SK_OK) {
+                fail(rc, std::string("Decoding failed: ") + sk_aac_decoder_last_error(s.fe));
+                break;
+            }
+            d.stream = s.engine_stream;
+            r.n_au_bytes += SK_AAC_UNIT_SIDE_BYTES;
         } else {
             sk_aac_frame_desc &d = descs[r.n_frames];
             const int rc = sk_aac_decoder_parse(s.fe, frame + pay_off, pay_len, coeffs + r.n_floats, &d);
@@ -325,8 +337,8 @@ void parse_some(sk_lane *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_fr
 
 void worker_main(sk_lane *p) {
     const uint32_t per_stream = p->cfg.max_stream_frames_per_tick;
-    const bool gpu_entropy = p->cfg.gpu_entropy != 0;
-    std::vector<float> coeffs(gpu_entropy ? 0 : (size_t)per_stream * 2 * 1024);
+    const bool gpu_entropy = p->cfg.gpu_entropy == 1, quant = p->cfg.gpu_entropy == 2;
+    std::vector<float> coeffs(gpu_entropy ? 0 : (size_t)per_stream * 2 * 1024);  // quant: the same storage holds i16 (half of it)
     std::vector<sk_aac_frame_desc> descs(per_stream);
     std::vector<uint8_t> au_stage;
     std::vector<sk_au_item> au_items(per_stream);
@@ -381,7 +393,8 @@ void worker_main(sk_lane *p) {
             p->room_cv.wait(lk, [&] {
                 const Batch &f = p->batches[p->filling];
                 return p->stop || (f.n_descs + r.n_frames <= p->cfg.max_frames_per_tick &&
-                                   (gpu_entropy ? f.au_used + r.n_au_bytes <= f.au_cap : f.n_floats + r.n_floats <= f.coeff_cap));
+                                   (gpu_entropy ? f.au_used + r.n_au_bytes <= f.au_cap : f.n_floats + r.n_floats <= f.coeff_cap) &&
+                                   (!quant || f.au_used + r.n_au_bytes <= f.au_cap));
             });
             if (p->stop) return;
             b = &p->batches[p->filling];
@@ -416,6 +429,10 @@ void worker_main(sk_lane *p) {
             std::memcpy(b->au_bytes + au_at, au_stage.data(), r.n_au_bytes);
             for (uint32_t k = 0; k < r.n_frames; ++k)
                 b->units[desc_at + k] = sk_au_item{(uint32_t)(au_at + au_items[k].byte_offset), au_items[k].byte_len};
+        } else if (r.n_frames && quant) {
+            std::memcpy(b->descs.data() + desc_at, descs.data(), r.n_frames * sizeof(sk_aac_frame_desc));
+            std::memcpy(reinterpret_cast<int16_t *>(b->coeffs) + float_at, coeffs.data(), r.n_floats * sizeof(int16_t));
+            std::memcpy(b->au_bytes + au_at, au_stage.data(), r.n_au_bytes);
         } else if (r.n_frames) {
             std::memcpy(b->descs.data() + desc_at, descs.data(), r.n_frames * sizeof(sk_aac_frame_desc));
             std::memcpy(b->coeffs + float_at, coeffs.data(), r.n_floats * sizeof(float));
@@ -490,7 +507,11 @@ void submit_main(sk_lane *p) {
                     b->rc = SK_ERR_OOM;
             }
             if (b->recs.size() < max_out) b->recs.resize(max_out);
-            if (b->rc == SK_OK && p->cfg.gpu_entropy)
+            if (b->rc == SK_OK && p->cfg.gpu_entropy == 2)
+                b->rc = sk_tick_run_q(p->engine, ts.data(), (uint32_t)ts.size(), b->descs.data(), b->au_bytes,
+                                      reinterpret_cast<const int16_t *>(b->coeffs), n_frames, b->out_pinned, b->out_pinned_cap, b->recs.data(),
+                                      max_out, &b->n_out, &used);
+            else if (b->rc == SK_OK && p->cfg.gpu_entropy)
                 b->rc = sk_tick_run_au(p->engine, ts.data(), (uint32_t)ts.size(), b->units.data(), n_frames, b->au_bytes,
                                        b->au_used + 8, b->out_pinned, b->out_pinned_cap, b->recs.data(), max_out, &b->n_out, &used);
             else if (b->rc == SK_OK)
@@ -547,7 +568,9 @@ void deliver_main(sk_lane *p) {
                 if (s.cancelled) continue;
                 if (r.status != 0) {
                     std::string msg = "Decoding failed: invalid AAC config: frame rejected by the synthesis engine";
-                    if (p->cfg.gpu_entropy && r.status <= -101 && r.status >= -108) {
+                    if (p->cfg.gpu_entropy == 2 && r.status <= -101 && r.status >= -108)
+                        msg = std::string("Decoding failed: ") + sk_strerror(r.status);  // found on the device (stereo tools, TNS) or in the unit's tail
+                    if (p->cfg.gpu_entropy == 1 && r.status <= -101 && r.status >= -108) {
                         // the device reports codes; the reference's text comes from parsing the stream's units of this
                         // tick once more on the host (errors are rare, <= max_stream_frames_per_tick units)
                         msg = std::string("Decoding failed: ") + sk_strerror(r.status);
@@ -706,12 +729,12 @@ int lane_create(sk_engine *e, const sk_pipeline_config *cfg, OutQueue *oq, uint3
     // With the front-end on the GPU every access unit is a lane of its own and a tick costs about the same whatever its
     // size (the time of one unit), so ticks should be big; with the host front-end the tick is PCIe-bound and the host
     // threads want their results back soon.
-    if (!p->cfg.max_frames_per_tick) p->cfg.max_frames_per_tick = p->cfg.gpu_entropy ? 65536 : 16384;
-    if (!p->cfg.max_stream_frames_per_tick) p->cfg.max_stream_frames_per_tick = p->cfg.gpu_entropy ? 16 : 8;
+    if (!p->cfg.max_frames_per_tick) p->cfg.max_frames_per_tick = p->cfg.gpu_entropy == 1 ? 65536 : 16384;
+    if (!p->cfg.max_stream_frames_per_tick) p->cfg.max_stream_frames_per_tick = p->cfg.gpu_entropy == 1 ? 16 : 8;
     if (p->cfg.max_stream_frames_per_tick > p->cfg.max_frames_per_tick) p->cfg.max_stream_frames_per_tick = p->cfg.max_frames_per_tick;
     if (!p->cfg.input_buffer) p->cfg.input_buffer = 128;   // DEFAULT_INPUT_BUFFER, lib.rs:77
     if (!p->cfg.output_buffer) p->cfg.output_buffer = 16;  // DEFAULT_OUTPUT_BUFFER, lib.rs:78
-    if (!p->cfg.tick_wait_us) p->cfg.tick_wait_us = p->cfg.gpu_entropy ? 2000 : 200;
+    if (!p->cfg.tick_wait_us) p->cfg.tick_wait_us = p->cfg.gpu_entropy == 1 ? 2000 : 200;
     if (hipSetDevice(sk_engine_device(e)) != hipSuccess) {
         delete p;
         return SK_ERR_NO_DEVICE;
@@ -720,7 +743,12 @@ int lane_create(sk_engine *e, const sk_pipeline_config *cfg, OutQueue *oq, uint3
         b.descs.resize(p->cfg.max_frames_per_tick);
         b.units.resize(p->cfg.max_frames_per_tick);
         hipError_t he;
-        if (p->cfg.gpu_entropy) {  // access units are ~0.4-0.8 KiB; 2 KiB each on average leaves room for any legal mix
+        if (p->cfg.gpu_entropy == 2) {  // quantised hand-over: i16 values in the spectra's place (half of it) + one side record per unit
+            b.coeff_cap = (size_t)p->cfg.max_frames_per_tick * 2 * 1024;
+            b.au_cap = (size_t)p->cfg.max_frames_per_tick * SK_AAC_UNIT_SIDE_BYTES + 64;
+            he = hipHostMalloc((void **)&b.coeffs, b.coeff_cap * sizeof(int16_t), hipHostMallocPortable);
+            if (he == hipSuccess) he = hipHostMalloc((void **)&b.au_bytes, b.au_cap + 64, hipHostMallocPortable);
+        } else if (p->cfg.gpu_entropy) {  // access units are ~0.4-0.8 KiB; 2 KiB each on average leaves room for any legal mix
             // ... and never less than one maximum-length ADTS frame (8191 bytes, padded) so that any single unit fits
             b.au_cap = std::max<size_t>((size_t)p->cfg.max_frames_per_tick * 2048, 8192 + 16) + 16384;
             p->au_pass_budget = b.au_cap;
@@ -748,7 +776,7 @@ int lane_create(sk_engine *e, const sk_pipeline_config *cfg, OutQueue *oq, uint3
     for (uint32_t i = 0; i < p->cfg.entropy_threads; ++i) p->workers.emplace_back(worker_main, p);
     p->submitter = std::thread(submit_main, p);
     // with the front-end on the GPU the entropy threads have little to do and delivery is the busiest host stage
-    p->n_deliver = p->cfg.gpu_entropy ? std::max(1u, std::min(4u, p->cfg.entropy_threads / 2)) : 1;
+    p->n_deliver = p->cfg.gpu_entropy == 1 ? std::max(1u, std::min(4u, p->cfg.entropy_threads / 2)) : 1;
     if (const char *env = std::getenv("SK_PIPELINE_DELIVER_THREADS")) {  // tuning / test override
         const int n = std::atoi(env);
         if (n >= 1 && n <= 16) p->n_deliver = (uint32_t)n;
@@ -954,10 +982,10 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
     // 8192 streams two lanes run half-empty ticks and lose (3.5-6.3 M against 5.5-6.8 M), so one lane stays the default
     // there.  With the host front-end the host threads are the limit and a second lane only splits them.
     if (!c.max_streams) c.max_streams = 1024;
-    const uint32_t tick_frames = c.max_frames_per_tick ? c.max_frames_per_tick : (c.gpu_entropy ? 65536u : 16384u);
-    const uint32_t stream_frames = c.max_stream_frames_per_tick ? c.max_stream_frames_per_tick : (c.gpu_entropy ? 16u : 8u);
+    const uint32_t tick_frames = c.max_frames_per_tick ? c.max_frames_per_tick : (c.gpu_entropy == 1 ? 65536u : 16384u);
+    const uint32_t stream_frames = c.max_stream_frames_per_tick ? c.max_stream_frames_per_tick : (c.gpu_entropy == 1 ? 16u : 8u);
     const uint32_t streams_per_tick = std::max(1u, tick_frames / std::max(1u, stream_frames));
-    uint32_t n_lanes = c.lanes ? c.lanes : ((c.gpu_entropy && c.max_streams >= 4 * streams_per_tick) ? 2u : 1u);
+    uint32_t n_lanes = c.lanes ? c.lanes : ((c.gpu_entropy == 1 && c.max_streams >= 4 * streams_per_tick) ? 2u : 1u);
     if (n_lanes > 8) return SK_ERR_INVALID_ARG;
     if (n_lanes > c.max_streams) n_lanes = c.max_streams;
     if (!c.entropy_threads) {

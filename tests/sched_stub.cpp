@@ -94,6 +94,10 @@ int sk_tick_run_au(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, c
     if (used) *used = cursor;
     return SK_OK;
 }
+int sk_tick_run_q(sk_engine *, const sk_tick_stream *, uint32_t, const sk_aac_frame_desc *, const void *, const int16_t *, uint32_t, uint8_t *,
+                  size_t, sk_tick_output *, uint32_t, uint32_t *, size_t *) {
+    return SK_ERR_UNSUPPORTED;  // the quantised hand-over needs the device: covered by the GPU suite
+}
 int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
                 uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs,
                 size_t *used) {

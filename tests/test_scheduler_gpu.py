@@ -14,12 +14,14 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aac")
 
 
-@pytest.fixture(scope="module", params=["host_front_end", "gpu_front_end", "gpu_front_end_two_lanes"])
+@pytest.fixture(scope="module", params=["host_front_end", "gpu_front_end", "gpu_front_end_two_lanes", "host_huffman_gpu_rest"])
 def sched(engine, request):
-    """Every scenario runs three times: entropy decode on host threads (sk_tick_run), on the GPU (sk_tick_run_au), and on
-    the GPU with the streams spread over two engines behind the one handle space (sk_pipeline_config.lanes)."""
+    """Every scenario runs four times: entropy decode on host threads (sk_tick_run), on the GPU (sk_tick_run_au), on the GPU
+    with the streams spread over two engines behind the one handle space (sk_pipeline_config.lanes), and split -- Huffman
+    decode on host threads, dequantisation / PNS / stereo tools / TNS on the GPU (sk_tick_run_q, gpu_entropy = 2)."""
     s = pipeline.BatchScheduler(engine, entropy_threads=4, max_streams=64, max_frames_per_tick=256, max_stream_frames_per_tick=4,
-                                gpu_entropy=int(request.param != "host_front_end"), lanes=2 if request.param.endswith("two_lanes") else 1)
+                                gpu_entropy={"host_front_end": 0, "host_huffman_gpu_rest": 2}.get(request.param, 1),
+                                lanes=2 if request.param.endswith("two_lanes") else 1)
     yield s
     s.close()
 
