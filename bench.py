@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")  # rocprofv3 --pmc passes of this same workload
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")  # rocprofv3 --pmc passes of this same workload (tools/profile_bench.sh)
 
 
 def pmc_traffic(kind, **config):
@@ -226,13 +226,14 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
     feeders = args.feeders
     import threading
     import soundkit_amd
+    front_mode = {"host": 0, "gpu": 1, "quant": 2}[args.front_end] if args.front_end else int(args.gpu_entropy)
     n_sched = max(1, args.schedulers)
     n_gen = n_sched  # one load generator (its own producer and consumer threads) per scheduler: wait_outputs is per pipeline
     per_streams = args.streams // n_sched
     engines = [eng] + [soundkit_amd.Engine(eng.device if hasattr(eng, "device") else 0, max(per_streams, 16)) for _ in range(n_sched - 1)]
     scheds = [pipeline.BatchScheduler(engines[i], entropy_threads=max(1, threads // n_sched), max_streams=per_streams,
                                       max_frames_per_tick=args.tick_frames, max_stream_frames_per_tick=args.stream_frames_per_tick,
-                                      gpu_entropy=int(args.gpu_entropy), tick_wait_us=args.tick_wait_us, lanes=args.lanes) for i in range(n_sched)]
+                                      gpu_entropy=front_mode, tick_wait_us=args.tick_wait_us, lanes=args.lanes) for i in range(n_sched)]
     opt = DecodeOptionsC(args.out_rate, 16, args.out_channels, 0)
 
     class Summed:
@@ -297,7 +298,8 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
                                                                      args.out_rate or src_rate,
                                                                      "mono" if args.out_channels == 1 else "source-channel", threads),
                    "streams_per_gpu": args.streams, "entropy_threads": threads, "feeder_threads": feeders, "host_cores": cores,
-                   "front_end": "gpu (k_aac_entropy_parse/link/finish, one access unit per lane)" if args.gpu_entropy else "host threads",
+                   "front_end": ["host threads (f32 spectra over PCIe)", "gpu (k_aac_entropy_parse/link/finish, one access unit per lane)",
+                                 "host Huffman decode, i16 + side records over PCIe, k_aac_expand_q/link/finish on the device"][front_mode],
                    "schedulers": n_sched, "lanes": int(after.get("lanes", n_sched)),
                    "host_cores_busy": ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / elapsed,
                    "host_cores_busy_system": (cpu1.system - cpu0.system) / elapsed,
@@ -397,6 +399,9 @@ def main():
                          "(their ticks overlap on the device)")
     ap.add_argument("--lanes", type=int, default=0, help="end_to_end: engines per scheduler (sk_pipeline_config.lanes; 0 = library default: 2 with --gpu-entropy, else 1)")
     ap.add_argument("--gpu-entropy", action="store_true", help="end_to_end: run the AAC front-end on the GPU too (host threads only frame ADTS)")
+    ap.add_argument("--front-end", default=None, choices=["host", "quant", "gpu"],
+                    help="end_to_end: where the AAC front-end runs -- host threads (f32 spectra over PCIe), host Huffman decode + device "
+                         "dequantisation / PNS / stereo tools / TNS (i16 + side records over PCIe), or all of it on the GPU")
     ap.add_argument("--clip", default="aac-stereo-48k.adts", help="end_to_end: ADTS file under tests/golden/aac to loop")
     ap.add_argument("--feeders", type=int, default=2, help="end_to_end: producer/consumer threads of the load generator")
     ap.add_argument("--out-rate", type=int, default=16000, help="end_to_end: DecodeOptions.output_sample_rate (0 = source rate)")
@@ -584,6 +589,23 @@ def main():
     torch.cuda.synchronize()
     from soundkit_amd import sharding
     elapsed = sharding.reduce_elapsed(time.perf_counter() - t0, device)  # max over ranks
+    synth_f32_ms = None
+    if rank == 0 and args.workload == "pipeline" and args.chain == "s16" and not args.separate_s16:
+        # reference point for the roofline: the same kernel writing f32 PCM (8 KiB per channel-frame instead of 6), a few
+        # launches outside the timed region.  The s16 variant is bound by vector issue (its 16 conversions per lane and
+        # frame), the f32 one by what this access pattern streams (profiles/r02_ab_synth_groups.md).
+        scratch = torch.empty_like(coeffs)
+        for _ in range(2):
+            plan.run_f32(coeffs, scratch)
+        eng.synchronize()
+        a0, b0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record(ext)
+        for _ in range(5):
+            plan.run_f32(coeffs, scratch)
+        b0.record(ext)
+        eng.synchronize()
+        synth_f32_ms = a0.elapsed_time(b0) / 5
+        del scratch
     mix_report = None
     if args.mix and args.workload in ("aac_synth", "pipeline") and rank == 0:
         # k_aac_synth alone on three batches of the same spectra: OnlyLong; one EightShort per bracket; three per bracket.
@@ -650,17 +672,27 @@ def main():
             rl["k_aac_synth"] = {
                 "kernel": "k_aac_synth", "bound": "hbm", "achieved": variant_bytes / (ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": variant_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("aac_synth", streams=streams, frames=frames, channels=ch), "avg_launch_ms": ms,
+                "traffic": pmc_traffic("aac_synth_s16out" if s16_between else "aac_synth", streams=streams, frames=frames, channels=ch),
+                "avg_launch_ms": ms,
                 "variant": "delay on-chip: %d B per channel-frame (4096 in + %d out) + 8192 B per channel per launch" % (4096 + out_b, out_b),
                 "achieved_canonical_32768B_per_stereo_frame": canonical_bytes / (ms * 1e-3) / 1e9,
             }
+            if s16_between:
+                rl["k_aac_synth"]["note"] = ("s16-output variant (k_aac_synth<true, true>): bound by vector issue, not by HBM -- the f32-output variant "
+                                             "of the same kernel moves 33 % more bytes in the same time (same_kernel_f32_out)")
+                if synth_f32_ms:
+                    f32_bytes = streams * frames * ch * 8192 + streams * ch * 8192
+                    rl["k_aac_synth"]["same_kernel_f32_out"] = {"avg_launch_ms": synth_f32_ms, "achieved": f32_bytes / (synth_f32_ms * 1e-3) / 1e9,
+                                                                "frac": f32_bytes / (synth_f32_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+                                                                "measured": "5 launches after the timed region, same batch"}
         if "k_fir_48k_16k" in per_kernel:
             ms = per_kernel["k_fir_48k_16k"]
             fir_in = frames * 1024 if args.workload == "pipeline" else 48000
             n_fir_out = eng.downsample_out_frames(fir_in)
             flops = streams * ch * n_fir_out * 512.0  # 512 flop per output sample
             fused = args.workload == "pipeline" and not args.separate_s16
-            pmc_kind = "fir" if args.workload == "fir" else ("fir_pipeline" if args.separate_s16 else "fir_pipeline_s16")
+            pmc_kind = "fir" if args.workload == "fir" else ("fir_pipeline" if args.separate_s16 else
+                                                             ("fir_pipeline_s16in" if args.chain == "s16" else "fir_pipeline_s16"))
             if os.environ.get("SK_FIR_F32") == "1":  # the f32-MFMA kernel (fir.hip), bounded by the f32 matrix peak
                 rl["k_fir_48k_16k"] = {
                     "kernel": "k_fir_48k_16k", "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12,

@@ -1,5 +1,5 @@
 /* Exhaustive check that the f64-free form of float_sample_to_i16 used on the device (csrc/sk_device.h,
- * dev_float_sample_to_i16_f32) equals the reference's f64 form (soundkit-decoder lib.rs:1815-1827) bit for bit.
+ * dev_float_sample_to_i16_f32, and its shorter sibling dev_float_sample_to_i16_v2) equals the reference's f64 form (soundkit-decoder lib.rs:1815-1827) bit for bit.
  *   gcc -O2 -ffp-contract=off -o check tools/check_f32_rounding.c -lm
  *   ./check FIRST_PART N_PARTS      (the 2^32 bit patterns are split into 16 parts of 2^28; 0 16 = all of them)
  * All 16 parts: 0 mismatches (run when the function was written); tests/test_oracle_pins.py runs the binades that
@@ -28,14 +28,24 @@ static int f32_form(float x) { /* keep in step with dev_float_sample_to_i16_f32 
     return x < 0.0f ? -neg : pos;
 }
 
+static int f32_form_v2(float x) { /* keep in step with dev_float_sample_to_i16_v2 (the synthesis kernel's s16 output) */
+    float m = isfinite(x) ? fminf(fabsf(x), 1.0f) : 0.0f;
+    float a = m * 32768.0f;
+    float d = a - floorf(a); /* v_fract_f32: exact here (a < 2^15 + 1) */
+    int ki = (int)a;
+    float mm = x < 0.0f ? 0.0f : m;
+    int r = ki + ((d - 0.5f >= mm) ? 1 : 0) - ((d + 0.5f < mm) ? 1 : 0);
+    return x < 0.0f ? -r : r;
+}
+
 static uint64_t sweep(uint64_t lo, uint64_t hi) {
     uint64_t bad = 0;
     for (uint64_t u = lo; u < hi; ++u) {
         uint32_t b = (uint32_t)u;
         float x;
         memcpy(&x, &b, 4);
-        if (reference_form(x) != f32_form(x)) {
-            if (bad < 10) printf("mismatch %a: %d vs %d\n", x, reference_form(x), f32_form(x));
+        if (reference_form(x) != f32_form(x) || reference_form(x) != f32_form_v2(x)) {
+            if (bad < 10) printf("mismatch %a: %d vs %d / %d\n", x, reference_form(x), f32_form(x), f32_form_v2(x));
             ++bad;
         }
     }
