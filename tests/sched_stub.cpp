@@ -94,9 +94,36 @@ int sk_tick_run_au(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, c
     if (used) *used = cursor;
     return SK_OK;
 }
-int sk_tick_run_q(sk_engine *, const sk_tick_stream *, uint32_t, const sk_aac_frame_desc *, const void *, const int16_t *, uint32_t, uint8_t *,
-                  size_t, sk_tick_output *, uint32_t, uint32_t *, size_t *) {
-    return SK_ERR_UNSUPPORTED;  // the quantised hand-over needs the device: covered by the GPU suite
+// the quantised hand-over's stand-in: one record per unit (stream, running unit number, checksum of its i16 values and
+// of its side record), with the checks engine.cpp makes on the table
+int sk_tick_run_q(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const void *sides,
+                  const int16_t *quant, uint32_t n_units, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap,
+                  uint32_t *n_outs, size_t *used) {
+    std::lock_guard<std::mutex> lk(e->mu);
+    std::map<uint32_t, int> seen;
+    uint32_t f = 0, k = 0;
+    size_t cursor = 0, at = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (seen[ts[i].stream]++) return SK_ERR_INVALID_ARG;
+        if (ts[i].stream >= e->open.size() || !e->open[ts[i].stream]) return SK_ERR_BAD_STREAM;
+        for (uint32_t j = 0; j < ts[i].n_frames; ++j, ++f) {
+            if (f >= n_units || descs[f].stream != ts[i].stream || k >= outs_cap || cursor + 64 > out_cap) return SK_ERR_INVALID_ARG;
+            const uint32_t ch = e->channels[ts[i].stream];
+            uint32_t sum = 0;
+            for (uint32_t c = 0; c < ch * 1024; ++c) sum = sum * 31u + (uint16_t)quant[at + c];
+            at += (size_t)ch * 1024;
+            const uint8_t *side = (const uint8_t *)sides + (size_t)f * SK_AAC_UNIT_SIDE_BYTES;
+            for (uint32_t c = 0; c < SK_AAC_UNIT_SIDE_BYTES; ++c) sum = sum * 31u + side[c];
+            uint32_t words[4] = {ts[i].stream, e->next_unit[ts[i].stream]++, sum, 0xabcd1234u};
+            std::memcpy(out + cursor, words, 16);
+            outs[k++] = sk_tick_output{i, 1024, cursor, 16, 0, (uint8_t)ch, 16, 0};
+            cursor += 64;
+        }
+    }
+    if (f != n_units) return SK_ERR_INVALID_ARG;
+    *n_outs = k;
+    if (used) *used = cursor;
+    return SK_OK;
 }
 int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
                 uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs,
@@ -130,6 +157,7 @@ int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, cons
 // ---- scenarios -------------------------------------------------------------------------------------------
 static std::vector<uint8_t> clip;
 static uint32_t g_lanes = 0;  // sk_pipeline_config::lanes of every scenario
+static uint32_t g_front_end = 0;  // sk_pipeline_config::gpu_entropy of scenario_many_streams
 static uint64_t rng_state = 88172645463325252ull;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
 
@@ -175,9 +203,10 @@ static int scenario_many_streams(sk_engine *e) {
     cfg.max_stream_frames_per_tick = 5;
     cfg.tick_wait_us = 50;
     cfg.lanes = g_lanes;
+    cfg.gpu_entropy = g_front_end;
     sk_pipeline *p = nullptr;
     CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
-    const uint32_t n = 32, loops = 3;
+    const uint32_t n = 32, loops = g_front_end == 2 ? 12 : 3;
     std::vector<uint32_t> handles(n);
     for (uint32_t i = 0; i < n; ++i) CHECK(sk_pipeline_spawn(p, nullptr, &handles[i]) == SK_OK);
     std::vector<std::thread> feeders;
@@ -205,7 +234,7 @@ static int scenario_many_streams(sk_engine *e) {
     for (auto &th : feeders) th.join();
     for (uint32_t i = 0; i < n; ++i) {
         CHECK(errors[i] == 0);
-        CHECK(got[i].size() == 48 * loops);
+        CHECK(got[i].size() == (size_t)48 * loops);
         for (size_t k = 0; k < got[i].size(); ++k) {
             CHECK(got[i][k].unit == k);                              // in order, none lost or duplicated
             CHECK(got[i][k].stream_tag == got[i][0].stream_tag);     // never another stream's data
@@ -459,6 +488,12 @@ int main(int argc, char **argv) {
     if (int rc = scenario_cancel_churn(&e)) return rc;
     g_lanes = 3;
     if (int rc = scenario_many_streams(&e)) return rc;
+    g_lanes = 1;
+    g_front_end = 2;  // host Huffman decode, i16 + side records to the engine
+    if (int rc = scenario_many_streams(&e)) return rc;
+    g_lanes = 2;
+    if (int rc = scenario_many_streams(&e)) return rc;
+    g_front_end = 0;
     g_lanes = 1;
     if (int rc = scenario_max_length_frames(&e)) return rc;
     g_lanes = 2;
