@@ -106,13 +106,10 @@ __device__ __forceinline__ const_entries as_constant(const SynthEntry *p) {
 
 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 // four PCM samples as the s16 the worker emits (float_sample_to_i16, soundkit-decoder lib.rs:1815-1827), packed
-// float_sample_to_i16 in its shortest exact form (sk_device.h; tools/check_f32_rounding.c sweeps all 2^32 inputs): the s16
-// variant of the kernel is bound by vector issue, a third of it these conversions (profiles/r02_pmc_aac_synth.md)
+// float_sample_to_i16 in its shortest exact form (through f64, sk_device.h; tools/check_f32_rounding.c sweeps all 2^32
+// inputs): the s16 variant of the kernel is bound by vector issue, and with the f32 form a third of it was these conversions
 __device__ __forceinline__ u2 pack4_s16(const f4 &v) {
-    typedef short s2 __attribute__((ext_vector_type(2)));
-    const s2 lo = __builtin_amdgcn_cvt_pk_i16(dev_float_sample_to_i16_v2(v.x), dev_float_sample_to_i16_v2(v.y));
-    const s2 hi = __builtin_amdgcn_cvt_pk_i16(dev_float_sample_to_i16_v2(v.z), dev_float_sample_to_i16_v2(v.w));
-    return (u2){__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+    return (u2){dev_pack2_s16(v.x, v.y), dev_pack2_s16(v.z, v.w)};
 }
 
 typedef __attribute__((address_space(3))) f2 lds_f2;

@@ -323,12 +323,7 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
         }
         // the worker's 16-bit output stage (float_sample_to_i16, interleave) on the four results a lane holds; the
         // conversions are ordinary vector work in the shadow of the matrix instructions
-        int c16[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c16[r] = dev_float_sample_to_i16_v2(v[r]);  // the shortest exact form (sk_device.h)
-        typedef short s16x2 __attribute__((ext_vector_type(2)));
-        const uint32_t mine01 = __builtin_bit_cast(uint32_t, (s16x2)__builtin_amdgcn_cvt_pk_i16(c16[0], c16[1]));
-        const uint32_t mine23 = __builtin_bit_cast(uint32_t, (s16x2)__builtin_amdgcn_cvt_pk_i16(c16[2], c16[3]));
+        const uint32_t mine01 = dev_pack2_s16(v[0], v[1]), mine23 = dev_pack2_s16(v[2], v[3]);  // shortest exact form (sk_device.h)
         if (OUT16 == 2) {
             // the neighbouring row's lane (lane ^ 1) holds the other channel: two packed dwords cross by DPP quad_perm [1,0,3,2]
             const uint32_t other01 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine01, 0xB1, 0xF, 0xF, true);
@@ -357,7 +352,7 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
                 asm volatile("; tile at an edge of the output, or unaligned rows" ::: "memory");
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (rel + r >= 0 && rel + r < (int32_t)a.out_count) dst[r] = (int16_t)c16[r];
+                    if (rel + r >= 0 && rel + r < (int32_t)a.out_count) dst[r] = (int16_t)((r < 2 ? mine01 : mine23) >> (16 * (r & 1)));
             }
         }
     };

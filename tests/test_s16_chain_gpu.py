@@ -72,6 +72,43 @@ def test_planar_s16_synthesis_is_the_rounded_f32_synthesis(engine, oracle, layou
         engine.close_stream(int(sid))
 
 
+@pytest.mark.parametrize("gain,poison", [(3.0e5, None), (1.0e12, None), (1.0e36, None), (9000.0, "nan"), (9000.0, "inf")])
+def test_planar_s16_synthesis_out_of_range_and_non_finite(engine, oracle, gain, poison):
+    """float_sample_to_i16's clamp and its non-finite -> 0 rule (soundkit-decoder lib.rs:1815-1827) on the kernel's own
+    conversion: PCM far beyond +-1 (also beyond the i32 range, and overflowing to inf inside the transform), NaN and inf
+    coefficients; every window sequence.  Expected = the oracle's conversion of the f32 kernel's output of the same frames."""
+    import torch
+    ch, n_streams, n_frames = 2, 4, 6
+    coeffs, seqs, shapes, sids, order, strides, packed, descs, n = make_batch(engine, oracle, "stream", ch, n_streams, n_frames, gain)
+    if poison:
+        packed = packed.copy()
+        packed[1::3, :, 5::97] = np.float32(np.nan if poison == "nan" else np.inf)
+        packed[2::3, 0, 11::131] = np.float32(np.nan if poison == "nan" else -np.inf)
+    plan = engine.plan(descs, n)
+    d_coeffs = torch.from_numpy(packed).cuda()
+    d_f32 = torch.empty_like(d_coeffs)
+    d_s16 = torch.zeros(d_coeffs.shape, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    plan.run_f32(d_coeffs, d_f32)
+    engine.synchronize()
+    for sid in sids:
+        engine.reset_stream(int(sid))
+    plan.run_s16_planar(d_coeffs, d_s16)
+    engine.synchronize()
+    f32 = d_f32.cpu().numpy()
+    want = oracle.pcm_convert("FLOAT_TO_I16_ROUND", f32.ravel()).reshape(f32.shape)
+    got = d_s16.cpu().numpy()
+    assert np.array_equal(got, want)
+    if poison:
+        assert not np.isfinite(f32).all() and (want[~np.isfinite(f32)] == 0).all()
+    else:
+        assert (got == 32767).any() and (got == -32768).any()
+        assert gain < 1e30 or (np.abs(f32) > 2.0 ** 40).any()   # beyond what the integer conversion itself can hold
+    plan.destroy()
+    for sid in sids:
+        engine.close_stream(int(sid))
+
+
 @pytest.mark.parametrize("ch,n_streams,n_frames,layout", [(2, 37, 5, "stream"), (1, 21, 3, "frame"), (2, 16, 7, "frame"), (1, 33, 4, "stream")])
 def test_fir_on_s16_rows(engine, oracle, ch, n_streams, n_frames, layout):
     """random full-range s16 rows (extremes included): the f32 result against the filter evaluated in f64 on s / 32768

@@ -38,14 +38,34 @@ static int f32_form_v2(float x) { /* keep in step with dev_float_sample_to_i16_v
     return x < 0.0f ? -r : r;
 }
 
+/* v_cvt_i32_f64: truncates, saturates, NaN -> 0;  v_cvt_pk_i16_i32: saturates to i16 */
+static int cvt_i32_f64(double t) {
+    if (t != t) return 0;
+    if (t >= 2147483647.0) return 2147483647;
+    if (t <= -2147483648.0) return (int)-2147483648LL;
+    return (int)t;
+}
+static int sat16(int k) { return k < -32768 ? -32768 : (k > 32767 ? 32767 : k); }
+
+static int f64_form_v3(float x) { /* keep in step with dev_float_sample_to_i16_sat (sk_device.h) */
+    float y = fmaf(x, 0.0f, x); /* NaN for +-inf and NaN, x otherwise */
+    double X = (double)y;
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    double half = (b >> 31) ? -0.5 : 0.5;
+    double h = fma(fabs(X), -0.5, half);
+    double t = fma(X, 32767.5, h); /* = x * 32767 (x >= 0) or x * 32768 (x < 0), plus half away from zero: exact for |x| <= 2 */
+    return sat16(cvt_i32_f64(t));
+}
+
 static uint64_t sweep(uint64_t lo, uint64_t hi) {
     uint64_t bad = 0;
     for (uint64_t u = lo; u < hi; ++u) {
         uint32_t b = (uint32_t)u;
         float x;
         memcpy(&x, &b, 4);
-        if (reference_form(x) != f32_form(x) || reference_form(x) != f32_form_v2(x)) {
-            if (bad < 10) printf("mismatch %a: %d vs %d / %d\n", x, reference_form(x), f32_form(x), f32_form_v2(x));
+        if (reference_form(x) != f32_form(x) || reference_form(x) != f32_form_v2(x) || reference_form(x) != f64_form_v3(x)) {
+            if (bad < 10) printf("mismatch %a: %d vs %d / %d / %d\n", x, reference_form(x), f32_form(x), f32_form_v2(x), f64_form_v3(x));
             ++bad;
         }
     }
