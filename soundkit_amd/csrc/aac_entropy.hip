@@ -83,14 +83,32 @@ __device__ __forceinline__ bool unit_of_lane(const EntropyArgs &a, uint32_t &k) 
     return lane < per_wave && k < a.n_units;
 }
 
+// The spectra of a wave's units, zeroed by all 64 lanes together (16 bytes per lane, whole cache lines) before any lane
+// decodes: left to the lanes it is 1024 stores per channel, each a single word per lane 8 KiB from its neighbour's.
+__device__ __forceinline__ void wave_zero_spectra(const EntropyArgs &a) {
+    const uint32_t per_wave = 64u >> a.lane_shift;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t l = 0; l < per_wave; ++l) {
+        const uint32_t k = wave * per_wave + l;  // wave-uniform
+        if (k >= a.n_units) break;
+        const EntropyUnit u = a.units[k];
+        const uint32_t quads = a.tasks[u.task].channels * 256u;
+        float4 *dst = reinterpret_cast<float4 *>(a.coeffs + (size_t)u.off1024 * 1024);
+        for (uint32_t i = lane; i < quads; i += 64) dst[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    // a lane's own stores to these addresses come later in the same wave's store stream; wait all the same
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 __global__ __launch_bounds__(512) void k_aac_entropy_parse(EntropyArgs a) {
     extern __shared__ uint4 lds_raw[];
     const sk_ec::Tables t = lds_tables(a, lds_raw);
+    wave_zero_spectra(a);
     uint32_t k;
     if (!unit_of_lane(a, k)) return;
     const EntropyUnit u = a.units[k];
     const EntropyTask tk = a.tasks[u.task];
-    sk_ec::Stream st{tk.sf_index, (int)tk.channels, 0u};
+    sk_ec::Stream st{tk.sf_index, (int)tk.channels, 0u, true};
     sk_ec::Scratch side;
     uint8_t seq[2] = {0, 0}, shape[2] = {0, 0};
     const int status = sk_ec::parse_unit(t, st, a.words + u.word_offset, u.byte_len, a.coeffs + (size_t)u.off1024 * 1024, seq, shape, side,

@@ -17,10 +17,12 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define SKE __host__ __device__ inline
+#define SKE_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #include <math.h>
 #include <string.h>
 #define SKE inline
+#define SKE_NOINLINE inline
 #endif
 
 namespace sk_ec {
@@ -460,6 +462,9 @@ struct Stream {  // what persists across the access units of one stream
     int sf_index;  // -1: explicit sample rate (no band tables)
     int channels;
     uint32_t pns_state;  // spectral.rs:2459, decoder.rs:76: starts at 0x1f2e3d4c
+    // device: the spectra of this launch's units were zeroed by the whole wave (coalesced) before the lanes started, so
+    // the decode does not have to clear them one scattered word per lane at a time
+    bool prefilled = false;
 };
 
 SKE int layout(const Tables &t, const Stream &st, const Ics &ics, const uint16_t **off, int *bands) {  // decoder.rs:376-383, sfb.rs:52-71
@@ -489,8 +494,8 @@ enum PnsMode {
 // 1).  A magnitude beyond i16 (only an escape sequence of more than 11 extra bits can produce one; ISO/IEC 14496-3 allows
 // 8191) is reported as an unsupported feature in that mode.  mode must be PNS_COUNT; coef is not touched.
 template <bool QUANT>
-SKE int decode_spectrum_t(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
-                          PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant) {
+SKE int decode_spectrum_nested(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
+                               PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant) {
     const Ics ics = ch.ics;
     const int stride = band_stride(ics);
     const int max_sfb = ics.max_sfb, num_groups = ics.num_groups;
@@ -505,7 +510,7 @@ SKE int decode_spectrum_t(const Tables &t, Stream &st, Bits &bits, const Channel
     EC_TRY(layout(t, st, ics, &off, &bands));
     if (QUANT) {
         for (int i = 0; i < 1024; ++i) quant[i] = 0;
-    } else {
+    } else if (!st.prefilled) {
         for (int i = 0; i < 1024; ++i) coef[i] = 0.0f;
     }
     Bits b = bits;  // a local copy: its fields stay in registers across the stores below
@@ -644,6 +649,188 @@ SKE int decode_spectrum_t(const Tables &t, Stream &st, Bits &bits, const Channel
         else EC_TRY(noise_band(ch.mult[sfb], st.pns_state, coef + s, e - s));
     }
     return EC_OK;
+}
+
+// The same function as ONE loop that takes one step per pass -- open a window group, open a band, or decode one codeword
+// -- instead of four nested loops.  Written for a wave of 64 lanes that each decode their own access unit: nested, the
+// wave runs every band for as many passes as its slowest lane needs (a lane in a four-value book next to one in a
+// two-value book idles half the time, one in a zero band idles for the whole band, and long and short windows take turns),
+// flat, every lane that still has codewords left decodes one per pass whatever band, book or window it is in.  Per lane
+// the operations, their order and therefore every result and every error code are those of the nested form
+// (tests/entropy_core_check.cpp runs both on every unit it sees; SK_EC_FLAT selects this form in a host build).
+template <bool QUANT>
+SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
+                             PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant) {
+    const Ics ics = ch.ics;
+    const int stride = band_stride(ics);
+    const int max_sfb = ics.max_sfb, num_groups = ics.num_groups;
+    if (!allow_intensity)
+        for (int g = 0; g < num_groups; ++g)
+            for (int sfb = 0; sfb < max_sfb; ++sfb) {
+                const int book = ch.book[g * stride + sfb];
+                if (book == BOOK_INTENSITY || book == BOOK_INTENSITY_NEG) return EC_INVALID_BITSTREAM;
+            }
+    const uint16_t *off;
+    int bands;
+    EC_TRY(layout(t, st, ics, &off, &bands));
+    if (QUANT) {
+        for (int i = 0; i < 1024; ++i) quant[i] = 0;
+    } else if (!st.prefilled) {
+        for (int i = 0; i < 1024; ++i) coef[i] = 0.0f;
+    }
+    const bool is_short = ics.sequence == SEQ_EIGHT_SHORT;
+    if (is_short && ch.pulse_present) return EC_INVALID_BITSTREAM;
+    const bool pulse_present = ch.pulse_present != 0;  // long windows only from here on
+    const int pulse_count = pulse_present ? ch.pulse_count : 0;
+    int target[4] = {-1, -1, -1, -1}, amp[4] = {0, 0, 0, 0};
+    bool start_known = false;
+    if (pulse_present && ch.pulse_start < max_sfb && ch.pulse_start + 1 <= bands) {
+        int index = off[ch.pulse_start];
+        start_known = true;
+        for (int i = 0; i < pulse_count; ++i) {
+            index += ch.pulse_offset[i];
+            target[i] = index;
+            amp[i] = ch.pulse_amp[i];
+        }
+    }
+    Bits b = bits;
+    uint32_t pns = st.pns_state;
+    int status = EC_OK;
+    // a long window is one group of one window of 1024 lines
+    const int limit = is_short ? 128 : 1024, groups = is_short ? num_groups : 1;
+    enum { OPEN_GROUP, OPEN_BAND, IN_BAND, DONE };
+    int phase = OPEN_GROUP;
+    int g = 0, sfb = 0, w0 = 0, glen = 0, w = 0, i = 0, s = 0, e = 0, dim = 4;
+    float scale = 0.0f;
+    BookRef br = BookRef{t.lut, t.tuples, 1};
+    int q[4];
+    while (phase != DONE) {
+        if (phase == OPEN_GROUP) {
+            if (g >= groups) {
+                phase = DONE;
+            } else {
+                glen = is_short ? ics.group_len[g] : 1;
+                if (is_short && (glen == 0 || w0 + glen > 8)) {
+                    status = EC_INVALID_BITSTREAM;
+                    phase = DONE;
+                } else {
+                    sfb = 0;
+                    phase = OPEN_BAND;
+                }
+            }
+        }
+        if (phase == OPEN_BAND) {
+            if (sfb >= max_sfb) {
+                w0 += glen;
+                ++g;
+                phase = OPEN_GROUP;
+            } else {
+                status = band_range(off, bands, sfb, &s, &e);
+                if (status == EC_OK && e > limit) status = EC_INVALID_CONFIG;
+                if (status != EC_OK) {
+                    phase = DONE;
+                } else {
+                    const int book = ch.book[g * stride + sfb];
+                    scale = ch.mult[g * stride + sfb];
+                    if (book >= 1 && book <= 11) {
+                        br = book_ref(t, book);
+                        dim = book <= 4 ? 4 : 2;
+                        if (s + dim <= e) {
+                            w = w0;
+                            i = s;
+                            phase = IN_BAND;
+                        } else {
+                            ++sfb;
+                        }
+                    } else {
+                        if (book == BOOK_NOISE && (is_short || !pulse_present)) {
+                            if (mode == PNS_COUNT) *noise_samples += (uint32_t)(glen * (e - s));
+                            else
+                                for (int ww = w0; ww < w0 + glen && status == EC_OK; ++ww)
+                                    status = noise_band(scale, pns, coef + (is_short ? ww * 128 : 0) + s, e - s);
+                            if (status != EC_OK) phase = DONE;
+                        }
+                        ++sfb;
+                    }
+                }
+            }
+        }
+        if (phase == IN_BAND) {
+            status = read_tuple(br, b, q);
+            if (status != EC_OK) {
+                phase = DONE;
+            } else {
+                for (int p = 0; p < pulse_count; ++p) {  // pulses apply in order; two may hit the same coefficient
+                    const int k = target[p] - i;
+                    if (k >= 0 && k < dim) q[k] += q[k] > 0 ? amp[p] : -amp[p];
+                }
+                const int at = (is_short ? w * 128 : 0) + i;
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= dim) break;
+                    if (QUANT) {
+                        if (q[k] > 32767 || q[k] < -32768) status = EC_UNSUPPORTED_FEATURE;
+                        quant[at + k] = (int16_t)q[k];
+                    } else {
+                        coef[at + k] = dequantize(t, q[k], scale);
+                    }
+                }
+                if (QUANT && status != EC_OK) {
+                    phase = DONE;
+                } else {
+                    i += dim;
+                    if (i + dim > e) {
+                        i = s;
+                        ++w;
+                        if (w >= w0 + glen) {
+                            ++sfb;
+                            phase = OPEN_BAND;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (is_short && status == EC_OK && w0 != 8) status = EC_INVALID_BITSTREAM;
+    bits = b;
+    st.pns_state = pns;
+    if (is_short || status != EC_OK || !pulse_present) return status;
+    // apply_pulse_data's checks (spectral.rs:2198-2247), in its order
+    if (ch.pulse_start >= max_sfb) return EC_INVALID_BITSTREAM;
+    if (!start_known) return EC_INVALID_CONFIG;  // band_range(start_sfb) failed
+    for (int p = 0; p < pulse_count; ++p) {
+        const int index = target[p];
+        if (index >= 1024) return EC_INVALID_BITSTREAM;
+        int band = -1;
+        for (int k = 0; k < max_sfb; ++k) {
+            int bs, be;
+            EC_TRY(band_range(off, bands, k, &bs, &be));
+            if (index >= bs && index < be) {
+                band = k;
+                break;
+            }
+        }
+        if (band < 0) return EC_INVALID_BITSTREAM;
+        const int book = ch.book[band];
+        if (!(book >= 1 && book <= 11)) return EC_INVALID_BITSTREAM;
+    }
+    for (int k = 0; k < max_sfb; ++k) {  // the noise bands of the pulse path come last
+        if (ch.book[k] != BOOK_NOISE) continue;
+        int bs, be;
+        EC_TRY(band_range(off, bands, k, &bs, &be));
+        if (mode == PNS_COUNT) *noise_samples += (uint32_t)(be - bs);
+        else EC_TRY(noise_band(ch.mult[k], st.pns_state, coef + bs, be - bs));
+    }
+    return EC_OK;
+}
+
+template <bool QUANT>
+SKE int decode_spectrum_t(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
+                          PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant) {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(SK_EC_FLAT)
+    return decode_spectrum_flat<QUANT>(t, st, bits, ch, allow_intensity, coef, mode, noise_samples, quant);
+#else
+    return decode_spectrum_nested<QUANT>(t, st, bits, ch, allow_intensity, coef, mode, noise_samples, quant);
+#endif
 }
 
 SKE int decode_spectrum(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,

@@ -6,21 +6,30 @@ then checked against the host path in tests/test_entropy_gpu.py."""
 import os
 import subprocess
 
+import pytest
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 FILES = ["aac-stereo-48k.adts", "stereo-music-44100-192k.aac", "mono16k_A_Tusk.aac", "A_Tusk_is_used_to_make_costly_gifts_encoded.aac"]
 
 
-def test_entropy_core_equals_host_front_end_under_sanitizers(tmp_path):
+# the spectral decode exists in two forms (aac_entropy_core.h): nested loops (host builds) and one flat loop (the device
+# build; -DSK_EC_FLAT selects it on the host) -- both are checked
+FORMS = [pytest.param([], id="nested"), pytest.param(["-DSK_EC_FLAT"], id="flat")]
+
+
+@pytest.mark.parametrize("form", FORMS)
+def test_entropy_core_equals_host_front_end_under_sanitizers(tmp_path, form):
     exe = str(tmp_path / "entropy_core_check")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-                           "-ffp-contract=off", "-Wno-subobject-linkage", "-o", exe, os.path.join(HERE, "entropy_core_check.cpp")],
+                           "-ffp-contract=off", "-Wno-subobject-linkage"] + form + ["-o", exe, os.path.join(HERE, "entropy_core_check.cpp")],
                           cwd=HERE)
     out = subprocess.run([exe, "6000"] + [os.path.join(HERE, "golden", "aac", f) for f in FILES], capture_output=True, text=True)
     assert out.returncode == 0 and "identical" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
     assert "checked 24273 access units" in out.stdout
 
 
-def test_entropy_core_equals_host_front_end_on_generated_units(tmp_path):
+@pytest.mark.parametrize("form", FORMS)
+def test_entropy_core_equals_host_front_end_on_generated_units(tmp_path, form):
     """the same harness on units from tests/au_builder.py (pulse data, escapes up to the 16-bit limit, every codebook and
     window grouping, values beyond the reference's tables) and on 300 mutants of each generated stream"""
     import numpy as np
@@ -28,7 +37,7 @@ def test_entropy_core_equals_host_front_end_on_generated_units(tmp_path):
     from au_builder import adts_frame, extreme_scalefactor_units, random_access_unit
     exe = str(tmp_path / "entropy_core_check")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-                           "-ffp-contract=off", "-Wno-subobject-linkage", "-o", exe, os.path.join(HERE, "entropy_core_check.cpp")],
+                           "-ffp-contract=off", "-Wno-subobject-linkage"] + form + ["-o", exe, os.path.join(HERE, "entropy_core_check.cpp")],
                           cwd=HERE)
     files, units = [], 0
     for k, (sf_index, channels) in enumerate([(3, 2), (4, 1), (8, 2), (11, 1), (0, 2)]):
