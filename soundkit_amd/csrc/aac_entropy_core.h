@@ -399,17 +399,27 @@ SKE BookRef book_ref(const Tables &t, int book) {
 
 SKE int read_tuple(const BookRef &br, Bits &b, int *q) {
     const int book = br.book;
-    uint32_t sym;
-    EC_TRY(huffman_in(br.lut, b, &sym));
-    const uint64_t tu = br.tuples[sym];  // bytes 0-3 values, byte 4 sign-bit count, byte 5 escape flag, bits 48.. sign positions
+    // ONE look at the bit window serves the codeword (<= 16 bits in every spectral book) and the sign bits behind it (<= 4):
+    // on the device every look costs the refill test of the whole wave
+    const uint32_t look = peek32(b);
+    uint32_t e = br.lut[look >> (32 - kPrimaryBits)];
+    if (e & 0x80000000u) {
+        const uint32_t extra = (e >> 24) & 0x7f;
+        e = br.lut[(e & 0xffffffu) + ((look << kPrimaryBits) >> (32 - extra))];
+    }
+    const uint32_t len = e >> 16;
+    if (len == 0 || len > b.total - b.pos) return EC_INVALID_BITSTREAM;  // huffman_in
+    b.pos += len;
+    const uint64_t tu = br.tuples[e & 0xffffu];  // bytes 0-3 values, byte 4 sign-bit count, byte 5 escape flag, bits 48.. sign positions
     const int dim = book <= 4 ? 4 : 2;
     for (int k = 0; k < dim; ++k) q[k] = (int8_t)(tu >> (8 * k));
     const uint32_t nsign = (uint32_t)(tu >> 32) & 0xffu;  // 0 for the signed books
     if (nsign == 0) return EC_OK;
     // the sign bits of the non-zero magnitudes follow the codeword, in order: taken in one read and handed out by
     // position (no per-value branch; lanes of a wave sit in different tuples)
-    uint32_t signs;
-    EC_TRY(read_bits(b, nsign, &signs));
+    if (b.total - b.pos < nsign) return EC_EOF;  // read_bits
+    const uint32_t signs = (look << len) >> (32 - nsign);
+    b.pos += nsign;
     for (int k = 0; k < dim; ++k) {
         const uint32_t at = (uint32_t)(tu >> (48 + 4 * k)) & 15u;  // 15: this value has no sign bit (signs < 16 >> 15 == 0)
         const int neg = (int)((signs >> at) & 1u);
@@ -771,7 +781,12 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
                         if (q[k] > 32767 || q[k] < -32768) status = EC_UNSUPPORTED_FEATURE;
                         quant[at + k] = (int16_t)q[k];
                     } else {
+#ifdef SK_EC_ABLATE_STORE  // timing experiment: the spectrum is computed but (almost) never stored
+                        const float dq = dequantize(t, q[k], scale);
+                        if (dq == 1.2345e30f) coef[at + k] = dq;
+#else
                         coef[at + k] = dequantize(t, q[k], scale);
+#endif
                     }
                 }
                 if (QUANT && status != EC_OK) {
@@ -1117,11 +1132,17 @@ SKE int unit_tail(const uint32_t *au, uint32_t len_bytes, uint32_t resume_pos);
 // unit (fill elements, END, the trailing-zero rule) from where the first phase stopped.
 SKE int finish_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len_bytes, float *coef, Scratch &s, bool fill) {
     Channel &left = s.ch[0], &right = s.ch[1];
+#ifndef SK_EC_ABLATE_NOISE  // the SK_EC_ABLATE_* switches are timing experiments (tools/build_ab.sh); results are wrong with them
     if (fill) {
         EC_TRY(fill_noise(t, st, left, coef));
         if (s.is_pair) EC_TRY(fill_noise(t, st, right, coef + 1024));
     }
+#endif
+#ifdef SK_EC_ABLATE_STEREO
+    if (false) {
+#else
     if (s.is_pair) {
+#endif
         if (!s.common_window) {  // decoder.rs:275-285
             const int stride = band_stride(right.ics);
             for (int g = 0; g < right.ics.num_groups; ++g)
@@ -1133,8 +1154,13 @@ SKE int finish_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t le
             EC_TRY(stereo_tools(t, st, s.mask, left.ics, left, right, coef, coef + 1024));
         }
     }
+#ifndef SK_EC_ABLATE_TNS
     if (left.tns_present) EC_TRY(apply_tns(t, st, left, coef));
     if (s.is_pair && right.tns_present) EC_TRY(apply_tns(t, st, right, coef + 1024));
+#endif
+#ifdef SK_EC_ABLATE_TAIL
+    return EC_OK;
+#endif
     return unit_tail(au, len_bytes, s.resume_pos);
 }
 
