@@ -565,6 +565,223 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
     if (lane == 0) a.prev_shape[state] = (uint8_t)prev_shape;
 }
 
+// ---- OnlyLong channels, two per wave ----------------------------------------------------------------------------------------
+// The walking kernel is bound by vector issue once its output is s16 (profiles/r02_pmc_aac_synth.md), and a third of what it
+// issues is not arithmetic: a complex value sits in one register pair, so the packed instructions work on (re, im) and every
+// multiplication by i, every twiddle product and every (1 +- i)/sqrt2 rotation needs halves swapped, broadcast or negated
+// around it (v_mov / v_pk_mov / v_xor, and scalar-width adds where no packing was found).  Here a wave owns TWO channels with
+// the same number of frames (normally the L and R of a stream, whose spectra are adjacent in memory) and every value is the
+// pair (channel A, channel B): all arithmetic is element-wise on such pairs, a twiddle is one broadcast operand, and nothing
+// is ever swapped.  Per channel the operations and their order are exactly those of k_aac_synth<.., true>, so the two kernels
+// agree bit for bit and a channel's samples do not depend on whether it found a partner.
+struct c2 {
+    f2 re, im;  // one complex value of channel A (.x) and of channel B (.y)
+};
+__device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ c2 cadd(c2 a, c2 b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ c2 csub(c2 a, c2 b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ c2 mul_mi(c2 a) { return {a.im, -a.re}; }
+// a * w for a twiddle common to both channels: cmul(a, w) per channel
+__device__ __forceinline__ c2 cmul_w(c2 a, f2 w) {
+    const f2 wr = splat(w.x), wi = splat(w.y);
+    return {fma2(a.re, wr, -(a.im * wi)), fma2(a.re, wi, a.im * wr)};
+}
+__device__ __forceinline__ void dft8(c2 (&x)[8]) {
+    const f2 h = splat(0.70710678118654752440f);
+    c2 t0 = cadd(x[0], x[4]), t1 = csub(x[0], x[4]);
+    c2 t2 = cadd(x[2], x[6]), t3 = mul_mi(csub(x[2], x[6]));
+    c2 e0 = cadd(t0, t2), e2 = csub(t0, t2), e1 = cadd(t1, t3), e3 = csub(t1, t3);
+    c2 u0 = cadd(x[1], x[5]), u1 = csub(x[1], x[5]);
+    c2 u2 = cadd(x[3], x[7]), u3 = mul_mi(csub(x[3], x[7]));
+    c2 o0 = cadd(u0, u2), o2 = csub(u0, u2), o1 = cadd(u1, u3), o3 = csub(u1, u3);
+    c2 w1 = {(o1.re + o1.im) * h, (o1.im - o1.re) * h};
+    c2 w2 = mul_mi(o2);
+    c2 w3 = {(o3.im - o3.re) * h, -((o3.re + o3.im) * h)};
+    x[0] = cadd(e0, o0); x[4] = csub(e0, o0);
+    x[1] = cadd(e1, w1); x[5] = csub(e1, w1);
+    x[2] = cadd(e2, w2); x[6] = csub(e2, w2);
+    x[3] = cadd(e3, w3); x[7] = csub(e3, w3);
+}
+// exchange slots hold (re A, re B, im A, im B); strides are in 16-byte slots: 66 and 72 keep both transposes free of bank
+// conflicts (16 lanes of a ds_*_b128 land on 16 different slots modulo 16)
+constexpr int kPairExchange = 576;
+__device__ __forceinline__ f4 as_slot(c2 v) { return (f4){v.re.x, v.re.y, v.im.x, v.im.y}; }
+__device__ __forceinline__ c2 from_slot(f4 v) { return {(f2){v.x, v.y}, (f2){v.z, v.w}}; }
+__device__ __forceinline__ void fft512(c2 (&z)[8], lds_f4 *ex, const lds_f2 *t64, f2 base2, int lane) {
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    dft8(z);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) z[k] = cmul_w(z[k], t64[8 * k + hi3]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ex[k * 66 + lane] = as_slot(z[k]);
+    wave_sync();
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) z[n2] = cmul_w(from_slot(ex[lo3 * 66 + 8 * n2 + hi3]), base2);
+    wave_sync();
+    dft8(z);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) z[k] = cmul_w(z[k], t64[8 * k + hi3]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ex[hi3 * 72 + k * 8 + lo3] = as_slot(z[k]);
+    wave_sync();
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) z[n3] = from_slot(ex[n3 * 72 + lane]);
+    wave_sync();
+    dft8(z);
+}
+
+template <bool OUT16>
+__global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(SynthArgs a) {
+    __shared__ f4 lds[kWavesPerBlock][kPairExchange];
+    __shared__ f2 tw_tab[512];
+    __shared__ f2 t64_tab[64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 512; i += kWavesPerBlock * 64) tw_tab[i] = reinterpret_cast<const f2 *>(a.t.tw_long)[i];
+    if (threadIdx.x < 64) t64_tab[threadIdx.x] = reinterpret_cast<const f2 *>(a.t.w64)[((threadIdx.x >> 3) * (threadIdx.x & 7)) & 63];
+    __syncthreads();
+
+    const uint32_t pair_id = blockIdx.x * kWavesPerBlock + wave;
+    if (2 * pair_id + 1 >= a.n_tasks) return;  // n_tasks is even: tasks 2p and 2p + 1 have the same count
+    lds_f4 *ex = (lds_f4 *)lds[wave];
+    const lds_f2 *tw_lds = (const lds_f2 *)tw_tab;
+    const lds_f2 *t64 = (const lds_f2 *)t64_tab;
+
+    const SynthTask task_a = a.tasks[2 * pair_id], task_b = a.tasks[2 * pair_id + 1];
+    const uint32_t count = __builtin_amdgcn_readfirstlane(task_a.count);
+    if (count == 0) return;
+    const uint32_t state_a = __builtin_amdgcn_readfirstlane(task_a.state), state_b = __builtin_amdgcn_readfirstlane(task_b.state);
+    const const_entries ent_a = as_constant(a.entries + __builtin_amdgcn_readfirstlane(task_a.begin));
+    const const_entries ent_b = as_constant(a.entries + __builtin_amdgcn_readfirstlane(task_b.begin));
+
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const f2 base2 = reinterpret_cast<const f2 *>(a.t.w512)[hi3 * lo3];
+
+    float *delay_a = a.delay + (size_t)state_a * 1024, *delay_b = a.delay + (size_t)state_b * 1024;
+    int prev_a = __builtin_amdgcn_readfirstlane((int)a.prev_shape[state_a]);
+    int prev_b = __builtin_amdgcn_readfirstlane((int)a.prev_shape[state_b]);
+    float dly_a[16], dly_b[16];
+    auto load_state = [&](const float *p, float (&d)[16]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 4 * lane + 256 * r;
+            const f4 f = *reinterpret_cast<const f4 *>(p + j);
+            const f4 m = *reinterpret_cast<const f4 *>(p + 1020 - j);
+            d[8 * r + 0] = f.x; d[8 * r + 1] = f.y; d[8 * r + 2] = f.z; d[8 * r + 3] = f.w;
+            d[8 * r + 4] = m.x; d[8 * r + 5] = m.y; d[8 * r + 6] = m.z; d[8 * r + 7] = m.w;
+        }
+    };
+    load_state(delay_a, dly_a);
+    load_state(delay_b, dly_b);
+
+    auto load_spectrum = [&](f2 (&xin)[8], const_entries entries, uint32_t e) {
+        const float *src = a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e].off1024) * 1024 + 2 * lane;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xin[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
+    };
+    struct Win {
+        f4 w1f[2], w1m[2], w2f[2], w2m[2];
+    };
+    auto load_windows = [&](Win &w, int prev_shape, int shape) {
+        const float *prev_long = a.t.win + 2048 * prev_shape;
+        const float *cur_long = a.t.win + 2048 * shape;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 4 * lane + 256 * r;
+            w.w1f[r] = *reinterpret_cast<const f4 *>(prev_long + j);
+            w.w1m[r] = *reinterpret_cast<const f4 *>(prev_long + 1020 - j);
+            w.w2f[r] = *reinterpret_cast<const f4 *>(cur_long + 1024 + j);
+            w.w2m[r] = *reinterpret_cast<const f4 *>(cur_long + 2044 - j);
+        }
+    };
+    // window + overlap-add + store of one channel's half r from its four post-twiddled bins (dsp.rs:267-279, 516-531)
+    auto emit = [&](int r, f2 F0, f2 F1, f2 M0, f2 M1, const Win &w, float (&dly)[16], float *out_ptr, int16_t *out16_ptr) {
+        const int j = 4 * lane + 256 * r;  // = 2 q, q = 2 lane + 128 r the first of the lane's two bins
+        const f4 W1f = w.w1f[r], W1m = w.w1m[r], W2f = w.w2f[r], W2m = w.w2m[r];
+        f4 f, m;
+        f.x = -F0.x * W1f.x + dly[8 * r + 0]; f.y = -M1.y * W1f.y + dly[8 * r + 1];
+        f.z = -F1.x * W1f.z + dly[8 * r + 2]; f.w = -M0.y * W1f.w + dly[8 * r + 3];
+        m.x = M0.y * W1m.x + dly[8 * r + 4]; m.y = F1.x * W1m.y + dly[8 * r + 5];
+        m.z = M1.y * W1m.z + dly[8 * r + 6]; m.w = F0.x * W1m.w + dly[8 * r + 7];
+        if (OUT16) {
+            SK_SYNTH_STORE(pack4_s16(f), reinterpret_cast<u2 *>(out16_ptr + j));
+            SK_SYNTH_STORE(pack4_s16(m), reinterpret_cast<u2 *>(out16_ptr + 1020 - j));
+        } else {
+            SK_SYNTH_STORE(f, reinterpret_cast<f4 *>(out_ptr + j));
+            SK_SYNTH_STORE(m, reinterpret_cast<f4 *>(out_ptr + 1020 - j));
+        }
+        dly[8 * r + 0] = F0.y * W2f.x; dly[8 * r + 1] = M1.x * W2f.y;
+        dly[8 * r + 2] = F1.y * W2f.z; dly[8 * r + 3] = M0.x * W2f.w;
+        dly[8 * r + 4] = M0.x * W2m.x; dly[8 * r + 5] = F1.y * W2m.y;
+        dly[8 * r + 6] = M1.x * W2m.z; dly[8 * r + 7] = F0.y * W2m.w;
+    };
+
+    f2 xa[8], xb[8];
+    load_spectrum(xa, ent_a, 0);
+    load_spectrum(xb, ent_b, 0);
+    for (uint32_t e = 0; e < count; ++e) {
+        const uint32_t off_a = __builtin_amdgcn_readfirstlane(ent_a[e].off1024), off_b = __builtin_amdgcn_readfirstlane(ent_b[e].off1024);
+        const int shape_a = (__builtin_amdgcn_readfirstlane(ent_a[e].win) >> 2) & 1;
+        const int shape_b = (__builtin_amdgcn_readfirstlane(ent_b[e].win) >> 2) & 1;
+        // ---- pre-twiddle (dsp.rs:495-503) of both channels ----
+        c2 z[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const f2 even = (f2){xa[r].x, xb[r].x};
+            const f2 odd = (f2){-__shfl(xa[7 - r].y, 63 - lane), -__shfl(xb[7 - r].y, 63 - lane)};
+            const f2 t = tw_lds[lane + 64 * r];
+            const f2 tx = splat(t.x), ty = splat(t.y);
+            z[r] = {odd * ty - even * tx, odd * tx + even * ty};
+        }
+        Win wa, wb;  // before the prefetch: vector-memory results return in issue order
+        load_windows(wa, prev_a, shape_a);
+        load_windows(wb, prev_b, shape_b);
+        {
+            const uint32_t ahead = e + 1 < count ? e + 1 : count - 1;  // unconditional, as in the one-channel kernel
+            load_spectrum(xa, ent_a, ahead);
+            load_spectrum(xb, ent_b, ahead);
+        }
+        fft512(z, ex, t64, base2, lane);
+        // ---- post-twiddle: value = twiddle * conj(fft) (dsp.rs:512, 523): cmul(tw, conj z) per channel ----
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f2 t = tw_lds[lane + 64 * j];
+            const f2 tx = splat(t.x), ty = splat(t.y);
+            const c2 v = {fma2(tx, z[j].re, -(ty * -z[j].im)), fma2(tx, -z[j].im, ty * z[j].re)};
+            ex[lane + 64 * j] = as_slot(v);
+        }
+        wave_sync();
+        float *out_a = OUT16 ? nullptr : a.pcm + (size_t)off_a * 1024, *out_b = OUT16 ? nullptr : a.pcm + (size_t)off_b * 1024;
+        int16_t *out16_a = OUT16 ? a.pcm16 + (size_t)off_a * 1024 : nullptr, *out16_b = OUT16 ? a.pcm16 + (size_t)off_b * 1024 : nullptr;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int q = 2 * lane + 128 * r;
+            const f4 F0 = ex[256 + q], F1 = ex[257 + q], M0 = ex[254 - q], M1 = ex[255 - q];
+            emit(r, (f2){F0.x, F0.z}, (f2){F1.x, F1.z}, (f2){M0.x, M0.z}, (f2){M1.x, M1.z}, wa, dly_a, out_a, out16_a);
+            emit(r, (f2){F0.y, F0.w}, (f2){F1.y, F1.w}, (f2){M0.y, M0.w}, (f2){M1.y, M1.w}, wb, dly_b, out_b, out16_b);
+        }
+        wave_sync();
+        prev_a = shape_a;  // decoder.rs:371
+        prev_b = shape_b;
+    }
+    auto store_state = [&](float *p, const float (&d)[16]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 4 * lane + 256 * r;
+            *reinterpret_cast<f4 *>(p + j) = (f4){d[8 * r + 0], d[8 * r + 1], d[8 * r + 2], d[8 * r + 3]};
+            *reinterpret_cast<f4 *>(p + 1020 - j) = (f4){d[8 * r + 4], d[8 * r + 5], d[8 * r + 6], d[8 * r + 7]};
+        }
+    };
+    store_state(delay_a, dly_a);
+    store_state(delay_b, dly_b);
+    if (lane == 0) {
+        a.prev_shape[state_a] = (uint8_t)prev_a;
+        a.prev_shape[state_b] = (uint8_t)prev_b;
+    }
+}
+
 // ---- OnlyLong channels, frames in parallel -------------------------------------------------------------------------------
 // The walking kernel above keeps a channel's overlap in registers by giving the whole channel to one long-lived wave;
 // what it pays is the shape: thousands of waves each creeping through their own 4 KiB pieces stream at ~5.1 TB/s on this
@@ -820,6 +1037,15 @@ hipError_t launch_aac_synth(const SynthArgs &a, hipStream_t s) {
         if (a.pcm16) hipLaunchKernelGGL((k_aac_synth<true, false>), dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
         else hipLaunchKernelGGL((k_aac_synth<false, false>), dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_aac_synth_pairs(const SynthArgs &a, hipStream_t s) {
+    if (a.n_tasks < 2) return hipSuccess;
+    if (a.n_tasks & 1) return hipErrorInvalidValue;
+    const uint32_t pairs = a.n_tasks / 2, blocks = (pairs + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (a.pcm16) hipLaunchKernelGGL(k_aac_synth_pair<true>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
+    else hipLaunchKernelGGL(k_aac_synth_pair<false>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
     return hipGetLastError();
 }
 

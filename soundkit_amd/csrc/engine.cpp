@@ -19,6 +19,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "aac_entropy_tables.h"
@@ -250,7 +251,7 @@ struct sk_aac_plan {
     sk::SynthTask *d_walk_tasks = nullptr, *d_long_tasks = nullptr;
     sk::SynthGroup *d_groups = nullptr;
     uint32_t *d_group_tasks = nullptr;
-    uint32_t n_walk_tasks = 0, n_long_tasks = 0, n_groups = 0, n_group_tasks = 0;
+    uint32_t n_walk_tasks = 0, n_long_tasks = 0, n_pair_tasks = 0, n_groups = 0, n_group_tasks = 0;
 };
 
 #define SK_HIP(expr, what)                               \
@@ -589,6 +590,7 @@ struct HostPlan {
     std::vector<sk::SynthTask> walk_tasks, long_tasks;
     std::vector<sk::SynthGroup> groups;
     std::vector<uint32_t> group_tasks;
+    uint32_t n_pair_tasks = 0;  // long_tasks[0 .. n_pair_tasks) are pairs of equal count (2p, 2p + 1) for the two-channel kernel
     uint32_t frames_ok = 0;
     uint64_t off1024 = 0;  // total packed size in units of 1024 f32
 };
@@ -681,6 +683,31 @@ int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, in
                 hp.groups.push_back(sk::SynthGroup{t, first, std::min(per_group, tasks[t].count - first), 0});
         }
     }
+    // OnlyLong tasks with the same number of frames go two to a wave (k_aac_synth_pair); a task meets the nearest earlier
+    // task of its count that is still alone -- the other channel of its stream, when there is one.  SK_SYNTH_PAIRS=0: none.
+    static const bool use_pairs = [] { const char *v = std::getenv("SK_SYNTH_PAIRS"); return !(v && v[0] == '0'); }();
+    hp.n_pair_tasks = 0;
+    if (use_pairs && hp.long_tasks.size() > 1) {
+        std::vector<sk::SynthTask> paired, alone;
+        std::unordered_map<uint32_t, uint32_t> waiting;  // count -> index into long_tasks
+        std::vector<uint8_t> taken(hp.long_tasks.size(), 0);
+        for (uint32_t t = 0; t < hp.long_tasks.size(); ++t) {
+            auto it = waiting.find(hp.long_tasks[t].count);
+            if (it == waiting.end()) {
+                waiting.emplace(hp.long_tasks[t].count, t);
+            } else {
+                paired.push_back(hp.long_tasks[it->second]);
+                paired.push_back(hp.long_tasks[t]);
+                taken[it->second] = taken[t] = 1;
+                waiting.erase(it);
+            }
+        }
+        for (uint32_t t = 0; t < hp.long_tasks.size(); ++t)
+            if (!taken[t]) alone.push_back(hp.long_tasks[t]);
+        hp.n_pair_tasks = (uint32_t)paired.size();
+        paired.insert(paired.end(), alone.begin(), alone.end());
+        hp.long_tasks.swap(paired);
+    }
     return SK_OK;
 }
 
@@ -711,6 +738,7 @@ int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n,
         if (he == hipSuccess && !hp.walk_tasks.empty()) he = upload(&p->d_walk_tasks, hp.walk_tasks);
         if (he == hipSuccess && !hp.long_tasks.empty()) he = upload(&p->d_long_tasks, hp.long_tasks);
         p->n_long_tasks = (uint32_t)hp.long_tasks.size();
+        p->n_pair_tasks = hp.n_pair_tasks;
         if (he == hipSuccess && !hp.groups.empty()) he = upload(&p->d_groups, hp.groups);
         if (he == hipSuccess && !hp.group_tasks.empty()) he = upload(&p->d_group_tasks, hp.group_tasks);
         p->n_walk_tasks = (uint32_t)hp.walk_tasks.size();
@@ -737,9 +765,12 @@ static int run_plan(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, f
     a.tasks = p->d_tasks;
     SK_HIP(sk::launch_aac_synth_groups(a, p->d_groups, p->n_groups, p->d_group_tasks, p->n_group_tasks, e->d_delay_next,
                                        e->d_shape_next, e->stream), "launch aac synth (groups)");
-    a.tasks = p->d_long_tasks;
-    a.n_tasks = p->n_long_tasks;
     a.only_long = 1;
+    a.tasks = p->d_long_tasks;
+    a.n_tasks = p->n_pair_tasks;
+    SK_HIP(sk::launch_aac_synth_pairs(a, e->stream), "launch aac synth (OnlyLong tasks, two per wave)");
+    a.tasks = p->d_long_tasks + p->n_pair_tasks;
+    a.n_tasks = p->n_long_tasks - p->n_pair_tasks;
     SK_HIP(sk::launch_aac_synth(a, e->stream), "launch aac synth (OnlyLong tasks)");
     a.tasks = p->d_walk_tasks;
     a.n_tasks = p->n_walk_tasks;
@@ -2217,9 +2248,14 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                                                e->d_delay_next, e->d_shape_next, e->stream), "launch tick synth (groups)");
         }
         if (!hp.long_tasks.empty()) {
-            SK_HIP(aux.put(hp.long_tasks, e->stream, &a.tasks), "upload tick OnlyLong tasks");
-            a.n_tasks = (uint32_t)hp.long_tasks.size();
+            const sk::SynthTask *d_long = nullptr;
+            SK_HIP(aux.put(hp.long_tasks, e->stream, &d_long), "upload tick OnlyLong tasks");
             a.only_long = 1;
+            a.tasks = d_long;
+            a.n_tasks = hp.n_pair_tasks;
+            SK_HIP(sk::launch_aac_synth_pairs(a, e->stream), "launch tick synth (OnlyLong tasks, two per wave)");
+            a.tasks = d_long + hp.n_pair_tasks;
+            a.n_tasks = (uint32_t)hp.long_tasks.size() - hp.n_pair_tasks;
             SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth (OnlyLong tasks)");
         }
         if (!hp.walk_tasks.empty()) {

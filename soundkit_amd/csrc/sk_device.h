@@ -54,6 +54,8 @@ struct FrameSpan {
 };
 
 hipError_t launch_aac_synth(const SynthArgs &a, hipStream_t s);
+// OnlyLong tasks two per wave: a.tasks[2p] and a.tasks[2p + 1] have the same count (a.n_tasks even)
+hipError_t launch_aac_synth_pairs(const SynthArgs &a, hipStream_t s);
 // tasks whose frames are all OnlyLong, cut into groups (a.tasks indexed by SynthGroup::task; task_ids lists those tasks)
 hipError_t launch_aac_synth_groups(const SynthArgs &a, const SynthGroup *groups, uint32_t n_groups, const uint32_t *task_ids,
                                    uint32_t n_group_tasks, float *delay_next, uint8_t *shape_next, hipStream_t s);
