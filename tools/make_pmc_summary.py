@@ -24,6 +24,8 @@ for spec in sys.argv[2:]:
     streams, frames, ch = cfg.get("streams_per_gpu"), cfg.get("frames_per_stream"), cfg.get("channels")
     for kernel, name, config in (("k_aac_synth", synth_name, {"streams": streams, "frames": frames, "channels": ch}),
                                  ("k_fir_48k_16k", fir_name, {"rows": (streams or 0) * (ch or 0), "frames": (frames or 0) * 1024})):
+        if kernel == "k_aac_synth" and name and not name.endswith("s16out"):
+            kernel = "k_aac_synth_f32out"  # tools/summarize_pmc.py keys the two output types apart
         if name and kernel in pmc:
             e = pmc[kernel]
             out[name] = {"config": config, "counters": e["counters"], "meta": e.get("meta"), "avg_ns_profiled": e.get("avg_ns_profiled"),
