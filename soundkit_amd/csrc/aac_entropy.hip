@@ -9,6 +9,24 @@
 #include "aac_entropy_core.h"
 #include "sk_device.h"
 
+#ifdef SK_EC_PROFILE  // timing build only: per-wave clock stamps of the parse kernel's phases, read back by tools/entropy_phases.py
+__device__ unsigned long long g_ec_stamp[8192][16];
+namespace sk_ec {
+__device__ void sk_ec_mark(int slot) {
+    const unsigned long long now = __builtin_readcyclecounter();
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave < 8192 && slot >= 0) g_ec_stamp[wave][slot] = now;  // every active lane writes the same wave's slot: last one wins
+}
+}  // namespace sk_ec
+extern "C" int sk_debug_ec_stamps(unsigned long long *out, int clear) {
+    if (clear) {
+        static unsigned long long zeros[8192][16];
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ec_stamp), zeros, sizeof(zeros));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ec_stamp), sizeof(g_ec_stamp));
+}
+#endif
+
 namespace sk {
 
 namespace {
@@ -94,7 +112,16 @@ __device__ __forceinline__ void wave_zero_spectra(const EntropyArgs &a) {
         const EntropyUnit u = a.units[k];
         const uint32_t quads = a.tasks[u.task].channels * 256u;
         float4 *dst = reinterpret_cast<float4 *>(a.coeffs + (size_t)u.off1024 * 1024);
-        for (uint32_t i = lane; i < quads; i += 64) dst[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#ifdef SK_EC_ABLATE_FILL  // timing experiment: stale spectra
+        if (quads == 12345u)
+#endif
+        for (uint32_t i = lane; i < quads; i += 64) {
+#ifdef SK_EC_NT_FILL
+            __builtin_nontemporal_store(0.0f, &dst[i].x);
+#else
+            dst[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#endif
+        }
     }
     // a lane's own stores to these addresses come later in the same wave's store stream; wait all the same
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -102,20 +129,31 @@ __device__ __forceinline__ void wave_zero_spectra(const EntropyArgs &a) {
 
 __global__ __launch_bounds__(512) void k_aac_entropy_parse(EntropyArgs a) {
     extern __shared__ uint4 lds_raw[];
+    EC_MARK(0);
     const sk_ec::Tables t = lds_tables(a, lds_raw);
     wave_zero_spectra(a);
+    EC_MARK(1);
     uint32_t k;
     if (!unit_of_lane(a, k)) return;
+#ifdef SK_EC_PROFILE_SAMEUNIT  // timing experiment: every lane decodes the bitstream of unit 0 (into its own output)
+    EntropyUnit u = a.units[k];
+    u.word_offset = a.units[0].word_offset;
+    u.byte_len = a.units[0].byte_len;
+#else
     const EntropyUnit u = a.units[k];
+#endif
     const EntropyTask tk = a.tasks[u.task];
     sk_ec::Stream st{tk.sf_index, (int)tk.channels, 0u, true};
+    if (tk.channels) EC_MARK(12);  // after the unit and task records have arrived
     sk_ec::Scratch side;
     uint8_t seq[2] = {0, 0}, shape[2] = {0, 0};
     const int status = sk_ec::parse_unit(t, st, a.words + u.word_offset, u.byte_len, a.coeffs + (size_t)u.off1024 * 1024, seq, shape, side,
                                          sk_ec::PNS_COUNT);
+    EC_MARK(6);
     a.status[k] = status;
     a.side[k] = side;
     for (uint32_t c = 0; c < tk.channels; ++c) a.entries[u.entry[c]].win = (uint32_t)seq[c] | ((uint32_t)shape[c] << 2);
+    EC_MARK(7);
 }
 
 // Phase one of the quantised hand-over: the host has done the Huffman decode; a lane rebuilds its unit's side
@@ -214,6 +252,9 @@ hipError_t launch_aac_entropy_parallel(const EntropyArgs &a, hipStream_t s) {
     const uint32_t per_wave = 64u >> a.lane_shift, waves = (a.n_units + per_wave - 1) / per_wave, blocks = (waves + 7) / 8;
     if (a.wire) hipLaunchKernelGGL(k_aac_expand_q, dim3(blocks), dim3(512), a.lds_bytes, s, a);
     else hipLaunchKernelGGL(k_aac_entropy_parse, dim3(blocks), dim3(512), a.lds_bytes, s, a);
+#ifdef SK_EC_PROFILE_TWICE  // timing build: the same launch again, everything it reads now warm; the stamps are the second launch's
+    if (!a.wire) hipLaunchKernelGGL(k_aac_entropy_parse, dim3(blocks), dim3(512), a.lds_bytes, s, a);
+#endif
     hipLaunchKernelGGL(k_aac_entropy_link, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_aac_entropy_finish, dim3(blocks), dim3(512), a.lds_bytes, s, a);
     hipLaunchKernelGGL(k_aac_entropy_seal, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);

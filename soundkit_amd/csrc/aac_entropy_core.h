@@ -36,6 +36,14 @@ enum : int {
     EC_INVALID_BITSTREAM = -108,    // SK_AAC_ERR_INVALID_BITSTREAM
 };
 
+// SK_EC_PROFILE (a timing build, tools/build_ab.sh): the device kernels stamp the clock at these points per wave
+#if defined(SK_EC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+__device__ void sk_ec_mark(int slot);
+#define EC_MARK(slot) ::sk_ec::sk_ec_mark(slot)
+#else
+#define EC_MARK(slot) ((void)0)
+#endif
+
 #define EC_TRY(expr)            \
     do {                        \
         const int _st = (expr); \
@@ -333,14 +341,17 @@ SKE int read_tns(Bits &b, Channel &ch) {  // tns.rs:34-83
     return EC_OK;
 }
 
-SKE int read_channel(const Tables &t, Bits &b, Channel &ch, const Ics *common, int16_t *sf_out = nullptr) {  // channel.rs:19-75
+SKE int read_channel(const Tables &t, Bits &b, Channel &ch, const Ics *common, int16_t *sf_out = nullptr, int mark = -100) {  // channel.rs:19-75
     uint32_t v;
     EC_TRY(read_bits(b, 8, &v));
     ch.global_gain = (uint8_t)v;
     if (common) ch.ics = *common;
     else EC_TRY(read_ics(b, ch.ics));
+    EC_MARK(mark);
     EC_TRY(read_sections(b, ch));
+    EC_MARK(mark + 1);
     EC_TRY(read_scalefactors(t, b, ch, sf_out));
+    EC_MARK(mark + 2);
     bool flag;
     EC_TRY(read_flag(b, &flag));
     ch.pulse_present = flag;
@@ -668,6 +679,9 @@ SKE int decode_spectrum_nested(const Tables &t, Stream &st, Bits &bits, const Ch
 // flat, every lane that still has codewords left decodes one per pass whatever band, book or window it is in.  Per lane
 // the operations, their order and therefore every result and every error code are those of the nested form
 // (tests/entropy_core_check.cpp runs both on every unit it sees; SK_EC_FLAT selects this form in a host build).
+#ifdef SK_EC_COUNT_PASSES
+static unsigned long g_flat_passes = 0, g_flat_codewords = 0;
+#endif
 template <bool QUANT>
 SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
                              PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant) {
@@ -715,6 +729,15 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
     BookRef br = BookRef{t.lut, t.tuples, 1};
     int q[4];
     while (phase != DONE) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SK_EC_THREADED_PHASES)
+        // keep this ONE loop: left alone, jump threading turns the state machine back into a loop per state, and a wave
+        // whose lanes are in different states runs those loops one after the other
+        asm volatile("" : "+v"(phase));
+#endif
+#ifdef SK_EC_COUNT_PASSES
+        ++g_flat_passes;
+        if (phase == IN_BAND) ++g_flat_codewords;
+#endif
         if (phase == OPEN_GROUP) {
             if (g >= groups) {
                 phase = DONE;
@@ -937,17 +960,34 @@ SKE int stereo_tools(const Tables &t, const Stream &st, const MsMask &mask, cons
                     float sign = rb == BOOK_INTENSITY ? 1.0f : -1.0f;  // stereo.rs:431-437
                     if (selected) sign = -sign;                        // stereo.rs:145-149
                     const float scale = rch.mult[g * stride + sfb];
-                    for (int w = w0; w < w0 + glen; ++w)
-                        for (int i = w * wlen + s; i < w * wlen + e; ++i) right[i] = left[i] * scale * sign;
+                    for (int w = w0; w < w0 + glen; ++w) {
+                        int i = w * wlen + s;
+                        for (; i + 4 <= w * wlen + e; i += 4) {  // four loads in flight (one lane per unit: each is a round trip)
+                            const float l0 = left[i], l1 = left[i + 1], l2 = left[i + 2], l3 = left[i + 3];
+                            right[i] = l0 * scale * sign;
+                            right[i + 1] = l1 * scale * sign;
+                            right[i + 2] = l2 * scale * sign;
+                            right[i + 3] = l3 * scale * sign;
+                        }
+                        for (; i < w * wlen + e; ++i) right[i] = left[i] * scale * sign;
+                    }
                 } else {
                     if (!selected) continue;
                     if (rb == BOOK_INTENSITY || rb == BOOK_INTENSITY_NEG || lb == BOOK_NOISE || rb == BOOK_NOISE) continue;
-                    for (int w = w0; w < w0 + glen; ++w)
-                        for (int i = w * wlen + s; i < w * wlen + e; ++i) {
+                    for (int w = w0; w < w0 + glen; ++w) {
+                        int i = w * wlen + s;
+                        for (; i + 4 <= w * wlen + e; i += 4) {  // eight loads in flight
+                            const float m0 = left[i], m1 = left[i + 1], m2 = left[i + 2], m3 = left[i + 3];
+                            const float s0 = right[i], s1 = right[i + 1], s2 = right[i + 2], s3 = right[i + 3];
+                            left[i] = m0 + s0; left[i + 1] = m1 + s1; left[i + 2] = m2 + s2; left[i + 3] = m3 + s3;
+                            right[i] = m0 - s0; right[i + 1] = m1 - s1; right[i + 2] = m2 - s2; right[i + 3] = m3 - s3;
+                        }
+                        for (; i < w * wlen + e; ++i) {
                             const float mid = left[i], side = right[i];
                             left[i] = mid + side;
                             right[i] = mid - side;
                         }
+                    }
                 }
             }
             w0 += glen;
@@ -969,6 +1009,39 @@ SKE int tns_coefficient(const Tables &t, int encoded, int coef_bits, int res_bit
     }
     *out = t.tns_sin[(res_bits - 3) * 17 + sgn + 8];  // sgn in [-7, 8]: the host's sinf, tabulated
     return EC_OK;
+}
+
+// The all-pole recursion of apply_tns_filter (tns.rs:237-276) over n lines from `first` in direction `step`, order <= TAPS.
+// The `order` outputs the recursion reads back stay in a register shift line (newest first), and the lines themselves move
+// in blocks of eight -- eight loads in flight, eight results, eight stores: one lane per access unit means every load is a
+// dependent, uncoalesced round trip, and one per line was most of the kernel's time.  Same operations in the same order as
+// the reference's loop (TAPS only bounds the unrolled tap loop; taps beyond min(done, order) are skipped as there).
+template <int TAPS>
+SKE void tns_filter(float *c, int first, int n, int step, int order, const float *lpc20) {
+    float hist[TAPS], lpc[TAPS];
+    for (int i = 0; i < TAPS; ++i) {
+        hist[i] = 0.0f;
+        lpc[i] = lpc20[i];
+    }
+    int pos = first;
+    for (int done = 0; done < n; done += 8, pos += 8 * step) {
+        const int m = n - done < 8 ? n - done : 8;
+        float x[8];
+        for (int j = 0; j < 8; ++j)
+            if (j < m) x[j] = c[pos + j * step];
+        for (int j = 0; j < 8; ++j) {
+            if (j >= m) break;
+            const int mo = done + j < order ? done + j : order;
+            float v = x[j];
+            for (int o = 1; o <= TAPS; ++o)
+                if (o <= mo) v -= hist[o - 1] * lpc[o - 1];
+            x[j] = v;
+            for (int k = TAPS - 1; k > 0; --k) hist[k] = hist[k - 1];
+            hist[0] = v;
+        }
+        for (int j = 0; j < 8; ++j)
+            if (j < m) c[pos + j * step] = x[j];
+    }
 }
 
 SKE int apply_tns(const Tables &t, const Stream &st, const Channel &ch, float *coef) {
@@ -1008,23 +1081,14 @@ SKE int apply_tns(const Tables &t, const Stream &st, const Channel &ch, float *c
                 }
                 for (int k = 0; k <= i; ++k) prev[k] = lpc[k];
             }
-            // apply_tns_filter, tns.rs:237-276.  The recursion reads the `order` outputs it has just produced: they stay
-            // in a register shift line (newest first) instead of being read back from memory -- on a GPU every such
-            // read would be a dependent, uncoalesced load.  Same operations in the same order as the reference's loop.
+            // apply_tns_filter, tns.rs:237-276
             float *c = coef + w * wlen;
-            float hist[20];
-            for (int i = 0; i < 20; ++i) hist[i] = 0.0f;
             const int n = end - start, step = flt.direction ? -1 : 1;
-            int pos = flt.direction ? end - 1 : start;
-            for (int done = 0; done < n; ++done, pos += step) {
-                const int mo = done < flt.order ? done : flt.order;
-                float v = c[pos];
-                for (int o = 1; o <= 20; ++o)
-                    if (o <= mo) v -= hist[o - 1] * lpc[o - 1];
-                c[pos] = v;
-                for (int k = 19; k > 0; --k) hist[k] = hist[k - 1];
-                hist[0] = v;
-            }
+            const int first = flt.direction ? end - 1 : start;
+            if (flt.order <= 4) tns_filter<4>(c, first, n, step, flt.order, lpc);
+            else if (flt.order <= 8) tns_filter<8>(c, first, n, step, flt.order, lpc);
+            else if (flt.order <= 12) tns_filter<12>(c, first, n, step, flt.order, lpc);
+            else tns_filter<20>(c, first, n, step, flt.order, lpc);
         }
     }
     return EC_OK;
@@ -1061,69 +1125,88 @@ SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len
                    Scratch &s, PnsMode mode, const QuantCapture *qc = nullptr) {
     Bits b = make_bits(au, len_bytes);
     s.noise_samples = 0;
+#if defined(SK_EC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the first scratch stores to the phase that issues them
+#endif
+    EC_MARK(15);
+    // The element loop only steps over leading fill elements; the channel element is parsed BEHIND it.  Inside the loop a
+    // wave whose lanes reach their channel element in different passes (one unit opens with a fill element -- FFmpeg's
+    // encoder string in the first unit of a stream -- the other 31 do not) would run the whole parse once per pass, one
+    // after the other: measured, half the waves of a tick took twice as long (profiles/r02_entropy_parse.md).
+    uint32_t id = 7, tag = 0;
+    bool found = false;
     while (b.total - b.pos >= 3) {  // each pass consumes >= 3 bits: bounded by the length of the access unit
-        uint32_t id, tag;
         EC_TRY(read_bits(b, 3, &id));
+        EC_MARK(13);
         if (id <= 5) EC_TRY(read_bits(b, 4, &tag));  // syntax.rs:54-63
-        if (id == 0) {  // single channel element, decoder.rs:165-183
-            if (st.channels != 1) return EC_INVALID_BITSTREAM;
-            Channel &ch = s.ch[0];
-            EC_TRY(read_channel(t, b, ch, nullptr, qc ? qc->sf[0] : nullptr));
-            if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, ch, false, nullptr, PNS_COUNT, &s.noise_samples, qc->quant));
-            else EC_TRY(decode_spectrum(t, st, b, ch, false, coef, mode, &s.noise_samples));
-            s.is_pair = 0;
-            s.common_window = 0;
-            sequence[0] = ch.ics.sequence;
-            shape[0] = ch.ics.shape;
-            sequence[1] = shape[1] = 0;
-            s.resume_pos = b.pos;
-            return EC_OK;
-        } else if (id == 1) {  // channel pair element, decoder.rs:185-218
-            if (st.channels != 2) return EC_INVALID_BITSTREAM;
-            bool common_window;
-            EC_TRY(read_flag(b, &common_window));
-            Ics common;
-            s.mask.mode = 0;
-            if (common_window) {
-                EC_TRY(read_ics(b, common));
-                EC_TRY(read_ms_mask(b, common, s.mask));
-            }
-            Channel &left = s.ch[0], &right = s.ch[1];
-            EC_TRY(read_channel(t, b, left, common_window ? &common : nullptr, qc ? qc->sf[0] : nullptr));
-            if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, left, false, nullptr, PNS_COUNT, &s.noise_samples, qc->quant));
-            else EC_TRY(decode_spectrum(t, st, b, left, false, coef, mode, &s.noise_samples));
-            EC_TRY(read_channel(t, b, right, common_window ? &common : nullptr, qc ? qc->sf[1] : nullptr));
-            if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, right, true, nullptr, PNS_COUNT, &s.noise_samples, qc->quant + 1024));
-            else EC_TRY(decode_spectrum(t, st, b, right, true, coef + 1024, mode, &s.noise_samples));
-            s.is_pair = 1;
-            s.common_window = common_window;
-            sequence[0] = left.ics.sequence;
-            shape[0] = left.ics.shape;
-            sequence[1] = right.ics.sequence;
-            shape[1] = right.ics.shape;
-            s.resume_pos = b.pos;
-            return EC_OK;
-        } else if (id >= 2 && id <= 5) {
-            return EC_UNSUPPORTED_FEATURE;  // CCE / LFE / DSE / PCE
-        } else if (id == 6) {  // fill element, decoder.rs:393-419
-            uint32_t count;
-            EC_TRY(read_bits(b, 4, &count));
-            if (count == 15) {
-                uint32_t ext;
-                EC_TRY(read_bits(b, 8, &ext));
-                if (ext == 0) return EC_INVALID_BITSTREAM;
-                count += ext - 1;
-            }
-            if (count == 0) continue;
-            if (b.total - b.pos < count * 8) return EC_EOF;
-            const uint32_t ext_type = peek32(b) >> 28;
-            if (ext_type == 13 || ext_type == 14) return EC_UNSUPPORTED_FEATURE;  // SBR
-            b.pos += count * 8;
-        } else {
-            break;  // END before any channel element
+        if (id != 6) {
+            found = true;
+            break;
         }
+        // fill element, decoder.rs:393-419
+        uint32_t count;
+        EC_TRY(read_bits(b, 4, &count));
+        if (count == 15) {
+            uint32_t ext;
+            EC_TRY(read_bits(b, 8, &ext));
+            if (ext == 0) return EC_INVALID_BITSTREAM;
+            count += ext - 1;
+        }
+        if (count == 0) continue;
+        if (b.total - b.pos < count * 8) return EC_EOF;
+        const uint32_t ext_type = peek32(b) >> 28;
+        if (ext_type == 13 || ext_type == 14) return EC_UNSUPPORTED_FEATURE;  // SBR
+        b.pos += count * 8;
     }
-    return EC_INVALID_BITSTREAM;  // "raw access unit does not contain an AAC-LC channel element"
+    (void)tag;
+    if (!found || id == 7) return EC_INVALID_BITSTREAM;  // END, or the unit ran out, before any channel element:
+                                                         // "raw access unit does not contain an AAC-LC channel element"
+    if (id >= 2) return EC_UNSUPPORTED_FEATURE;          // CCE / LFE / DSE / PCE
+    if (id == 0) {  // single channel element, decoder.rs:165-183
+        if (st.channels != 1) return EC_INVALID_BITSTREAM;
+        Channel &ch = s.ch[0];
+        EC_TRY(read_channel(t, b, ch, nullptr, qc ? qc->sf[0] : nullptr));
+        if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, ch, false, nullptr, PNS_COUNT, &s.noise_samples, qc->quant));
+        else EC_TRY(decode_spectrum(t, st, b, ch, false, coef, mode, &s.noise_samples));
+        s.is_pair = 0;
+        s.common_window = 0;
+        sequence[0] = ch.ics.sequence;
+        shape[0] = ch.ics.shape;
+        sequence[1] = shape[1] = 0;
+        s.resume_pos = b.pos;
+        return EC_OK;
+    }
+    // channel pair element, decoder.rs:185-218
+    if (st.channels != 2) return EC_INVALID_BITSTREAM;
+    bool common_window;
+    EC_TRY(read_flag(b, &common_window));
+    Ics common;
+    s.mask.mode = 0;
+    if (common_window) {
+        EC_TRY(read_ics(b, common));
+        EC_MARK(14);
+        EC_TRY(read_ms_mask(b, common, s.mask));
+    }
+    Channel &left = s.ch[0], &right = s.ch[1];
+    EC_MARK(8);
+    EC_TRY(read_channel(t, b, left, common_window ? &common : nullptr, qc ? qc->sf[0] : nullptr, 9));
+    EC_MARK(2);
+    if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, left, false, nullptr, PNS_COUNT, &s.noise_samples, qc->quant));
+    else EC_TRY(decode_spectrum(t, st, b, left, false, coef, mode, &s.noise_samples));
+    EC_MARK(3);
+    EC_TRY(read_channel(t, b, right, common_window ? &common : nullptr, qc ? qc->sf[1] : nullptr));
+    EC_MARK(4);
+    if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, right, true, nullptr, PNS_COUNT, &s.noise_samples, qc->quant + 1024));
+    else EC_TRY(decode_spectrum(t, st, b, right, true, coef + 1024, mode, &s.noise_samples));
+    EC_MARK(5);
+    s.is_pair = 1;
+    s.common_window = common_window;
+    sequence[0] = left.ics.sequence;
+    shape[0] = left.ics.shape;
+    sequence[1] = right.ics.sequence;
+    shape[1] = right.ics.shape;
+    s.resume_pos = b.pos;
+    return EC_OK;
 }
 
 SKE int unit_tail(const uint32_t *au, uint32_t len_bytes, uint32_t resume_pos);

@@ -170,5 +170,8 @@ int main(int argc, char **argv) {
         sk_aac_decoder_destroy(dec);
     }
     printf("checked %zu access units, %zu accepted: identical\n", checked, accepted);
+#ifdef SK_EC_COUNT_PASSES
+    printf("flat loop passes %lu, codeword passes %lu\n", sk_ec::g_flat_passes, sk_ec::g_flat_codewords);
+#endif
     return 0;
 }

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Per-phase clock time of k_aac_entropy_parse from a timing build (tools/build_ab.sh aac_entropy SK_EC_PROFILE):
+  SOUNDKIT_AMD_LIB=soundkit_amd/ab/lib_SK_EC_PROFILE.so SK_ENTROPY_LANE_SHIFT=1 python3 tools/entropy_phases.py 3400"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import soundkit_amd
+from soundkit_amd import aac_lc, _lib
+
+n_streams = int(sys.argv[1])
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "aac", "aac-stereo-48k.adts")
+aus = [au for _, au in aac_lc.split_adts(open(root, "rb").read())]
+eng = soundkit_amd.Engine(0, max(n_streams, 16))
+sids = []
+for i in range(n_streams):
+    sid = eng.open_stream(48000, 2)
+    eng.resampler_open(sid, 48000, 16000)
+    sids.append(sid)
+lib = _lib.lib
+stamps = np.zeros((8192, 16), np.uint64)
+for t in range(2):
+    table, units = [], []
+    for i, sid in enumerate(sids):
+        take = [aus[(7 * i + 16 * t + k) % len(aus)] for k in range(16)]
+        table.append({"stream": sid, "n_frames": 16, "out_bits": 16, "out_channels": 1, "resample": True, "flush": False})
+        units += take
+    lib.sk_debug_ec_stamps(None, 1)
+    res = eng.tick_run_au(table, units)
+    bad = [r for r in res if r[1] != 0]
+    if bad: print("records with errors:", len(bad), bad[:2])
+lib.sk_debug_ec_stamps(stamps.ctypes.data_as(C.c_void_p), 0)
+used = stamps[stamps[:, 7] != 0].astype(np.int64)
+order = [0, 1, 12, 15, 13, 14, 8, 9, 10, 11, 2, 3, 4, 5, 6, 7]
+names = ["tables + zero fill", "unit + task records", "stream record, bit reader set up, first scratch store", "first 3 bits of the unit", "tag, common_window, common ics", "ms mask", "L: global gain (+ ics)", "L: sections", "L: scale factors",
+         "L: pulse, tns flags/data", "spectrum L", "header R", "spectrum R", "after spectrum", "side record store"]
+sel = used[:, order]
+d = np.diff(sel, axis=1)
+print("waves", len(used), "mean wave time (clock ticks)", int((used[:, 7] - used[:, 0]).mean()))
+for i, n in enumerate(names):
+    print("  %-48s mean %9.0f  max %9.0f ticks  (%4.1f %% of a wave's time)" % (n, d[:, i].mean(), d[:, i].max(), 100.0 * d[:, i].sum() / d.sum()))
+
+if os.environ.get("SK_PHASE_DUMP"):
+    col = order.index(13) - 1
+    print("first-read phase per wave (first 48 waves):", d[:48, col].tolist())
+    print("spectrum L per wave:", d[:48, order.index(3) - 1].tolist())
+eng.close()
