@@ -18,6 +18,14 @@ __device__ void sk_ec_mark(int slot) {
     if (wave < 8192 && slot >= 0) g_ec_stamp[wave][slot] = now;  // every active lane writes the same wave's slot: last one wins
 }
 }  // namespace sk_ec
+__device__ unsigned g_ec_count[8192][4][64];
+namespace sk_ec {
+__device__ void sk_ec_count(int what, unsigned n) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave < 8192) g_ec_count[wave][what][threadIdx.x & 63] = n;
+}
+}  // namespace sk_ec
+extern "C" int sk_debug_ec_counts(unsigned *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ec_count), sizeof(g_ec_count)); }
 extern "C" int sk_debug_ec_stamps(unsigned long long *out, int clear) {
     if (clear) {
         static unsigned long long zeros[8192][16];

@@ -39,9 +39,12 @@ enum : int {
 // SK_EC_PROFILE (a timing build, tools/build_ab.sh): the device kernels stamp the clock at these points per wave
 #if defined(SK_EC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 __device__ void sk_ec_mark(int slot);
+__device__ void sk_ec_count(int what, unsigned n);
 #define EC_MARK(slot) ::sk_ec::sk_ec_mark(slot)
+#define EC_COUNT(what, n) ::sk_ec::sk_ec_count(what, n)
 #else
 #define EC_MARK(slot) ((void)0)
+#define EC_COUNT(what, n) ((void)0)
 #endif
 
 #define EC_TRY(expr)            \
@@ -728,7 +731,10 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
     float scale = 0.0f;
     BookRef br = BookRef{t.lut, t.tuples, 1};
     int q[4];
+    unsigned n_passes = 0, n_codewords = 0;  // read by the timing build only
     while (phase != DONE) {
+        ++n_passes;
+        if (phase == IN_BAND) ++n_codewords;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SK_EC_THREADED_PHASES)
         // keep this ONE loop: left alone, jump threading turns the state machine back into a loop per state, and a wave
         // whose lanes are in different states runs those loops one after the other
@@ -829,6 +835,8 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
         }
     }
     if (is_short && status == EC_OK && w0 != 8) status = EC_INVALID_BITSTREAM;
+    EC_COUNT(allow_intensity ? 2 : 0, n_passes);
+    EC_COUNT(allow_intensity ? 3 : 1, n_codewords);
     bits = b;
     st.pns_state = pns;
     if (is_short || status != EC_OK || !pulse_present) return status;

@@ -43,6 +43,14 @@ print("waves", len(used), "mean wave time (clock ticks)", int((used[:, 7] - used
 for i, n in enumerate(names):
     print("  %-48s mean %9.0f  max %9.0f ticks  (%4.1f %% of a wave's time)" % (n, d[:, i].mean(), d[:, i].max(), 100.0 * d[:, i].sum() / d.sum()))
 
+counts = np.zeros((8192, 4, 64), np.uint32)
+lib.sk_debug_ec_counts(counts.ctypes.data_as(C.c_void_p))
+cw = counts[:len(used)]
+for ch, name in ((0, "first"), (2, "second")):
+    passes, words = cw[:, ch, :32].astype(np.int64), cw[:, ch + 1, :32].astype(np.int64)
+    i = order.index(3 if ch == 0 else 5) - 1
+    print("  spectrum of the %s channel: passes per lane mean %.0f, per wave (max over lanes) mean %.0f; codewords per lane %.0f; "
+          "ticks per wave-pass %.0f" % (name, passes.mean(), passes.max(axis=1).mean(), words.mean(), d[:, i].mean() / passes.max(axis=1).mean()))
 if os.environ.get("SK_PHASE_DUMP"):
     col = order.index(13) - 1
     print("first-read phase per wave (first 48 waves):", d[:48, col].tolist())
