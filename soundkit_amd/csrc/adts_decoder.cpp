@@ -83,6 +83,17 @@ int sk_adts_decoder_decode_i16(sk_adts_decoder *d, const uint8_t *input, size_t 
     // frame the buffered bytes: whole frames only, as many as fit in the output
     d->descs.clear();
     size_t n_floats = 0, room = out_cap;
+    // An error ends the call, but the frames framed and parsed before it in this call have been decoded as far as the
+    // reference's decoder is concerned (soundkit-aac lib.rs:150-245 returns Err after decoding them: their PCM is lost, its
+    // overlap state has advanced).  Run them through the synthesis before failing so that the stream's carried state
+    // matches; what lands in `output` is not reported (*written stays 0).
+    auto fail_after_parsed = [&](int rc, const std::string &msg) {
+        if (!d->descs.empty()) {
+            d->status.assign(d->descs.size(), 0);
+            (void)sk_aac_synthesize_s16(d->engine, d->descs.data(), d->coeffs.data(), output, (uint32_t)d->descs.size(), d->status.data());
+        }
+        return fail(rc, msg);
+    };
     for (;;) {
         size_t avail = d->input.size() - d->pos, frame_len = 0, pay_off = 0, pay_len = 0;
         uint8_t asc[2];
@@ -106,19 +117,19 @@ int sk_adts_decoder_decode_i16(sk_adts_decoder *d, const uint8_t *input, size_t 
             rc = sk_stream_open(d->engine, d->fe_rate, d->fe_channels, &d->stream);
             if (rc != SK_OK) return fail(rc, std::string("Decoding error: ") + sk_strerror(rc));
         } else if (asc[0] != d->asc[0] || asc[1] != d->asc[1]) {
-            return fail(SK_AAC_ERR_UNSUPPORTED_FEATURE, "Decoding error: AAC configuration changed mid-stream");
+            return fail_after_parsed(SK_AAC_ERR_UNSUPPORTED_FEATURE, "Decoding error: AAC configuration changed mid-stream");
         }
         const size_t frame_samples = (size_t)d->fe_channels * SK_AAC_FRAME_LEN;
         if (room == 0) break;
         if (room < frame_samples)
-            return fail(SK_ERR_CAPACITY, "Output buffer too small for decoded frame (needed " + std::to_string(frame_samples) +
-                                             ", had " + std::to_string(room) + ")");
+            return fail_after_parsed(SK_ERR_CAPACITY, "Output buffer too small for decoded frame (needed " + std::to_string(frame_samples) +
+                                                          ", had " + std::to_string(room) + ")");
         if (d->coeffs.size() < n_floats + frame_samples) d->coeffs.resize(n_floats + frame_samples + 16 * frame_samples);
         sk_aac_frame_desc desc{};
         const int rc = sk_aac_decoder_parse(d->front, d->input.data() + d->pos + pay_off, pay_len, d->coeffs.data() + n_floats, &desc);
         if (rc != SK_OK) {
             d->pos += frame_len;  // the frame is consumed either way
-            return fail(rc, std::string("Decoding error: ") + sk_aac_decoder_last_error(d->front));
+            return fail_after_parsed(rc, std::string("Decoding error: ") + sk_aac_decoder_last_error(d->front));
         }
         desc.stream = d->stream;
         d->descs.push_back(desc);

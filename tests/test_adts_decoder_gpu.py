@@ -85,3 +85,32 @@ def test_crc_protected_adts_decodes_the_same(engine):
     nb = b.decode_i16(with_crc(data), out)
     assert na == nb == 48 * 2048 and np.array_equal(out[:nb], want)
     a.close(), b.close()
+
+
+def test_frames_before_an_error_in_the_same_call_advance_the_state(engine):
+    """soundkit-aac lib.rs:150-245: when a call returns Err, the frames decoded earlier in that call are lost but the decoder's
+    overlap state has moved past them.  Here: frames 0-4 and a damaged frame 5 in ONE call (error), then frames 6-9; the PCM
+    of 6-9 must equal what a decoder gives that was fed 0-4 in their own call, then the damaged frame alone (error), then 6-9."""
+    data = open(os.path.join(GOLD, "aac-stereo-48k.adts"), "rb").read()
+    frames = aac_lc.split_adts(data)
+    sizes = [len(au) + 7 for _, au in frames]
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    k = 20                                  # frames 20-24, a damaged frame 25, frames 26-29: the clip is loud there
+    bad = bytearray(data[starts[k + 5]:starts[k + 6]])
+    bad[7] = (bad[7] & 0x1f) | (2 << 5)   # first element becomes a CCE: UnsupportedFeature, the frame is consumed
+    head, tail = data[starts[k]:starts[k + 5]], data[starts[k + 6]:starts[k + 10]]
+    out = np.zeros(SCRATCH, np.int16)
+    a, b, c = aac.AacDecoder(engine), aac.AacDecoder(engine), aac.AacDecoder(engine)
+    with pytest.raises(ValueError):
+        a.decode_i16(head + bytes(bad), out)          # one call: five good frames, then the error
+    na = a.decode_i16(tail, out)
+    got = out[:na].copy()
+    assert b.decode_i16(head, out) == 5 * 2048         # the same frames, the error in a call of its own
+    with pytest.raises(ValueError):
+        b.decode_i16(bytes(bad), out)
+    nb = b.decode_i16(tail, out)
+    assert na == nb == 4 * 2048 and np.array_equal(got, out[:nb])
+    nc = c.decode_i16(tail, out)                       # a decoder that never saw frames 20-24: another first frame
+    assert nc == na and not np.array_equal(got[:2048], out[:2048]) and np.array_equal(got[2048:], out[2048:nc])
+    for d in (a, b, c):
+        d.close()
