@@ -608,8 +608,10 @@ def main():
         del scratch
     mix_report = None
     if args.mix and args.workload in ("aac_synth", "pipeline") and rank == 0:
-        # k_aac_synth alone on three batches of the same spectra: OnlyLong; one EightShort per bracket; three per bracket.
-        # Two unknowns (a transition frame, a short frame) from the two differences.
+        # The synthesis alone on three batches of the same spectra: OnlyLong; one EightShort per bracket; three per bracket.
+        # Channels without an EightShort frame run the two-channel long kernel (LongStart / LongStop are the same code with
+        # another window table); in the two mixes every channel has EightShort frames, so all of their frames run the general
+        # one-channel kernel: two unknowns there (a long-transform frame, a short frame) from the two mixes.
         def synth_ms(shorts):
             d2, n2 = soundkit_amd.descs_from_arrays(ids, ch, sequences(shorts), shapes)
             p2 = eng.plan(d2, n2)
@@ -630,17 +632,19 @@ def main():
         t1, n_short1, n_trans1 = synth_ms(1)
         t3, n_short3, n_trans3 = synth_ms(3)
         total_cf = streams * frames * ch
-        c_long = t_long / total_cf
-        # t = c_long * (total - n_short - n_trans) + c_short * n_short + c_trans * n_trans
-        A = np.array([[n_short1, n_trans1], [n_short3, n_trans3]], np.float64)
-        rhs = np.array([t1 - c_long * (total_cf - n_short1 - n_trans1), t3 - c_long * (total_cf - n_short3 - n_trans3)])
-        c_short, c_trans = np.linalg.solve(A, rhs)
+        c_pair = t_long / total_cf
+        # t = c_general_long * (total - n_short) + c_short * n_short
+        A = np.array([[total_cf - n_short1, n_short1], [total_cf - n_short3, n_short3]], np.float64)
+        c_glong, c_short = np.linalg.solve(A, np.array([t1, t3]))
         mix_report = {"k_aac_synth_ms": {"only_long": t_long, "one_short_per_bracket (10 % EightShort)": t1, "three_shorts_per_bracket": t3},
                       "channel_frames": total_cf, "short_frames_in_mix": n_short1, "transition_frames_in_mix": n_trans1,
-                      "ns_per_channel_frame": {"OnlyLong": c_long * 1e6, "EightShort": c_short * 1e6, "LongStart/LongStop": c_trans * 1e6},
-                      "cost_relative_to_only_long": {"EightShort": c_short / c_long, "LongStart/LongStop": c_trans / c_long},
-                      "note": "launch time attributed per frame class (chip-wide average, f32 output); a wave that meets a rare frame "
-                              "runs synth_rare_frame for it (aac_synth.hip)"}
+                      "ns_per_channel_frame": {"long-transform frame, two-channel kernel (channels without EightShort)": c_pair * 1e6,
+                                               "long-transform frame (OnlyLong / LongStart / LongStop), general kernel": c_glong * 1e6,
+                                               "EightShort frame, general kernel": c_short * 1e6},
+                      "cost_relative_to_the_general_kernels_long_frame": {"EightShort": c_short / c_glong},
+                      "note": "launch time attributed per frame class (chip-wide average, f32 output).  LongStart / LongStop frames "
+                              "run the long path with tabulated windows; a wave that meets an EightShort frame runs "
+                              "synth_rare_frame for it (aac_synth.hip)"}
 
     if rank == 0:
         per_kernel = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in kernel_ms.items()}

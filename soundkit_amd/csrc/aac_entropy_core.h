@@ -837,6 +837,7 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
     if (is_short && status == EC_OK && w0 != 8) status = EC_INVALID_BITSTREAM;
     EC_COUNT(allow_intensity ? 2 : 0, n_passes);
     EC_COUNT(allow_intensity ? 3 : 1, n_codewords);
+    (void)n_passes, (void)n_codewords;
     bits = b;
     st.pns_state = pns;
     if (is_short || status != EC_OK || !pulse_present) return status;

@@ -112,6 +112,15 @@ __device__ __forceinline__ u2 pack4_s16(const f4 &v) {
     return (u2){dev_pack2_s16(v.x, v.y), dev_pack2_s16(v.z, v.w)};
 }
 
+// first-half and second-half window of a long-transform frame (dsp.rs:353-387): the long window of the previous / current
+// shape, or for LongStop / LongStart the piecewise half that engine.cpp tabulates behind the four windows
+__device__ __forceinline__ const float *first_half_window(const float *win, int seq, int prev_shape) {
+    return seq == 3 ? win + 6656 + 1024 * prev_shape : win + 2048 * prev_shape;
+}
+__device__ __forceinline__ const float *second_half_window(const float *win, int seq, int shape) {
+    return seq == 1 ? win + 4608 + 1024 * shape : win + 2048 * shape + 1024;
+}
+
 typedef __attribute__((address_space(3))) f2 lds_f2;
 typedef __attribute__((address_space(3))) f4 lds_f4;
 typedef __attribute__((address_space(3))) float lds_f;
@@ -135,24 +144,6 @@ __device__ __forceinline__ void write_positions(lds_f *buf, int lane, const floa
         *reinterpret_cast<lds_f4 *>(buf + j) = (f4){v[8 * r + 0], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3]};
         *reinterpret_cast<lds_f4 *>(buf + 1020 - j) = (f4){v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]};
     }
-}
-
-// dsp.rs:353-368 / 370-387 for the two transition sequences (rare path: per-element lookups)
-__device__ __forceinline__ float first_window(int seq, const float *prev_long, const float *prev_short, int i) {
-    if (seq == 3) {  // LongStop
-        if (i < 448) return 0.0f;
-        if (i < 576) return prev_short[i - 448];
-        return 1.0f;
-    }
-    return prev_long[i];
-}
-__device__ __forceinline__ float second_window(int seq, const float *cur_long, const float *cur_short, int i) {
-    if (seq == 1) {  // LongStart
-        if (i < 448) return 1.0f;
-        if (i < 576) return cur_short[128 + i - 448];
-        return 0.0f;
-    }
-    return cur_long[i + 1024];
 }
 
 // sample t (0..255) of a 128-input IMDCT from its post-twiddled spectrum v[0..63] (dsp.rs:511-532)
@@ -214,9 +205,9 @@ __device__ __forceinline__ void fft512(f2 (&z)[8], lds_f2 *ex, const lds_f2 *t64
     dft8(z);  // over n3 -> k3
 }
 
-// Everything after the pre-twiddle for a frame that is NOT OnlyLong (LongStart, LongStop,
-// EightShort: a few percent of real frames).  Kept out of line on purpose: inlined, its
-// registers and hoisted table loads are charged to the OnlyLong loop and halve the occupancy.
+// Everything after the pre-twiddle for an EightShort frame (a few percent of real frames; LongStart and LongStop
+// run the long path with their piecewise windows as tables).  Kept out of line on purpose: inlined, its
+// registers and hoisted table loads are charged to the long loop and halve the occupancy.
 // Its vector inputs and outputs travel through the wave's LDS, so that nothing but scalars and
 // pointers is live across the call:
 //   in : ex[64 r + lane] = pre-twiddled FFT input z[r] (long: element 64 r + lane; short: element
@@ -228,9 +219,7 @@ __device__ __attribute__((noinline)) void synth_rare_frame(lds_f2 *ex, lds_f *st
                                                             float *out_ptr, int16_t *out16_ptr, int seq, int prev_shape,
                                                             int shape, int lane) {
     const int hi3 = lane >> 3, lo3 = lane & 7;
-    const f2 base2 = (f2){base2_re, base2_im};
-    const float *prev_long = win + 2048 * prev_shape;
-    const float *cur_long = win + 2048 * shape;
+    (void)base2_re, (void)base2_im, (void)t64, (void)tw_lds, (void)seq;  // only the short transform is left here
     const float *prev_short = win + 4096 + 256 * prev_shape;
     const float *cur_short = win + 4096 + 256 * shape;
     f2 z[8];
@@ -241,39 +230,7 @@ __device__ __attribute__((noinline)) void synth_rare_frame(lds_f2 *ex, lds_f *st
     wave_sync();
     float o[16], d[16];  // windowed first half / second half at this lane's 16 positions
 
-    if (seq != 2) {
-        fft512(z, ex, t64, base2, lane);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ex[lane + 64 * j] = cmul(tw_lds[lane + 64 * j], (f2){z[j].x, -z[j].y});
-        wave_sync();
-        // piecewise windows of LongStart / LongStop: built in LDS by a rolled loop, read back per position
-#pragma unroll 1
-        for (int k = 0; k < 16; ++k) {
-            const int i = 64 * k + lane;
-            stage[i] = first_window(seq, prev_long, prev_short, i);
-        }
-        wave_sync();
-        read_positions(stage, lane, o);
-        wave_sync();
-#pragma unroll 1
-        for (int k = 0; k < 16; ++k) {
-            const int i = 64 * k + lane;
-            stage[i] = second_window(seq, cur_long, cur_short, i);
-        }
-        wave_sync();
-        read_positions(stage, lane, d);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int q = 2 * lane + 128 * r;
-            const f4 F = *reinterpret_cast<const lds_f4 *>(&ex[256 + q]);
-            const f4 M = *reinterpret_cast<const lds_f4 *>(&ex[254 - q]);
-            o[8 * r + 0] *= -F.x; o[8 * r + 1] *= -M.w; o[8 * r + 2] *= -F.z; o[8 * r + 3] *= -M.y;
-            o[8 * r + 4] *= M.y; o[8 * r + 5] *= F.z; o[8 * r + 6] *= M.w; o[8 * r + 7] *= F.x;
-            d[8 * r + 0] *= F.y; d[8 * r + 1] *= M.z; d[8 * r + 2] *= F.w; d[8 * r + 3] *= M.x;
-            d[8 * r + 4] *= M.x; d[8 * r + 5] *= F.w; d[8 * r + 6] *= M.z; d[8 * r + 7] *= F.y;
-        }
-        wave_sync();
-    } else {
+    {
         // eight short windows (dsp.rs:284-338): 8 independent 64-point FFTs, lane = 8 w + a,
         // n = a + 8 b, k = kb + 8 ka
 #pragma unroll
@@ -408,14 +365,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
     auto frame = [&](f2 (&xin)[8], uint32_t e) __attribute__((always_inline)) {
         const uint32_t ent_off = entries[e].off1024, ent_win = entries[e].win;
         const uint32_t win = __builtin_amdgcn_readfirstlane(ent_win);
-        const int seq = ONLY_LONG ? 0 : (int)(win & 3);
+        const int seq = (int)(win & 3);  // ONLY_LONG: never 2
         const int shape = (win >> 2) & 1;
         float *out_ptr = OUT16 ? nullptr : a.pcm + (size_t)__builtin_amdgcn_readfirstlane(ent_off) * 1024;
         int16_t *out16_ptr = OUT16 ? a.pcm16 + (size_t)__builtin_amdgcn_readfirstlane(ent_off) * 1024 : nullptr;
 
         // ---- pre-twiddle (dsp.rs:495-503): consumes xin so the next spectrum can land in it ----
         f2 z[8];
-        if (seq != 2) {
+        if (ONLY_LONG || seq != 2) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {  // z[64 r + lane]
                 const float even = xin[r].x;
@@ -434,9 +391,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
                 z[w] = (f2){odd * tws.y - even * tws.x, odd * tws.x + even * tws.y};
             }
         }
-        if (seq == 0) {
-            const float *prev_long = a.t.win + 2048 * prev_shape;
-            const float *cur_long = a.t.win + 2048 * shape;
+        if (ONLY_LONG || seq != 2) {
+            const float *w1 = first_half_window(a.t.win, seq, prev_shape);
+            const float *w2 = second_half_window(a.t.win, seq, shape);
 #if SK_WIN_EARLY
             // Window loads go out BEFORE the prefetch: vector-memory results return in issue order, so
             // windows queued behind the next spectrum would make the epilogue wait for that HBM fetch.
@@ -444,10 +401,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int j = 4 * lane + 256 * r;
-                w1f[r] = *reinterpret_cast<const f4 *>(prev_long + j);
-                w1m[r] = *reinterpret_cast<const f4 *>(prev_long + 1020 - j);
-                w2f[r] = *reinterpret_cast<const f4 *>(cur_long + 1024 + j);
-                w2m[r] = *reinterpret_cast<const f4 *>(cur_long + 2044 - j);
+                w1f[r] = *reinterpret_cast<const f4 *>(w1 + j);
+                w1m[r] = *reinterpret_cast<const f4 *>(w1 + 1020 - j);
+                w2f[r] = *reinterpret_cast<const f4 *>(w2 + j);
+                w2m[r] = *reinterpret_cast<const f4 *>(w2 + 1020 - j);
             }
 #endif
             // next spectrum in flight while this one is transformed.  Unconditional (the last frames re-read the task's
@@ -486,10 +443,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
 #if SK_WIN_EARLY
                 const f4 W1f = w1f[r], W1m = w1m[r], W2f = w2f[r], W2m = w2m[r];
 #else
-                const f4 W1f = *reinterpret_cast<const f4 *>(prev_long + j);
-                const f4 W1m = *reinterpret_cast<const f4 *>(prev_long + 1020 - j);
-                const f4 W2f = *reinterpret_cast<const f4 *>(cur_long + 1024 + j);
-                const f4 W2m = *reinterpret_cast<const f4 *>(cur_long + 2044 - j);
+                const f4 W1f = *reinterpret_cast<const f4 *>(w1 + j);
+                const f4 W1m = *reinterpret_cast<const f4 *>(w1 + 1020 - j);
+                const f4 W2f = *reinterpret_cast<const f4 *>(w2 + j);
+                const f4 W2m = *reinterpret_cast<const f4 *>(w2 + 1020 - j);
 #endif
                 f4 f, m;
                 // out0[j..j+3] = -F0.re, -M1.im, -F1.re, -M0.im   (dsp.rs:516, 528)
@@ -684,16 +641,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(Synth
     struct Win {
         f4 w1f[2], w1m[2], w2f[2], w2m[2];
     };
-    auto load_windows = [&](Win &w, int prev_shape, int shape) {
-        const float *prev_long = a.t.win + 2048 * prev_shape;
-        const float *cur_long = a.t.win + 2048 * shape;
+    auto load_windows = [&](Win &w, int seq, int prev_shape, int shape) {
+        const float *w1 = first_half_window(a.t.win, seq, prev_shape);
+        const float *w2 = second_half_window(a.t.win, seq, shape);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int j = 4 * lane + 256 * r;
-            w.w1f[r] = *reinterpret_cast<const f4 *>(prev_long + j);
-            w.w1m[r] = *reinterpret_cast<const f4 *>(prev_long + 1020 - j);
-            w.w2f[r] = *reinterpret_cast<const f4 *>(cur_long + 1024 + j);
-            w.w2m[r] = *reinterpret_cast<const f4 *>(cur_long + 2044 - j);
+            w.w1f[r] = *reinterpret_cast<const f4 *>(w1 + j);
+            w.w1m[r] = *reinterpret_cast<const f4 *>(w1 + 1020 - j);
+            w.w2f[r] = *reinterpret_cast<const f4 *>(w2 + j);
+            w.w2m[r] = *reinterpret_cast<const f4 *>(w2 + 1020 - j);
         }
     };
     // window + overlap-add + store of one channel's half r from its four post-twiddled bins (dsp.rs:267-279, 516-531)
@@ -723,8 +680,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(Synth
     load_spectrum(xb, ent_b, 0);
     for (uint32_t e = 0; e < count; ++e) {
         const uint32_t off_a = __builtin_amdgcn_readfirstlane(ent_a[e].off1024), off_b = __builtin_amdgcn_readfirstlane(ent_b[e].off1024);
-        const int shape_a = (__builtin_amdgcn_readfirstlane(ent_a[e].win) >> 2) & 1;
-        const int shape_b = (__builtin_amdgcn_readfirstlane(ent_b[e].win) >> 2) & 1;
+        const uint32_t win_a = __builtin_amdgcn_readfirstlane(ent_a[e].win), win_b = __builtin_amdgcn_readfirstlane(ent_b[e].win);
+        const int shape_a = (win_a >> 2) & 1, shape_b = (win_b >> 2) & 1;
         // ---- pre-twiddle (dsp.rs:495-503) of both channels ----
         c2 z[8];
 #pragma unroll
@@ -736,8 +693,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(Synth
             z[r] = {odd * ty - even * tx, odd * tx + even * ty};
         }
         Win wa, wb;  // before the prefetch: vector-memory results return in issue order
-        load_windows(wa, prev_a, shape_a);
-        load_windows(wb, prev_b, shape_b);
+        load_windows(wa, (int)(win_a & 3), prev_a, shape_a);
+        load_windows(wb, (int)(win_b & 3), prev_b, shape_b);
         {
             const uint32_t ahead = e + 1 < count ? e + 1 : count - 1;  // unconditional, as in the one-channel kernel
             load_spectrum(xa, ent_a, ahead);

@@ -281,11 +281,22 @@ int build_tables(sk_engine *e) {
     make_twiddle(128, tw_short);
     make_roots(64, w64);
     make_roots(512, w512);
-    std::vector<float> win(2048 * 2 + 256 * 2);
+    std::vector<float> win(2048 * 2 + 256 * 2 + 4 * 1024);
     sine_window(2048, win.data());
     kbd_window(2048, 4.0f, win.data() + 2048);
     sine_window(256, win.data() + 4096);
     kbd_window(256, 6.0f, win.data() + 4096 + 256);
+    // the piecewise halves of the two transition sequences as tables (dsp.rs:353-387), so that LongStart / LongStop frames
+    // run the OnlyLong code with another window pointer: [4608 + 1024 shape] = LongStart's second half {1 | short[128..256) | 0},
+    // [6656 + 1024 shape] = LongStop's first half {0 | short[0..128) | 1}
+    for (int shape = 0; shape < 2; ++shape) {
+        const float *sh = win.data() + 4096 + 256 * shape;
+        float *start2 = win.data() + 4608 + 1024 * shape, *stop1 = win.data() + 6656 + 1024 * shape;
+        for (int i = 0; i < 1024; ++i) {
+            start2[i] = i < 448 ? 1.0f : (i < 576 ? sh[128 + i - 448] : 0.0f);
+            stop1[i] = i < 448 ? 0.0f : (i < 576 ? sh[i - 448] : 1.0f);
+        }
+    }
 
     std::vector<float> all;
     const size_t o_twl = 0, o_tws = o_twl + tw_long.size(), o_w64 = o_tws + tw_short.size(),
@@ -671,11 +682,16 @@ int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, in
     hp.group_tasks.clear();
     const uint32_t per_group = sk::synth_group_frames();
     for (uint32_t t = 0; t < tasks.size(); ++t) {
-        bool only_long = windows_known;
-        for (uint32_t k = 0; only_long && k < tasks[t].count; ++k) only_long = (entries[tasks[t].begin + k].win & 3u) == 0;
+        // "long" = no EightShort frame: OnlyLong, LongStart and LongStop are one code path (the transition windows are tables)
+        bool only_long = windows_known, pure_long = windows_known;
+        for (uint32_t k = 0; only_long && k < tasks[t].count; ++k) {
+            const uint32_t seq = entries[tasks[t].begin + k].win & 3u;
+            only_long = seq != 2;
+            pure_long = pure_long && seq == 0;
+        }
         if (!only_long) {
             hp.walk_tasks.push_back(tasks[t]);
-        } else if (!use_groups) {
+        } else if (!use_groups || !pure_long) {
             hp.long_tasks.push_back(tasks[t]);
         } else {
             hp.group_tasks.push_back(t);

@@ -31,7 +31,8 @@ struct SynthTables {
     const float2 *tw_short;  // [64]   same, input_len 128
     const float2 *w64;       // [64]   e^{-2 pi i m/64}
     const float2 *w512;      // [512]  e^{-2 pi i m/512}
-    const float *win;        // long_sine[2048] long_kbd[2048] short_sine[256] short_kbd[256]
+    const float *win;        // long_sine[2048] long_kbd[2048] short_sine[256] short_kbd[256], then the transition halves:
+                             // start2_sine[1024] start2_kbd[1024] (LongStart's second half) stop1_sine[1024] stop1_kbd[1024]
 };
 
 struct SynthArgs {
@@ -43,7 +44,7 @@ struct SynthArgs {
     const SynthTask *tasks;
     const SynthEntry *entries;
     uint32_t n_tasks;
-    uint32_t only_long;   // 1: the caller vouches that every entry of every task is OnlyLong (straight-line kernel)
+    uint32_t only_long;   // 1: the caller vouches that no entry of any task is EightShort (straight-line kernel)
     SynthTables t;
 };
 

@@ -69,3 +69,32 @@ def test_a_channel_does_not_depend_on_its_partner(engine, oracle, out):
     plan.destroy()
     for sid in sids:
         engine.close_stream(sid)
+
+
+def test_transition_frames_take_the_long_kernels(engine, oracle):
+    """LongStart / LongStop frames run the long code path with their piecewise windows as tables (engine.cpp build_tables,
+    dsp.rs:353-387): a stereo stream with transitions but no EightShort frame goes to the two-channel kernel, a mono stream of
+    another length to the one-channel long kernel; both against the oracle, and the shared channel bit for bit."""
+    from soundkit_amd import aac_lc
+    seq_l = [0, 1, 3, 0, 1, 3, 3, 1, 0, 0]          # not a sequence an encoder would emit; the arithmetic does not care
+    seq_r = [1, 3, 0, 0, 0, 1, 1, 3, 3, 0]
+    n = len(seq_l)
+    coeffs = np.stack([np.stack([oracle.seeded_spectrum(1024, 0x777 + 5 * f + c) * np.float32(6000.0) for c in range(2)]) for f in range(n)])
+    seqs = np.array(list(zip(seq_l, seq_r)), np.uint8)
+    shapes = np.array([[(f // 2) & 1, (f // 3) & 1] for f in range(n)], np.uint8)
+    sid = engine.open_stream(48000, 2)
+    pcm, status = aac_lc.synthesize_batch(engine, [sid] * n, 2, coeffs, seqs, shapes)
+    assert np.all(status == 0)
+    want, chans = oracle.synthesize_stream(coeffs, seqs, shapes)
+    den = np.sqrt(np.mean(want.astype(np.float64) ** 2))
+    assert np.sqrt(np.mean((pcm.astype(np.float64) - want) ** 2)) / den < 1.0e-6
+    assert np.abs(pcm - want).max() < 2e-6 * np.abs(want).max()
+    delay, shape = engine.get_state(sid, 2)
+    for c in range(2):
+        assert np.abs(delay[c] - chans[c].delay).max() < 2e-6 * max(1e-9, np.abs(chans[c].delay).max()) and shape[c] == chans[c].prev_shape
+    engine.close_stream(sid)
+    # the left channel again as a mono stream of 9 frames (no partner of that length: one-channel kernel)
+    mono = engine.open_stream(48000, 1)
+    pcm1, status = aac_lc.synthesize_batch(engine, [mono] * (n - 1), 1, coeffs[:n - 1, :1], seqs[:n - 1], shapes[:n - 1])
+    assert np.all(status == 0) and np.array_equal(pcm1[:, 0], pcm[:n - 1, 0])
+    engine.close_stream(mono)
