@@ -18,7 +18,7 @@ __device__ void sk_ec_mark(int slot) {
     if (wave < 8192 && slot >= 0) g_ec_stamp[wave][slot] = now;  // every active lane writes the same wave's slot: last one wins
 }
 }  // namespace sk_ec
-__device__ unsigned g_ec_count[8192][4][64];
+__device__ unsigned g_ec_count[8192][10][64];
 namespace sk_ec {
 __device__ void sk_ec_count(int what, unsigned n) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;

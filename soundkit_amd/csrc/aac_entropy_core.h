@@ -83,7 +83,7 @@ struct Tables {
 };
 
 // ---- bit reader over 32-bit big-endian-packed words (the buffer is 4-byte aligned and zero-padded by >= 8 bytes) ----
-constexpr uint32_t kPow43Lo = 32;
+constexpr uint32_t kPow43Lo = 256;  // 1 KiB of LDS: magnitudes beyond it (escape sequences of 4+ extra bits) are rare
 // The largest quantised magnitude: an escape of 16 extra bits (spectral.rs:214-230) is 2^17 - 1, four pulses add at most
 // 4 * 15 (pulse.rs:20-35).  The reference computes powf beyond its 8192-entry table; a device powf is not the host's,
 // so every reachable value is tabulated (host libm, once) and the device never evaluates a transcendental.
@@ -387,16 +387,32 @@ SKE float dequantize(const Tables &t, int q, float scale) {  // dsp.rs:397-405
     return sign * m * scale;
 }
 
-SKE int read_escape(Bits &b, int *value) {  // spectral.rs:214-230
-    uint32_t extra = 4;
-    for (;;) {
-        bool one;
-        EC_TRY(read_flag(b, &one));
-        if (!one) break;
-        if (++extra > 16) return EC_UNSUPPORTED_FEATURE;
-    }
-    uint32_t low;
-    EC_TRY(read_bits(b, extra, &low));
+SKE uint32_t ec_leading_ones(uint32_t v) {  // of a 32-bit word
+    const uint32_t inv = ~v;
+    if (inv == 0) return 32;
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__GNUC__)
+    return (uint32_t)__builtin_clz(inv);
+#else
+    uint32_t n = 0;
+    while (!((inv << n) & 0x80000000u)) ++n;
+    return n;
+#endif
+}
+
+// An escape sequence is N ones, a zero and N + 4 value bits (spectral.rs:214-230; N <= 12, beyond that the reference gives up):
+// at most 29 bits, so ONE look at the bit window replaces the reference's bit-by-bit loop -- on the device every lane of a
+// wave waits for the lane that is in that loop.  Same results and the same errors in the same order: the loop fails with
+// UnexpectedEof at the first bit that is not there, with UnsupportedFeature at the 13th one.
+SKE int read_escape(Bits &b, int *value) {
+    const uint32_t avail = b.total - b.pos;
+    const uint32_t look = peek32(b);             // bits past the end read as zero: they end the count below
+    const uint32_t ones = ec_leading_ones(look);
+    if (ones >= 13) return EC_UNSUPPORTED_FEATURE;  // thirteen real ones (padding is zero)
+    if (avail < ones + 1) return EC_EOF;            // the terminating zero is padding: the loop ran out of bits
+    const uint32_t extra = 4 + ones;
+    if (avail - (ones + 1) < extra) return EC_EOF;  // read_bits(extra)
+    const uint32_t low = (look << (ones + 1)) >> (32 - extra);
+    b.pos += ones + 1 + extra;
     *value = (int)((1u << extra) + low);
     return EC_OK;
 }
@@ -732,6 +748,17 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
     BookRef br = BookRef{t.lut, t.tuples, 1};
     int q[4];
     unsigned n_passes = 0, n_codewords = 0;  // read by the timing build only
+#if defined(SK_EC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long t_open = 0, t_tuple = 0, t_rest = 0, t_prev = __builtin_readcyclecounter();
+#define EC_LAP(acc)                                                  \
+    do {                                                             \
+        const unsigned long long _now = __builtin_readcyclecounter(); \
+        acc += _now - t_prev;                                        \
+        t_prev = _now;                                               \
+    } while (0)
+#else
+#define EC_LAP(acc) ((void)0)
+#endif
     while (phase != DONE) {
         ++n_passes;
         if (phase == IN_BAND) ++n_codewords;
@@ -794,8 +821,10 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
                 }
             }
         }
+        EC_LAP(t_open);
         if (phase == IN_BAND) {
             status = read_tuple(br, b, q);
+            EC_LAP(t_tuple);
             if (status != EC_OK) {
                 phase = DONE;
             } else {
@@ -833,8 +862,14 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
                 }
             }
         }
+        EC_LAP(t_rest);
     }
     if (is_short && status == EC_OK && w0 != 8) status = EC_INVALID_BITSTREAM;
+#if defined(SK_EC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    EC_COUNT(allow_intensity ? 7 : 4, (unsigned)(t_open >> 4));
+    EC_COUNT(allow_intensity ? 8 : 5, (unsigned)(t_tuple >> 4));
+    EC_COUNT(allow_intensity ? 9 : 6, (unsigned)(t_rest >> 4));
+#endif
     EC_COUNT(allow_intensity ? 2 : 0, n_passes);
     EC_COUNT(allow_intensity ? 3 : 1, n_codewords);
     (void)n_passes, (void)n_codewords;

@@ -43,7 +43,7 @@ print("waves", len(used), "mean wave time (clock ticks)", int((used[:, 7] - used
 for i, n in enumerate(names):
     print("  %-48s mean %9.0f  max %9.0f ticks  (%4.1f %% of a wave's time)" % (n, d[:, i].mean(), d[:, i].max(), 100.0 * d[:, i].sum() / d.sum()))
 
-counts = np.zeros((8192, 4, 64), np.uint32)
+counts = np.zeros((8192, 10, 64), np.uint32)
 lib.sk_debug_ec_counts(counts.ctypes.data_as(C.c_void_p))
 cw = counts[:len(used)]
 for ch, name in ((0, "first"), (2, "second")):
@@ -51,6 +51,11 @@ for ch, name in ((0, "first"), (2, "second")):
     i = order.index(3 if ch == 0 else 5) - 1
     print("  spectrum of the %s channel: passes per lane mean %.0f, per wave (max over lanes) mean %.0f; codewords per lane %.0f; "
           "ticks per wave-pass %.0f" % (name, passes.mean(), passes.max(axis=1).mean(), words.mean(), d[:, i].mean() / passes.max(axis=1).mean()))
+for base, name in ((4, "first"), (7, "second")):
+    t = cw[:, base:base + 3, 0].astype(np.float64) * 16.0   # wave-level clocks (lane 0's copy)
+    tot = t.sum()
+    print("  spectral loop of the %s channel, share of its time: open group/band %.0f %%, codeword (look, tables, signs, escapes) %.0f %%, "
+          "pulses + dequantise + store + advance %.0f %%" % (name, 100 * t[:, 0].sum() / tot, 100 * t[:, 1].sum() / tot, 100 * t[:, 2].sum() / tot))
 if os.environ.get("SK_PHASE_DUMP"):
     col = order.index(13) - 1
     print("first-read phase per wave (first 48 waves):", d[:48, col].tolist())
