@@ -240,8 +240,8 @@ __global__ __launch_bounds__(512) void k_aac_entropy_finish(EntropyArgs a) {
     int status = a.status[k];
     if (status == sk_ec::EC_OK) {
         sk_ec::Stream st{tk.sf_index, (int)tk.channels, a.pns_start[k]};
-        sk_ec::Scratch side = a.side[k];
-        status = sk_ec::finish_unit(t, st, a.words + u.word_offset, u.byte_len, coef, side, true);
+        // the side record is read where parse left it (global memory): a private copy is 3.1 KB per lane through scratch
+        status = sk_ec::finish_unit(t, st, a.words + u.word_offset, u.byte_len, coef, a.side[k], true);
         if (status == sk_ec::EC_OK && a.wire) status = a.wire[k].tail_status;  // the host has looked at the rest of the unit
         a.status[k] = status;
     }
