@@ -467,6 +467,7 @@ void sk_engine_destroy(sk_engine *e) {
         e->tick_arena.release();
         e->tick_au.release();
         e->tick_side.release();
+        e->tick_q.release();
         if (e->h_arena) (void)hipHostFree(e->h_arena);
         if (e->stream) (void)hipStreamDestroy(e->stream);
     }
