@@ -2187,12 +2187,6 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             } else {
                 SK_HIP(e->tick_au.reserve(au_len + 16), "alloc tick access units");
                 SK_HIP(hipMemcpyAsync(e->tick_au.p, au_bytes, au_len, hipMemcpyHostToDevice, e->stream), "H2D access units");
-                if (std::getenv("SK_TICK_DEBUG_PTR")) {
-                    hipPointerAttribute_t at{};
-                    hipError_t pe = hipPointerGetAttributes(&at, e->tick_au.p);
-                    std::fprintf(stderr, "tick_au %p len %zu: err %d type %d device %d managed %d devptr %p hostptr %p\n", e->tick_au.p, (size_t)au_len,
-                                 (int)pe, (int)at.type, at.device, (int)at.isManaged, at.devicePointer, at.hostPointer);
-                }
             }
             std::vector<sk::EntropyUnit> eu(n_frames);
             std::vector<sk::EntropyTask> et;

@@ -448,9 +448,7 @@ class Engine:
         blob = bytearray()
         for k, au in enumerate(access_units):
             items[k] = (len(blob), len(au))
-            align = int(os.environ.get("SK_AU_ALIGN", "4"))  # experiment knob: alignment of the next unit (a multiple of 4)
-            blob += bytes(au) + b"\0" * 8
-            blob += b"\0" * ((-len(blob)) % align)   # >= 8 zero bytes, next unit 4-byte aligned
+            blob += bytes(au) + b"\0" * (8 + (-len(au)) % 4)   # >= 8 zero bytes, next unit 4-byte aligned
         blob = np.frombuffer(bytes(blob) + b"\0" * 8, np.uint8)
         max_out = C.c_uint32()
         cap = lib.sk_tick_out_bound(ts, len(streams), C.byref(max_out))
