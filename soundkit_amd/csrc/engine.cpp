@@ -216,7 +216,7 @@ struct sk_engine {
     float *d_tables = nullptr;
     sk::SynthTables synth_tables{};
     float *d_pow43 = nullptr, *d_sftab = nullptr, *d_taps = nullptr, *d_afrag = nullptr, *d_zeros = nullptr;
-    uint32_t *d_afrag16 = nullptr;
+    uint32_t *d_afrag16 = nullptr, *d_afrag_f16 = nullptr;
     std::vector<float> h_taps;
     std::vector<RatioTable> ratio_tables;
 
@@ -273,6 +273,37 @@ hipError_t upload(T **dst, const std::vector<T> &src) {
     hipError_t e = hipMalloc((void **)dst, src.size() * sizeof(T));
     if (e != hipSuccess) return e;
     return hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+// IEEE binary16 <-> binary32 (round to nearest even, subnormals kept): the host side of the f16 tap planes
+uint16_t f32_to_f16_rn(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | 0x7c00u);  // >= 65536 (not reached: taps * 2^16 < 2^15)
+    if (x < 0x38800000u) {                                     // below 2^-14: subnormal half, in units of 2^-24
+        float a;
+        std::memcpy(&a, &x, 4);
+        const float scaled = a * 16777216.0f;                  // exact
+        const uint32_t q = (uint32_t)std::nearbyint(scaled);   // default rounding mode: to nearest even
+        return (uint16_t)(sign | q);
+    }
+    const uint32_t mant = x & 0x7fffffu, exp = (x >> 23) - 112;
+    uint32_t h = (exp << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;  // a carry out of the mantissa moves into the exponent: still right
+    return (uint16_t)(sign | h);
+}
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 31u, mant = h & 0x3ffu;
+    float v;
+    if (exp == 0) v = (float)mant * (1.0f / 16777216.0f);
+    else {
+        const uint32_t bits = ((exp + 112) << 23) | (mant << 13);
+        std::memcpy(&v, &bits, 4);
+    }
+    return sign ? -v : v;
 }
 
 int build_tables(sk_engine *e) {
@@ -351,6 +382,22 @@ int build_tables(sk_engine *e) {
                 }
             }
     SK_HIP(upload(&e->d_afrag16, afrag16), "upload bf16 tap fragments");
+    // f16 A fragments for s16 rows: h * 2^16 = h1 + h2 + r with h1 = f16(h * 2^16), h2 = f16(h * 2^16 - h1), both rounded to
+    // nearest (|r| <= 2^-24 |h1|, or 2^-25 absolute where h2 is subnormal); same window / lane / element layout, two planes
+    std::vector<uint32_t> afrag_f16((size_t)10 * 2 * 64 * 4, 0u);
+    for (int s = 0; s < 10; ++s)
+        for (int l = 0; l < 64; ++l)
+            for (int el = 0; el < 8; ++el) {
+                const int p = 32 * s + 8 * (l >> 4) + el - 3 * (l & 15) - 3;
+                if (p < 0 || p >= 256) continue;
+                float rest = e->h_taps[p] * 65536.0f;  // exact
+                for (int k = 0; k < 2; ++k) {
+                    const uint16_t hbits = f32_to_f16_rn(rest);
+                    rest -= f16_to_f32(hbits);  // exact: the piece is rest rounded to 11 significand bits
+                    afrag_f16[((size_t)(s * 2 + k) * 64 + l) * 4 + el / 2] |= (uint32_t)hbits << (16 * (el & 1));
+                }
+            }
+    SK_HIP(upload(&e->d_afrag_f16, afrag_f16), "upload f16 tap fragments");
     std::vector<float> zeros(8192, 0.0f);
     SK_HIP(upload(&e->d_zeros, zeros), "upload zeros");
     return SK_OK;
@@ -452,7 +499,7 @@ void sk_engine_destroy(sk_engine *e) {
         DeviceGuard guard(e->device);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         for (void *p : {(void *)e->d_mp3_tables, (void *)e->d_mp3_state, (void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_delay_next, (void *)e->d_shape_next, (void *)e->d_rs, (void *)e->d_tables,
-                        (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag, (void *)e->d_afrag16,
+                        (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag, (void *)e->d_afrag16, (void *)e->d_afrag_f16,
                         (void *)e->d_zeros})
             if (p) (void)hipFree(p);
         for (RatioTable &t : e->ratio_tables)
@@ -1084,6 +1131,7 @@ static sk::FirArgs fir_base(sk_engine *e) {
     a.zeros = e->d_zeros;
     a.afrag = e->d_afrag;
     a.afrag16 = e->d_afrag16;
+    a.afrag_f16 = e->d_afrag_f16;
     a.taps = e->d_taps;
     return a;
 }

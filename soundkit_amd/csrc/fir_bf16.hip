@@ -27,6 +27,7 @@
 // gaps) and written to a 192-sample LDS ring per plane; B operands are one ds_read_b128 per plane.
 #include "sk_device.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace sk {
@@ -53,6 +54,14 @@ __device__ constexpr int kProducts[kWindows] = {1, 3, 6, 6, 6, 6, 6, 3, 3, 1};
 // input plane and the product x3h1 do not exist -- 36 MFMAs per tile, two LDS planes, half the input bytes.  The factor
 // 2^-15 is applied to the accumulated sums (a power of two: it commutes with every rounding).
 __host__ __device__ constexpr int products_of(int s, bool in16) { return in16 && kProducts[s] > 5 ? 5 : kProducts[s]; }
+// s16 input on the f16 matrix instruction (the default for s16 rows): both operands as two f16 values,
+//     x = x1 + x2 (x1 = x toward zero in f16, x2 = x - x1: exact, |x2| < 2^-10 |x|),
+//     h * 2^16 = h1 + h2 + r (rounded to nearest: |h2| <= 2^-12 |h1|, |r| <= 2^-24 |h1|)
+// so that x1h1 + x1h2 + x2h1 leaves out only x2h2 < 2^-22 |x||h| and r -- measured against an f64 evaluation 1.0e-7 relative
+// RMS (tests/fir_split_model.py; the bf16 form with five products: 1.4e-7).  Eleven significand bits per value instead of eight: three products where bf16 needs five, and a
+// window whose largest tap is below 2^-13 of the peak needs only x1h1.  24 MFMAs per tile instead of 36.
+__device__ constexpr int kProductsF16[kWindows] = {1, 3, 3, 3, 3, 3, 3, 3, 1, 1};
+__host__ __device__ constexpr int products_of(int s, bool in16, bool f16) { return f16 ? kProductsF16[s] : products_of(s, in16); }
 #ifndef SK_BF_AHEAD
 #define SK_BF_AHEAD 2
 #endif
@@ -92,6 +101,16 @@ __device__ __forceinline__ void split_pair16(uint32_t u, uint32_t &p1, uint32_t 
     const float b0 = (float)(u & 0xffu), b1 = (float)((u >> 16) & 0xffu);
     p1 = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
     p2 = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(b0), 0x07060302u);
+}
+
+// two s16 samples in one dword (the earlier one low) -> their two f16 planes: p1 = the sample rounded TOWARD ZERO to f16 (eleven
+// significand bits; no overflow at 32767), p2 = the rest (same sign, below 32: exact).  Four vector instructions per sample.
+__device__ __forceinline__ void split_pair16_f16(uint32_t u, uint32_t &p1, uint32_t &p2) {
+    const float f0 = (float)(short)(u & 0xffffu), f1 = (float)((int)u >> 16);
+    const auto a = __builtin_amdgcn_cvt_pkrtz(f0, f1);
+    const float r0 = f0 - (float)a[0], r1 = f1 - (float)a[1];  // exact
+    p1 = __builtin_bit_cast(uint32_t, a);
+    p2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 
 template <bool IN16>
@@ -178,15 +197,20 @@ __device__ __forceinline__ void stage_issue(const FirArgs &a, int lane, uint32_t
 }
 
 // split loads [ld0, ld1) and write them to the ring at sample position `ring_at` (of the chunk's first sample)
-template <bool ALIGNED, bool IN16>
+template <bool ALIGNED, bool IN16, bool F16 = false>
 __device__ __forceinline__ void stage_commit(unsigned char *lds, int lane, int ring_at, const Stage<IN16> &st, int half, int slot) {
 #pragma unroll
     for (int e2 = 0; e2 < 2; ++e2) {
         const int ld = 2 * half + e2, sl = 2 * slot + e2;
         if constexpr (IN16) {
             uint32_t p1a, p2a, p1b, p2b;
-            split_pair16(st.v[sl][0], p1a, p2a);
-            split_pair16(st.v[sl][1], p1b, p2b);
+            if constexpr (F16) {
+                split_pair16_f16(st.v[sl][0], p1a, p2a);
+                split_pair16_f16(st.v[sl][1], p1b, p2b);
+            } else {
+                split_pair16(st.v[sl][0], p1a, p2a);
+                split_pair16(st.v[sl][1], p1b, p2b);
+            }
             unsigned char *dst = lds + (4 * ld + (lane >> 4)) * kRowBytes + 2 * (ring_at + 4 * (lane & 15));
             *reinterpret_cast<u32x2 *>(dst) = (u32x2){p1a, p1b};
             *reinterpret_cast<u32x2 *>(dst + kPlaneBytes) = (u32x2){p2a, p2b};
@@ -225,11 +249,17 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 &av, const u32x4 &bv, con
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
 }
 
-// OUT16: 0 = f32 rows out
-template <bool ALIGNED, bool PACKED, int OUT16, bool IN16 = false>
+__device__ __forceinline__ f32x4 mfma_f16(const u32x4 &av, const u32x4 &bv, const f32x4 &c) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
+}
+
+// OUT16: 0 = f32 rows out.  F16 (with IN16): f16 planes and the f16 matrix instruction instead of bf16.
+template <bool ALIGNED, bool PACKED, int OUT16, bool IN16 = false, bool F16 = false>
 __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t pair0, int32_t pair_end, int32_t pairs_per_seg,
                                                             uint32_t n_segs, int out_vec) {
     static_assert(!IN16 || ALIGNED, "s16 rows are read four samples at a time");
+    static_assert(!F16 || IN16, "the f16 planes exist for s16 rows");
     constexpr int kPlanes = IN16 ? 2 : 3;
     __shared__ __attribute__((aligned(16))) unsigned char lds[kPlanes * kPlaneBytes];
 
@@ -252,11 +282,12 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
 
     u32x4 af[kWindows][3];
     {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.afrag16);
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(F16 ? a.afrag_f16 : a.afrag16);
+        constexpr int kTapPlanes = F16 ? 2 : 3;
 #pragma unroll
         for (int s = 0; s < kWindows; ++s)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) af[s][k] = src[(s * 3 + k) * 64 + lane];
+            for (int k = 0; k < kTapPlanes; ++k) af[s][k] = src[(s * kTapPlanes + k) * 64 + lane];
     }
 
     Stage<IN16> st;
@@ -270,8 +301,8 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
     for (int c = -2; c < 0; ++c) {
         stage_issue<ALIGNED, PACKED, false, IN16>(a, lane, row0, n_begin + 64 * c, st, 0, 0);
         stage_issue<ALIGNED, PACKED, false, IN16>(a, lane, row0, n_begin + 64 * c, st, 1, 1);
-        stage_commit<ALIGNED, IN16>(lds, lane, ring_index(64 * c), st, 0, 0);
-        stage_commit<ALIGNED, IN16>(lds, lane, ring_index(64 * c), st, 1, 1);
+        stage_commit<ALIGNED, IN16, F16>(lds, lane, ring_index(64 * c), st, 0, 0);
+        stage_commit<ALIGNED, IN16, F16>(lds, lane, ring_index(64 * c), st, 1, 1);
     }
 #pragma unroll
     for (int i = 0; i < kAhead; ++i) stage_issue<ALIGNED, PACKED, false, IN16>(a, lane, row0, n_begin + 64 * (i >> 1), st, i & 1, i % kAhead);
@@ -298,7 +329,8 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
     // s16: the lane of a stream's first channel writes the interleaved frames of all its channels
     int16_t *out16_ptr = to_s16 ? a.out16 + (size_t)((row_exists ? out_row : 0) / (OUT16 ? OUT16 : 1)) * a.out16_stride * OUT16 : nullptr;
     auto store_tile = [&](auto itag, const f32x4 &vraw, int32_t pair, int parity) __attribute__((always_inline)) {
-        const f32x4 v = IN16 ? vraw * (1.0f / 32768.0f) : vraw;  // the samples went in as integers
+        // the samples went in as integers (and the f16 taps times 2^16): powers of two, they commute with every rounding
+        const f32x4 v = F16 ? vraw * (1.0f / 2147483648.0f) : (IN16 ? vraw * (1.0f / 32768.0f) : vraw);
         // INTERIOR: every tile of the body lies inside the segment and the output range, all 16 rows exist, stores are
         // vector stores -- no branch, so a whole body is one scheduling region
         constexpr bool INTERIOR = decltype(itag)::value;
@@ -379,7 +411,7 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
                 // the scheduler works on one step at a time: across a whole branch-free body it hoists loads and LDS reads
                 // far enough to spill
                 __builtin_amdgcn_sched_barrier(0);
-                stage_commit<ALIGNED, IN16>(lds, lane, ring_index(64 * (step >> 1)), st, step & 1, step % kAhead);
+                stage_commit<ALIGNED, IN16, F16>(lds, lane, ring_index(64 * (step >> 1)), st, step & 1, step % kAhead);
                 stage_issue<ALIGNED, PACKED, INTERIOR, IN16>(a, lane, row0, n_body + 64 * ((step + kAhead) >> 1), st,
                                                              (step + kAhead) & 1, step % kAhead);
             }
@@ -392,15 +424,16 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
                 // products in an order that never puts two MFMAs on one accumulator back to back
 #pragma unroll
                 for (int prod = 0; prod < 6; ++prod) {
-                    constexpr int hk[6] = {0, 1, 0, 1, 2, 0};
+                    constexpr int hk[6] = {0, 1, 0, 1, 2, 0};  // with f16 planes only the first three: x1h1 | x1h2, x2h1
                     constexpr int xk[6] = {0, 0, 1, 1, 0, 2};
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const int s = 3 * d + wi;
-                        if (s >= kWindows || prod >= products_of(s, IN16)) continue;
+                        if (s >= kWindows || prod >= products_of(s, IN16, F16)) continue;
                         f32x4 &c = acc[par][(K - d + 4) & 3];
-                        if (s == 0 && prod == 0) c = mfma_bf16(af[s][hk[prod]], bcur.p[xk[prod]], (f32x4){0.f, 0.f, 0.f, 0.f});
-                        else c = mfma_bf16(af[s][hk[prod]], bcur.p[xk[prod]], c);
+                        const f32x4 c0 = (s == 0 && prod == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : c;
+                        if constexpr (F16) c = mfma_f16(af[s][hk[prod]], bcur.p[xk[prod]], c0);
+                        else c = mfma_bf16(af[s][hk[prod]], bcur.p[xk[prod]], c0);
                     }
                 }
                 // the tile that took its last step (s = 9, wi = 0) one half-step ago is stored now, behind 20 MFMAs
@@ -423,7 +456,7 @@ __global__ __launch_bounds__(64, 2) void k_fir_48k_16k_bf16(FirArgs a, int32_t p
                 int mfmas = 0;
 #pragma unroll
                 for (int d = 0; d < 4; ++d)
-                    if (3 * d + wi < kWindows) mfmas += 2 * products_of(3 * d + wi, IN16);
+                    if (3 * d + wi < kWindows) mfmas += 2 * products_of(3 * d + wi, IN16, F16);
 #pragma unroll
                 for (int g = 0; g < mfmas; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
@@ -512,12 +545,21 @@ hipError_t launch_fir_48k_16k_bf16(const FirArgs &a, hipStream_t s) {
                        (int32_t)pps, n_segs, out_vec)
     if (a.in16) {  // planar s16 from the synthesis kernel: frame-packed, aligned
         if (!packed || !aligned) return hipErrorInvalidValue;
-        if (!a.out16) hipLaunchKernelGGL((k_fir_48k_16k_bf16<true, true, 0, true>), grid, block, 0, s, a, (int32_t)first_pair,
-                                         (int32_t)end_pair, (int32_t)pps, n_segs, out_vec);
-        else if (a.out16_ch == 2) hipLaunchKernelGGL((k_fir_48k_16k_bf16<true, true, 2, true>), grid, block, 0, s, a, (int32_t)first_pair,
-                                                (int32_t)end_pair, (int32_t)pps, n_segs, out_vec);
-        else hipLaunchKernelGGL((k_fir_48k_16k_bf16<true, true, 1, true>), grid, block, 0, s, a, (int32_t)first_pair, (int32_t)end_pair,
-                                (int32_t)pps, n_segs, out_vec);
+        // f16 planes (24 MFMAs per tile) unless SK_FIR_S16_BF16=1 asks for the bf16 form (36) of the same filter
+        static const bool use_f16 = [] { const char *v = std::getenv("SK_FIR_S16_BF16"); return !(v && v[0] == '1'); }();
+#define SK_FIR_LAUNCH16(O16, F)                                                                                                    \
+    hipLaunchKernelGGL((k_fir_48k_16k_bf16<true, true, O16, true, F>), grid, block, 0, s, a, (int32_t)first_pair, (int32_t)end_pair, \
+                       (int32_t)pps, n_segs, out_vec)
+        if (use_f16 && a.afrag_f16) {
+            if (!a.out16) SK_FIR_LAUNCH16(0, true);
+            else if (a.out16_ch == 2) SK_FIR_LAUNCH16(2, true);
+            else SK_FIR_LAUNCH16(1, true);
+        } else {
+            if (!a.out16) SK_FIR_LAUNCH16(0, false);
+            else if (a.out16_ch == 2) SK_FIR_LAUNCH16(2, false);
+            else SK_FIR_LAUNCH16(1, false);
+        }
+#undef SK_FIR_LAUNCH16
     } else if (a.out16) {  // the fused 16-bit output exists for the frame-packed input of the synthesis kernel
         if (!packed) return hipErrorInvalidValue;
         if (aligned && a.out16_ch == 2) SK_FIR_LAUNCH(true, true, 2);

@@ -153,6 +153,7 @@ struct FirArgs {
     const float *zeros;   // >= 1 KiB of zeros (source for out-of-range input)
     const float *afrag;   // [76][64] MFMA A-operand fragments of the Toeplitz tap matrix
     const uint32_t *afrag16;  // [10][3][64][4] bf16 A-operand fragments (fir_bf16.hip); null = f32 kernel only
+    const uint32_t *afrag_f16;  // [10][2][64][4] f16 A-operand fragments of the taps times 2^16 (s16 rows)
     const float *taps;    // [256]
     size_t in_stride, out_stride;
     // frame-packed input (in_block 0 = plain rows; otherwise 1024 with in_ch 1 or 2): sample n of row r lives at
