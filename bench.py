@@ -654,8 +654,8 @@ def main():
             "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32 (synthesis f32; s16 between the kernels as in the reference; FIR: taps split exactly into 3 x bf16, the 16-bit "
-                      "samples into 2 x bf16, f32 accumulate)" if args.workload == "pipeline" and args.chain == "s16" and not args.separate_s16
+            "dtype": ("f32 (synthesis f32; s16 between the kernels as in the reference; FIR: the 16-bit samples as 2 x f16 exactly, the "
+                      "f32 taps as 2 x f16 to 2^-24, f32 accumulate; 1.0e-7 rel. RMS vs f64)" if args.workload == "pipeline" and args.chain == "s16" and not args.separate_s16
                       else "f32 (FIR: exact 3 x bf16 split of both operands, f32 accumulate; 2.2e-7 rel. RMS vs f64)"
                       if args.workload in ("pipeline", "fir") and os.environ.get("SK_FIR_F32") != "1" else "f32"),
             "data": "synthetic",
