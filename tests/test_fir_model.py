@@ -18,3 +18,19 @@ def test_left_out_products_are_below_f32_rounding():
     full, cut = err["60 MFMAs per tile (all six products everywhere)"], err["41 (kProducts)"]
     assert full[0] < 1.6e-7 and cut[0] < 1.6e-7 and cut[0] < full[0] * 1.05  # relative RMS against f64
     assert cut[1] < 1e-6                                                     # max abs, full-scale input
+
+
+def test_f16_planes_of_s16_rows_stay_inside_the_bound():
+    """the f16 form (two planes per operand, products x1h1 | x1h2, x2h1, 24 per tile): <= 2e-7 relative RMS against f64 at
+    full scale and at small amplitudes alike (the remainder plane scales with the sample, not with full scale)"""
+    import fir_split_model as model
+    src = open(os.path.join(HERE, "..", "soundkit_amd", "csrc", "fir_bf16.hip")).read()
+    table = re.search(r"kProductsF16\[kWindows\] = \{([0-9, ]+)\}", src).group(1)
+    assert [int(v) for v in table.split(",")] == model.F16_SETS["f16, 24 (kProductsF16)"]
+    r = model.errors_f16(n=12000)
+    for (label, amp), (rms, _) in r.items():
+        assert rms < 2.0e-7, (label, amp, rms)
+    kept = {amp: rms for (label, amp), (rms, _) in r.items() if "kProductsF16" in label}
+    full = {amp: rms for (label, amp), (rms, _) in r.items() if "all four" in label}
+    for amp in kept:
+        assert kept[amp] < 1.1 * full[amp] + 1e-9   # what kProductsF16 leaves out does not show
