@@ -10,7 +10,7 @@
 #include "sk_device.h"
 
 #ifdef SK_EC_PROFILE  // timing build only: per-wave clock stamps of the parse kernel's phases, read back by tools/entropy_phases.py
-__device__ unsigned long long g_ec_stamp[8192][16];
+__device__ unsigned long long g_ec_stamp[8192][24];
 namespace sk_ec {
 __device__ void sk_ec_mark(int slot) {
     const unsigned long long now = __builtin_readcyclecounter();
@@ -28,7 +28,7 @@ __device__ void sk_ec_count(int what, unsigned n) {
 extern "C" int sk_debug_ec_counts(unsigned *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ec_count), sizeof(g_ec_count)); }
 extern "C" int sk_debug_ec_stamps(unsigned long long *out, int clear) {
     if (clear) {
-        static unsigned long long zeros[8192][16];
+        static unsigned long long zeros[8192][24];
         return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ec_stamp), zeros, sizeof(zeros));
     }
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ec_stamp), sizeof(g_ec_stamp));
@@ -238,6 +238,7 @@ __global__ __launch_bounds__(512) void k_aac_entropy_finish(EntropyArgs a) {
     const EntropyTask tk = a.tasks[u.task];
     float *coef = a.coeffs + (size_t)u.off1024 * 1024;
     int status = a.status[k];
+    EC_MARK(16);
     if (status == sk_ec::EC_OK) {
         sk_ec::Stream st{tk.sf_index, (int)tk.channels, a.pns_start[k]};
         // the side record is read where parse left it (global memory): a private copy is 3.1 KB per lane through scratch
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(512) void k_aac_entropy_finish(EntropyArgs a) {
         if (status == sk_ec::EC_OK && a.wire) status = a.wire[k].tail_status;  // the host has looked at the rest of the unit
         a.status[k] = status;
     }
+    EC_MARK(22);
     if (status != sk_ec::EC_OK) {  // failed or skipped: silence for the synthesis launch that follows
         for (uint32_t i = 0; i < tk.channels * 1024u; ++i) coef[i] = 0.0f;
         for (uint32_t c = 0; c < tk.channels; ++c) a.entries[u.entry[c]].win = 0;

@@ -978,8 +978,36 @@ SKE int read_ms_mask(Bits &b, const Ics &ics, MsMask &m) {  // channel.rs:222-25
     return EC_OK;
 }
 
-SKE int stereo_tools(const Tables &t, const Stream &st, const MsMask &mask, const Ics &ics, const Channel &lch, const Channel &rch,
+struct alignas(16) Quad {
+    float v[4];
+};
+
+SKE int stereo_tools(const Tables &t, const Stream &st, const MsMask &mask, const Ics &ics_in, const Channel &lch, const Channel &rch,
                      float *left, float *right) {
+    // Everything the band loops ask of the side record is fetched ONCE: the record sits in memory the float stores below may
+    // alias as far as the compiler knows (its fields are bytes), so through references every loop condition and every band's
+    // codebook / mask lookup is a reload -- on the device a global-memory round trip per band, twice over.  The per-band facts
+    // become four 128-bit masks (index g * stride + sfb): M/S selected, right band intensity, its sign, band exempt from M/S.
+    const Ics ics = ics_in;
+    const uint8_t mask_mode = mask.mode;
+    uint64_t sel[2] = {0, 0}, is_band[2] = {0, 0}, is_neg[2] = {0, 0}, exempt[2] = {0, 0};
+    const int words_used = ics.sequence == SEQ_EIGHT_SHORT ? 4 * (int)ics.num_groups : ((int)ics.max_sfb + 3) / 4;
+    for (int wd = 0; wd < 32 && wd < words_used; ++wd) {  // entries g * stride + sfb with sfb < max_sfb (<= 15 / <= 51)
+        uint32_t lw, rw, uw;
+        memcpy(&lw, lch.book + 4 * wd, 4);
+        memcpy(&rw, rch.book + 4 * wd, 4);
+        memcpy(&uw, mask.used + 4 * wd, 4);
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t lb = (lw >> (8 * b)) & 0xffu, rb = (rw >> (8 * b)) & 0xffu, used = (uw >> (8 * b)) & 0xffu;
+            const int at = 4 * wd + b;
+            const uint64_t bit = (uint64_t)1 << (at & 63);
+            const bool intensity = rb == BOOK_INTENSITY || rb == BOOK_INTENSITY_NEG;
+            if (mask_mode == 2 || (mask_mode == 1 && used)) sel[at >> 6] |= bit;
+            if (intensity) is_band[at >> 6] |= bit;
+            if (rb == BOOK_INTENSITY_NEG) is_neg[at >> 6] |= bit;
+            if (intensity || lb == BOOK_NOISE || rb == BOOK_NOISE) exempt[at >> 6] |= bit;
+        }
+    }
     const uint16_t *off;
     int bands;
     EC_TRY(layout(t, st, ics, &off, &bands));
@@ -997,11 +1025,11 @@ SKE int stereo_tools(const Tables &t, const Stream &st, const MsMask &mask, cons
                 int s, e;
                 EC_TRY(band_range(off, bands, sfb, &s, &e));
                 if (e > wlen) return EC_INVALID_CONFIG;
-                const int rb = rch.book[g * stride + sfb], lb = lch.book[g * stride + sfb];
-                const bool selected = mask.mode == 2 || (mask.mode == 1 && mask.used[g * stride + sfb]);
+                const int at = g * stride + sfb;
+                const bool selected = (sel[at >> 6] >> (at & 63)) & 1u;
                 if (pass == 0) {
-                    if (rb != BOOK_INTENSITY && rb != BOOK_INTENSITY_NEG) continue;
-                    float sign = rb == BOOK_INTENSITY ? 1.0f : -1.0f;  // stereo.rs:431-437
+                    if (!((is_band[at >> 6] >> (at & 63)) & 1u)) continue;
+                    float sign = ((is_neg[at >> 6] >> (at & 63)) & 1u) ? -1.0f : 1.0f;  // stereo.rs:431-437
                     if (selected) sign = -sign;                        // stereo.rs:145-149
                     const float scale = rch.mult[g * stride + sfb];
                     for (int w = w0; w < w0 + glen; ++w) {
@@ -1017,14 +1045,22 @@ SKE int stereo_tools(const Tables &t, const Stream &st, const MsMask &mask, cons
                     }
                 } else {
                     if (!selected) continue;
-                    if (rb == BOOK_INTENSITY || rb == BOOK_INTENSITY_NEG || lb == BOOK_NOISE || rb == BOOK_NOISE) continue;
+                    if ((exempt[at >> 6] >> (at & 63)) & 1u) continue;
                     for (int w = w0; w < w0 + glen; ++w) {
                         int i = w * wlen + s;
-                        for (; i + 4 <= w * wlen + e; i += 4) {  // eight loads in flight
-                            const float m0 = left[i], m1 = left[i + 1], m2 = left[i + 2], m3 = left[i + 3];
-                            const float s0 = right[i], s1 = right[i + 1], s2 = right[i + 2], s3 = right[i + 3];
-                            left[i] = m0 + s0; left[i + 1] = m1 + s1; left[i + 2] = m2 + s2; left[i + 3] = m3 + s3;
-                            right[i] = m0 - s0; right[i + 1] = m1 - s1; right[i + 2] = m2 - s2; right[i + 3] = m3 - s3;
+                        // One lane per unit: a scalar load is 32-64 separate cache lines per wave instruction, and the rate at
+                        // which those are looked up, not their latency, bounds this loop.  Bands start and end on multiples of
+                        // four lines (checked), the spectra are 4 KiB-aligned: 16-byte accesses, four lines per look-up.
+                        if ((((uintptr_t)left | (uintptr_t)right) & 15u) == 0 && ((i | (w * wlen + e)) & 3) == 0) {
+                            for (; i + 4 <= w * wlen + e; i += 4) {
+                                Quad mq, sq;
+                                memcpy(&mq, (const Quad *)__builtin_assume_aligned(left + i, 16), 16);
+                                memcpy(&sq, (const Quad *)__builtin_assume_aligned(right + i, 16), 16);
+                                const Quad lo = {{mq.v[0] + sq.v[0], mq.v[1] + sq.v[1], mq.v[2] + sq.v[2], mq.v[3] + sq.v[3]}};
+                                const Quad ro = {{mq.v[0] - sq.v[0], mq.v[1] - sq.v[1], mq.v[2] - sq.v[2], mq.v[3] - sq.v[3]}};
+                                memcpy((Quad *)__builtin_assume_aligned(left + i, 16), &lo, 16);
+                                memcpy((Quad *)__builtin_assume_aligned(right + i, 16), &ro, 16);
+                            }
                         }
                         for (; i < w * wlen + e; ++i) {
                             const float mid = left[i], side = right[i];
@@ -1067,29 +1103,33 @@ SKE void tns_filter(float *c, int first, int n, int step, int order, const float
         hist[i] = 0.0f;
         lpc[i] = lpc20[i];
     }
-    int pos = first;
-    for (int done = 0; done < n; done += 8, pos += 8 * step) {
-        const int m = n - done < 8 ? n - done : 8;
-        float x[8];
-        for (int j = 0; j < 8; ++j)
-            if (j < m) x[j] = c[pos + j * step];
-        for (int j = 0; j < 8; ++j) {
-            if (j >= m) break;
-            const int mo = done + j < order ? done + j : order;
-            float v = x[j];
-            for (int o = 1; o <= TAPS; ++o)
-                if (o <= mo) v -= hist[o - 1] * lpc[o - 1];
-            x[j] = v;
-            for (int k = TAPS - 1; k > 0; --k) hist[k] = hist[k - 1];
-            hist[0] = v;
-        }
-        for (int j = 0; j < 8; ++j)
-            if (j < m) c[pos + j * step] = x[j];
+    int pos = first, done = 0;
+    auto line = [&](float v, int at) {  // one step of the recursion; `at` = lines done before this one
+        const int mo = at < order ? at : order;
+        for (int o = 1; o <= TAPS; ++o)
+            if (o <= mo) v -= hist[o - 1] * lpc[o - 1];
+        for (int k = TAPS - 1; k > 0; --k) hist[k] = hist[k - 1];
+        hist[0] = v;
+        return v;
+    };
+    // whole blocks: the next block's eight loads are in flight while this one is filtered and stored
+    float x[8], nx[8];
+    if (n >= 8)
+        for (int j = 0; j < 8; ++j) x[j] = c[pos + j * step];
+    for (; done + 8 <= n; done += 8, pos += 8 * step) {
+        const bool more = done + 16 <= n;
+        if (more)
+            for (int j = 0; j < 8; ++j) nx[j] = c[pos + (8 + j) * step];
+        for (int j = 0; j < 8; ++j) x[j] = line(x[j], done + j);
+        for (int j = 0; j < 8; ++j) c[pos + j * step] = x[j];
+        if (more)
+            for (int j = 0; j < 8; ++j) x[j] = nx[j];
     }
+    for (; done < n; ++done, pos += step) c[pos] = line(c[pos], done);
 }
 
 SKE int apply_tns(const Tables &t, const Stream &st, const Channel &ch, float *coef) {
-    const Ics &ics = ch.ics;
+    const Ics ics = ch.ics;  // a copy: through the reference every use is a reload (see stereo_tools)
     if (st.sf_index < 0) return EC_UNSUPPORTED_FEATURE;
     if (st.sf_index > 12) return EC_UNSUPPORTED_SF_INDEX;
     const bool is_short = ics.sequence == SEQ_EIGHT_SHORT;
@@ -1259,12 +1299,14 @@ SKE int unit_tail(const uint32_t *au, uint32_t len_bytes, uint32_t resume_pos);
 // unit (fill elements, END, the trailing-zero rule) from where the first phase stopped.
 SKE int finish_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len_bytes, float *coef, Scratch &s, bool fill) {
     Channel &left = s.ch[0], &right = s.ch[1];
+    EC_MARK(17);
 #ifndef SK_EC_ABLATE_NOISE  // the SK_EC_ABLATE_* switches are timing experiments (tools/build_ab.sh); results are wrong with them
     if (fill) {
         EC_TRY(fill_noise(t, st, left, coef));
         if (s.is_pair) EC_TRY(fill_noise(t, st, right, coef + 1024));
     }
 #endif
+    EC_MARK(18);
 #ifdef SK_EC_ABLATE_STEREO
     if (false) {
 #else
@@ -1281,10 +1323,13 @@ SKE int finish_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t le
             EC_TRY(stereo_tools(t, st, s.mask, left.ics, left, right, coef, coef + 1024));
         }
     }
+    EC_MARK(19);
 #ifndef SK_EC_ABLATE_TNS
     if (left.tns_present) EC_TRY(apply_tns(t, st, left, coef));
+    EC_MARK(20);
     if (s.is_pair && right.tns_present) EC_TRY(apply_tns(t, st, right, coef + 1024));
 #endif
+    EC_MARK(21);
 #ifdef SK_EC_ABLATE_TAIL
     return EC_OK;
 #endif

@@ -109,7 +109,13 @@ typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 // float_sample_to_i16 in its shortest exact form (through f64, sk_device.h; tools/check_f32_rounding.c sweeps all 2^32
 // inputs): the s16 variant of the kernel is bound by vector issue, and with the f32 form a third of it was these conversions
 __device__ __forceinline__ u2 pack4_s16(const f4 &v) {
+#ifdef SK_SYNTH_ABLATE_CVT  // timing experiment: a wrong, two-instruction conversion
+    typedef short s2v __attribute__((ext_vector_type(2)));
+    return (u2){__builtin_bit_cast(uint32_t, (s2v)__builtin_amdgcn_cvt_pk_i16((int)(v.x * 32768.0f), (int)(v.y * 32768.0f))),
+                __builtin_bit_cast(uint32_t, (s2v)__builtin_amdgcn_cvt_pk_i16((int)(v.z * 32768.0f), (int)(v.w * 32768.0f)))};
+#else
     return (u2){dev_pack2_s16(v.x, v.y), dev_pack2_s16(v.z, v.w)};
+#endif
 }
 
 // first-half and second-half window of a long-transform frame (dsp.rs:353-387): the long window of the previous / current

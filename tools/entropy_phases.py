@@ -21,7 +21,7 @@ for i in range(n_streams):
     eng.resampler_open(sid, 48000, 16000)
     sids.append(sid)
 lib = _lib.lib
-stamps = np.zeros((8192, 16), np.uint64)
+stamps = np.zeros((8192, 24), np.uint64)
 for t in range(2):
     table, units = [], []
     for i, sid in enumerate(sids):
@@ -43,6 +43,11 @@ print("waves", len(used), "mean wave time (clock ticks)", int((used[:, 7] - used
 for i, n in enumerate(names):
     print("  %-48s mean %9.0f  max %9.0f ticks  (%4.1f %% of a wave's time)" % (n, d[:, i].mean(), d[:, i].max(), 100.0 * d[:, i].sum() / d.sum()))
 
+fin = used[:, [16, 17, 18, 19, 20, 21, 22]]
+fd = np.diff(fin, axis=1)
+print("finish kernel, mean wave time %d ticks" % int((fin[:, -1] - fin[:, 0]).mean()))
+for i, n in enumerate(["tables, records, status", "noise fill (both channels)", "stereo tools", "TNS, first channel", "TNS, second channel", "rest of the unit, status"]):
+    print("  %-48s mean %9.0f  max %9.0f ticks  (%4.1f %% of a wave's time)" % (n, fd[:, i].mean(), fd[:, i].max(), 100.0 * fd[:, i].sum() / fd.sum()))
 counts = np.zeros((8192, 10, 64), np.uint32)
 lib.sk_debug_ec_counts(counts.ctypes.data_as(C.c_void_p))
 cw = counts[:len(used)]
