@@ -475,6 +475,9 @@ SKE int band_range(const uint16_t *off, int bands, int sfb, int *s, int *e) {  /
     return EC_OK;
 }
 
+struct alignas(16) NoiseQuad {
+    float v[4];
+};
 SKE int noise_band(float scale, uint32_t &state, float *__restrict__ out, int n) {  // spectral.rs:2416-2450
     if (n == 0) return EC_OK;
     // the reference writes the raw noise, sums its energy, then scales in place; here the generator runs twice from the
@@ -491,7 +494,18 @@ SKE int noise_band(float scale, uint32_t &state, float *__restrict__ out, int n)
         return EC_INVALID_BITSTREAM;
     }
     const float normalizer = scale / ec_sqrtf(energy);
-    for (int i = 0; i < n; ++i) {
+    int i = 0;
+    if ((((uintptr_t)out) & 15u) == 0) {  // bands start on multiples of four lines of a 4 KiB-aligned spectrum: 16-byte stores
+        for (; i + 4 <= n; i += 4) {
+            NoiseQuad q4;
+            for (int k = 0; k < 4; ++k) {
+                state = state * 1664525u + 1013904223u;
+                q4.v[k] = (float)(int16_t)((int32_t)state >> 16) * normalizer;
+            }
+            memcpy((NoiseQuad *)__builtin_assume_aligned(out + i, 16), &q4, 16);
+        }
+    }
+    for (; i < n; ++i) {
         state = state * 1664525u + 1013904223u;
         out[i] = (float)(int16_t)((int32_t)state >> 16) * normalizer;
     }
@@ -833,6 +847,21 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
                     if (k >= 0 && k < dim) q[k] += q[k] > 0 ? amp[p] : -amp[p];
                 }
                 const int at = (is_short ? w * 128 : 0) + i;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SK_EC_SCALAR_STORES)
+                // device: a codeword's values leave in ONE store (16 bytes for the four-value books, 8 for the others; bands
+                // start on multiples of four lines): a scalar store is a separate partial cache line per lane and value
+                if (!QUANT && (((uintptr_t)coef) & 15u) == 0 && (at & (dim - 1)) == 0) {
+                    if (dim == 4) {
+                        NoiseQuad v4;
+                        for (int k = 0; k < 4; ++k) v4.v[k] = dequantize(t, q[k], scale);
+                        memcpy((NoiseQuad *)__builtin_assume_aligned(coef + at, 16), &v4, 16);
+                    } else {
+                        struct alignas(8) Pair { float v[2]; } v2;
+                        for (int k = 0; k < 2; ++k) v2.v[k] = dequantize(t, q[k], scale);
+                        memcpy((Pair *)__builtin_assume_aligned(coef + at, 8), &v2, 8);
+                    }
+                } else
+#endif
                 for (int k = 0; k < 4; ++k) {
                     if (k >= dim) break;
                     if (QUANT) {
