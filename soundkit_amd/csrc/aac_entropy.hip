@@ -105,8 +105,10 @@ __device__ __forceinline__ sk_ec::Tables lds_tables(const EntropyArgs &a, uint4 
 __device__ __forceinline__ bool unit_of_lane(const EntropyArgs &a, uint32_t &k) {
     const uint32_t per_wave = 64u >> a.lane_shift;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    k = wave * per_wave + lane;
-    return lane < per_wave && k < a.n_units;
+    const uint32_t slot = wave * per_wave + lane;
+    const bool mine = lane < per_wave && slot < a.n_units;
+    k = (mine && a.order) ? a.order[slot] : slot;
+    return mine;
 }
 
 // The spectra of a wave's units, zeroed by all 64 lanes together (16 bytes per lane, whole cache lines) before any lane
@@ -115,9 +117,9 @@ __device__ __forceinline__ void wave_zero_spectra(const EntropyArgs &a) {
     const uint32_t per_wave = 64u >> a.lane_shift;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     for (uint32_t l = 0; l < per_wave; ++l) {
-        const uint32_t k = wave * per_wave + l;  // wave-uniform
-        if (k >= a.n_units) break;
-        const EntropyUnit u = a.units[k];
+        const uint32_t slot = wave * per_wave + l;  // wave-uniform
+        if (slot >= a.n_units) break;
+        const EntropyUnit u = a.units[a.order ? a.order[slot] : slot];
         const uint32_t quads = a.tasks[u.task].channels * 256u;
         float4 *dst = reinterpret_cast<float4 *>(a.coeffs + (size_t)u.off1024 * 1024);
 #ifdef SK_EC_ABLATE_FILL  // timing experiment: stale spectra

@@ -2280,6 +2280,16 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                     return v && v[0] >= '0' && v[0] <= '4' ? (int)(v[0] - '0') : -1;
                 }();
                 ea.lane_shift = forced_shift >= 0 ? (uint32_t)forced_shift : (n_frames <= 32768 ? 2u : (n_frames <= 131072 ? 1u : 0u));
+                // slot -> unit, by size (a counting sort on byte_len / 8): a wave's lanes then carry units with about the same
+                // number of codewords instead of waiting for the largest of 32 arbitrary ones.  SK_ENTROPY_UNSORTED=1: as given.
+                static const bool unsorted = std::getenv("SK_ENTROPY_UNSORTED") != nullptr;
+                if (!q_mode && !unsorted && n_frames > 64) {
+                    std::vector<uint32_t> order(n_frames), start(1026, 0);
+                    for (uint32_t k = 0; k < n_frames; ++k) ++start[std::min<uint32_t>(eu[k].byte_len >> 3, 1023) + 1];
+                    for (uint32_t b = 1; b < 1026; ++b) start[b] += start[b - 1];
+                    for (uint32_t k = 0; k < n_frames; ++k) order[start[std::min<uint32_t>(eu[k].byte_len >> 3, 1023)]++] = k;
+                    SK_HIP(aux.put(order, e->stream, &ea.order), "upload entropy unit order");
+                }
                 ea.side = (sk_ec::Scratch *)e->tick_side.p;
                 ea.pns_start = (uint32_t *)((uint8_t *)e->tick_side.p + (((size_t)n_frames * sizeof(sk_ec::Scratch) + 15) & ~(size_t)15));
                 SK_HIP(sk::launch_aac_entropy_parallel(ea, e->stream), "launch entropy decode");

@@ -258,6 +258,8 @@ struct EntropyArgs {
     sk_ec::Scratch *side;  // [n_units] side information handed from the first phase to the third
     uint32_t *pns_start;   // [n_units] generator state each unit starts from
     uint32_t lane_shift;   // the first 64 >> lane_shift lanes of a wave carry a unit each (0..4)
+    const uint32_t *order; // [n_units] or null: slot -> unit.  A wave runs until its slowest lane is done: the host hands out the
+                           // units sorted by size, so that a wave's lanes have about the same number of codewords
     // quantised hand-over (sk_tick_run_q): instead of parsing, phase one rebuilds the side information from the host's
     // record and dequantises the host's integers; phase three ends with the host's verdict on the rest of the unit
     const sk_ec::WireUnit *wire;  // [n_units], null in the other modes

@@ -10,19 +10,26 @@ import soundkit_amd
 from soundkit_amd import aac_lc
 
 n_streams, n_ticks = int(sys.argv[1]), int(sys.argv[2])
-root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "aac", "aac-stereo-48k.adts")
-frames = aac_lc.split_adts(open(root, "rb").read())
-aus = [au for _, au in frames]
+gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "aac")
+# SK_TICK_CLIPS=all: streams take turns over the three stereo fixtures (48 + 131 + 46 distinct access units, three sampling
+# rates) instead of the 48 kHz clip alone -- fewer identical units side by side in a wave
+names = ["aac-stereo-48k.adts", "stereo-music-44100-192k.aac", "A_Tusk_is_used_to_make_costly_gifts_encoded.aac"] \
+    if os.environ.get("SK_TICK_CLIPS") == "all" else ["aac-stereo-48k.adts"]
+rates = {"aac-stereo-48k.adts": 48000, "stereo-music-44100-192k.aac": 44100, "A_Tusk_is_used_to_make_costly_gifts_encoded.aac": 16000}
+clips = [(rates[n], [au for _, au in aac_lc.split_adts(open(os.path.join(gold, n), "rb").read())]) for n in names]
 eng = soundkit_amd.Engine(0, max(n_streams, 16))
-sids = []
+sids, clip_of = [], []
 for i in range(n_streams):
-    sid = eng.open_stream(48000, 2)
-    eng.resampler_open(sid, 48000, 16000)
+    rate, _ = clips[i % len(clips)]
+    sid = eng.open_stream(rate, 2)
+    eng.resampler_open(sid, rate, 16000)
     sids.append(sid)
-pos = [(7 * i) % len(aus) for i in range(n_streams)]
+    clip_of.append(i % len(clips))
+pos = [(7 * i) % len(clips[clip_of[i]][1]) for i in range(n_streams)]
 for t in range(n_ticks):
     table, units = [], []
     for i, sid in enumerate(sids):
+        aus = clips[clip_of[i]][1]
         take = [aus[(pos[i] + k) % len(aus)] for k in range(16)]
         pos[i] = (pos[i] + 16) % len(aus)
         table.append({"stream": sid, "n_frames": 16, "out_bits": 16, "out_channels": 1, "resample": True, "flush": False})
