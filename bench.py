@@ -592,8 +592,7 @@ def main():
     synth_f32_ms = None
     if rank == 0 and args.workload == "pipeline" and args.chain == "s16" and not args.separate_s16:
         # reference point for the roofline: the same kernel writing f32 PCM (8 KiB per channel-frame instead of 6), a few
-        # launches outside the timed region.  The s16 variant is bound by vector issue (its 16 conversions per lane and
-        # frame), the f32 one by what this access pattern streams (profiles/r02_ab_synth_groups.md).
+        # launches outside the timed region (profiles/r02_pmc_aac_synth.md has both under the counters).
         scratch = torch.empty_like(coeffs)
         for _ in range(2):
             plan.run_f32(coeffs, scratch)
@@ -682,8 +681,9 @@ def main():
                 "achieved_canonical_32768B_per_stereo_frame": canonical_bytes / (ms * 1e-3) / 1e9,
             }
             if s16_between:
-                rl["k_aac_synth"]["note"] = ("s16-output variant (k_aac_synth<true, true>): bound by vector issue, not by HBM -- the f32-output variant "
-                                             "of the same kernel moves 33 % more bytes in the same time (same_kernel_f32_out)")
+                rl["k_aac_synth"]["note"] = ("s16-output variant (k_aac_synth_pair<true>: two channels per wave, float_sample_to_i16 fused); the "
+                                             "f32-output instance of the same kernel, timed after the run, is in same_kernel_f32_out")
+                rl["k_aac_synth"]["kernel"] = "k_aac_synth_pair (channels without a partner: k_aac_synth)"
                 if synth_f32_ms:
                     f32_bytes = streams * frames * ch * 8192 + streams * ch * 8192
                     rl["k_aac_synth"]["same_kernel_f32_out"] = {"avg_launch_ms": synth_f32_ms, "achieved": f32_bytes / (synth_f32_ms * 1e-3) / 1e9,
@@ -703,8 +703,8 @@ def main():
                     "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                     "traffic": pmc_traffic(pmc_kind + "_f32", rows=streams * ch, frames=fir_in), "avg_launch_ms": ms}
             else:
-                # fir_bf16.hip: 41 bf16 MFMAs per 16 x 16 outputs = 2624 issued flop per output, 1/16 of the time
-                # they would take on the f32 matrix path; what bounds the launch now is its own HBM traffic:
+                # fir_bf16.hip: 24 (s16 rows, f16) to 41 (f32 rows, bf16) MFMAs per 16 x 16 outputs, 1/16 of the time they would take
+                # on the f32 matrix path; the bound the line reports is the kernel's own HBM traffic:
                 # 4 B per input sample + 4 B (f32) or 2 B (s16) per output sample
                 in_b = 2.0 if (fused and args.chain == "s16") else 4.0
                 fir_bytes = streams * ch * (fir_in * in_b + n_fir_out * (2.0 if fused else 4.0))
@@ -713,7 +713,11 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fir_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic": pmc_traffic(pmc_kind, rows=streams * ch, frames=fir_in), "avg_launch_ms": ms,
                     "algorithmic_tflops": flops / (ms * 1e-3) / 1e12,
-                    "issued_bf16_tflops": flops * (4.5 if in_b == 2.0 else 5.125) / (ms * 1e-3) / 1e12, "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TF,
+                    # issued = algorithmic x MFMAs per tile / 8 (one 16x16x32 MFMA = 256 outputs x 32 taps): f16 form of the s16 rows 24,
+                    # its bf16 form 36 (SK_FIR_S16_BF16=1), f32 rows 41; f16 and bf16 matrix peaks are the same
+                    "issued_matrix_tflops": flops * ((3.0 if os.environ.get("SK_FIR_S16_BF16") != "1" else 4.5) if in_b == 2.0 else 5.125) / (ms * 1e-3) / 1e12,
+                    "matrix_form": ("f16, 24 MFMAs per tile" if os.environ.get("SK_FIR_S16_BF16") != "1" else "bf16, 36 MFMAs per tile") if in_b == 2.0 else "bf16, 41 MFMAs per tile",
+                    "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TF,
                     "bytes_per_output_sample": 3 * in_b + (2.0 if fused else 4.0)}
         if "k_convert" in per_kernel:
             ms = per_kernel["k_convert"]
