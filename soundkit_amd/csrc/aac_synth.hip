@@ -43,7 +43,10 @@ namespace {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int kWavesPerBlock = 4;
+#ifndef SK_SYNTH_BLOCK_WAVES
+#define SK_SYNTH_BLOCK_WAVES 4
+#endif
+constexpr int kWavesPerBlock = SK_SYNTH_BLOCK_WAVES;
 #ifndef SK_WAVES_PER_SIMD
 #define SK_WAVES_PER_SIMD 3
 #endif
