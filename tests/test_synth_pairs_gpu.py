@@ -98,3 +98,69 @@ def test_transition_frames_take_the_long_kernels(engine, oracle):
     pcm1, status = aac_lc.synthesize_batch(engine, [mono] * (n - 1), 1, coeffs[:n - 1, :1], seqs[:n - 1], shapes[:n - 1])
     assert np.all(status == 0) and np.array_equal(pcm1[:, 0], pcm[:n - 1, 0])
     engine.close_stream(mono)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_plans_against_the_oracle(engine, oracle, seed):
+    """Random batches for the schedule builder: mono and stereo streams with 1-7 frames each in an arbitrary interleaving,
+    random window sequences (no EightShort / with transitions / with EightShort) and shapes -- so that one plan holds
+    two-channel-kernel pairs (equal counts), leftover one-channel long tasks and general tasks -- in two consecutive calls
+    (carried state), f32 against the oracle and s16 = float_sample_to_i16 of the f32 result."""
+    rng = np.random.default_rng(4000 + seed)
+    n_streams = 29
+    chans = [int(rng.integers(1, 3)) for _ in range(n_streams)]
+    sids = [engine.open_stream(48000, c) for c in chans]
+    kind = [int(rng.integers(0, 3)) for _ in range(n_streams)]   # 0 OnlyLong, 1 long + transitions, 2 anything
+    history = {s: ([], [], []) for s in range(n_streams)}          # coeffs, seqs, shapes over both calls
+    got_f32 = {s: [] for s in range(n_streams)}
+    for call in range(2):
+        counts = [int(rng.integers(1, 8)) if rng.random() > 0.15 else 0 for _ in range(n_streams)]
+        if seed == 1:
+            counts = [c if c == 0 else 4 + (s % 2) for s, c in enumerate(counts)]   # many equal counts: many pairs
+        frames = [(s, f) for s in range(n_streams) for f in range(counts[s])]
+        order = rng.permutation(len(frames))
+        per = {}
+        for s in range(n_streams):
+            c = chans[s]
+            x = np.stack([np.stack([oracle.seeded_spectrum(1024, 77 * seed + 1000 * call + 31 * s + 7 * f + ch) * np.float32(5000.0)
+                                    for ch in range(c)]) for f in range(counts[s])]) if counts[s] else np.zeros((0, c, 1024), np.float32)
+            choices = {0: [0], 1: [0, 1, 3], 2: [0, 1, 2, 3]}[kind[s]]
+            seqs = rng.choice(choices, (counts[s], 2)).astype(np.uint8)
+            shapes = rng.integers(0, 2, (counts[s], 2)).astype(np.uint8)
+            per[s] = (x, seqs, shapes)
+            for k, v in zip(range(3), (x, seqs, shapes)):
+                history[s][k].append(v)
+        # frames of a stream keep their order inside the interleaving
+        seen = {s: 0 for s in range(n_streams)}
+        sequence = []
+        for i in order:
+            s = frames[i][0]
+            sequence.append((s, seen[s]))
+            seen[s] += 1
+        descs = [(sids[s], chans[s], per[s][1][f], per[s][2][f]) for s, f in sequence]
+        arr, n = soundkit_amd.make_descs(descs)
+        coeffs = np.concatenate([per[s][0][f].ravel() for s, f in sequence]) if sequence else np.zeros(0, np.float32)
+        states = [engine.get_state(sids[s], chans[s]) for s in range(n_streams)]
+        pcm, status = engine.aac_synthesize(arr, n, coeffs)
+        assert np.all(status == 0)
+        for s in range(n_streams):   # the same call again from the same state, s16 out: the rounded f32
+            engine.set_state(sids[s], *states[s])
+        s16, status = engine.aac_synthesize(arr, n, coeffs, out="s16")
+        assert np.all(status == 0)
+        off = 0
+        for s, f in sequence:
+            size = chans[s] * 1024
+            got = pcm[off:off + size].reshape(chans[s], 1024)
+            got_f32[s].append(got)
+            assert np.array_equal(s16[off:off + size].reshape(1024, chans[s]), oracle.planar_f32_to_s16_interleaved(got).reshape(1024, chans[s]))
+            off += size
+    for s in range(n_streams):
+        x, seqs, shapes = (np.concatenate(history[s][k]) for k in range(3))
+        if len(x) == 0:
+            continue
+        want, _ = oracle.synthesize_stream(x, seqs, shapes)
+        got = np.stack(got_f32[s])
+        den = np.sqrt(np.mean(want.astype(np.float64) ** 2))
+        assert np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)) / den < 1.0e-6, (s, kind[s], chans[s])
+    for sid in sids:
+        engine.close_stream(sid)
