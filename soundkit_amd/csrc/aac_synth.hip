@@ -155,37 +155,6 @@ __device__ __forceinline__ void write_positions(lds_f *buf, int lane, const floa
     }
 }
 
-// sample t (0..255) of a 128-input IMDCT from its post-twiddled spectrum v[0..63] (dsp.rs:511-532)
-__device__ __forceinline__ float short_sample(const lds_f2 *v, int t) {
-    const int seg = t >> 6, u = t & 63;
-    const bool odd = u & 1;
-    const int lo = odd ? (63 - u) >> 1 : u >> 1;
-    switch (seg) {
-    case 0: return odd ? -v[lo].y : -v[32 + lo].x;
-    case 1: return odd ? v[32 + lo].x : v[lo].y;
-    case 2: return odd ? v[lo].x : v[32 + lo].y;
-    default: return odd ? v[32 + lo].y : v[lo].x;
-    }
-}
-
-// value at position p (0..2047) of the eight-short overlap buffer (dsp.rs:303-330)
-__device__ __forceinline__ float short_buffer_value(const lds_f2 *v, int p, const float *prev_short,
-                                                    const float *cur_short) {
-    const int q = p - 448;
-    if (q < 0 || q >= 1152) return 0.0f;
-    const int hi = q >> 7;
-    float acc = 0.0f;
-#pragma unroll
-    for (int d = 1; d >= 0; --d) {  // block hi-1 was accumulated before block hi
-        const int w = hi - d;
-        if (w < 0 || w > 7) continue;
-        const int t = q - 128 * w;
-        const float win = (w == 0 && t < 128) ? prev_short[t] : cur_short[t];
-        acc += short_sample(v + 64 * w, t) * win;
-    }
-    return acc;
-}
-
 // 512-point forward FFT of z (z[r] = element 64 r + lane) through two LDS exchanges:
 // n = 64 n1 + 8 n2 + n3, k = k1 + 8 k2 + 64 k3; on return z[j] = Z[lane + 64 j].
 // Stage 1 (lane = 8 n2 + n3) needs W64^{n2 k1}; stage 2 (lane = 8 n3 + k1) needs
@@ -264,22 +233,53 @@ __device__ __attribute__((noinline)) void synth_rare_frame(lds_f2 *ex, lds_f *st
             ex[64 * hi3 + k] = cmul(tw_short[k], (f2){z[ka].x, -z[ka].y});
         }
         wave_sync();
-#pragma unroll 1
-        for (int k = 0; k < 16; ++k) {
-            const int i = 64 * k + lane;
-            stage[i] = short_buffer_value(ex, i, prev_short, cur_short);
+        // The eight-short overlap buffer (dsp.rs:303-330), one 1024-sample half at a time in `stage`: block w puts its 256 windowed
+        // samples at 448 + 128 w; lane l takes samples t = l + 64 m (m = 0..3) of every block.  For those, the four-segment
+        // pattern of the 128-input IMDCT (dsp.rs:511-532) needs just two bins, v[lo] and v[32 + lo], lo = l / 2 for even
+        // lanes and (63 - l) / 2 for odd ones; which half a (w, m) falls into is the same for the whole wave and known at
+        // compile time (448 + 128 w + 64 m is a multiple of 64).  Even blocks do not overlap each other, nor do odd ones: the
+        // even blocks are added to the zeroed half first, the odd ones after them -- every sample is 0 + a + b as in the
+        // reference (its a and b may come the other way round: the sum of two numbers does not care).
+        const bool odd_lane = lane & 1;
+        const int lo = odd_lane ? (63 - lane) >> 1 : lane >> 1;
+        float cw[4], pw[2];  // this lane's window values: the current shape's short window at l + 64 m, the previous one's rising half
+#pragma unroll
+        for (int m = 0; m < 4; ++m) cw[m] = cur_short[lane + 64 * m];
+        pw[0] = prev_short[lane];
+        pw[1] = prev_short[lane + 64];
+        float smp[8][4];  // windowed sample m of block w
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const f2 A = ex[64 * w + lo], B = ex[64 * w + 32 + lo];
+            const float s0 = odd_lane ? -A.y : -B.x, s1 = odd_lane ? B.x : A.y, s2 = odd_lane ? A.x : B.y, s3 = odd_lane ? B.y : A.x;
+            smp[w][0] = s0 * (w == 0 ? pw[0] : cw[0]);
+            smp[w][1] = s1 * (w == 0 ? pw[1] : cw[1]);
+            smp[w][2] = s2 * cw[2];
+            smp[w][3] = s3 * cw[3];
         }
         wave_sync();
-        read_positions(stage, lane, o);
-        wave_sync();
-#pragma unroll 1
-        for (int k = 0; k < 16; ++k) {
-            const int i = 64 * k + lane;
-            stage[i] = short_buffer_value(ex, 1024 + i, prev_short, cur_short);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<lds_f4 *>(stage + 4 * lane + 256 * r) = (f4){0.f, 0.f, 0.f, 0.f};
+            wave_sync();
+#pragma unroll
+            for (int parity = 0; parity < 2; ++parity) {
+#pragma unroll
+                for (int w = parity; w < 8; w += 2)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int base = 448 + 128 * w + 64 * m;  // of lane 0; a multiple of 64
+                        if ((base >> 10) != half) continue;
+                        lds_f *at = stage + (base & 1023) + lane;
+                        *at = *at + smp[w][m];
+                    }
+                wave_sync();
+            }
+            if (half == 0) read_positions(stage, lane, o);
+            else read_positions(stage, lane, d);
+            wave_sync();
         }
-        wave_sync();
-        read_positions(stage, lane, d);
-        wave_sync();
     }
 
     // overlap-add (dsp.rs:277-278, 333-334)
