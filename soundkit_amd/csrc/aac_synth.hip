@@ -282,25 +282,16 @@ __device__ __attribute__((noinline)) void synth_rare_frame(lds_f2 *ex, lds_f *st
         }
     }
 
-    // overlap-add (dsp.rs:277-278, 333-334)
+    // overlap-add (dsp.rs:277-278, 333-334).  The PCM goes back through LDS too (the spectra in `ex` are used up): the caller
+    // stores it behind its spectrum prefetch, so that both arms of its frame loop leave the same memory operations in flight
+    // in the same order and the loop head can wait for the spectrum alone (see k_aac_synth)
+    float pcm[16];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int j = 4 * lane + 256 * r;
-        f4 f, m;
-        f.x = o[8 * r + 0] + dly[8 * r + 0]; f.y = o[8 * r + 1] + dly[8 * r + 1];
-        f.z = o[8 * r + 2] + dly[8 * r + 2]; f.w = o[8 * r + 3] + dly[8 * r + 3];
-        m.x = o[8 * r + 4] + dly[8 * r + 4]; m.y = o[8 * r + 5] + dly[8 * r + 5];
-        m.z = o[8 * r + 6] + dly[8 * r + 6]; m.w = o[8 * r + 7] + dly[8 * r + 7];
-        if (out16_ptr) {  // wave-uniform
-            *reinterpret_cast<u2 *>(out16_ptr + j) = pack4_s16(f);
-            *reinterpret_cast<u2 *>(out16_ptr + 1020 - j) = pack4_s16(m);
-        } else {
-            *reinterpret_cast<f4 *>(out_ptr + j) = f;
-            *reinterpret_cast<f4 *>(out_ptr + 1020 - j) = m;
-        }
-    }
+    for (int i = 0; i < 16; ++i) pcm[i] = o[i] + dly[i];
+    write_positions((lds_f *)ex, lane, pcm);
     write_positions(stage, lane, d);
     wave_sync();
+    (void)out_ptr, (void)out16_ptr;
 }
 
 // OUT16: the PCM leaves as planar s16 (float_sample_to_i16 of every sample; same [off1024][1024] packing, two bytes
@@ -491,20 +482,28 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
             synth_rare_frame(ex, stage, tw_lds, t64, base2.x, base2.y, a.t.win, reinterpret_cast<const f2 *>(a.t.w64),
                              reinterpret_cast<const f2 *>(a.t.tw_short), out_ptr, out16_ptr, seq, prev_shape, shape, lane);
             read_positions(stage, lane, dly);
+            float pcm[16];
+            read_positions((const lds_f *)ex, lane, pcm);
             wave_sync();
-            if (e + kDepth < count) {
-                const float *src =
-                    a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e + kDepth].off1024) * 1024 + 2 * lane;
+            // as in the long arm: the next spectrum first (unconditional), then this frame's four stores
+            {
+                const uint32_t ahead = e + kDepth < count ? e + kDepth : count - 1;
+                const float *src = a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[ahead].off1024) * 1024 + 2 * lane;
 #pragma unroll
-#ifdef SK_SYNTH_ABLATE_F4LOAD
-                for (int r = 0; r < 4; ++r) {
-                    const f4 v = *reinterpret_cast<const f4 *>(src + 2 * lane + 256 * r);
-                    xin[2 * r] = (f2){v.x, v.y};
-                    xin[2 * r + 1] = (f2){v.z, v.w};
-                }
-#else
                 for (int r = 0; r < 8; ++r) xin[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
-#endif
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int j = 4 * lane + 256 * r;
+                const f4 f = (f4){pcm[8 * r + 0], pcm[8 * r + 1], pcm[8 * r + 2], pcm[8 * r + 3]};
+                const f4 m = (f4){pcm[8 * r + 4], pcm[8 * r + 5], pcm[8 * r + 6], pcm[8 * r + 7]};
+                if (OUT16) {
+                    SK_SYNTH_STORE(pack4_s16(f), reinterpret_cast<u2 *>(out16_ptr + j));
+                    SK_SYNTH_STORE(pack4_s16(m), reinterpret_cast<u2 *>(out16_ptr + 1020 - j));
+                } else {
+                    SK_SYNTH_STORE(f, reinterpret_cast<f4 *>(out_ptr + j));
+                    SK_SYNTH_STORE(m, reinterpret_cast<f4 *>(out_ptr + 1020 - j));
+                }
             }
         }
         prev_shape = shape;  // decoder.rs:371
