@@ -157,6 +157,10 @@ struct sk_lane {
     uint32_t n_deliver = 1;
 
     std::atomic<uint64_t> n_ticks{0}, n_frames{0}, n_outputs{0}, n_errors{0}, parse_ns{0}, tick_ns{0}, idle_ns{0}, deliver_ns{0};
+    // SK_PIPELINE_WATCHDOG=<seconds>: a thread that prints where everybody stands when no tick has finished for that long
+    std::thread watchdog;
+    std::atomic<int> submit_where{0};     // 0 waits for work, 1 lets the batch fill, 2 waits for writers / a free batch, 3 in the tick, 4 hands over
+    std::atomic<uint32_t> workers_waiting_room{0}, workers_waiting_ready{0}, deliverers_waiting{0};
 };
 
 namespace {
@@ -390,12 +394,14 @@ void worker_main(sk_lane *p) {
         size_t desc_at, float_at, au_at;
         {
             std::unique_lock<std::mutex> lk(p->batch_mu);
+            p->workers_waiting_room.fetch_add(1);
             p->room_cv.wait(lk, [&] {
                 const Batch &f = p->batches[p->filling];
                 return p->stop || (f.n_descs + r.n_frames <= p->cfg.max_frames_per_tick &&
                                    (gpu_entropy ? f.au_used + r.n_au_bytes <= f.au_cap : f.n_floats + r.n_floats <= f.coeff_cap) &&
                                    (!quant || f.au_used + r.n_au_bytes <= f.au_cap));
             });
+            p->workers_waiting_room.fetch_sub(1);
             if (p->stop) return;
             b = &p->batches[p->filling];
             desc_at = b->n_descs;
@@ -461,8 +467,10 @@ void submit_main(sk_lane *p) {
         {
             std::unique_lock<std::mutex> lk(p->batch_mu);
             const Clock::time_point t_idle = Clock::now();
+            p->submit_where = 0;
             p->batch_cv.wait(lk, [&] { return p->stop || !p->batches[p->filling].ts.empty(); });
             if (p->stop) return;
+            p->submit_where = 1;
             // let the batch fill for a moment unless it is already full
             // (system_clock deadline: pthread_cond_timedwait, which every sanitizer runtime understands)
             const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(p->cfg.tick_wait_us);
@@ -470,8 +478,10 @@ void submit_main(sk_lane *p) {
                 return p->stop || p->batches[p->filling].n_descs + p->cfg.max_stream_frames_per_tick > p->cfg.max_frames_per_tick;
             });
             // the workers move on to a free batch while this one runs
+            p->submit_where = 2;
             p->batch_cv.wait(lk, [&] { return p->stop || (p->batches[p->filling].writers == 0 && !p->free_batches.empty()); });
             if (p->stop) return;
+            p->submit_where = 3;
             p->idle_ns.fetch_add(ns_since(t_idle));
             index = p->filling;
             b = &p->batches[index];
@@ -518,6 +528,7 @@ void submit_main(sk_lane *p) {
                 b->rc = sk_tick_run(p->engine, ts.data(), (uint32_t)ts.size(), b->descs.data(), b->coeffs, n_frames, b->out_pinned,
                                     b->out_pinned_cap, b->recs.data(), max_out, &b->n_out, &used);
         }
+        p->submit_where = 4;
         p->tick_ns.fetch_add(ns_since(t0));
         p->n_ticks.fetch_add(1);
         p->n_frames.fetch_add(n_frames);
@@ -537,6 +548,8 @@ void submit_main(sk_lane *p) {
     }
 }
 
+void watchdog_main(sk_lane *p, int secs);
+
 // Hands a finished tick's outputs to the streams' queues: outputs first (in order), then the end-of-stream /
 // error notes, then the stream is free to be parsed again.
 void deliver_main(sk_lane *p) {
@@ -548,7 +561,9 @@ void deliver_main(sk_lane *p) {
         uint32_t slice;
         {
             std::unique_lock<std::mutex> lk(p->batch_mu);
+            p->deliverers_waiting.fetch_add(1);
             p->deliver_cv.wait(lk, [&] { return p->stop || !p->to_deliver.empty(); });
+            p->deliverers_waiting.fetch_sub(1);
             if (p->stop) return;
             index = p->to_deliver.front();
             p->to_deliver.pop_front();
@@ -782,8 +797,61 @@ int lane_create(sk_engine *e, const sk_pipeline_config *cfg, OutQueue *oq, uint3
         if (n >= 1 && n <= 16) p->n_deliver = (uint32_t)n;
     }
     for (uint32_t d = 0; d < p->n_deliver; ++d) p->deliverers.emplace_back(deliver_main, p);
+    if (const char *env = std::getenv("SK_PIPELINE_WATCHDOG")) {
+        const int secs = std::atoi(env);
+        if (secs > 0) p->watchdog = std::thread(watchdog_main, p, secs);
+    }
     *out = p;
     return SK_OK;
+}
+
+// SK_PIPELINE_WATCHDOG: no locks are taken for the stream table (a dump of a stuck pipeline must not get stuck itself);
+// the batch fields are read under batch_mu with try_lock
+void watchdog_main(sk_lane *p, int secs) {
+    uint64_t last = p->n_ticks.load();
+    int quiet = 0;
+    for (;;) {
+        for (int i = 0; i < 10; ++i) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            if (p->stop) return;
+        }
+        const uint64_t now = p->n_ticks.load();
+        quiet = now == last ? quiet + 1 : 0;
+        last = now;
+        if (quiet < secs || quiet % secs) continue;
+        size_t with_input = 0, busy = 0, queued = 0, out_full = 0, open = 0, more = 0, finished = 0;
+        for (auto &sp : p->streams) {
+            PStream &s = *sp;
+            if (!s.open) continue;
+            ++open;
+            with_input += !s.in.empty();
+            busy += s.busy;
+            queued += s.queued;
+            more += s.more;
+            finished += s.finished;
+            out_full += s.out.size() >= p->cfg.output_buffer;
+        }
+        std::fprintf(stderr, "[sk_pipeline watchdog] lane %u: no tick for %d s (ticks %llu) | submitter at %d | workers waiting: room %u | "
+                             "deliverers waiting %u | streams open %zu input %zu busy %zu queued %zu more %zu finished %zu out-full %zu\n",
+                     p->lane_index, quiet, (unsigned long long)now, p->submit_where.load(), p->workers_waiting_room.load(),
+                     p->deliverers_waiting.load(), open, with_input, busy, queued, more, finished, out_full);
+        if (p->batch_mu.try_lock()) {
+            std::fprintf(stderr, "    filling %d free %zu to_deliver %zu |", p->filling, p->free_batches.size(), p->to_deliver.size());
+            for (int i = 0; i < sk_lane::kBatches; ++i)
+                std::fprintf(stderr, " batch %d: streams %zu frames %zu writers %u slices %u/%u |", i, p->batches[i].ts.size(), p->batches[i].n_descs,
+                             p->batches[i].writers, p->batches[i].slices_done, p->batches[i].next_slice);
+            std::fprintf(stderr, "\n");
+            p->batch_mu.unlock();
+        } else {
+            std::fprintf(stderr, "    batch_mu is held\n");
+        }
+        if (p->rq_mu.try_lock()) {
+            std::fprintf(stderr, "    ready queue %zu\n", p->ready.size());
+            p->rq_mu.unlock();
+        } else {
+            std::fprintf(stderr, "    rq_mu is held\n");
+        }
+    }
 }
 
 void lane_destroy(sk_lane *p) {
@@ -800,6 +868,7 @@ void lane_destroy(sk_lane *p) {
     for (std::thread &t : p->workers) t.join();
     if (p->submitter.joinable()) p->submitter.join();
     for (std::thread &t : p->deliverers) t.join();
+    if (p->watchdog.joinable()) p->watchdog.join();
     for (auto &s : p->streams) release_device_side(p, *s);
     for (Batch &b : p->batches) {
         if (b.coeffs) (void)hipHostFree(b.coeffs);
