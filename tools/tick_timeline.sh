@@ -22,7 +22,7 @@ rows = []
 for a, b in zip(starts, starts[1:]):
     seg = ev[a:b]
     parse = seg[0][1] - seg[0][0]
-    if parse < 1.0e6: continue  # small ticks
+    if parse < 0.4e6: continue  # small ticks
     busy = {}
     last_end = seg[0][0]; gap = 0
     for s, e, n in seg:
