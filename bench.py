@@ -251,6 +251,13 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
             t.start()
         for t in ths:
             t.join()
+        if any(rc == -8 for rc in rcs):
+            # the load generator's progress deadline: its record (the scheduler's threads, batches, stream table and the
+            # engine's stage) is on stderr.  Leave at once, without tearing the pipeline down: a device that stopped
+            # answering would hold the teardown too, and the record is what matters.
+            sys.stderr.write("bench.py: the end-to-end run stalled (SK_ERR_TIMEOUT from the load generator); state dumped above\n")
+            sys.stderr.flush()
+            os._exit(3)
         if any(rcs) or any(r.errors for r in results):
             raise SystemExit("load generator failed: rc %s, %d stream errors" % (rcs, sum(r.errors for r in results)))
         tot = Summed()

@@ -47,7 +47,8 @@ typedef enum sk_status {
     SK_ERR_OOM = -4,
     SK_ERR_BAD_STREAM = -5,  /* stream id not open */
     SK_ERR_UNSUPPORTED = -6, /* e.g. resample ratio other than 48k->16k on the MFMA path */
-    SK_ERR_CAPACITY = -7     /* max_streams exhausted */
+    SK_ERR_CAPACITY = -7,    /* max_streams exhausted */
+    SK_ERR_TIMEOUT = -8      /* the device did not finish a tick within the engine's wait bound (sk_engine_set_wait_bound) */
 } sk_status;
 
 /* per-frame status words written by the AAC entry points */
@@ -83,6 +84,13 @@ uint32_t sk_engine_max_streams(const sk_engine *);
 void *sk_engine_hip_stream(sk_engine *); /* hipStream_t */
 int sk_engine_synchronize(sk_engine *);
 const char *sk_engine_last_hip_error(const sk_engine *);
+/* Diagnostics (no reference counterpart).  sk_engine_where: the stage the engine's current tick is in, as static text,
+ * readable from any thread without the engine's lock ("idle" outside a tick).  sk_engine_set_wait_bound: how long a
+ * tick waits for the device before it gives up with SK_ERR_TIMEOUT (default 120 s) instead of blocking for good.
+ * sk_engine_debug_fail_after: the n-th HIP call from now fails as a launch failure (error-path tests; 0 disarms). */
+const char *sk_engine_where(const sk_engine *);
+int sk_engine_set_wait_bound(sk_engine *, double seconds);
+int sk_engine_debug_fail_after(sk_engine *, int n_hip_calls);
 const char *sk_strerror(int status);
 const char *sk_version(void);
 
@@ -161,10 +169,11 @@ int sk_aac_decoder_parse(sk_aac_decoder *, const uint8_t *access_unit, size_t le
  * values + scalefactor bytes"): quant receives channels x 1024 i16 quantised values (pulses applied, spectral.rs:327-423,
  * 2198-2247), side a SK_AAC_UNIT_SIDE_BYTES record (section codebooks, transmitted scale factors, grouping, mid/side mask,
  * TNS filters, noise-sample count, and the verdict on the rest of the unit), desc the window fields.  Dequantisation
- * (dsp.rs:397-405), PNS, intensity + mid/side and TNS then run on the device: sk_tick_run_q.  5.3 KiB per stereo
+ * (dsp.rs:397-405), PNS, intensity + mid/side and TNS then run on the device: sk_tick_run_q.  5.6 KiB per stereo
  * access unit cross PCIe instead of 8 KiB.  A quantised magnitude beyond i16 (illegal in ISO/IEC 14496-3, which stops at
- * 8191; the reference accepts escapes up to 2^17) is SK_AAC_ERR_UNSUPPORTED_FEATURE here. */
-#define SK_AAC_UNIT_SIDE_BYTES 1308u
+ * 8191; the reference accepts escapes up to 2^17, spectral.rs:214-228) travels in the record's list of wide values, up
+ * to 48 per access unit; the 49th is SK_AAC_ERR_UNSUPPORTED_FEATURE in this mode only. */
+#define SK_AAC_UNIT_SIDE_BYTES 1600u
 int sk_aac_decoder_parse_q(sk_aac_decoder *, const uint8_t *access_unit, size_t len, int16_t *quant /*[ch][1024]*/,
                            void *side /*SK_AAC_UNIT_SIDE_BYTES*/, sk_aac_frame_desc *desc);
 int sk_adts_parse(const uint8_t *data, size_t len, size_t *frame_len, size_t *payload_off, size_t *payload_len,
@@ -420,6 +429,14 @@ int sk_tick_run_au(sk_engine *, const sk_tick_stream *streams, uint32_t n_stream
 int sk_tick_run_q(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, const sk_aac_frame_desc *descs,
                   const void *sides /*[n_units][SK_AAC_UNIT_SIDE_BYTES]*/, const int16_t *quant, uint32_t n_units, uint8_t *out_bytes,
                   size_t out_cap, sk_tick_output *outputs, uint32_t outputs_cap, uint32_t *n_outputs, size_t *out_bytes_used);
+/* The device half of the quantised hand-over alone (what sk_aac_entropy_decode is for the full device front-end): the
+ * records and integers of sk_aac_decoder_parse_q in, and back come the finished spectra [unit][channels][1024] (dequantised,
+ * noise filled, intensity / mid-side, TNS: dsp.rs:397-405, spectral.rs:2408-2460, stereo.rs:114-448, tns.rs:103-276), the
+ * window fields and one sk_aac_status per unit -- nothing is synthesised.  descs[k].stream names the unit's stream as
+ * in sk_tick_run_q; the streams' PNS generators advance as in a tick. */
+int sk_aac_expand_q_decode(sk_engine *, const uint32_t *streams, const uint32_t *units_per_stream, uint32_t n_streams,
+                           const sk_aac_frame_desc *descs, const void *sides /*[n_units][SK_AAC_UNIT_SIDE_BYTES]*/, const int16_t *quant,
+                           uint32_t n_units, float *coeffs_out, sk_aac_frame_desc *descs_out, int32_t *status_out);
 
 /* The front-end alone, batched on the GPU: AacLcDecoder::decode_access_unit (soundkit-aac-lc/src/decoder.rs:104-164) up to
  * the hand-over to synthesis (decoder.rs:336) for every listed unit -- the device counterpart of sk_aac_decoder_parse.
@@ -511,6 +528,9 @@ int sk_pipeline_wait_outputs(sk_pipeline *, uint32_t *handles, uint32_t cap, uin
 int sk_pipeline_cancel(sk_pipeline *, uint32_t handle); /* cancel() / Drop, lib.rs:2860-2889: frees the handle */
 size_t sk_pipeline_queued_input_bytes(sk_pipeline *, uint32_t handle); /* lib.rs:2863-2866 */
 int sk_pipeline_get_stats(sk_pipeline *, sk_pipeline_stats *out);
+/* Where every thread of the scheduler stands, the batches, the stream table in counts and the engine's stage, as text
+ * (what SK_PIPELINE_WATCHDOG=<seconds> prints when ticks stop).  Takes no lock it could block on.  Returns the length. */
+size_t sk_pipeline_debug_dump(sk_pipeline *, char *buf, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("SOUNDKIT_AMD_LIB") or os.path.join(_HERE, "libsoundki
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "soundkit_amd.h")
 
 SK_OK = 0
-AAC_UNIT_SIDE_BYTES = 1308  # SK_AAC_UNIT_SIDE_BYTES
+AAC_UNIT_SIDE_BYTES = 1600  # SK_AAC_UNIT_SIDE_BYTES
 ERR_NAMES = {0: "SK_OK", -1: "SK_ERR_INVALID_ARG", -2: "SK_ERR_NO_DEVICE", -3: "SK_ERR_HIP", -4: "SK_ERR_OOM",
              -5: "SK_ERR_BAD_STREAM", -6: "SK_ERR_UNSUPPORTED", -7: "SK_ERR_CAPACITY",
              -101: "UnexpectedEof", -102: "InvalidAudioObjectType", -103: "UnsupportedAudioObjectType",
@@ -199,6 +199,11 @@ _sig = {
     "sk_mp3_hybrid_synthesize_s16": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "sk_mp3_hybrid_synthesize_f32_dev": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "sk_aac_entropy_decode": (_i, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _sz, _vp, _vp, _vp]),
+    "sk_aac_expand_q_decode": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "sk_engine_where": (C.c_char_p, [_vp]),
+    "sk_engine_set_wait_bound": (_i, [_vp, C.c_double]),
+    "sk_engine_debug_fail_after": (_i, [_vp, _i]),
+    "sk_pipeline_debug_dump": (_sz, [_vp, _vp, _sz]),
     "sk_tick_out_bound": (_sz, [_vp, _u32, C.POINTER(_u32)]),
     "sk_tick_run": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
 }
@@ -227,6 +232,6 @@ class SoundkitError(RuntimeError):
 def check(status, what, engine_handle=None):
     if status != SK_OK:
         detail = ""
-        if engine_handle is not None and status in (-3, -4):
+        if engine_handle is not None and status in (-3, -4, -8):
             detail = lib.sk_engine_last_hip_error(engine_handle).decode()
         raise SoundkitError(status, what, detail)

@@ -176,16 +176,20 @@ __global__ __launch_bounds__(512) void k_aac_expand_q(EntropyArgs a) {
     const EntropyUnit u = a.units[k];
     const EntropyTask tk = a.tasks[u.task];
     const sk_ec::Stream st{tk.sf_index, (int)tk.channels, 0u};
-    sk_ec::Scratch side;
-    sk_ec::unpack_unit(t, a.wire[k], side);
+    // every byte of the record the later phases read is defined: link / finish / seal take it from global memory, and
+    // sk_tick_run_q is a public entry point (a caller's record is checked, not trusted)
+    sk_ec::Scratch side{};
+    int status = sk_ec::unpack_unit(t, a.wire[k], side);
+    if (status == sk_ec::EC_OK && (uint32_t)a.wire[k].channels != tk.channels) status = sk_ec::EC_INVALID_CONFIG;
     float *coef = a.coeffs + (size_t)u.off1024 * 1024;
     const int16_t *q = a.quant + (size_t)u.off1024 * 1024;
-    int status = (uint32_t)a.wire[k].channels == tk.channels ? sk_ec::EC_OK : sk_ec::EC_INVALID_CONFIG;
     for (uint32_t c = 0; c < tk.channels && status == sk_ec::EC_OK; ++c) status = sk_ec::dequant_channel(t, st, side.ch[c], q + 1024 * c, coef + 1024 * c);
+    if (status == sk_ec::EC_OK) status = sk_ec::apply_wide(a.wire[k], tk.channels, side, t, st, q, coef);
+    if (status != sk_ec::EC_OK) side.noise_samples = 0;  // a record that was rejected consumed no noise
     a.status[k] = status;
     a.side[k] = side;
     for (uint32_t c = 0; c < tk.channels; ++c)
-        a.entries[u.entry[c]].win = (uint32_t)side.ch[c].ics.sequence | ((uint32_t)side.ch[c].ics.shape << 2);
+        a.entries[u.entry[c]].win = status == sk_ec::EC_OK ? ((uint32_t)side.ch[c].ics.sequence | ((uint32_t)side.ch[c].ics.shape << 2)) : 0u;
 }
 
 __global__ __launch_bounds__(64) void k_aac_entropy_link(EntropyArgs a) {

@@ -545,11 +545,31 @@ enum PnsMode {
 
 // QUANT: instead of the dequantised spectrum, the quantised values themselves (pulses applied) go to `quant` as i16 --
 // what the host front-end hands to the device when dequantisation, noise, stereo tools and TNS run there (SURVEY 8f rank
-// 1).  A magnitude beyond i16 (only an escape sequence of more than 11 extra bits can produce one; ISO/IEC 14496-3 allows
-// 8191) is reported as an unsupported feature in that mode.  mode must be PNS_COUNT; coef is not touched.
+// 1).  The reference accepts escape sequences of up to 16 extra bits (spectral.rs:214-228: magnitudes to 131071; ISO/IEC
+// 14496-3 allows 8191), which an i16 cannot hold: a value beyond +-32767 leaves the marker -32768 in `quant` and goes,
+// with its position, into the unit's short list of wide values (kWideMax per access unit; one more is reported as an
+// unsupported feature -- no encoder produces even one).  mode must be PNS_COUNT; coef is not touched.
+constexpr int kWideMax = 48;
+constexpr int16_t kWideMarker = -32768;
+struct WideList {
+    uint32_t n;
+    uint16_t pos[kWideMax];  // channel * 1024 + line
+    int32_t val[kWideMax];
+};
+SKE int16_t quant_store(int q, int pos, WideList *wide, int *status) {
+    if (q <= 32767 && q >= -32767) return (int16_t)q;
+    if (!wide || wide->n >= (uint32_t)kWideMax) {
+        *status = EC_UNSUPPORTED_FEATURE;
+        return 0;
+    }
+    wide->pos[wide->n] = (uint16_t)pos;
+    wide->val[wide->n] = q;
+    wide->n += 1;
+    return kWideMarker;
+}
 template <bool QUANT>
 SKE int decode_spectrum_nested(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
-                               PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant) {
+                               PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant, WideList *wide = nullptr, int wide_base = 0) {
     const Ics ics = ch.ics;
     const int stride = band_stride(ics);
     const int max_sfb = ics.max_sfb, num_groups = ics.num_groups;
@@ -599,8 +619,7 @@ SKE int decode_spectrum_nested(const Tables &t, Stream &st, Bits &bits, const Ch
                             if (status != EC_OK) break;
                             for (int k = 0; k < dim; ++k) {
                                 if (QUANT) {
-                                    if (q[k] > 32767 || q[k] < -32768) status = EC_UNSUPPORTED_FEATURE;
-                                    quant[w * 128 + i + k] = (int16_t)q[k];
+                                    quant[w * 128 + i + k] = quant_store(q[k], wide_base + w * 128 + i + k, wide, &status);
                                 } else {
                                     coef[w * 128 + i + k] = dequantize(t, q[k], scale);
                                 }
@@ -660,8 +679,7 @@ SKE int decode_spectrum_nested(const Tables &t, Stream &st, Bits &bits, const Ch
                 }
                 for (int k = 0; k < dim; ++k) {
                     if (QUANT) {
-                        if (q[k] > 32767 || q[k] < -32768) status = EC_UNSUPPORTED_FEATURE;
-                        quant[i + k] = (int16_t)q[k];
+                        quant[i + k] = quant_store(q[k], wide_base + i + k, wide, &status);
                     } else {
                         coef[i + k] = dequantize(t, q[k], scale);
                     }
@@ -717,7 +735,7 @@ static unsigned long g_flat_passes = 0, g_flat_codewords = 0;
 #endif
 template <bool QUANT>
 SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
-                             PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant) {
+                             PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant, WideList *wide = nullptr, int wide_base = 0) {
     const Ics ics = ch.ics;
     const int stride = band_stride(ics);
     const int max_sfb = ics.max_sfb, num_groups = ics.num_groups;
@@ -865,8 +883,7 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
                 for (int k = 0; k < 4; ++k) {
                     if (k >= dim) break;
                     if (QUANT) {
-                        if (q[k] > 32767 || q[k] < -32768) status = EC_UNSUPPORTED_FEATURE;
-                        quant[at + k] = (int16_t)q[k];
+                        quant[at + k] = quant_store(q[k], wide_base + at + k, wide, &status);
                     } else {
 #ifdef SK_EC_ABLATE_STORE  // timing experiment: the spectrum is computed but (almost) never stored
                         const float dq = dequantize(t, q[k], scale);
@@ -936,11 +953,11 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
 
 template <bool QUANT>
 SKE int decode_spectrum_t(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
-                          PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant) {
+                          PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant, WideList *wide = nullptr, int wide_base = 0) {
 #if defined(__HIP_DEVICE_COMPILE__) || defined(SK_EC_FLAT)
-    return decode_spectrum_flat<QUANT>(t, st, bits, ch, allow_intensity, coef, mode, noise_samples, quant);
+    return decode_spectrum_flat<QUANT>(t, st, bits, ch, allow_intensity, coef, mode, noise_samples, quant, wide, wide_base);
 #else
-    return decode_spectrum_nested<QUANT>(t, st, bits, ch, allow_intensity, coef, mode, noise_samples, quant);
+    return decode_spectrum_nested<QUANT>(t, st, bits, ch, allow_intensity, coef, mode, noise_samples, quant, wide, wide_base);
 #endif
 }
 
@@ -1232,6 +1249,7 @@ struct Scratch {  // an access unit's side information: per-lane working storage
 struct QuantCapture {  // host side of the quantised hand-over: where parse_unit leaves the integers
     int16_t *quant;    // [channels][1024] quantised spectral values, pulses applied
     int16_t *sf[2];    // [128] each: transmitted scale factor / noise energy / intensity position per band
+    WideList *wide;    // values beyond i16 (kWideMarker in quant); may be null: such a value is then an unsupported feature
 };
 
 SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len_bytes, float *coef, uint8_t *sequence, uint8_t *shape,
@@ -1279,7 +1297,7 @@ SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len
         if (st.channels != 1) return EC_INVALID_BITSTREAM;
         Channel &ch = s.ch[0];
         EC_TRY(read_channel(t, b, ch, nullptr, qc ? qc->sf[0] : nullptr));
-        if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, ch, false, nullptr, PNS_COUNT, &s.noise_samples, qc->quant));
+        if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, ch, false, nullptr, PNS_COUNT, &s.noise_samples, qc->quant, qc->wide, 0));
         else EC_TRY(decode_spectrum(t, st, b, ch, false, coef, mode, &s.noise_samples));
         s.is_pair = 0;
         s.common_window = 0;
@@ -1304,12 +1322,12 @@ SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len
     EC_MARK(8);
     EC_TRY(read_channel(t, b, left, common_window ? &common : nullptr, qc ? qc->sf[0] : nullptr, 9));
     EC_MARK(2);
-    if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, left, false, nullptr, PNS_COUNT, &s.noise_samples, qc->quant));
+    if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, left, false, nullptr, PNS_COUNT, &s.noise_samples, qc->quant, qc->wide, 0));
     else EC_TRY(decode_spectrum(t, st, b, left, false, coef, mode, &s.noise_samples));
     EC_MARK(3);
     EC_TRY(read_channel(t, b, right, common_window ? &common : nullptr, qc ? qc->sf[1] : nullptr));
     EC_MARK(4);
-    if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, right, true, nullptr, PNS_COUNT, &s.noise_samples, qc->quant + 1024));
+    if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, right, true, nullptr, PNS_COUNT, &s.noise_samples, qc->quant + 1024, qc->wide, 1024));
     else EC_TRY(decode_spectrum(t, st, b, right, true, coef + 1024, mode, &s.noise_samples));
     EC_MARK(5);
     s.is_pair = 1;
@@ -1439,10 +1457,18 @@ struct WireUnit {
     uint32_t noise_samples;  // PNS samples the unit consumes: the generator jump of the units behind it
     uint8_t ms_used[16];     // bit i = MsMask::used[i]
     WireChannel ch[2];
+    uint16_t n_wide, wide_pos[kWideMax + 1];  // quantised values beyond i16 (kWideMarker in the i16 array): position = channel * 1024 + line
+    int32_t wide_val[kWideMax];
 };
 
-SKE void pack_unit(const Scratch &s, int channels, const int16_t *const sf[2], int32_t tail_status, WireUnit &w) {
+SKE void pack_unit(const Scratch &s, int channels, const int16_t *const sf[2], int32_t tail_status, WireUnit &w, const WideList *wide = nullptr) {
     for (size_t i = 0; i < sizeof w; ++i) reinterpret_cast<uint8_t *>(&w)[i] = 0;
+    if (wide)
+        for (uint32_t i = 0; i < wide->n && i < (uint32_t)kWideMax; ++i) {
+            w.wide_pos[i] = wide->pos[i];
+            w.wide_val[i] = wide->val[i];
+            w.n_wide = (uint16_t)(i + 1);
+        }
     w.channels = (uint8_t)channels;
     w.is_pair = s.is_pair;
     w.common_window = s.common_window;
@@ -1486,16 +1512,29 @@ SKE void pack_unit(const Scratch &s, int channels, const int16_t *const sf[2], i
 
 // the device's side of it: the record back into the structures finish_unit works on (multipliers from the tables, as
 // read_scalefactors derives them)
-SKE void unpack_unit(const Tables &t, const WireUnit &w, Scratch &s) {
+// Returns EC_INVALID_CONFIG for a record no parse_unit could have produced: the counts below drive loops and index
+// arrays in dequant_channel / finish_unit, and sk_tick_run_q is a public entry point.
+SKE int unpack_unit(const Tables &t, const WireUnit &w, Scratch &s) {
+    if (w.channels < 1 || w.channels > 2 || w.is_pair != (w.channels == 2 ? 1 : 0) || w.common_window > 1 || w.ms_mode > 3) return EC_INVALID_CONFIG;
     s.is_pair = w.is_pair;
     s.common_window = w.common_window;
     s.resume_pos = 0;
     s.noise_samples = w.noise_samples;
     s.mask.mode = w.ms_mode;
     for (int i = 0; i < 128; ++i) s.mask.used[i] = (uint8_t)((w.ms_used[i >> 3] >> (i & 7)) & 1u);
-    for (int c = 0; c < (int)w.channels && c < 2; ++c) {
+    for (int c = 0; c < (int)w.channels; ++c) {
         const WireChannel &wc = w.ch[c];
         Channel &ch = s.ch[c];
+        const bool is_short = wc.sequence == SEQ_EIGHT_SHORT;
+        if (wc.sequence > 3 || wc.shape > 1 || wc.num_windows != (is_short ? 8 : 1) || wc.num_groups < 1 || wc.num_groups > (is_short ? 8 : 1) ||
+            wc.max_sfb > (is_short ? 15 : 51) || wc.tns_present > 1 || wc.n_filters > 8)
+            return EC_INVALID_CONFIG;
+        int windows = 0;
+        for (int g = 0; g < (int)wc.num_groups; ++g) {
+            if (wc.group_len[g] < 1 || wc.group_len[g] > 8) return EC_INVALID_CONFIG;
+            windows += wc.group_len[g];
+        }
+        if (windows != (int)wc.num_windows) return EC_INVALID_CONFIG;
         ch.ics.sequence = wc.sequence;
         ch.ics.shape = wc.shape;
         ch.ics.max_sfb = wc.max_sfb;
@@ -1505,9 +1544,11 @@ SKE void unpack_unit(const Tables &t, const WireUnit &w, Scratch &s) {
         ch.global_gain = 0;
         ch.pulse_present = 0;
         ch.pulse_start = ch.pulse_count = 0;
+        for (int i = 0; i < 4; ++i) ch.pulse_offset[i] = ch.pulse_amp[i] = 0;
         ch.tns_present = wc.tns_present;
         for (int i = 0; i < 128; ++i) {
             const int book = wc.book[i], sf = wc.sf[i];
+            if (book > 15 || book == 12) return EC_INVALID_CONFIG;
             ch.book[i] = (uint8_t)book;
             float m = 0.0f;
             if (book == BOOK_INTENSITY || book == BOOK_INTENSITY_NEG) m = (sf >= -256 && sf <= 255) ? t.is_mult[sf + 256] : t.is_wide[sf + 32768];
@@ -1515,14 +1556,20 @@ SKE void unpack_unit(const Tables &t, const WireUnit &w, Scratch &s) {
             ch.mult[i] = m;
         }
         for (int win = 0; win < 8; ++win) {
+            if (wc.tns_filter_count[win] > 4 || (win >= (int)wc.num_windows && wc.tns_filter_count[win])) return EC_INVALID_CONFIG;
             ch.tns[win].filter_count = wc.tns_filter_count[win];
             ch.tns[win].coef_res = wc.tns_coef_res[win];
+            for (int f = 0; f < 4; ++f) {
+                TnsFilter &z = ch.tns[win].filter[f];
+                z.length = z.order = z.direction = z.coef_bits = 0;
+                for (int i = 0; i < 20; ++i) z.coef[i] = 0;
+            }
         }
         int slot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < (int)wc.n_filters && k < 8; ++k) {
+        for (int k = 0; k < (int)wc.n_filters; ++k) {
             const WireTnsFilter &src = wc.filter[k];
             const int win = src.window & 7;
-            if (slot[win] >= 4) continue;
+            if (src.window > 7 || slot[win] >= (int)wc.tns_filter_count[win] || src.order > 20) return EC_INVALID_CONFIG;
             TnsFilter &dst = ch.tns[win].filter[slot[win]++];
             dst.length = src.length;
             dst.order = src.order;
@@ -1530,7 +1577,10 @@ SKE void unpack_unit(const Tables &t, const WireUnit &w, Scratch &s) {
             dst.coef_bits = src.coef_bits;
             for (int i = 0; i < 20; ++i) dst.coef[i] = src.coef[i];
         }
+        for (int win = 0; win < 8; ++win)
+            if (wc.tns_present && slot[win] != (int)wc.tns_filter_count[win]) return EC_INVALID_CONFIG;  // every counted filter was sent
     }
+    return EC_OK;
 }
 
 // dsp.rs:397-405 over one channel's coded bands (decode_spectrum's stores, from the integers): zero, noise and intensity
@@ -1569,6 +1619,43 @@ SKE int dequant_channel(const Tables &t, const Stream &st, const Channel &ch, co
         if (e > 1024) return EC_INVALID_CONFIG;
         const float scale = ch.mult[sfb];
         for (int i = s; i < e; ++i) coef[i] = dequantize(t, quant[i], scale);
+    }
+    return EC_OK;
+}
+
+// The values the i16 array could not hold (WireUnit::wide_*), dequantised into their lines with their band's multiplier:
+// what dequant_channel's loop would have stored had the integer fitted.  A position whose line is not the marker, or
+// lies outside a band coded with books 1..11, is a record no parse produced.
+SKE int apply_wide(const WireUnit &w, uint32_t channels, const Scratch &s, const Tables &t, const Stream &st, const int16_t *__restrict__ quant,
+                   float *__restrict__ coef) {
+    if (w.n_wide > (uint16_t)kWideMax) return EC_INVALID_CONFIG;
+    for (uint32_t n = 0; n < w.n_wide; ++n) {
+        const uint32_t pos = w.wide_pos[n], c = pos >> 10, line = pos & 1023u;
+        if (c >= channels || quant[pos] != kWideMarker) return EC_INVALID_CONFIG;
+        const Channel &ch = s.ch[c];
+        const Ics ics = ch.ics;
+        const uint16_t *off;
+        int bands;
+        EC_TRY(layout(t, st, ics, &off, &bands));
+        const bool is_short = ics.sequence == SEQ_EIGHT_SHORT;
+        const int window = is_short ? (int)(line >> 7) : 0, within = is_short ? (int)(line & 127u) : (int)line;
+        int group = 0;
+        if (is_short) {
+            int w0 = 0;
+            group = -1;
+            for (int g = 0; g < ics.num_groups; ++g) {
+                if (window >= w0 && window < w0 + ics.group_len[g]) group = g;
+                w0 += ics.group_len[g];
+            }
+            if (group < 0) return EC_INVALID_CONFIG;
+        }
+        int band = -1;
+        for (int sfb = 0; sfb < ics.max_sfb && sfb < bands; ++sfb)
+            if (within >= off[sfb] && within < off[sfb + 1]) band = sfb;
+        if (band < 0) return EC_INVALID_CONFIG;
+        const int slot = group * band_stride(ics) + band;
+        if (!(ch.book[slot] >= 1 && ch.book[slot] <= 11)) return EC_INVALID_CONFIG;
+        coef[pos] = dequantize(t, w.wide_val[n], ch.mult[slot]);
     }
     return EC_OK;
 }

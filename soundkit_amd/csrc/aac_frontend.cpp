@@ -1120,7 +1120,9 @@ int sk_aac_decoder_parse_q(sk_aac_decoder *dec, const uint8_t *au, size_t len, i
     if (len) std::memcpy(words.data(), au, len);
     sk_ec::Stream st{dec->d.sf_index, dec->d.channels, 0u};
     int16_t sf0[128], sf1[128];
-    const sk_ec::QuantCapture qc{quant, {sf0, sf1}};
+    sk_ec::WideList wide;
+    wide.n = 0;
+    const sk_ec::QuantCapture qc{quant, {sf0, sf1}, &wide};
     sk_ec::Scratch scratch;
     uint8_t seq[2] = {0, 0}, shape[2] = {0, 0};
     int rc = sk_ec::parse_unit(view, st, words.data(), (uint32_t)len, nullptr, seq, shape, scratch, sk_ec::PNS_COUNT, &qc);
@@ -1137,7 +1139,7 @@ int sk_aac_decoder_parse_q(sk_aac_decoder *dec, const uint8_t *au, size_t len, i
     }
     const int32_t tail = sk_ec::unit_tail(words.data(), (uint32_t)len, scratch.resume_pos);
     const int16_t *sfs[2] = {sf0, sf1};
-    sk_ec::pack_unit(scratch, dec->d.channels, sfs, tail, *reinterpret_cast<sk_ec::WireUnit *>(side));
+    sk_ec::pack_unit(scratch, dec->d.channels, sfs, tail, *reinterpret_cast<sk_ec::WireUnit *>(side), &wide);
     desc->channels = (uint8_t)dec->d.channels;
     for (int c = 0; c < 2; ++c) {
         desc->window_sequence[c] = c < dec->d.channels ? seq[c] : 0;

@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <new>
@@ -233,6 +235,11 @@ struct sk_engine {
     uint8_t *h_arena = nullptr;
     size_t h_arena_cap = 0;
     std::vector<uint32_t> state_count, state_task;  // plan construction scratch
+    // diagnostics: where the current tick stands (read by sk_pipeline_debug_dump without the engine's lock), the bound on
+    // its waits for the device, and a failure-injection countdown for the error-path tests (sk_engine_debug_fail_after)
+    std::atomic<const char *> where{"idle"};
+    double sync_timeout_s = 120.0;
+    std::atomic<int> fail_after{0};
 
     int hip_fail(hipError_t e, const char *what) {
         last_hip_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -257,6 +264,8 @@ struct sk_aac_plan {
 #define SK_HIP(expr, what)                               \
     do {                                                  \
         hipError_t _e = (expr);                           \
+        if (_e == hipSuccess && e->fail_after.load(std::memory_order_relaxed) > 0 && e->fail_after.fetch_sub(1) == 1) \
+            _e = hipErrorLaunchFailure; /* injected by a test */ \
         if (_e != hipSuccess) return e->hip_fail(_e, what); \
     } while (0)
 
@@ -445,6 +454,7 @@ const char *sk_strerror(int status) {
     case SK_AAC_ERR_UNSUPPORTED_AOT: return "unsupported AAC audio object type";
     case SK_AAC_ERR_UNSUPPORTED_SF_INDEX: return "unsupported AAC sampling frequency index";
     case SK_AAC_ERR_UNSUPPORTED_CHANNEL_CONFIG: return "unsupported AAC channel configuration";
+    case SK_ERR_TIMEOUT: return "the device did not finish in time";
     case SK_AAC_ERR_UNSUPPORTED_FEATURE: return "unsupported AAC feature";
     case SK_AAC_ERR_INVALID_CONFIG: return "invalid AAC config";
     case SK_AAC_ERR_INVALID_BITSTREAM: return "invalid AAC bitstream";
@@ -525,6 +535,21 @@ int sk_engine_device(const sk_engine *e) { return e ? e->device : -1; }
 uint32_t sk_engine_max_streams(const sk_engine *e) { return e ? e->max_streams : 0; }
 void *sk_engine_hip_stream(sk_engine *e) { return e ? (void *)e->stream : nullptr; }
 const char *sk_engine_last_hip_error(const sk_engine *e) { return e ? e->last_hip_error.c_str() : ""; }
+
+const char *sk_engine_where(const sk_engine *e) { return e ? e->where.load() : ""; }
+
+int sk_engine_debug_fail_after(sk_engine *e, int n_hip_calls) {
+    if (!e || n_hip_calls < 0) return SK_ERR_INVALID_ARG;
+    e->fail_after.store(n_hip_calls);
+    return SK_OK;
+}
+
+int sk_engine_set_wait_bound(sk_engine *e, double seconds) {
+    if (!e || !(seconds > 0.0)) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->sync_timeout_s = seconds;
+    return SK_OK;
+}
 
 int sk_engine_synchronize(sk_engine *e) {
     if (!e) return SK_ERR_INVALID_ARG;
@@ -1513,6 +1538,10 @@ int mp3_synthesize(sk_engine *e, const sk_mp3_granule_desc *descs, const float *
     // one task per (stream, channel), granules in array order (the AAC plan's layout with 576-line units)
     std::vector<uint32_t> touched;
     std::vector<uint8_t> ok(n, 0);
+    // a call with a channel count outside 1..2 is rejected as a whole -- before the loop below starts counting in
+    // state_count, which the AAC plan builder shares and expects to find all-zero
+    for (uint32_t i = 0; i < n; ++i)
+        if (descs[i].channels < 1 || descs[i].channels > SK_MAX_CHANNELS) return SK_ERR_INVALID_ARG;
     for (uint32_t i = 0; i < n; ++i) {
         const sk_mp3_granule_desc &d = descs[i];
         int32_t st = SK_FRAME_OK;
@@ -1521,7 +1550,6 @@ int mp3_synthesize(sk_engine *e, const sk_mp3_granule_desc *descs, const float *
         else
             for (uint32_t c = 0; c < d.channels; ++c)
                 if (d.block_type[c] > 3 || d.mixed_block_flag[c] > 1) st = SK_FRAME_BAD_WINDOW;
-        if (d.channels < 1 || d.channels > SK_MAX_CHANNELS) return SK_ERR_INVALID_ARG;
         if (status) status[i] = st;
         if (st != SK_FRAME_OK) continue;
         ok[i] = 1;
@@ -2104,16 +2132,47 @@ int sf_index_of(uint32_t rate) {
 // units themselves do, and the front-end runs on the device before the synthesis.
 constexpr uint32_t kMaxAccessUnitBytes = 8192;
 
+// The tick's waits for the device.  hipStreamSynchronize has no bound: a launch that never finishes (or a completion the
+// runtime never sees) would park the scheduler's submission thread for good with nothing on record.  Polling the stream
+// turns that into SK_ERR_TIMEOUT with the stage in sk_engine_last_hip_error; the poll interval (tens of microseconds) is
+// noise against a tick of milliseconds.
+int wait_stream(sk_engine *e, const char *what) {
+    e->where.store(what);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(e->stream);
+        if (q == hipSuccess) return SK_OK;
+        if (q != hipErrorNotReady) return e->hip_fail(q, what);
+        if (++spins < 64) {
+            std::this_thread::yield();
+            continue;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if ((spins & 1023u) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > e->sync_timeout_s) {
+            e->last_hip_error = std::string(what) + ": the device did not finish within the engine's wait bound";
+            return SK_ERR_TIMEOUT;
+        }
+    }
+}
+
+struct TickWhere {  // marks the engine as inside a tick for sk_engine_where; "idle" again on every exit
+    sk_engine *e;
+    explicit TickWhere(sk_engine *eng) : e(eng) { e->where.store("tick: host planning"); }
+    ~TickWhere() { e->where.store("idle"); }
+};
+
 struct EntropyProbe {  // sk_aac_entropy_decode: stop after the front-end and hand its results to the caller
     float *spectra;
     sk_aac_frame_desc *descs;
     int32_t *status;
 };
 
-int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
+int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
               const sk_au_item *units, const uint8_t *au_bytes, size_t au_len, uint32_t n_frames, uint8_t *out, size_t out_cap,
-              sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes, const EntropyProbe *probe = nullptr,
-              const uint8_t *q_sides = nullptr, const int16_t *q_quant = nullptr) {
+              sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes, const EntropyProbe *probe,
+              const uint8_t *q_sides, const int16_t *q_quant) {
     const bool au_mode = units != nullptr;
     const bool q_mode = q_sides != nullptr;  // quantised hand-over: descs from the host, spectra rebuilt on the device
     std::vector<sk_aac_frame_desc> au_descs;
@@ -2124,7 +2183,6 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     *n_outs = 0;
     if (out_bytes) *out_bytes = 0;
     if (n_streams == 0) return n_frames == 0 ? SK_OK : SK_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e->device);
     if (au_mode) {  // the descs are implied: every unit of a stream carries that stream's channel count
         uint64_t total = 0;
@@ -2342,7 +2400,9 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
         if (au_mode || q_mode) {  // which units failed decides what the later stages may use
             const TClock::time_point q0 = TClock::now();
             t_au[0] = std::chrono::duration<double, std::milli>(q0 - t_mark).count();
-            SK_HIP(hipStreamSynchronize(e->stream), "entropy sync");
+            rc = wait_stream(e, "tick: waiting for the front-end kernels and the synthesis (mid-tick status read-back)");
+            if (rc != SK_OK) return rc;
+            e->where.store("tick: resampler rounds, pack");
             t_au[1] = std::chrono::duration<double, std::milli>(TClock::now() - q0).count();
             for (uint32_t i = 0; i < n_streams; ++i) {
                 tc[i].good = ts[i].n_frames;
@@ -2539,7 +2599,8 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
         SK_HIP(hipMemcpyAsync(out, d_out, cursor, hipMemcpyDeviceToHost, e->stream), "D2H tick output");
     }
     lap(3);
-    SK_HIP(hipStreamSynchronize(e->stream), "tick sync");
+    rc = wait_stream(e, "tick: waiting for the device at the end of the tick");
+    if (rc != SK_OK) return rc;
     lap(4);
     if (trace)
         std::fprintf(stderr, "sk_tick_run: %u streams %u frames | plan %.2f  h2d+synth %.2f  resample %.2f  pack %.2f  sync %.2f ms | au: queue %.2f wait %.2f\n",
@@ -2547,6 +2608,44 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     *n_outs = n_rec;
     if (out_bytes) *out_bytes = cursor;
     return SK_OK;
+}
+
+// The tick proper (tick_body) under the engine's lock, with the host-side state it advances -- the streaming resamplers'
+// fill, chunk count and time index -- put back when it fails part-way: a failed launch leaves the batch's streams to be
+// ended by the caller, and the engine's bookkeeping must not have run ahead of what the device did.
+int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
+              const sk_au_item *units, const uint8_t *au_bytes, size_t au_len, uint32_t n_frames, uint8_t *out, size_t out_cap,
+              sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes, const EntropyProbe *probe = nullptr,
+              const uint8_t *q_sides = nullptr, const int16_t *q_quant = nullptr) {
+    if (!e) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    TickWhere where(e);
+    struct Saved {
+        uint32_t id, fill;
+        uint64_t chunks;
+        double last;
+    };
+    std::vector<Saved> saved;
+    for (uint32_t i = 0; ts && i < n_streams; ++i)
+        if (ts[i].resample && stream_ok(e, ts[i].stream) && e->streams[ts[i].stream].rs_open) {
+            const StreamInfo &s = e->streams[ts[i].stream];
+            saved.push_back(Saved{ts[i].stream, s.rs_fill, s.rs_chunks, s.rs_last_index});
+        }
+    const int rc = tick_body(e, ts, n_streams, descs, coeffs, units, au_bytes, au_len, n_frames, out, out_cap, outs, outs_cap, n_outs,
+                             out_bytes, probe, q_sides, q_quant);
+    if (rc != SK_OK) {
+        for (const Saved &v : saved) {
+            StreamInfo &s = e->streams[v.id];
+            s.rs_fill = v.fill;
+            s.rs_chunks = v.chunks;
+            s.rs_last_index = v.last;
+        }
+        if (n_outs) *n_outs = 0;
+        if (out_bytes) *out_bytes = 0;
+        // whatever was queued before the failure must be off the stream before the caller reuses its buffers
+        if (rc != SK_ERR_TIMEOUT) (void)hipStreamSynchronize(e->stream);
+    }
+    return rc;
 }
 
 }  // namespace
@@ -2580,6 +2679,21 @@ int sk_aac_entropy_decode(sk_engine *e, const uint32_t *streams, const uint32_t 
     uint32_t n_outs = 0;
     return tick_impl(e, ts.data(), n_streams, nullptr, nullptr, units, au_bytes, au_bytes_len, n_units, nullptr, 0, nullptr, 0, &n_outs,
                      nullptr, &probe);
+}
+
+int sk_aac_expand_q_decode(sk_engine *e, const uint32_t *streams, const uint32_t *units_per_stream, uint32_t n_streams,
+                           const sk_aac_frame_desc *descs, const void *sides, const int16_t *quant, uint32_t n_units, float *coeffs_out,
+                           sk_aac_frame_desc *descs_out, int32_t *status_out) {
+    if (!e || (n_streams && (!streams || !units_per_stream)) ||
+        (n_units && (!descs || !sides || !quant || !coeffs_out || !descs_out || !status_out)))
+        return SK_ERR_INVALID_ARG;
+    if (n_units == 0) return SK_OK;
+    std::vector<sk_tick_stream> ts(n_streams);
+    for (uint32_t i = 0; i < n_streams; ++i) ts[i] = sk_tick_stream{streams[i], units_per_stream[i], 16, 1, 0, 0};
+    const EntropyProbe probe{coeffs_out, descs_out, status_out};
+    uint32_t n_outs = 0;
+    return tick_impl(e, ts.data(), n_streams, descs, nullptr, nullptr, nullptr, 0, n_units, nullptr, 0, nullptr, 0, &n_outs, nullptr, &probe,
+                     (const uint8_t *)sides, quant);
 }
 
 int sk_tick_run_au(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_au_item *units, uint32_t n_units,

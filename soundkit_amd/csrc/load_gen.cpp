@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -40,7 +42,9 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
                            sk_load_result *res, const sk_load_check *chk);
 
 // Every stream receives `loops` copies of the clip in chunks of chunk_bytes, then finish().  Returns when every
-// stream has ended and is drained.
+// stream has ended and is drained -- or SK_ERR_TIMEOUT when neither a send succeeded nor an output arrived for
+// SK_LOADGEN_STALL_S seconds (default 30): the scheduler's state (sk_pipeline_debug_dump) and the generator's own counts
+// go to stderr first, so that a stall leaves a record instead of a harness kill.
 int sk_loadgen_run(sk_pipeline *p, const uint8_t *clip, size_t clip_len, uint32_t clip_units, uint32_t n_streams,
                    uint32_t loops, const sk_decode_options *opt, uint32_t feeder_threads, uint32_t chunk_bytes,
                    sk_load_result *res) {
@@ -62,11 +66,17 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
         }
     }
     std::atomic<uint64_t> outputs{0}, pcm_frames{0}, pcm_bytes{0}, errors{0}, input_full{0};
+    std::atomic<uint64_t> progress{0}, sends_ok{0}, finishes_ok{0}, closed_seen{0}, received{0};
+    std::atomic<bool> abort_run{false};
+    std::atomic<uint32_t> threads_done{0};
     std::atomic<uint32_t> live{n_streams};
     uint32_t max_handle = 0;
     for (uint32_t h : handles) max_handle = std::max(max_handle, h);
+    // a completion queue can still hold handles of an earlier run on the same pipeline (a handle is listed again while it
+    // is being drained); one that is not a stream of this run must not count as one of its ends
     std::vector<std::atomic<char>> ended(max_handle + 1);
-    for (auto &e : ended) e.store(0);
+    for (auto &e : ended) e.store(1);
+    for (uint32_t h : handles) ended[h].store(0);
     std::vector<uint32_t> index_of(chk ? max_handle + 1 : 0, 0);
     std::vector<int32_t> capture_slot(chk ? n_streams : 0, -1);
     std::unique_ptr<std::mutex[]> locks(chk ? new std::mutex[n_streams] : nullptr);
@@ -103,7 +113,7 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
             const uint64_t total = (uint64_t)clip_len * loops;
             size_t open = mine.size();
             uint64_t full = 0;
-            while (open) {
+            while (open && !abort_run.load(std::memory_order_relaxed)) {
                 bool progressed = false;
                 for (St &s : mine) {
                     if (s.finished) continue;
@@ -114,6 +124,8 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
                                 s.finished = true;
                                 --open;
                                 progressed = true;
+                                finishes_ok.fetch_add(1, std::memory_order_relaxed);
+                                progress.fetch_add(1, std::memory_order_relaxed);
                             } else {
                                 ++full;
                             }
@@ -125,6 +137,8 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
                         if (rc == SK_OK) {
                             s.sent += n;
                             progressed = true;
+                            sends_ok.fetch_add(1, std::memory_order_relaxed);
+                            progress.fetch_add(1, std::memory_order_relaxed);
                         } else if (rc == SK_PIPE_CLOSED) {
                             s.finished = true;
                             --open;
@@ -138,6 +152,7 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
                 if (!progressed) std::this_thread::sleep_for(std::chrono::microseconds(200));
             }
             input_full += full;
+            threads_done.fetch_add(1);
         });
     }
     // consumers: block on sk_pipeline_wait_outputs and drain whatever handles it reports
@@ -147,7 +162,7 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
             std::vector<uint32_t> ready(1024);
             sk_audio_info info;
             uint64_t o = 0, f = 0, b = 0, e = 0;
-            while (live.load() > 0) {
+            while (live.load() > 0 && !abort_run.load(std::memory_order_relaxed)) {
                 const int n = sk_pipeline_wait_outputs(p, ready.data(), (uint32_t)ready.size(), 20);
                 for (int k = 0; k < n; ++k) {
                     const uint32_t h = ready[(size_t)k];
@@ -158,6 +173,8 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
                     for (;;) {
                         const int rc = sk_pipeline_try_recv(p, h, buf.data(), buf.size(), &info);
                         if (rc == 1) {
+                            received.fetch_add(1, std::memory_order_relaxed);
+                            progress.fetch_add(1, std::memory_order_relaxed);
                             if (info.is_error) ++e;
                             else {
                                 ++o;
@@ -188,7 +205,11 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
                             }
                             continue;
                         }
-                        if (rc == SK_PIPE_CLOSED && h <= max_handle && !ended[h].exchange(1)) live.fetch_sub(1);
+                        if (rc == SK_PIPE_CLOSED && h <= max_handle && !ended[h].exchange(1)) {
+                            live.fetch_sub(1);
+                            closed_seen.fetch_add(1, std::memory_order_relaxed);
+                            progress.fetch_add(1, std::memory_order_relaxed);
+                        }
                         break;
                     }
                 }
@@ -197,7 +218,37 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
             pcm_frames += f;
             pcm_bytes += b;
             errors += e;
+            threads_done.fetch_add(1);
         });
+    }
+    // the run's own watchdog: progress = a send accepted, a finish accepted, an output received or an end seen
+    double stall_s = 30.0;
+    if (const char *env = std::getenv("SK_LOADGEN_STALL_S")) stall_s = std::max(0.5, std::atof(env));
+    bool stalled = false;
+    {
+        uint64_t last = progress.load();
+        auto last_change = std::chrono::steady_clock::now();
+        while (threads_done.load() < threads.size()) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            const uint64_t now = progress.load();
+            const auto t = std::chrono::steady_clock::now();
+            if (now != last) {
+                last = now;
+                last_change = t;
+            } else if (std::chrono::duration<double>(t - last_change).count() > stall_s) {
+                stalled = true;
+                std::vector<char> text(32768);
+                sk_pipeline_debug_dump(p, text.data(), text.size());
+                std::fprintf(stderr,
+                             "[sk_loadgen] STALL: no send accepted and no output received for %.1f s | streams %u, still live %u | "
+                             "sends accepted %llu, finishes accepted %llu, outputs received %llu, ends seen %llu\n%s",
+                             stall_s, n_streams, live.load(), (unsigned long long)sends_ok.load(), (unsigned long long)finishes_ok.load(),
+                             (unsigned long long)received.load(), (unsigned long long)closed_seen.load(), text.data());
+                std::fflush(stderr);
+                abort_run.store(true);
+                break;
+            }
+        }
     }
     for (std::thread &th : threads) th.join();
     res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -208,7 +259,7 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
     res->pcm_bytes = pcm_bytes.load();
     res->errors = errors.load();
     res->input_full = input_full.load();
-    return SK_OK;
+    return stalled ? SK_ERR_TIMEOUT : SK_OK;
 }
 
 }  // extern "C"

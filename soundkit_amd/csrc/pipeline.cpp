@@ -76,6 +76,10 @@ struct BatchEntry {  // bookkeeping beside one sk_tick_stream
     bool failed = false;
     int32_t fail_status = 0;
     std::string fail_msg;
+    // quantised hand-over only: the access units of this pass as they came off the wire, so that a status the device finds
+    // (stereo tools, TNS, the unit's tail) can be given the reference's message by parsing them again on the host
+    std::vector<uint8_t> raw;
+    std::vector<uint32_t> raw_len;
 };
 
 struct Batch {
@@ -95,6 +99,7 @@ struct Batch {
     size_t out_pinned_cap = 0;
     std::vector<sk_tick_output> recs;
     std::vector<uint32_t> row_of;  // tick row -> entry
+    std::vector<uint32_t> entry_row;  // entry -> tick row, kNoStream for a stream that never reached the device
     std::vector<uint32_t> rec_begin;  // tick row -> its first output record (rows + 1 entries)
     uint32_t n_out = 0;
     int rc = SK_OK;
@@ -106,6 +111,7 @@ struct Batch {
         ts.clear();
         entries.clear();
         row_of.clear();
+        entry_row.clear();
         rec_begin.clear();
         n_out = 0;
         rc = SK_OK;
@@ -160,7 +166,7 @@ struct sk_lane {
     // SK_PIPELINE_WATCHDOG=<seconds>: a thread that prints where everybody stands when no tick has finished for that long
     std::thread watchdog;
     std::atomic<int> submit_where{0};     // 0 waits for work, 1 lets the batch fill, 2 waits for writers / a free batch, 3 in the tick, 4 hands over
-    std::atomic<uint32_t> workers_waiting_room{0}, workers_waiting_ready{0}, deliverers_waiting{0};
+    std::atomic<uint32_t> workers_waiting_room{0}, workers_waiting_ready{0}, workers_parsing{0}, deliverers_waiting{0};
 };
 
 namespace {
@@ -216,6 +222,8 @@ struct Parsed {  // what one worker pass produced for one stream
     bool budget_stop = false;  // stopped early because the staged bytes reached what one batch can take
     int32_t fail_status = 0;
     std::string fail_msg;
+    std::vector<uint8_t> raw;  // quantised hand-over: the pass's access units, kept for the error text (BatchEntry::raw)
+    std::vector<uint32_t> raw_len;
 };
 
 // Pulls ADTS frames out of the stream's byte queue and runs the front-end on them, at most `limit` frames.
@@ -324,6 +332,8 @@ void parse_some(sk_lane *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_fr
             }
             d.stream = s.engine_stream;
             r.n_au_bytes += SK_AAC_UNIT_SIDE_BYTES;
+            r.raw.insert(r.raw.end(), frame + pay_off, frame + pay_off + pay_len);
+            r.raw_len.push_back((uint32_t)pay_len);
         } else {
             sk_aac_frame_desc &d = descs[r.n_frames];
             const int rc = sk_aac_decoder_parse(s.fe, frame + pay_off, pay_len, coeffs + r.n_floats, &d);
@@ -350,7 +360,9 @@ void worker_main(sk_lane *p) {
         uint32_t handle;
         {
             std::unique_lock<std::mutex> lk(p->rq_mu);
+            p->workers_waiting_ready.fetch_add(1);
             p->rq_cv.wait(lk, [&] { return p->stop || !p->ready.empty(); });
+            p->workers_waiting_ready.fetch_sub(1);
             if (p->stop) return;
             handle = p->ready.front();
             p->ready.pop_front();
@@ -366,13 +378,18 @@ void worker_main(sk_lane *p) {
             s.busy = true;
         }
         Parsed r;
+        p->workers_parsing.fetch_add(1);
         const Clock::time_point t0 = Clock::now();
         // room in the output queue bounds the access units of this pass: one AudioData per unit, or -- through the
         // streaming resampler -- one per completed chunk of 4096 source frames = 4 units (lib.rs:1970-2003)
         const uint32_t limit = std::min(per_stream, s.resample ? (room > per_stream / 4 ? per_stream : 4 * room) : room);
         parse_some(p, s, limit, coeffs.data(), descs.data(), au_stage, au_items.data(), r);
-        s.more = (r.n_frames == limit || r.budget_stop) && !r.eof && !r.failed;
+        {
+            std::lock_guard<std::mutex> lk(s.mu);  // read by mark_schedulable and the state dump
+            s.more = (r.n_frames == limit || r.budget_stop) && !r.eof && !r.failed;
+        }
         p->parse_ns.fetch_add(ns_since(t0));
+        p->workers_parsing.fetch_sub(1);
         if (r.n_frames == 0 && !r.eof && !r.failed) {  // nothing complete yet
             bool dropped;
             {
@@ -423,6 +440,8 @@ void worker_main(sk_lane *p) {
             be.failed = r.failed;
             be.fail_status = r.fail_status;
             be.fail_msg = std::move(r.fail_msg);
+            be.raw = std::move(r.raw);
+            be.raw_len = std::move(r.raw_len);
             if (s.engine_stream == kNoStream) {  // ended before a single header was seen: nothing for the device
                 t.n_frames = 0;
                 t.flush = 0;
@@ -495,10 +514,12 @@ void submit_main(sk_lane *p) {
         // a stream may have ended without ever reaching the device: it gets no row in the tick's table
         ts.clear();
         b->row_of.clear();
+        b->entry_row.assign(n_streams, kNoStream);
         for (uint32_t i = 0; i < n_streams; ++i) {
             PStream &s = *p->streams[b->entries[i].handle];
             if (s.engine_stream == kNoStream) continue;
             ts.push_back(b->ts[i]);
+            b->entry_row[i] = (uint32_t)b->row_of.size();
             b->row_of.push_back(i);
         }
         uint32_t max_out = 0;
@@ -548,6 +569,42 @@ void submit_main(sk_lane *p) {
     }
 }
 
+// The message behind a status the device reported for a unit of this entry.  The device reports codes; the reference's
+// text comes from parsing the entry's access units of this tick once more on the host (errors are rare, and an entry holds
+// at most max_stream_frames_per_tick units).
+std::string device_error_text(sk_lane *p, const Batch *b, uint32_t entry, const PStream &s, int32_t status) {
+    std::string msg = "Decoding failed: invalid AAC config: frame rejected by the synthesis engine";
+    if (!(p->cfg.gpu_entropy && status <= -101 && status >= -108)) return msg;
+    msg = std::string("Decoding failed: ") + sk_strerror(status);  // found on the device (stereo tools, TNS) or in the unit's tail
+    sk_aac_decoder *probe = nullptr;
+    if (sk_aac_decoder_create(s.asc, 2, &probe) != SK_OK) return msg;
+    std::vector<float> sink(2048);
+    sk_aac_frame_desc d;
+    if (p->cfg.gpu_entropy == 1) {
+        size_t first = 0;
+        for (uint32_t q = 0; q < entry; ++q) first += b->ts[q].n_frames;
+        for (uint32_t u = 0; u < b->ts[entry].n_frames; ++u) {
+            const sk_au_item &it = b->units[first + u];
+            if (sk_aac_decoder_parse(probe, b->au_bytes + it.byte_offset, it.byte_len, sink.data(), &d) != SK_OK) {
+                msg = std::string("Decoding failed: ") + sk_aac_decoder_last_error(probe);
+                break;
+            }
+        }
+    } else {  // quantised hand-over: the worker kept the pass's access units beside the entry for exactly this
+        const BatchEntry &be = b->entries[entry];
+        size_t at = 0;
+        for (uint32_t len : be.raw_len) {
+            if (sk_aac_decoder_parse(probe, be.raw.data() + at, len, sink.data(), &d) != SK_OK) {
+                msg = std::string("Decoding failed: ") + sk_aac_decoder_last_error(probe);
+                break;
+            }
+            at += len;
+        }
+    }
+    sk_aac_decoder_destroy(probe);
+    return msg;
+}
+
 void watchdog_main(sk_lane *p, int secs);
 
 // Hands a finished tick's outputs to the streams' queues: outputs first (in order), then the end-of-stream /
@@ -574,60 +631,38 @@ void deliver_main(sk_lane *p) {
         const Clock::time_point t_deliver = Clock::now();
         const uint32_t n_streams = (uint32_t)b->ts.size();
         const int rc = b->rc;
-        for (uint32_t row = slice; row < b->row_of.size(); row += n_slices) {  // the outputs of a tick row are contiguous in recs
-            const BatchEntry &be = b->entries[b->row_of[row]];
-            PStream &s = *p->streams[be.handle];
-            std::lock_guard<std::mutex> lk(s.mu);
-            for (uint32_t k = b->rec_begin[row]; rc == SK_OK && k < b->rec_begin[row + 1]; ++k) {
-                const sk_tick_output &r = b->recs[k];
-                if (s.cancelled) continue;
-                if (r.status != 0) {
-                    std::string msg = "Decoding failed: invalid AAC config: frame rejected by the synthesis engine";
-                    if (p->cfg.gpu_entropy == 2 && r.status <= -101 && r.status >= -108)
-                        msg = std::string("Decoding failed: ") + sk_strerror(r.status);  // found on the device (stereo tools, TNS) or in the unit's tail
-                    if (p->cfg.gpu_entropy == 1 && r.status <= -101 && r.status >= -108) {
-                        // the device reports codes; the reference's text comes from parsing the stream's units of this
-                        // tick once more on the host (errors are rare, <= max_stream_frames_per_tick units)
-                        msg = std::string("Decoding failed: ") + sk_strerror(r.status);
-                        size_t first = 0;
-                        for (uint32_t q = 0; q < b->row_of[row]; ++q) first += b->ts[q].n_frames;
-                        sk_aac_decoder *probe = nullptr;
-                        if (sk_aac_decoder_create(s.asc, 2, &probe) == SK_OK) {
-                            std::vector<float> sink(2048);
-                            sk_aac_frame_desc d;
-                            for (uint32_t u = 0; u < b->ts[b->row_of[row]].n_frames; ++u) {
-                                const sk_au_item &it = b->units[first + u];
-                                if (sk_aac_decoder_parse(probe, b->au_bytes + it.byte_offset, it.byte_len, sink.data(), &d) != SK_OK) {
-                                    msg = std::string("Decoding failed: ") + sk_aac_decoder_last_error(probe);
-                                    break;
-                                }
-                            }
-                            sk_aac_decoder_destroy(probe);
-                        }
-                    }
-                    push_error(s, r.status, msg);
-                    s.finished = true;
-                    p->n_errors.fetch_add(1);
-                    continue;
-                }
-                Output o;
-                o.rate = s.opt.output_sample_rate ? s.opt.output_sample_rate : s.rate;
-                o.frames = r.frames;
-                o.bits = r.bits;
-                o.channels = r.channels;
-                o.data.assign(b->out_pinned + r.byte_offset, b->out_pinned + r.byte_offset + r.bytes);
-                s.out.push_back(std::move(o));
-                p->n_outputs.fetch_add(1);
-            }
-        }
         wake.clear();
         listed.clear();
+        // One delivery thread serves an entry completely -- its outputs (the records of its tick row are contiguous), then
+        // the end-of-stream / error note, then the stream is free again -- under one hold of the stream's lock.  (Rows and
+        // entries used to be sliced separately: with several delivery threads a stream without a tick row in front of
+        // another shifted the two numberings against each other, and that stream's end could be announced by one thread
+        // before another had queued its last outputs.)
         for (uint32_t i = slice; i < n_streams; i += n_slices) {
             BatchEntry &be = b->entries[i];
             PStream &s = *p->streams[be.handle];
+            const uint32_t row = b->entry_row[i];
             bool release = false;
             {
                 std::lock_guard<std::mutex> lk(s.mu);
+                for (uint32_t k = row == kNoStream ? 0 : b->rec_begin[row]; row != kNoStream && rc == SK_OK && k < b->rec_begin[row + 1]; ++k) {
+                    const sk_tick_output &r = b->recs[k];
+                    if (s.cancelled || s.finished) continue;
+                    if (r.status != 0) {
+                        push_error(s, r.status, device_error_text(p, b, i, s, r.status));
+                        s.finished = true;
+                        p->n_errors.fetch_add(1);
+                        continue;
+                    }
+                    Output o;
+                    o.rate = s.opt.output_sample_rate ? s.opt.output_sample_rate : s.rate;
+                    o.frames = r.frames;
+                    o.bits = r.bits;
+                    o.channels = r.channels;
+                    o.data.assign(b->out_pinned + r.byte_offset, b->out_pinned + r.byte_offset + r.bytes);
+                    s.out.push_back(std::move(o));
+                    p->n_outputs.fetch_add(1);
+                }
                 if (rc != SK_OK && !s.finished) {
                     push_error(s, rc, std::string("Decoding failed: engine tick: ") + sk_strerror(rc));
                     s.finished = true;
@@ -805,11 +840,85 @@ int lane_create(sk_engine *e, const sk_pipeline_config *cfg, OutQueue *oq, uint3
     return SK_OK;
 }
 
-// SK_PIPELINE_WATCHDOG: no locks are taken for the stream table (a dump of a stuck pipeline must not get stuck itself);
-// the batch fields are read under batch_mu with try_lock
+// Where every thread of a lane stands and what the stream table looks like, as text.  Takes no lock it could wait for: the
+// stream records and the queues are read under try_lock (a dump of a stuck pipeline must not get stuck itself, and the
+// deques must not be read while a worker pushes to them); what could not be locked is counted as "held".
+size_t lane_dump(sk_lane *p, char *buf, size_t cap) {
+    size_t at = 0;
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Wformat-security"  // every format below is a literal of this function
+    auto put = [&](const char *fmt, auto... args) {
+        if (at >= cap) return;
+        const int n = std::snprintf(buf + at, cap - at, fmt, args...);
+        if (n > 0) at += std::min<size_t>((size_t)n, cap - at - 1);
+    };
+#pragma GCC diagnostic pop
+    size_t with_input = 0, busy = 0, queued = 0, out_full = 0, open = 0, more = 0, finished = 0, held = 0, with_output = 0, listed = 0,
+           schedulable = 0;
+    for (auto &sp : p->streams) {
+        PStream &s = *sp;
+        if (!s.mu.try_lock()) {
+            ++held;
+            continue;
+        }
+        if (s.open) {
+            ++open;
+            with_input += !s.in.empty();
+            busy += s.busy;
+            queued += s.queued;
+            more += s.more && !s.busy;
+            finished += s.finished;
+            out_full += s.out.size() >= p->cfg.output_buffer;
+            with_output += !s.out.empty();
+            listed += s.out_listed;
+            // would be scheduled if anybody asked: a non-zero count on a quiet pipeline is a lost wake-up
+            schedulable += !s.busy && !s.queued && !s.finished && !s.cancelled && (!s.in.empty() || s.more) && s.out.size() < p->cfg.output_buffer;
+        }
+        s.mu.unlock();
+    }
+    put("[sk_pipeline] lane %u mode %u: ticks %llu frames %llu outputs %llu errors %llu | submitter at %d "
+        "(0 idle, 1 filling, 2 waits for writers / a free batch, 3 in the tick, 4 hand-over) | workers: waiting for a stream %u, "
+        "parsing %u, waiting for batch room %u of %zu | deliverers waiting %u of %u\n",
+        p->lane_index, p->cfg.gpu_entropy, (unsigned long long)p->n_ticks.load(), (unsigned long long)p->n_frames.load(),
+        (unsigned long long)p->n_outputs.load(), (unsigned long long)p->n_errors.load(), p->submit_where.load(),
+        p->workers_waiting_ready.load(), p->workers_parsing.load(), p->workers_waiting_room.load(), p->workers.size(),
+        p->deliverers_waiting.load(), p->n_deliver);
+    put("    streams: open %zu (locked by others %zu) | input queued %zu | held by a worker or a tick %zu | in the ready queue %zu | "
+        "stopped at the frame limit %zu | finished %zu | outputs waiting %zu, at the bound %zu, listed for wait_outputs %zu | "
+        "schedulable but not queued %zu\n",
+        open, held, with_input, busy, queued, more, finished, with_output, out_full, listed, schedulable);
+    if (p->batch_mu.try_lock()) {
+        put("    batches: filling %d, free %zu, to deliver %zu |", p->filling, p->free_batches.size(), p->to_deliver.size());
+        for (int i = 0; i < sk_lane::kBatches; ++i)
+            put(" [%d] streams %zu units %zu writers %u slices %u/%u |", i, p->batches[i].ts.size(), p->batches[i].n_descs, p->batches[i].writers,
+                p->batches[i].slices_done, p->batches[i].next_slice);
+        put("%s", "\n");
+        p->batch_mu.unlock();
+    } else {
+        put("    batch_mu is held\n");
+    }
+    if (p->rq_mu.try_lock()) {
+        put("    ready queue %zu\n", p->ready.size());
+        p->rq_mu.unlock();
+    } else {
+        put("    rq_mu is held\n");
+    }
+    if (p->oq->mu.try_lock()) {
+        put("    completion queue %zu\n", p->oq->ready.size());
+        p->oq->mu.unlock();
+    } else {
+        put("    completion queue mutex is held\n");
+    }
+    const char *where = sk_engine_where(p->engine);
+    put("    engine: %s\n", where ? where : "?");
+    return at;
+}
+
+// SK_PIPELINE_WATCHDOG=<seconds>: prints lane_dump when no tick has finished for that long
 void watchdog_main(sk_lane *p, int secs) {
     uint64_t last = p->n_ticks.load();
     int quiet = 0;
+    std::vector<char> text(8192);
     for (;;) {
         for (int i = 0; i < 10; ++i) {
             std::this_thread::sleep_for(std::chrono::milliseconds(100));
@@ -819,38 +928,8 @@ void watchdog_main(sk_lane *p, int secs) {
         quiet = now == last ? quiet + 1 : 0;
         last = now;
         if (quiet < secs || quiet % secs) continue;
-        size_t with_input = 0, busy = 0, queued = 0, out_full = 0, open = 0, more = 0, finished = 0;
-        for (auto &sp : p->streams) {
-            PStream &s = *sp;
-            if (!s.open) continue;
-            ++open;
-            with_input += !s.in.empty();
-            busy += s.busy;
-            queued += s.queued;
-            more += s.more;
-            finished += s.finished;
-            out_full += s.out.size() >= p->cfg.output_buffer;
-        }
-        std::fprintf(stderr, "[sk_pipeline watchdog] lane %u: no tick for %d s (ticks %llu) | submitter at %d | workers waiting: room %u | "
-                             "deliverers waiting %u | streams open %zu input %zu busy %zu queued %zu more %zu finished %zu out-full %zu\n",
-                     p->lane_index, quiet, (unsigned long long)now, p->submit_where.load(), p->workers_waiting_room.load(),
-                     p->deliverers_waiting.load(), open, with_input, busy, queued, more, finished, out_full);
-        if (p->batch_mu.try_lock()) {
-            std::fprintf(stderr, "    filling %d free %zu to_deliver %zu |", p->filling, p->free_batches.size(), p->to_deliver.size());
-            for (int i = 0; i < sk_lane::kBatches; ++i)
-                std::fprintf(stderr, " batch %d: streams %zu frames %zu writers %u slices %u/%u |", i, p->batches[i].ts.size(), p->batches[i].n_descs,
-                             p->batches[i].writers, p->batches[i].slices_done, p->batches[i].next_slice);
-            std::fprintf(stderr, "\n");
-            p->batch_mu.unlock();
-        } else {
-            std::fprintf(stderr, "    batch_mu is held\n");
-        }
-        if (p->rq_mu.try_lock()) {
-            std::fprintf(stderr, "    ready queue %zu\n", p->ready.size());
-            p->rq_mu.unlock();
-        } else {
-            std::fprintf(stderr, "    rq_mu is held\n");
-        }
+        lane_dump(p, text.data(), text.size());
+        std::fprintf(stderr, "[sk_pipeline watchdog] no tick for %d s\n%s", quiet, text.data());
     }
 }
 
@@ -1190,6 +1269,15 @@ int sk_pipeline_wait_outputs(sk_pipeline *p, uint32_t *handles, uint32_t cap, ui
         s->out_listed = false;
     }
     return (int)n;
+}
+
+size_t sk_pipeline_debug_dump(sk_pipeline *p, char *buf, size_t cap) {
+    if (!p || !buf || !cap) return 0;
+    size_t at = 0;
+    buf[0] = 0;
+    for (sk_lane *l : p->lanes)
+        if (at + 1 < cap) at += lane_dump(l, buf + at, cap - at);
+    return at;
 }
 
 size_t sk_pipeline_queued_input_bytes(sk_pipeline *p, uint32_t handle) {  // lib.rs:2863-2866

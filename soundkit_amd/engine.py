@@ -491,6 +491,49 @@ class Engine:
         return out
 
 
+    def expand_q_decode(self, streams, parsed):
+        """sk_aac_expand_q_decode: the device half of the quantised hand-over alone.  streams: [(stream id, unit count)];
+        parsed: AacLcFrontEnd.parse_q's results (quant, side, sequences, shapes) of all units, stream by stream.
+        -> [(status, coeffs [ch][1024] f32, window_sequence[ch], window_shape[ch])] per unit."""
+        from ._lib import AAC_UNIT_SIDE_BYTES
+        n = len(parsed)
+        ids = np.array([s for s, _ in streams], np.uint32)
+        counts = np.array([c for _, c in streams], np.uint32)
+        assert int(counts.sum()) == n
+        ch = np.repeat(np.array([self._channels[int(s)] for s in ids], np.uint32), counts) if n else np.zeros(0, np.uint32)
+        owner = np.repeat(ids, counts) if n else np.zeros(0, np.uint32)
+        descs_in = (FrameDesc * max(n, 1))()
+        for k, (q, side, seqs, shapes) in enumerate(parsed):
+            descs_in[k].stream, descs_in[k].channels = int(owner[k]), int(ch[k])
+            for c in range(int(ch[k])):
+                descs_in[k].window_sequence[c], descs_in[k].window_shape[c] = int(seqs[c]), int(shapes[c])
+        sides = np.ascontiguousarray(np.stack([p[1] for p in parsed]) if n else np.zeros((1, AAC_UNIT_SIDE_BYTES)), np.uint8)
+        quant = np.ascontiguousarray(np.concatenate([p[0].ravel() for p in parsed]) if n else np.zeros(1), np.int16)
+        coeffs = np.zeros(max(int(ch.sum()) * 1024, 1), np.float32)
+        descs = (FrameDesc * max(n, 1))()
+        status = np.zeros(max(n, 1), np.int32)
+        check(lib.sk_aac_expand_q_decode(self._h, _ptr(ids), _ptr(counts), len(streams), descs_in, _ptr(sides), _ptr(quant), n,
+                                         _ptr(coeffs), descs, _ptr(status)), "sk_aac_expand_q_decode", self._h)
+        out, off = [], 0
+        for k in range(n):
+            c = int(ch[k])
+            out.append((int(status[k]), coeffs[off:off + c * 1024].reshape(c, 1024).copy(),
+                        [int(descs[k].window_sequence[i]) for i in range(c)], [int(descs[k].window_shape[i]) for i in range(c)]))
+            off += c * 1024
+        return out
+
+    def where(self):
+        """sk_engine_where: the stage of the engine's current tick ("idle" outside one)"""
+        return lib.sk_engine_where(self._h).decode()
+
+    def set_wait_bound(self, seconds):
+        check(lib.sk_engine_set_wait_bound(self._h, float(seconds)), "sk_engine_set_wait_bound")
+
+    def debug_fail_after(self, n_hip_calls):
+        """error-path tests: the n-th HIP call from now fails as a launch failure"""
+        check(lib.sk_engine_debug_fail_after(self._h, int(n_hip_calls)), "sk_engine_debug_fail_after")
+
+
 _default = None
 
 

@@ -24,7 +24,7 @@ def make_descs(granules):
     arr = (Mp3GranuleDesc * max(len(granules), 1))()
     for i, (stream, ch, block_types, mixed) in enumerate(granules):
         arr[i].stream, arr[i].channels = stream, ch
-        for c in range(ch):
+        for c in range(min(ch, 2)):  # a count outside 1..2 is the engine's to reject
             arr[i].block_type[c] = block_types[c]
             arr[i].mixed_block_flag[c] = mixed[c]
     return arr, len(granules)

@@ -163,6 +163,11 @@ def _tns(rng, w, ics):
                     w.put(int(rng.integers(1 << bits)), bits)
 
 
+# extra bits of an escape sequence beyond the first four (N ones): the reference takes up to 12 (magnitudes to 131071,
+# spectral.rs:214-228).  The default stays below i16; tests of the quantised hand-over's wide values widen it.
+ESCAPE_SIZES = [0, 0, 0, 1, 2, 4, 8, 9]
+
+
 def _band(rng, w, book, count, loud):
     if book <= 4:
         for _ in range(count // 4):
@@ -189,7 +194,7 @@ def _band(rng, w, book, count, loud):
         if book == 11:
             for x in v:
                 if x == 16:  # escape: N ones, a zero, N + 4 bits  ->  2^(N+4) + bits
-                    n = int(rng.choice([0, 0, 0, 1, 2, 4, 8, 9]))
+                    n = int(rng.choice(ESCAPE_SIZES))
                     for _ in range(n):
                         w.put(1, 1)
                     w.put(0, 1)

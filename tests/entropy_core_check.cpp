@@ -10,6 +10,7 @@
 #include <vector>
 
 static uint64_t rng = 0x9E3779B97F4A7C15ull;
+static size_t g_wide_values = 0;  // quantised values beyond i16 that went through the hand-over's list
 static uint32_t next() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)(rng >> 16); }
 
 static sk_ec::Tables make_tables() {
@@ -93,21 +94,27 @@ int main(int argc, char **argv) {
             {  // the quantised hand-over: host parse to integers -> wire record -> unpack, dequantise, finish == the above
                 sk_ec::Stream st3{st.sf_index, st.channels, pns_before};
                 std::vector<int16_t> quant(2048, 0), sf0(128, 0), sf1(128, 0);
-                const sk_ec::QuantCapture qc{quant.data(), {sf0.data(), sf1.data()}};
+                sk_ec::WideList wide_list;
+                wide_list.n = 0;
+                const sk_ec::QuantCapture qc{quant.data(), {sf0.data(), sf1.data()}, &wide_list};
                 uint8_t seq3[2] = {0, 0}, shape3[2] = {0, 0};
                 sk_ec::Scratch sc3;
                 int rc3 = sk_ec::parse_unit(tables, st3, words.data(), (uint32_t)au.size(), nullptr, seq3, shape3, sc3, sk_ec::PNS_COUNT, &qc);
-                const bool wide = rc3 == sk_ec::EC_UNSUPPORTED_FEATURE && rc_got != sk_ec::EC_UNSUPPORTED_FEATURE;  // |q| > 32767
+                // more values beyond i16 than the record's list holds (kWideMax): the one case this mode refuses on its own
+                const bool wide = rc3 == sk_ec::EC_UNSUPPORTED_FEATURE && rc_got != sk_ec::EC_UNSUPPORTED_FEATURE && wide_list.n == (uint32_t)sk_ec::kWideMax;
+                g_wide_values += wide_list.n;
                 if (rc3 == 0) {
                     const int32_t tail = sk_ec::unit_tail(words.data(), (uint32_t)au.size(), sc3.resume_pos);
                     const int16_t *sfs[2] = {sf0.data(), sf1.data()};
                     sk_ec::WireUnit wire;
-                    sk_ec::pack_unit(sc3, st.channels, sfs, tail, wire);
-                    sk_ec::Scratch back;
-                    sk_ec::unpack_unit(tables, wire, back);
+                    sk_ec::pack_unit(sc3, st.channels, sfs, tail, wire, &wide_list);
+                    sk_ec::Scratch back{};
+                    rc3 = sk_ec::unpack_unit(tables, wire, back);
+                    if (rc3 != 0) { printf("%s %zu: the record of a parsed unit does not unpack (%d)\n", what, index, rc3); return false; }
                     std::vector<float> qout(2048, 0.0f);
                     rc3 = sk_ec::dequant_channel(tables, st3, back.ch[0], quant.data(), qout.data());
                     if (rc3 == 0 && st.channels == 2) rc3 = sk_ec::dequant_channel(tables, st3, back.ch[1], quant.data() + 1024, qout.data() + 1024);
+                    if (rc3 == 0) rc3 = sk_ec::apply_wide(wire, (uint32_t)st.channels, back, tables, st3, quant.data(), qout.data());
                     static const uint32_t no_bits[4] = {0, 0, 0, 0};
                     if (rc3 == 0) rc3 = sk_ec::finish_unit(tables, st3, no_bits, 0, qout.data(), back, true);
                     if (rc3 == 0) rc3 = wire.tail_status;
@@ -170,6 +177,7 @@ int main(int argc, char **argv) {
         sk_aac_decoder_destroy(dec);
     }
     printf("checked %zu access units, %zu accepted: identical\n", checked, accepted);
+    printf("wide values %zu\n", g_wide_values);
 #ifdef SK_EC_COUNT_PASSES
     printf("flat loop passes %lu, codeword passes %lu\n", sk_ec::g_flat_passes, sk_ec::g_flat_codewords);
 #endif

@@ -5,6 +5,7 @@
 // checked without a GPU.  (Test infrastructure: the product library never contains this file.)
 #include "../soundkit_amd/csrc/pipeline.cpp"
 #include "../soundkit_amd/csrc/aac_frontend.cpp"
+#include "../soundkit_amd/csrc/load_gen.cpp"  // the bench's load generator: its feeder / consumer loops run under the sanitizers too
 
 #include <atomic>
 #include <cstdio>
@@ -21,15 +22,25 @@ struct sk_engine {
     std::mutex mu;
     std::vector<uint8_t> open, channels;
     std::vector<uint32_t> next_unit;
+    std::vector<uint32_t> rs_fill;  // resampling streams: access units waiting for their chunk of four (lib.rs:1970-2003)
+    std::atomic<int> fail_ticks{0}; // the next n ticks fail (a launch failure in the real engine)
 };
+// the slow-tick regime: every tick holds the engine for this long (the device as the slowest stage)
+static std::atomic<uint32_t> g_tick_delay_us{0};
+static void tick_delay() {
+    const uint32_t us = g_tick_delay_us.load();
+    if (us) std::this_thread::sleep_for(std::chrono::microseconds(us));
+}
 extern "C" {
 int sk_engine_device(const sk_engine *) { return 0; }
+const char *sk_engine_where(const sk_engine *) { return "stub"; }
 uint32_t sk_engine_max_streams(const sk_engine *e) { return (uint32_t)e->open.size(); }
 int sk_engine_create(int, uint32_t max_streams, sk_engine **out) {  // lanes 1.. of a pipeline make their own
     sk_engine *e = new sk_engine();
     e->open.assign(max_streams, 0);
     e->channels.assign(max_streams, 0);
     e->next_unit.assign(max_streams, 0);
+    e->rs_fill.assign(max_streams, 0);
     *out = e;
     return SK_OK;
 }
@@ -42,6 +53,8 @@ int sk_stream_open(sk_engine *e, uint32_t, uint8_t ch, uint32_t *out) {
             e->open[i] = 1;
             e->channels[i] = ch;
             e->next_unit[i] = 0;
+            if (e->rs_fill.size() < e->open.size()) e->rs_fill.assign(e->open.size(), 0);
+            e->rs_fill[i] = 0;
             *out = i;
             return SK_OK;
         }
@@ -64,92 +77,124 @@ size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n, uint32_t *max_out
     *max_outputs = outs;
     return bytes;
 }
-// the device front-end's stand-in: checks the unit table the way engine.cpp does and answers one record per unit
-// (stream, running unit number, byte checksum)
+// What every stand-in tick shares: one "AudioData" per access unit -- or, for a resampling stream, per chunk of four
+// units plus the flush tail, the boundaries of the real tick (lib.rs:1970-2003) -- carrying (stream, running unit
+// number, checksum, magic).
+struct Emit {
+    sk_engine *e;
+    uint8_t *out;
+    size_t out_cap;
+    sk_tick_output *outs;
+    uint32_t outs_cap;
+    uint32_t k = 0;
+    size_t cursor = 0;
+    int put(const sk_tick_stream &t, uint32_t row, uint32_t frames, uint32_t sum) {
+        if (k >= outs_cap || cursor + 64 > out_cap) return SK_ERR_INVALID_ARG;
+        uint32_t words[4] = {t.stream, e->next_unit[t.stream], sum, 0xabcd1234u};
+        std::memcpy(out + cursor, words, 16);
+        outs[k++] = sk_tick_output{row, frames, cursor, 16, 0, e->channels[t.stream], 16, 0};
+        cursor += 64;
+        return SK_OK;
+    }
+    int unit(const sk_tick_stream &t, uint32_t row, uint32_t sum) {
+        int rc = SK_OK;
+        if (!t.resample) rc = put(t, row, 1024, sum);
+        else if (++e->rs_fill[t.stream] == 4) {
+            e->rs_fill[t.stream] = 0;
+            rc = put(t, row, 4096, sum);
+        }
+        ++e->next_unit[t.stream];
+        return rc;
+    }
+    int end_of_row(const sk_tick_stream &t, uint32_t row) {
+        if (!t.resample || !t.flush || !e->rs_fill[t.stream]) return SK_OK;
+        const uint32_t left = e->rs_fill[t.stream];
+        e->rs_fill[t.stream] = 0;
+        return put(t, row, 1024 * left, 0);
+    }
+};
+#define STUB_TICK_PROLOGUE()                                                             \
+    std::lock_guard<std::mutex> lk(e->mu);                                               \
+    tick_delay();                                                                        \
+    if (e->fail_ticks.load() > 0 && e->fail_ticks.fetch_sub(1) > 0) return SK_ERR_HIP; \
+    std::map<uint32_t, int> seen;                                                        \
+    Emit em{e, out, out_cap, outs, outs_cap}
+
+// the device front-end's stand-in: checks the unit table the way engine.cpp does
 int sk_tick_run_au(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_au_item *units, uint32_t n_units,
                    const uint8_t *au, size_t au_len, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap,
                    uint32_t *n_outs, size_t *used) {
-    std::lock_guard<std::mutex> lk(e->mu);
-    std::map<uint32_t, int> seen;
-    uint32_t f = 0, k = 0;
-    size_t cursor = 0;
+    STUB_TICK_PROLOGUE();
+    uint32_t f = 0;
     for (uint32_t i = 0; i < n_streams; ++i) {
         if (seen[ts[i].stream]++) return SK_ERR_INVALID_ARG;
         if (ts[i].stream >= e->open.size() || !e->open[ts[i].stream]) return SK_ERR_BAD_STREAM;
         for (uint32_t j = 0; j < ts[i].n_frames; ++j, ++f) {
-            if (f >= n_units || k >= outs_cap || cursor + 64 > out_cap) return SK_ERR_INVALID_ARG;
+            if (f >= n_units) return SK_ERR_INVALID_ARG;
             if (units[f].byte_len > 8192 || units[f].byte_offset % 4 || (size_t)units[f].byte_offset + units[f].byte_len + 8 > au_len)
                 return SK_ERR_INVALID_ARG;
             uint32_t sum = 0;
             for (uint32_t c = 0; c < units[f].byte_len + 8; ++c)  // the 8 bytes after a unit must be there (and zero)
                 sum = sum * 31u + au[units[f].byte_offset + c];
-            uint32_t words[4] = {ts[i].stream, e->next_unit[ts[i].stream]++, sum, 0xabcd1234u};
-            std::memcpy(out + cursor, words, 16);
-            outs[k++] = sk_tick_output{i, 1024, cursor, 16, 0, e->channels[ts[i].stream], 16, 0};
-            cursor += 64;
+            if (int rc = em.unit(ts[i], i, sum)) return rc;
         }
+        if (int rc = em.end_of_row(ts[i], i)) return rc;
     }
     if (f != n_units) return SK_ERR_INVALID_ARG;
-    *n_outs = k;
-    if (used) *used = cursor;
+    *n_outs = em.k;
+    if (used) *used = em.cursor;
     return SK_OK;
 }
-// the quantised hand-over's stand-in: one record per unit (stream, running unit number, checksum of its i16 values and
-// of its side record), with the checks engine.cpp makes on the table
+// the quantised hand-over's stand-in: checksum of a unit's i16 values and of its side record, with the checks engine.cpp
+// makes on the table
 int sk_tick_run_q(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const void *sides,
                   const int16_t *quant, uint32_t n_units, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap,
                   uint32_t *n_outs, size_t *used) {
-    std::lock_guard<std::mutex> lk(e->mu);
-    std::map<uint32_t, int> seen;
-    uint32_t f = 0, k = 0;
-    size_t cursor = 0, at = 0;
+    STUB_TICK_PROLOGUE();
+    uint32_t f = 0;
+    size_t at = 0;
     for (uint32_t i = 0; i < n_streams; ++i) {
         if (seen[ts[i].stream]++) return SK_ERR_INVALID_ARG;
         if (ts[i].stream >= e->open.size() || !e->open[ts[i].stream]) return SK_ERR_BAD_STREAM;
         for (uint32_t j = 0; j < ts[i].n_frames; ++j, ++f) {
-            if (f >= n_units || descs[f].stream != ts[i].stream || k >= outs_cap || cursor + 64 > out_cap) return SK_ERR_INVALID_ARG;
+            if (f >= n_units || descs[f].stream != ts[i].stream) return SK_ERR_INVALID_ARG;
             const uint32_t ch = e->channels[ts[i].stream];
             uint32_t sum = 0;
             for (uint32_t c = 0; c < ch * 1024; ++c) sum = sum * 31u + (uint16_t)quant[at + c];
             at += (size_t)ch * 1024;
             const uint8_t *side = (const uint8_t *)sides + (size_t)f * SK_AAC_UNIT_SIDE_BYTES;
             for (uint32_t c = 0; c < SK_AAC_UNIT_SIDE_BYTES; ++c) sum = sum * 31u + side[c];
-            uint32_t words[4] = {ts[i].stream, e->next_unit[ts[i].stream]++, sum, 0xabcd1234u};
-            std::memcpy(out + cursor, words, 16);
-            outs[k++] = sk_tick_output{i, 1024, cursor, 16, 0, (uint8_t)ch, 16, 0};
-            cursor += 64;
+            if (int rc = em.unit(ts[i], i, sum)) return rc;
         }
+        if (int rc = em.end_of_row(ts[i], i)) return rc;
     }
     if (f != n_units) return SK_ERR_INVALID_ARG;
-    *n_outs = k;
-    if (used) *used = cursor;
+    *n_outs = em.k;
+    if (used) *used = em.cursor;
     return SK_OK;
 }
 int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
                 uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs,
                 size_t *used) {
-    std::lock_guard<std::mutex> lk(e->mu);
-    std::map<uint32_t, int> seen;
-    uint32_t f = 0, k = 0;
-    size_t cursor = 0, fl = 0;
+    STUB_TICK_PROLOGUE();
+    uint32_t f = 0;
+    size_t fl = 0;
     for (uint32_t i = 0; i < n_streams; ++i) {
         if (seen[ts[i].stream]++) return SK_ERR_INVALID_ARG;  // the scheduler must never put a stream twice in a tick
         if (ts[i].stream >= e->open.size() || !e->open[ts[i].stream]) return SK_ERR_BAD_STREAM;
         for (uint32_t j = 0; j < ts[i].n_frames; ++j, ++f) {
-            if (f >= n_frames || descs[f].stream != ts[i].stream || k >= outs_cap || cursor + 64 > out_cap) return SK_ERR_INVALID_ARG;
+            if (f >= n_frames || descs[f].stream != ts[i].stream) return SK_ERR_INVALID_ARG;
             const uint32_t ch = e->channels[ts[i].stream];
             double sum = 0;
             for (uint32_t c = 0; c < ch * 1024; ++c) sum += coeffs[fl + c];
             fl += (size_t)ch * 1024;
-            uint32_t words[4] = {ts[i].stream, e->next_unit[ts[i].stream]++, (uint32_t)(int64_t)(sum * 16.0), 0xabcd1234u};
-            std::memcpy(out + cursor, words, 16);
-            outs[k++] = sk_tick_output{i, 1024, cursor, 16, 0, (uint8_t)ch, 16, 0};
-            cursor += 64;
+            if (int rc = em.unit(ts[i], i, (uint32_t)(int64_t)(sum * 16.0))) return rc;
         }
+        if (int rc = em.end_of_row(ts[i], i)) return rc;
     }
     if (f != n_frames) return SK_ERR_INVALID_ARG;
-    *n_outs = k;
-    if (used) *used = cursor;
+    *n_outs = em.k;
+    if (used) *used = em.cursor;
     return SK_OK;
 }
 }
@@ -208,8 +253,30 @@ static int scenario_many_streams(sk_engine *e) {
     CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
     const uint32_t n = 32, loops = g_front_end == 2 ? 12 : 3;
     std::vector<uint32_t> handles(n);
-    for (uint32_t i = 0; i < n; ++i) CHECK(sk_pipeline_spawn(p, nullptr, &handles[i]) == SK_OK);
+    // streams of bytes that never frame sit between the real ones: they end without ever reaching the engine, so their
+    // batch entries have no tick row -- with several delivery threads the rows and the entries of a batch then number
+    // differently, and a real stream's end must still not overtake its last outputs
+    std::vector<uint32_t> junk_handles;
+    std::vector<uint8_t> junk(3000);
+    for (auto &b : junk) b = (uint8_t)(rnd() | 1) & 0x7f;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i % 6 == 1) {
+            uint32_t h;
+            CHECK(sk_pipeline_spawn(p, nullptr, &h) == SK_OK);
+            junk_handles.push_back(h);
+        }
+        CHECK(sk_pipeline_spawn(p, nullptr, &handles[i]) == SK_OK);
+    }
     std::vector<std::thread> feeders;
+    feeders.emplace_back([&] {
+        for (int rep = 0; rep < 8; ++rep)
+            for (uint32_t h : junk_handles) {
+                (void)sk_pipeline_send(p, h, junk.data(), junk.size());
+                std::this_thread::sleep_for(std::chrono::microseconds(300));
+            }
+        for (uint32_t h : junk_handles)
+            while (sk_pipeline_finish(p, h) != SK_OK) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    });
     for (int t = 0; t < 2; ++t)
         feeders.emplace_back([&, t] {
             for (uint32_t i = (uint32_t)t; i < n; i += 2) {
@@ -232,6 +299,13 @@ static int scenario_many_streams(sk_engine *e) {
     std::vector<int> errors(n, 0);
     CHECK(drain_all(p, handles, got, errors) == 0);
     for (auto &th : feeders) th.join();
+    {
+        std::vector<std::vector<Got>> jg(junk_handles.size());
+        std::vector<int> je(junk_handles.size(), 0);
+        CHECK(drain_all(p, junk_handles, jg, je) == 0);
+        for (size_t i = 0; i < junk_handles.size(); ++i) CHECK(jg[i].empty() && je[i] == 0);
+        for (uint32_t h : junk_handles) CHECK(sk_pipeline_cancel(p, h) == SK_OK);
+    }
     for (uint32_t i = 0; i < n; ++i) {
         CHECK(errors[i] == 0);
         CHECK(got[i].size() == (size_t)48 * loops);
@@ -427,6 +501,58 @@ static int scenario_max_length_frames(sk_engine *e) {
     return 0;
 }
 
+// A tick that fails (a launch failure in the real engine): every stream of that batch is ended with one error after the
+// outputs it already had, the streams of other batches are untouched, nothing stalls and every handle comes back.
+static int scenario_tick_failure(sk_engine *e) {
+    sk_pipeline_config cfg{};
+    cfg.entropy_threads = 3;
+    cfg.max_streams = 12;
+    cfg.max_frames_per_tick = 16;
+    cfg.max_stream_frames_per_tick = 4;
+    cfg.tick_wait_us = 50;
+    cfg.lanes = g_lanes;
+    cfg.gpu_entropy = g_front_end;
+    sk_pipeline *p = nullptr;
+    CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
+    const uint32_t n = 12;
+    std::vector<uint32_t> handles(n);
+    for (auto &h : handles) CHECK(sk_pipeline_spawn(p, nullptr, &h) == SK_OK);
+    g_tick_delay_us.store(300);
+    std::thread feeder([&] {
+        for (int loop = 0; loop < 3; ++loop)
+            for (uint32_t i = 0; i < n; ++i) {
+                int rc;
+                while ((rc = sk_pipeline_send(p, handles[i], clip.data(), clip.size())) == SK_PIPE_INPUT_FULL)
+                    std::this_thread::sleep_for(std::chrono::microseconds(100));
+                if (loop == 1 && i == 3)
+                    for (sk_lane *l : p->lanes) l->engine->fail_ticks.store(2);  // two ticks of every lane's engine fail from here
+            }
+        for (uint32_t i = 0; i < n; ++i) {
+            int rc;
+            while ((rc = sk_pipeline_finish(p, handles[i])) == SK_PIPE_INPUT_FULL) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+    });
+    std::vector<std::vector<Got>> got(n);
+    std::vector<int> errors(n, 0);
+    CHECK(drain_all(p, handles, got, errors) == 0);
+    feeder.join();
+    g_tick_delay_us.store(0);
+    uint32_t failed = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        CHECK(errors[i] <= 1);
+        failed += (uint32_t)errors[i];
+        if (!errors[i]) CHECK(got[i].size() == 48 * 3);
+        for (size_t k = 0; k < got[i].size(); ++k) CHECK(got[i][k].unit == k);  // what did arrive is in order and complete up to the error
+    }
+    CHECK(failed >= 1 && failed < n * (g_lanes ? g_lanes : 1) + 1);
+    sk_pipeline_stats st;
+    CHECK(sk_pipeline_get_stats(p, &st) == SK_OK && st.errors == failed);
+    for (uint32_t h : handles) CHECK(sk_pipeline_cancel(p, h) == SK_OK);
+    sk_pipeline_destroy(p);
+    for (uint8_t o : e->open) CHECK(o == 0);
+    return 0;
+}
+
 static int scenario_cancel_churn(sk_engine *e);
 static int scenario_cancel_churn(sk_engine *e) {
     sk_pipeline_config cfg{};
@@ -462,6 +588,72 @@ static int scenario_cancel_churn(sk_engine *e) {
     return 0;
 }
 
+// The regime of the end-to-end bench in which a stall was seen twice and never reproduced: the tick is the
+// slowest stage, so all three batches are in rotation, the workers wait for batch room holding a parsed stream each,
+// most streams sit at their output bound and the feeders bounce off InputBufferFull.  The bench's own load generator
+// (csrc/load_gen.cpp) drives it, twice on the same pipeline as bench.py does (warm-up, then the timed run), with its
+// progress deadline armed: a stall fails the scenario with the scheduler's state on stderr.
+static int scenario_slow_tick(uint32_t front_end, uint32_t lanes, bool resample, uint32_t n_streams, uint32_t loops, uint32_t tick_us,
+                              uint32_t feeder_threads, uint32_t entropy_threads, uint32_t tick_frames, uint32_t per_stream) {
+    sk_engine *e = nullptr;
+    CHECK(sk_engine_create(0, n_streams, &e) == SK_OK);
+    sk_pipeline_config cfg{};
+    cfg.entropy_threads = entropy_threads;
+    cfg.max_streams = n_streams;
+    cfg.max_frames_per_tick = tick_frames;
+    cfg.max_stream_frames_per_tick = per_stream;
+    cfg.lanes = lanes;
+    cfg.gpu_entropy = front_end;
+    sk_pipeline *p = nullptr;
+    CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
+    sk_decode_options opt{};
+    if (resample) {
+        opt.output_sample_rate = 16000;
+        opt.output_channels = 1;
+    }
+    g_tick_delay_us.store(tick_us);
+    int rc = 0;
+    for (int run = 0; run < 2 && rc == 0; ++run) {
+        sk_load_result res{};
+        const int lrc = sk_loadgen_run(p, clip.data(), clip.size(), 48, n_streams, run == 0 ? 1 : loops, &opt, feeder_threads, 0, &res);
+        const uint64_t units = (uint64_t)48 * (run == 0 ? 1 : loops) * n_streams;
+        const uint64_t want_out = resample ? units / 4 : units;  // 48 units per loop: whole chunks of four, no flush tail
+        if (lrc != SK_OK || res.errors != 0 || res.outputs != want_out) {
+            std::fprintf(stderr, "slow-tick scenario (front-end %u, lanes %u, resample %d, run %d): rc %d errors %llu outputs %llu (want %llu)\n",
+                         front_end, lanes, (int)resample, run, lrc, (unsigned long long)res.errors, (unsigned long long)res.outputs,
+                         (unsigned long long)want_out);
+            rc = 1;
+        }
+    }
+    g_tick_delay_us.store(0);
+    sk_pipeline_destroy(p);
+    sk_engine_destroy(e);
+    return rc;
+}
+
+// `sched_stub <clip> slow <repeats> [seed]`: the slow-tick scenario over and over with drawn shapes (tests/test_scheduler_cpu.py
+// runs a few under the sanitizers; tools/sched_soak.sh runs thousands without)
+static int slow_tick_main(int argc, char **argv) {
+    const int repeats = argc > 3 ? std::atoi(argv[3]) : 4;
+    if (argc > 4) rng_state ^= (uint64_t)std::strtoull(argv[4], nullptr, 10) * 0x9e3779b97f4a7c15ull;
+    setenv("SK_LOADGEN_STALL_S", "20", 0);
+    for (int r = 0; r < repeats; ++r) {
+        const uint32_t front_end = r % 3 == 0 ? 2 : rnd() % 3;
+        const uint32_t lanes = 1 + rnd() % 3 / 2;
+        const bool resample = rnd() % 4 != 0;
+        const uint32_t n_streams = 24 + rnd() % 232;
+        const uint32_t per_stream = 1 + rnd() % 16;
+        const uint32_t tick_frames = std::max(per_stream, n_streams * per_stream / (2 + rnd() % 6));
+        const uint32_t tick_us = 200 + rnd() % 3000;
+        const uint32_t feeders = 2 + rnd() % 5, workers = 1 + rnd() % 6, loops = 1 + rnd() % 3;
+        std::fprintf(stderr, "slow tick %d: front-end %u lanes %u resample %d streams %u per-stream %u tick %u units / %u us feeders %u workers %u loops %u\n",
+                     r, front_end, lanes, (int)resample, n_streams, per_stream, tick_frames, tick_us, feeders, workers, loops);
+        if (int rc = scenario_slow_tick(front_end, lanes, resample, n_streams, loops, tick_us, feeders, workers, tick_frames, per_stream)) return rc;
+    }
+    std::puts("slow-tick scenarios ok");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) return 64;
     FILE *f = std::fopen(argv[1], "rb");
@@ -473,6 +665,8 @@ int main(int argc, char **argv) {
     e.open.assign(64, 0);
     e.channels.assign(64, 0);
     e.next_unit.assign(64, 0);
+    e.rs_fill.assign(64, 0);
+    if (argc > 2 && std::string(argv[2]) == "slow") return slow_tick_main(argc, argv);
     if (int rc = scenario_many_streams(&e)) return rc;
     setenv("SK_PIPELINE_DELIVER_THREADS", "3", 1);  // the sliced delivery path, as the GPU front-end mode uses it
     if (int rc = scenario_many_streams(&e)) return rc;
@@ -493,6 +687,13 @@ int main(int argc, char **argv) {
     if (int rc = scenario_many_streams(&e)) return rc;
     g_lanes = 2;
     if (int rc = scenario_many_streams(&e)) return rc;
+    for (uint32_t fe = 0; fe < 3; ++fe) {
+        g_front_end = fe;
+        g_lanes = 1;
+        if (int rc = scenario_tick_failure(&e)) return rc;
+    }
+    g_lanes = 2;
+    if (int rc = scenario_tick_failure(&e)) return rc;
     g_front_end = 0;
     g_lanes = 1;
     if (int rc = scenario_max_length_frames(&e)) return rc;

@@ -51,3 +51,32 @@ def test_entropy_core_equals_host_front_end_on_generated_units(tmp_path, form):
     out = subprocess.run([exe, "300"] + files, capture_output=True, text=True)
     assert out.returncode == 0 and "identical" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
     assert "checked %d access units" % units in out.stdout
+
+
+def test_quantised_hand_over_carries_values_beyond_i16(tmp_path):
+    """escape sequences of up to 16 extra bits (magnitudes to 131071, spectral.rs:214-228): the quantised hand-over's list
+    of wide values must reproduce the f32 path bit for bit (host build of the core, sanitizers on)"""
+    import re
+
+    import numpy as np
+
+    import au_builder
+    from au_builder import adts_frame, random_access_unit
+    exe = str(tmp_path / "entropy_core_check")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-ffp-contract=off", "-Wno-subobject-linkage", "-o", exe, os.path.join(HERE, "entropy_core_check.cpp")], cwd=HERE)
+    saved = au_builder.ESCAPE_SIZES
+    au_builder.ESCAPE_SIZES = [0, 4, 9, 11, 12]
+    try:
+        files = []
+        for k, (sf_index, channels) in enumerate([(3, 2), (4, 1), (8, 2)]):
+            rng = np.random.default_rng(1900 + k)
+            aus = [random_access_unit(rng, sf_index, channels) for _ in range(60)]
+            path = str(tmp_path / ("wide%d.adts" % k))
+            open(path, "wb").write(b"".join(adts_frame(au, sf_index, channels) for au in aus))
+            files.append(path)
+    finally:
+        au_builder.ESCAPE_SIZES = saved
+    out = subprocess.run([exe, "100"] + files, capture_output=True, text=True)
+    assert out.returncode == 0 and "identical" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+    assert int(re.search(r"wide values (\d+)", out.stdout).group(1)) > 50, out.stdout[-200:]

@@ -180,6 +180,99 @@ def test_gpu_front_end_rejects_what_the_oracle_rejects(engine):
             engine.close_stream(sid)
 
 
+def test_quantised_hand_over_equals_oracle_on_every_fixture_unit(engine):
+    """SURVEY 8f rank 1 against the ORACLE: every fixture access unit through sk_aac_decoder_parse_q (host: Huffman decode to
+    i16 + side record) and sk_aac_expand_q_decode (device: dequantisation dsp.rs:397-405, noise, intensity / mid-side
+    stereo.rs:114-448, TNS tns.rs:237-276) -- spectra bit for bit and the window fields of oracle/aac_frontend.py, in two
+    calls per stream (the PNS generator is carried in the engine between them)."""
+    from oracle import aac_frontend as OF
+    loaded = []
+    for name in FILES:
+        frames = OF.split_adts(open(os.path.join(GOLD, name), "rb").read())
+        dec = OF.Decoder(frames[0][0])
+        want = [dec.decode_access_unit(au) for _, au in frames]
+        fe = aac_lc.AacLcFrontEnd(frames[0][0])
+        loaded.append((engine.open_stream(dec.sample_rate, dec.channels), [fe.parse_q(au) for _, au in frames], want))
+    try:
+        total = 0
+        for part in (0, 1):
+            spans = [(0, len(u) // 3) if part == 0 else (len(u) // 3, len(u)) for _, u, _ in loaded]
+            got = engine.expand_q_decode([(sid, b - a) for (sid, _, _), (a, b) in zip(loaded, spans)],
+                                         [q for (_, u, _), (a, b) in zip(loaded, spans) for q in u[a:b]])
+            pos = 0
+            for (sid, units, want), (a, b) in zip(loaded, spans):
+                for i in range(a, b):
+                    status, coeffs, seq, shape = got[pos]
+                    pos += 1
+                    assert status == 0, (sid, i, status)
+                    assert (seq, shape) == (want[i][1], want[i][2]), (sid, i)
+                    assert np.array_equal(coeffs.view(np.uint32), want[i][0].view(np.uint32)), (sid, i, np.abs(coeffs - want[i][0]).max())
+                    total += 1
+        assert total == 273
+    finally:
+        for sid, _, _ in loaded:
+            engine.close_stream(sid)
+
+
+def test_quantised_hand_over_rejects_what_the_oracle_rejects(engine):
+    """The damaged access units of the test above this one's model (1200 mutations), each on a fresh stream: the two
+    halves of the quantised hand-over together give the oracle's verdict -- the host half (parse_q) rejects what fails
+    up to the spectral data, the device half what fails in the stereo tools, TNS or the rest of the unit -- with the
+    reference's error kind, identical spectra when both accept."""
+    from oracle import aac_frontend as OF
+    from soundkit_amd._lib import ERR_NAMES
+    state = 0x2545F4914F6CDD1D
+    cases = []
+    host_rejected = 0
+    for name in ("aac-stereo-48k.adts", "mono16k_A_Tusk.aac", "stereo-music-44100-192k.aac"):
+        frames = OF.split_adts(open(os.path.join(GOLD, name), "rb").read())
+        for trial in range(400):
+            state ^= (state << 13) & 0xFFFFFFFFFFFFFFFF
+            state ^= state >> 7
+            state ^= (state << 17) & 0xFFFFFFFFFFFFFFFF
+            au = bytearray(frames[(state >> 8) % len(frames)][1])
+            for k in range(1 + (state >> 20) % 3):
+                r = (state >> (24 + 9 * k)) & 0xFFFFFF
+                if r % 3 == 0:
+                    au[(r >> 4) % len(au)] ^= 1 << (r & 7)
+                elif r % 3 == 1:
+                    au[(r >> 4) % len(au)] = (r >> 12) & 0xFF
+                else:
+                    del au[(r >> 4) % len(au):]
+                    if not au:
+                        au = bytearray(b"\0")
+            oracle = OF.Decoder(frames[0][0])
+            try:
+                want = oracle.decode_access_unit(bytes(au))
+            except OF.AacError as e:
+                want = e
+            fe = aac_lc.AacLcFrontEnd(frames[0][0])
+            try:
+                parsed = fe.parse_q(bytes(au))
+            except aac_lc.AacLcError as e:
+                assert isinstance(want, OF.AacError) and e.kind == want.kind and str(want) in str(e), (name, trial, str(e), str(want))
+                host_rejected += 1
+                continue
+            cases.append((engine.open_stream(oracle.sample_rate, oracle.channels), parsed, want))
+    try:
+        got = engine.expand_q_decode([(sid, 1) for sid, _, _ in cases], [q for _, q, _ in cases])
+        accepted = rejected = 0
+        for k, ((sid, q, want), (status, coeffs, seq, shape)) in enumerate(zip(cases, got)):
+            if isinstance(want, OF.AacError):
+                assert status != 0 and ERR_NAMES[status] == want.kind, (k, status, want.kind, str(want))
+                assert not coeffs.any()
+                rejected += 1
+            else:
+                assert status == 0, (k, status)
+                assert (seq, shape) == (want[1], want[2]), k
+                assert np.array_equal(coeffs.view(np.uint32), want[0].view(np.uint32)), k
+                accepted += 1
+        assert accepted > 50 and host_rejected > 200 and rejected > 20, (accepted, host_rejected, rejected)
+    finally:
+        for sid, _, _ in cases:
+            engine.close_stream(sid)
+
+
 def sf_index(rate):
     return [96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000, 7350].index(rate)
 

@@ -210,3 +210,65 @@ def test_a_failed_unit_leaves_the_stream_where_the_sequential_decoder_does(engin
             assert np.array_equal(got[i][1].view(np.uint32), later[i][0].view(np.uint32)), (damage, i)
     finally:
         engine.close_stream(sid)
+
+
+@pytest.mark.gpu
+def test_quantised_hand_over_equals_oracle_on_random_units(engine):
+    """The generated units of every configuration (pulse data, every codebook, multi-filter TNS, grouping) through the
+    quantised hand-over -- sk_aac_decoder_parse_q on the host, sk_aac_expand_q_decode on the device -- against the oracle,
+    in two calls per stream; then the same with escape sequences of up to 16 extra bits, magnitudes an i16 cannot hold:
+    they travel in the side record's list of wide values and come out as the oracle's."""
+    import au_builder
+    from soundkit_amd._lib import ERR_NAMES
+    rates = OF.RATES
+    for sizes, seed0 in ((None, 5000), ([0, 4, 9, 11, 12], 6000)):
+        saved = au_builder.ESCAPE_SIZES
+        if sizes:
+            au_builder.ESCAPE_SIZES = sizes
+        try:
+            streams = []
+            for k, (sf_index, channels) in enumerate(CONFIGS):
+                for run in range(4):
+                    u = make_stream(seed0 + 10 * k + run, sf_index, channels, 24)
+                    want, err = oracle_decode(asc_for(sf_index, channels), u)
+                    streams.append((engine.open_stream(rates[sf_index], channels), asc_for(sf_index, channels), u, want, err))
+        finally:
+            au_builder.ESCAPE_SIZES = saved
+        wide_units = 0
+        try:
+            fes = [aac_lc.AacLcFrontEnd(asc) for _, asc, _, _, _ in streams]
+            alive = [True] * len(streams)
+            for first, last in ((0, 9), (9, 24)):
+                table, parsed, owners = [], [], []
+                for si, (sid, asc, u, want, err) in enumerate(streams):
+                    mine = []
+                    for i in range(first, last):
+                        if not alive[si]:
+                            break
+                        try:
+                            mine.append(fes[si].parse_q(u[i]))
+                        except aac_lc.AacLcError as e:   # the host half rejects what fails up to the spectral data
+                            assert i == len(want) and e.kind == err.kind and str(err) in str(e), (si, i, str(e), str(err))
+                            alive[si] = False
+                    if mine:
+                        table.append((sid, len(mine)))
+                        parsed += mine
+                        owners += [(si, first + j) for j in range(len(mine))]
+                got = engine.expand_q_decode(table, parsed)
+                for (si, i), (q, side, _, _), (status, coeffs, seq, shape) in zip(owners, parsed, got):
+                    sid, asc, u, want, err = streams[si]
+                    wide_units += bool((q == -32768).any())
+                    if i < len(want):
+                        assert status == 0, (si, i, status)
+                        assert (seq, shape) == (want[i][1], want[i][2]), (si, i)
+                        assert np.array_equal(coeffs.view(np.uint32), want[i][0].view(np.uint32)), (si, i, np.abs(coeffs - want[i][0]).max())
+                    elif i == len(want):
+                        assert ERR_NAMES[status] == err.kind, (si, i, status, err.kind)
+                        assert not coeffs.any()
+                        alive[si] = False
+            assert sum(len(w) for _, _, _, w, _ in streams) > 300
+            if sizes:
+                assert wide_units >= 10, wide_units
+        finally:
+            for sid, _, _, _, _ in streams:
+                engine.close_stream(sid)

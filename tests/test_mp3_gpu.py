@@ -95,6 +95,33 @@ def test_s16_tail_and_rejected_granules(engine, oracle):
         engine.close_stream(a), engine.close_stream(b)
 
 
+def test_a_rejected_call_leaves_the_engine_usable(engine, oracle):
+    """A call whose table holds a channel count outside 1..2 is rejected as a whole (SK_ERR_INVALID_ARG) -- and must not
+    leave counts behind in the plan-building scratch it shares with the AAC path: the same granules without the bad
+    entry, and an AAC synthesis call, give what a fresh engine gives."""
+    from soundkit_amd import aac_lc
+    from soundkit_amd._lib import SoundkitError
+    mp3.set_synthesis_window(D, engine)
+    rng = np.random.default_rng(21)
+    xr = (rng.standard_normal((4, 2, 576)) * 0.1).astype(np.float32)
+    a, b = engine.open_stream(44100, 2), engine.open_stream(44100, 2)
+    try:
+        good = [(a, 2, [0, 0], [0, 0]), (b, 2, [0, 0], [0, 0]), (a, 2, [0, 0], [0, 0])]
+        want, status = mp3.hybrid_synthesize(good, xr[:3], engine)
+        assert not status.any()
+        engine.reset_stream(a), engine.reset_stream(b)
+        with pytest.raises(SoundkitError):
+            mp3.hybrid_synthesize(good + [(b, 3, [0, 0], [0, 0])], np.concatenate([xr[:3], xr[3:4]]), engine)
+        got, status = mp3.hybrid_synthesize(good, xr[:3], engine)
+        assert not status.any() and np.array_equal(got, want)
+        # the AAC plan builder uses the same scratch
+        coeffs = (rng.standard_normal((2, 2, 1024)) * 100).astype(np.float32)
+        pcm, st = aac_lc.synthesize_batch(engine, [a, b], 2, coeffs, [[0, 0], [0, 0]], [[0, 0], [0, 0]])
+        assert not st.any() and np.isfinite(pcm).all() and pcm.any()
+    finally:
+        engine.close_stream(a), engine.close_stream(b)
+
+
 def test_full_batch_properties():
     """4096 stereo streams x 2 granules (one MPEG-1 frame each) in one launch: every stream that gets the same lines gives
     the same PCM, the transform is linear, and two calls of one granule equal one call of two (state carried exactly)"""

@@ -1,6 +1,7 @@
 """BASELINE config 5's stream count under the driver: 8192 concurrent ADTS AAC-LC streams through the batch scheduler
 (sk_pipeline_*), 96 access units each (the reference's 48 kHz stereo TS sample, looped as one continuous stream),
-48 kHz stereo -> 16 kHz mono s16 -- once with the entropy front-end on host threads, once on the GPU.
+48 kHz stereo -> 16 kHz mono s16 -- once with the entropy front-end on host threads, once on the GPU, once split (host
+Huffman decode, the rest of the front-end on the GPU: the quantised hand-over).
 
 Every stream gets the same bytes, so every stream must deliver the same AudioData sequence: the harness
 (csrc/load_gen.cpp, sk_loadgen_run_checked) keeps per stream an order-sensitive FNV-1a over (frames, channels, bits,
@@ -55,7 +56,7 @@ def expected(oracle):
     return len(frames), want
 
 
-@pytest.mark.parametrize("gpu_entropy", [0, 1], ids=["host_front_end", "gpu_front_end"])
+@pytest.mark.parametrize("gpu_entropy", [0, 1, 2], ids=["host_front_end", "gpu_front_end", "host_huffman_gpu_rest"])
 def test_8192_streams_through_the_scheduler(engine, expected, gpu_entropy):
     units, want = expected
     from soundkit_amd import aac_lc
@@ -77,7 +78,7 @@ def test_8192_streams_through_the_scheduler(engine, expected, gpu_entropy):
         res = Result()
         opt = DecodeOptionsC(16000, 16, 1, 0)
         rc = lg.sk_loadgen_run_checked(sched._h, clip, len(clip), units, STREAMS, LOOPS, C.byref(opt), 6, 0, C.byref(res), C.byref(chk))
-        assert rc == 0
+        assert rc == 0, "load generator: %d (-8 = its progress deadline: the scheduler's state is on stderr)" % rc
     finally:
         sched.close()
     # every stream: no error, and exactly what the CPU chain sends -- count, bytes, order (the hash is order-sensitive)

@@ -142,3 +142,41 @@ def test_tick_rejects_bad_tables(engine):
     res = engine.tick_run([ok, dict(ok, stream=other)], descs, n, np.concatenate([c.ravel(), c.ravel()]))
     assert [(r[0], r[1] != 0, r[2]) for r in res] == [(0, True, 0), (1, False, 1024)]
     engine.close_stream(sid), engine.close_stream(other)
+
+
+def test_a_failed_launch_does_not_run_the_bookkeeping_ahead(engine):
+    """A HIP call that fails part-way through a tick (injected: sk_engine_debug_fail_after makes the n-th call from now
+    report a launch failure, n = 1, 2, ... until a tick gets through): the tick returns SK_ERR_HIP with the stage in the
+    engine's error text, the engine is idle again, and the streaming resampler's fill -- advanced on the host while the
+    appends are queued -- is put back, so the stream is exactly two access units into its first 4096-frame chunk after the
+    first tick that succeeds however many failed before it: no output then, one chunk's output after two more units."""
+    from soundkit_amd._lib import SoundkitError
+    rate, ch, frames = parsed("aac-stereo-48k.adts")
+    sid = engine.open_stream(rate, ch)
+    engine.resampler_open(sid, rate, 16000)
+    table = [{"stream": sid, "n_frames": 2, "out_bits": 16, "out_channels": 1, "resample": True}]
+
+    def tick(first):
+        take = frames[first:first + 2]
+        descs, n = make_descs([(sid, ch, list(seqs), list(shapes)) for _, seqs, shapes in take])
+        return engine.tick_run(table, descs, n, np.concatenate([c.ravel() for c, _, _ in take]))
+    try:
+        failures, res = 0, None
+        for n in range(1, 200):
+            engine.debug_fail_after(n)
+            try:
+                res = tick(0)
+            except SoundkitError as e:
+                assert e.status == -3, str(e)
+                assert engine.where() == "idle"
+                failures += 1
+                continue
+            break
+        engine.debug_fail_after(0)
+        assert failures >= 8 and res is not None, failures      # the tick is at least that many HIP calls long
+        assert res == []                                         # 2048 frames into the chunk: nothing to send yet
+        res = tick(2)
+        assert len(res) == 1 and res[0][1] == 0 and 1300 <= res[0][2] <= 1400, [(r[1], r[2]) for r in res]
+    finally:
+        engine.debug_fail_after(0)
+        engine.close_stream(sid)
