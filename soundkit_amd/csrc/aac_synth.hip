@@ -596,9 +596,127 @@ __device__ __forceinline__ void fft512(c2 (&z)[8], lds_f4 *ex, const lds_f2 *t64
     dft8(z);
 }
 
-template <bool OUT16>
+// this lane's 16 positions (4l+256r+e, 1020-4l-256r+e) of a 1024-element LDS array of (channel A, channel B) pairs
+__device__ __forceinline__ void read_positions2(const lds_f2 *buf, int lane, f2 (&v)[16]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 4 * lane + 256 * r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f4 f = *reinterpret_cast<const lds_f4 *>(buf + j + 2 * h);
+            const f4 m = *reinterpret_cast<const lds_f4 *>(buf + 1020 - j + 2 * h);
+            v[8 * r + 2 * h] = (f2){f.x, f.y}; v[8 * r + 2 * h + 1] = (f2){f.z, f.w};
+            v[8 * r + 4 + 2 * h] = (f2){m.x, m.y}; v[8 * r + 4 + 2 * h + 1] = (f2){m.z, m.w};
+        }
+    }
+}
+__device__ __forceinline__ void write_positions2(lds_f2 *buf, int lane, const f2 (&v)[16]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 4 * lane + 256 * r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<lds_f4 *>(buf + j + 2 * h) = (f4){v[8 * r + 2 * h].x, v[8 * r + 2 * h].y, v[8 * r + 2 * h + 1].x, v[8 * r + 2 * h + 1].y};
+            *reinterpret_cast<lds_f4 *>(buf + 1020 - j + 2 * h) =
+                (f4){v[8 * r + 4 + 2 * h].x, v[8 * r + 4 + 2 * h].y, v[8 * r + 4 + 2 * h + 1].x, v[8 * r + 4 + 2 * h + 1].y};
+        }
+    }
+}
+
+// synth_rare_frame for the two channels of a pair at once (dsp.rs:284-338), every value the pair (channel A, channel B) as
+// in the pair kernel's long arm: per channel the operations of synth_rare_frame in its order, so the results are its
+// results bit for bit.  Out of line for the same reason; vector state through the wave's LDS:
+//   in : ex[64 w + lane] = pre-twiddled element `lane` of short block w (slot = re A, re B, im A, im B);
+//        stage = the two overlap delays as pairs at this lane's 16 positions (write_positions2)
+//   out: ex, viewed as 1024 pairs, = PCM; stage = new delays (both at this lane's 16 positions)
+__device__ __attribute__((noinline)) void synth_rare_pair(lds_f4 *ex, lds_f2 *stage, const float *win, const f2 *w64, const f2 *tw_short,
+                                                          int prev_a, int shape_a, int prev_b, int shape_b, int lane) {
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const float *prev_short_a = win + 4096 + 256 * prev_a, *cur_short_a = win + 4096 + 256 * shape_a;
+    const float *prev_short_b = win + 4096 + 256 * prev_b, *cur_short_b = win + 4096 + 256 * shape_b;
+    c2 z[8];
+    f2 dly[16];
+    read_positions2(stage, lane, dly);
+    // eight 64-point FFTs, lane = 8 w + a, n = a + 8 b, k = kb + 8 ka (the blocks lie in ex as the first pass wants them)
+#pragma unroll
+    for (int b2 = 0; b2 < 8; ++b2) z[b2] = from_slot(ex[64 * hi3 + lo3 + 8 * b2]);
+    wave_sync();
+    dft8(z);  // over b -> kb
+#pragma unroll
+    for (int kb = 1; kb < 8; ++kb) z[kb] = cmul_w(z[kb], w64[lo3 * kb]);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) ex[64 * hi3 + 8 * kb + lo3] = as_slot(z[kb]);
+    wave_sync();
+#pragma unroll
+    for (int aa = 0; aa < 8; ++aa) z[aa] = from_slot(ex[64 * hi3 + 8 * lo3 + aa]);  // lane = 8 w + kb
+    wave_sync();
+    dft8(z);  // over a -> ka: z[ka] = Z_w[kb + 8 ka]
+#pragma unroll
+    for (int ka = 0; ka < 8; ++ka) {
+        const int k = lo3 + 8 * ka;
+        const f2 t = tw_short[k];
+        const f2 tx = splat(t.x), ty = splat(t.y);
+        const c2 v = {fma2(tx, z[ka].re, -(ty * -z[ka].im)), fma2(tx, -z[ka].im, ty * z[ka].re)};  // tw * conj(z), per channel
+        ex[64 * hi3 + k] = as_slot(v);
+    }
+    wave_sync();
+    // the eight-short overlap buffer (dsp.rs:303-330), one 1024-sample half at a time in `stage`: see synth_rare_frame
+    const bool odd_lane = lane & 1;
+    const int lo = odd_lane ? (63 - lane) >> 1 : lane >> 1;
+    f2 cw[4], pw[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) cw[m] = (f2){cur_short_a[lane + 64 * m], cur_short_b[lane + 64 * m]};
+    pw[0] = (f2){prev_short_a[lane], prev_short_b[lane]};
+    pw[1] = (f2){prev_short_a[lane + 64], prev_short_b[lane + 64]};
+    f2 smp[8][4];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const c2 A = from_slot(ex[64 * w + lo]), B = from_slot(ex[64 * w + 32 + lo]);
+        const f2 s0 = odd_lane ? -A.im : -B.re, s1 = odd_lane ? B.re : A.im, s2 = odd_lane ? A.re : B.im, s3 = odd_lane ? B.im : A.re;
+        smp[w][0] = s0 * (w == 0 ? pw[0] : cw[0]);
+        smp[w][1] = s1 * (w == 0 ? pw[1] : cw[1]);
+        smp[w][2] = s2 * cw[2];
+        smp[w][3] = s3 * cw[3];
+    }
+    wave_sync();
+    f2 o[16], d[16];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) *reinterpret_cast<lds_f4 *>(stage + 2 * lane + 128 * r) = (f4){0.f, 0.f, 0.f, 0.f};
+        wave_sync();
+#pragma unroll
+        for (int parity = 0; parity < 2; ++parity) {
+#pragma unroll
+            for (int w = parity; w < 8; w += 2)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int base = 448 + 128 * w + 64 * m;  // of lane 0; a multiple of 64
+                    if ((base >> 10) != half) continue;
+                    lds_f2 *at = stage + (base & 1023) + lane;
+                    *at = *at + smp[w][m];
+                }
+            wave_sync();
+        }
+        if (half == 0) read_positions2(stage, lane, o);
+        else read_positions2(stage, lane, d);
+        wave_sync();
+    }
+    f2 pcm[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pcm[i] = o[i] + dly[i];
+    write_positions2((lds_f2 *)ex, lane, pcm);
+    write_positions2(stage, lane, d);
+    wave_sync();
+}
+
+// WITH_SHORT: frames in which BOTH channels are EightShort take a wave-uniform arm (synth_rare_frame per channel, as the
+// one-channel kernel calls it); the host pairs only channels whose EightShort frames coincide.  The long arm is the same
+// code in both instantiations, and per channel both arms do what k_aac_synth does: bit-identical results.
+template <bool OUT16, bool WITH_SHORT>
 __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(SynthArgs a) {
     __shared__ f4 lds[kWavesPerBlock][kPairExchange];
+    __shared__ f2 stage_lds[WITH_SHORT ? kWavesPerBlock : 1][WITH_SHORT ? kStage : 2];  // eight-short arm only: 1024 (A, B) pairs per wave
     __shared__ f2 tw_tab[512];
     __shared__ f2 t64_tab[64];
 
@@ -683,6 +801,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(Synth
         dly[8 * r + 6] = M1.x * W2m.z; dly[8 * r + 7] = F0.y * W2m.w;
     };
 
+    lds_f2 *stage = (lds_f2 *)stage_lds[WITH_SHORT ? wave : 0];
+    auto store_pcm = [&](const float (&pcm)[16], uint32_t off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 4 * lane + 256 * r;
+            const f4 f = (f4){pcm[8 * r + 0], pcm[8 * r + 1], pcm[8 * r + 2], pcm[8 * r + 3]};
+            const f4 m = (f4){pcm[8 * r + 4], pcm[8 * r + 5], pcm[8 * r + 6], pcm[8 * r + 7]};
+            if (OUT16) {
+                SK_SYNTH_STORE(pack4_s16(f), reinterpret_cast<u2 *>(a.pcm16 + (size_t)off * 1024 + j));
+                SK_SYNTH_STORE(pack4_s16(m), reinterpret_cast<u2 *>(a.pcm16 + (size_t)off * 1024 + 1020 - j));
+            } else {
+                SK_SYNTH_STORE(f, reinterpret_cast<f4 *>(a.pcm + (size_t)off * 1024 + j));
+                SK_SYNTH_STORE(m, reinterpret_cast<f4 *>(a.pcm + (size_t)off * 1024 + 1020 - j));
+            }
+        }
+    };
+
     f2 xa[8], xb[8];
     load_spectrum(xa, ent_a, 0);
     load_spectrum(xb, ent_b, 0);
@@ -690,6 +825,61 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(Synth
         const uint32_t off_a = __builtin_amdgcn_readfirstlane(ent_a[e].off1024), off_b = __builtin_amdgcn_readfirstlane(ent_b[e].off1024);
         const uint32_t win_a = __builtin_amdgcn_readfirstlane(ent_a[e].win), win_b = __builtin_amdgcn_readfirstlane(ent_b[e].win);
         const int shape_a = (win_a >> 2) & 1, shape_b = (win_b >> 2) & 1;
+        if constexpr (WITH_SHORT) {
+            if ((win_a & 3u) == 2u) {  // wave-uniform; channel B's frame is EightShort too (the host pairs no others)
+                // both channels' EightShort frame (dsp.rs:284-338) through synth_rare_pair: pre-twiddled blocks and the two
+                // overlaps in through the wave's LDS, PCM and new overlaps back the same way
+                {
+                    int opq = 0;  // keeps this rare-path table load inside the branch
+                    asm volatile("" : "+v"(opq));
+                    const f2 tws = reinterpret_cast<const f2 *>(a.t.tw_short)[lane + opq];
+                    const f2 tx = splat(tws.x), ty = splat(tws.y);
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {  // z_w[lane] of short block w (dsp.rs:495-503 with input_len 128)
+                        const f2 even = (f2){xa[w].x, xb[w].x};
+                        const f2 odd = (f2){-__shfl(xa[w].y, 63 - lane), -__shfl(xb[w].y, 63 - lane)};
+                        const c2 zw = {odd * ty - even * tx, odd * tx + even * ty};
+                        ex[64 * w + lane] = as_slot(zw);
+                    }
+                    f2 both[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) both[i] = (f2){dly_a[i], dly_b[i]};
+                    write_positions2(stage, lane, both);
+                    wave_sync();
+                }
+                synth_rare_pair(ex, stage, a.t.win, reinterpret_cast<const f2 *>(a.t.w64), reinterpret_cast<const f2 *>(a.t.tw_short),
+                                prev_a, shape_a, prev_b, shape_b, lane);
+                float pcm_a[16], pcm_b[16];
+                {
+                    f2 both[16];
+                    read_positions2(stage, lane, both);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        dly_a[i] = both[i].x;
+                        dly_b[i] = both[i].y;
+                    }
+                    read_positions2((const lds_f2 *)ex, lane, both);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        pcm_a[i] = both[i].x;
+                        pcm_b[i] = both[i].y;
+                    }
+                    wave_sync();
+                }
+                // as in the long arm: the next spectra first (unconditional), then this frame's stores.  (Issued in front of
+                // the call instead, they gain nothing: the compiler drains the memory pipeline at a call, so the wave would wait
+                // for them there -- measured 0.877-0.886 ms against 0.870 on the mixed batch; inlining the routine spills in the
+                // long arm: 0.946 against 0.896, profiles/r03_ab_mix.md.)
+                const uint32_t ahead = e + 1 < count ? e + 1 : count - 1;
+                load_spectrum(xa, ent_a, ahead);
+                load_spectrum(xb, ent_b, ahead);
+                store_pcm(pcm_a, off_a);
+                store_pcm(pcm_b, off_b);
+                prev_a = shape_a;
+                prev_b = shape_b;
+                continue;
+            }
+        }
         // ---- pre-twiddle (dsp.rs:495-503) of both channels ----
         c2 z[8];
 #pragma unroll
@@ -745,182 +935,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(Synth
         a.prev_shape[state_a] = (uint8_t)prev_a;
         a.prev_shape[state_b] = (uint8_t)prev_b;
     }
-}
-
-// ---- OnlyLong channels, frames in parallel -------------------------------------------------------------------------------
-// The walking kernel above keeps a channel's overlap in registers by giving the whole channel to one long-lived wave;
-// what it pays is the shape: thousands of waves each creeping through their own 4 KiB pieces stream at ~5.1 TB/s on this
-// part where a grid of short-lived blocks sweeping memory in address order reaches 6.2 (tools/probe/stream_probe.hip).
-// The overlap is not a recurrence -- delay_e depends on X_e alone (dsp.rs:267-279) -- so a channel can be cut anywhere at
-// the price of transforming the frame before the cut once more.  Here a workgroup of kGroupWaves waves takes
-// kGroupFrames = 2 kGroupWaves - 1 consecutive OnlyLong frames of one channel: wave w transforms the frames A = 2w - 1
-// and B = 2w of the group (A of wave 0 is the frame BEFORE the group, kept only for its second half -- or the channel's
-// carried state when the group opens the launch).  B's overlap is A's second half, in registers; A's is the second half
-// of the previous wave's B, handed over through LDS behind the block's one barrier.  The wave that holds the channel's
-// last frame writes the new state to `delay_next` / `shape_next` (another group of the same channel may not have read the
-// old state yet); k_commit_state moves it over.
-#ifndef SK_GROUP_MINW
-#define SK_GROUP_MINW 3
-#endif
-constexpr int kGroupWaves = 8;
-constexpr int kGroupFrames = 2 * kGroupWaves - 1;
-
-template <bool OUT16>
-__global__ __launch_bounds__(kGroupWaves * 64, SK_GROUP_MINW) void k_aac_synth_group(SynthArgs a, const SynthGroup *groups, float *delay_next,
-                                                                          uint8_t *shape_next) {
-    __shared__ f2 lds[kGroupWaves][kExchange];
-    __shared__ f2 tw_tab[512];
-    __shared__ f2 t64_tab[64];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < 512; i += kGroupWaves * 64) tw_tab[i] = reinterpret_cast<const f2 *>(a.t.tw_long)[i];
-    if (threadIdx.x < 64) t64_tab[threadIdx.x] = reinterpret_cast<const f2 *>(a.t.w64)[((threadIdx.x >> 3) * (threadIdx.x & 7)) & 63];
-
-    const SynthGroup g = groups[blockIdx.x];
-    const SynthTask task = a.tasks[g.task];
-    const uint32_t first = __builtin_amdgcn_readfirstlane(g.first), n_out = __builtin_amdgcn_readfirstlane(g.count);
-    const uint32_t state = __builtin_amdgcn_readfirstlane(task.state), t_count = __builtin_amdgcn_readfirstlane(task.count);
-    const const_entries entries = as_constant(a.entries + __builtin_amdgcn_readfirstlane(task.begin));
-    lds_f2 *ex = (lds_f2 *)lds[wave];
-    const lds_f2 *tw_lds = (const lds_f2 *)tw_tab;
-    const lds_f2 *t64 = (const lds_f2 *)t64_tab;
-    const int hi3 = lane >> 3, lo3 = lane & 7;
-
-    // frame A: output 2w - 1 of the group (wave 0: the frame before it, or the carried state); frame B: output 2w
-    const bool from_state = wave == 0 && first == 0;
-    const bool a_active = wave == 0 ? first > 0 : (uint32_t)(2 * wave - 1) < n_out;
-    const bool b_active = (uint32_t)(2 * wave) < n_out;
-    const uint32_t ea = first + 2u * (uint32_t)wave - 1u, eb = ea + 1u;  // entries of A and B (when active)
-    f2 xa[8], xb[8];
-    uint32_t win_a = 0, win_b = 0;
-    size_t off_a = 0, off_b = 0;
-    if (a_active) {
-        win_a = __builtin_amdgcn_readfirstlane(entries[ea].win);
-        off_a = (size_t)__builtin_amdgcn_readfirstlane(entries[ea].off1024) * 1024;
-        const float *src = a.coeffs + off_a + 2 * lane;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) xa[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
-    }
-    if (b_active) {
-        win_b = __builtin_amdgcn_readfirstlane(entries[eb].win);
-        off_b = (size_t)__builtin_amdgcn_readfirstlane(entries[eb].off1024) * 1024;
-        const float *src = a.coeffs + off_b + 2 * lane;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) xb[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
-    }
-    const int shape_a = (win_a >> 2) & 1, shape_b = (win_b >> 2) & 1;
-    // the window shape before A: the entry before it, or the carried shape at the start of the launch
-    int shape_before_a = 0;
-    if (a_active && wave >= 1)
-        shape_before_a = ea > 0 ? (int)((__builtin_amdgcn_readfirstlane(entries[ea - 1].win) >> 2) & 1u)
-                                : __builtin_amdgcn_readfirstlane((int)a.prev_shape[state]);
-    const int shape_before_b = from_state ? __builtin_amdgcn_readfirstlane((int)a.prev_shape[state]) : shape_a;
-    float da[16];  // A's windowed second half (or the carried state): B's overlap
-    if (from_state) {
-        const float *delay_ptr = a.delay + (size_t)state * 1024;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int j = 4 * lane + 256 * r;
-            const f4 f = *reinterpret_cast<const f4 *>(delay_ptr + j);
-            const f4 m = *reinterpret_cast<const f4 *>(delay_ptr + 1020 - j);
-            da[8 * r + 0] = f.x; da[8 * r + 1] = f.y; da[8 * r + 2] = f.z; da[8 * r + 3] = f.w;
-            da[8 * r + 4] = m.x; da[8 * r + 5] = m.y; da[8 * r + 6] = m.z; da[8 * r + 7] = m.w;
-        }
-    }
-    __syncthreads();  // twiddles in place
-    const f2 base2 = reinterpret_cast<const f2 *>(a.t.w512)[hi3 * lo3];
-
-    // one frame: first half x W1 -> o, second half x W2 -> d, at this lane's 16 positions (the walking kernel's products,
-    // in its order: dsp.rs:516-531)
-    auto transform = [&](const f2 (&xin)[8], int prev_shape, int shape, float (&o)[16], float (&d)[16]) __attribute__((always_inline)) {
-        const float *w1 = a.t.win + 2048 * prev_shape, *w2 = a.t.win + 2048 * shape + 1024;
-        f4 w1f[2], w1m[2], w2f[2], w2m[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int j = 4 * lane + 256 * r;
-            w1f[r] = *reinterpret_cast<const f4 *>(w1 + j);
-            w1m[r] = *reinterpret_cast<const f4 *>(w1 + 1020 - j);
-            w2f[r] = *reinterpret_cast<const f4 *>(w2 + j);
-            w2m[r] = *reinterpret_cast<const f4 *>(w2 + 1020 - j);
-        }
-        f2 z[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {  // pre-twiddle (dsp.rs:495-503)
-            const float even = xin[r].x;
-            const float odd = -__shfl(xin[7 - r].y, 63 - lane);
-            const f2 t = tw_lds[lane + 64 * r];
-            z[r] = (f2){odd * t.y - even * t.x, odd * t.x + even * t.y};
-        }
-        fft512(z, ex, t64, base2, lane);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ex[lane + 64 * j] = cmul(tw_lds[lane + 64 * j], (f2){z[j].x, -z[j].y});
-        wave_sync();
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int q = 2 * lane + 128 * r;
-            const f4 F = *reinterpret_cast<const lds_f4 *>(&ex[256 + q]);
-            const f4 M = *reinterpret_cast<const lds_f4 *>(&ex[254 - q]);
-            const f4 W1f = w1f[r], W1m = w1m[r], W2f = w2f[r], W2m = w2m[r];
-            o[8 * r + 0] = -F.x * W1f.x; o[8 * r + 1] = -M.w * W1f.y; o[8 * r + 2] = -F.z * W1f.z; o[8 * r + 3] = -M.y * W1f.w;
-            o[8 * r + 4] = M.y * W1m.x; o[8 * r + 5] = F.z * W1m.y; o[8 * r + 6] = M.w * W1m.z; o[8 * r + 7] = F.x * W1m.w;
-            d[8 * r + 0] = F.y * W2f.x; d[8 * r + 1] = M.z * W2f.y; d[8 * r + 2] = F.w * W2f.z; d[8 * r + 3] = M.x * W2f.w;
-            d[8 * r + 4] = M.x * W2m.x; d[8 * r + 5] = F.w * W2m.y; d[8 * r + 6] = M.z * W2m.z; d[8 * r + 7] = F.y * W2m.w;
-        }
-        wave_sync();
-    };
-    auto store_pcm = [&](size_t off, const float (&o)[16], const float (&p)[16]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int j = 4 * lane + 256 * r;
-            const f4 f = (f4){o[8 * r + 0] + p[8 * r + 0], o[8 * r + 1] + p[8 * r + 1], o[8 * r + 2] + p[8 * r + 2], o[8 * r + 3] + p[8 * r + 3]};
-            const f4 m = (f4){o[8 * r + 4] + p[8 * r + 4], o[8 * r + 5] + p[8 * r + 5], o[8 * r + 6] + p[8 * r + 6], o[8 * r + 7] + p[8 * r + 7]};
-            if (OUT16) {
-                SK_SYNTH_STORE(pack4_s16(f), reinterpret_cast<u2 *>(a.pcm16 + off + j));
-                SK_SYNTH_STORE(pack4_s16(m), reinterpret_cast<u2 *>(a.pcm16 + off + 1020 - j));
-            } else {
-                SK_SYNTH_STORE(f, reinterpret_cast<f4 *>(a.pcm + off + j));
-                SK_SYNTH_STORE(m, reinterpret_cast<f4 *>(a.pcm + off + 1020 - j));
-            }
-        }
-    };
-    auto store_state = [&](const float (&d)[16], int shape) __attribute__((always_inline)) {
-        float *dst = delay_next + (size_t)state * 1024;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int j = 4 * lane + 256 * r;
-            *reinterpret_cast<f4 *>(dst + j) = (f4){d[8 * r + 0], d[8 * r + 1], d[8 * r + 2], d[8 * r + 3]};
-            *reinterpret_cast<f4 *>(dst + 1020 - j) = (f4){d[8 * r + 4], d[8 * r + 5], d[8 * r + 6], d[8 * r + 7]};
-        }
-        if (lane == 0) shape_next[state] = (uint8_t)shape;
-    };
-
-    float oa[16], ob[16], db[16];
-    if (a_active) {
-        transform(xa, shape_before_a, shape_a, oa, da);
-        if (ea + 1 == t_count) store_state(da, shape_a);
-    }
-    if (b_active) {
-        transform(xb, shape_before_b, shape_b, ob, db);
-        store_pcm(off_b, ob, da);
-        if (eb + 1 == t_count) store_state(db, shape_b);
-        write_positions((lds_f *)ex, lane, db);  // the next wave's A overlaps with this
-    }
-    __syncthreads();
-    if (!a_active || wave == 0) return;
-    float prev[16];
-    read_positions((const lds_f *)lds[wave - 1], lane, prev);
-    store_pcm(off_a, oa, prev);
-}
-
-// the states the group kernel left in delay_next / shape_next become the channels' carried states
-__global__ __launch_bounds__(256) void k_commit_state(const SynthTask *tasks, const uint32_t *task_ids, uint32_t n, float *delay,
-                                                      const float *delay_next, uint8_t *shape, const uint8_t *shape_next) {
-    const uint32_t k = blockIdx.x;
-    if (k >= n) return;
-    const uint32_t state = tasks[task_ids[k]].state;
-    reinterpret_cast<f4 *>(delay + (size_t)state * 1024)[threadIdx.x] = reinterpret_cast<const f4 *>(delay_next + (size_t)state * 1024)[threadIdx.x];
-    if (threadIdx.x == 0) shape[state] = shape_next[state];
 }
 
 // planar f32 [ch][1024] -> interleaved i16 [1024][ch] with float_sample_to_i16
@@ -1005,26 +1019,20 @@ hipError_t launch_aac_synth(const SynthArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_aac_synth_pairs(const SynthArgs &a, hipStream_t s) {
+hipError_t launch_aac_synth_pairs(const SynthArgs &a, bool with_short, hipStream_t s) {
     if (a.n_tasks < 2) return hipSuccess;
     if (a.n_tasks & 1) return hipErrorInvalidValue;
     const uint32_t pairs = a.n_tasks / 2, blocks = (pairs + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (a.pcm16) hipLaunchKernelGGL(k_aac_synth_pair<true>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
-    else hipLaunchKernelGGL(k_aac_synth_pair<false>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, s, a);
+    const dim3 grid(blocks), block(kWavesPerBlock * 64);
+    if (with_short) {
+        if (a.pcm16) hipLaunchKernelGGL((k_aac_synth_pair<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_aac_synth_pair<false, true>), grid, block, 0, s, a);
+    } else {
+        if (a.pcm16) hipLaunchKernelGGL((k_aac_synth_pair<true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_aac_synth_pair<false, false>), grid, block, 0, s, a);
+    }
     return hipGetLastError();
 }
-
-hipError_t launch_aac_synth_groups(const SynthArgs &a, const SynthGroup *groups, uint32_t n_groups, const uint32_t *task_ids,
-                                   uint32_t n_group_tasks, float *delay_next, uint8_t *shape_next, hipStream_t s) {
-    if (n_groups == 0) return hipSuccess;
-    if (a.pcm16) hipLaunchKernelGGL(k_aac_synth_group<true>, dim3(n_groups), dim3(kGroupWaves * 64), 0, s, a, groups, delay_next, shape_next);
-    else hipLaunchKernelGGL(k_aac_synth_group<false>, dim3(n_groups), dim3(kGroupWaves * 64), 0, s, a, groups, delay_next, shape_next);
-    hipLaunchKernelGGL(k_commit_state, dim3(n_group_tasks), dim3(256), 0, s, a.tasks, task_ids, n_group_tasks, a.delay, delay_next,
-                       a.prev_shape, shape_next);
-    return hipGetLastError();
-}
-
-uint32_t synth_group_frames() { return kGroupFrames; }
 
 hipError_t launch_frames_to_s16(const float *planar, int16_t *out, const FrameSpan *frames, uint32_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;

@@ -207,8 +207,6 @@ struct sk_engine {
 
     float *d_delay = nullptr;
     uint8_t *d_prev_shape = nullptr;
-    float *d_delay_next = nullptr;      // where the OnlyLong group kernel leaves new states until k_commit_state moves them
-    uint8_t *d_shape_next = nullptr;
     float *d_rs = nullptr;  // [max_streams * 2][kRsRow], allocated on first sk_resampler_open
     // MP3 hybrid synthesis (mp3_hybrid.hip): tables and per-(stream, channel) state, allocated on first use
     float *d_mp3_tables = nullptr, *d_mp3_state = nullptr;
@@ -254,11 +252,10 @@ struct sk_aac_plan {
     sk::SynthTask *d_tasks = nullptr;
     sk::SynthEntry *d_entries = nullptr;
     sk::FrameSpan *d_spans = nullptr;
-    // tasks whose frames are all OnlyLong run as groups of frames (k_aac_synth_group), the others walk (k_aac_synth)
-    sk::SynthTask *d_walk_tasks = nullptr, *d_long_tasks = nullptr;
-    sk::SynthGroup *d_groups = nullptr;
-    uint32_t *d_group_tasks = nullptr;
-    uint32_t n_walk_tasks = 0, n_long_tasks = 0, n_pair_tasks = 0, n_groups = 0, n_group_tasks = 0;
+    // the tasks again, by the kernel that runs them (build_plan_host): two channels per wave without / with EightShort frames,
+    // one channel per wave without / with them
+    sk::SynthTask *d_pair_tasks = nullptr, *d_spair_tasks = nullptr, *d_long_tasks = nullptr, *d_walk_tasks = nullptr;
+    uint32_t n_pair_tasks = 0, n_spair_tasks = 0, n_long_tasks = 0, n_walk_tasks = 0;
 };
 
 #define SK_HIP(expr, what)                               \
@@ -480,8 +477,6 @@ int sk_engine_create(int device, uint32_t max_streams, sk_engine **out) {
         he = hipMalloc((void **)&e->d_delay, states * 1024 * sizeof(float));
         if (he != hipSuccess) { rc = e->hip_fail(he, "alloc delay"); break; }
         he = hipMalloc((void **)&e->d_prev_shape, states);
-        if (he == hipSuccess) he = hipMalloc((void **)&e->d_delay_next, states * 1024 * sizeof(float));
-        if (he == hipSuccess) he = hipMalloc((void **)&e->d_shape_next, states);
         if (he != hipSuccess) { rc = e->hip_fail(he, "alloc prev_shape"); break; }
         (void)hipMemset(e->d_delay, 0, states * 1024 * sizeof(float));
         (void)hipMemset(e->d_prev_shape, 0, states);
@@ -508,7 +503,7 @@ void sk_engine_destroy(sk_engine *e) {
     {
         DeviceGuard guard(e->device);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
-        for (void *p : {(void *)e->d_mp3_tables, (void *)e->d_mp3_state, (void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_delay_next, (void *)e->d_shape_next, (void *)e->d_rs, (void *)e->d_tables,
+        for (void *p : {(void *)e->d_mp3_tables, (void *)e->d_mp3_state, (void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
                         (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag, (void *)e->d_afrag16, (void *)e->d_afrag_f16,
                         (void *)e->d_zeros})
             if (p) (void)hipFree(p);
@@ -652,8 +647,8 @@ void sk_aac_plan_destroy(sk_aac_plan *p) {
         if (p->d_spans) (void)hipFree(p->d_spans);
         if (p->d_walk_tasks) (void)hipFree(p->d_walk_tasks);
         if (p->d_long_tasks) (void)hipFree(p->d_long_tasks);
-        if (p->d_groups) (void)hipFree(p->d_groups);
-        if (p->d_group_tasks) (void)hipFree(p->d_group_tasks);
+        if (p->d_pair_tasks) (void)hipFree(p->d_pair_tasks);
+        if (p->d_spair_tasks) (void)hipFree(p->d_spair_tasks);
     }
     delete p;
 }
@@ -670,11 +665,8 @@ struct HostPlan {
     std::vector<sk::SynthEntry> entries;
     std::vector<sk::FrameSpan> spans;
     std::vector<uint32_t> entry_of;  // [frame * 2 + channel] -> index into entries (valid frames only)
-    // split of `tasks` by kernel: all-OnlyLong tasks cut into groups of frames, the rest for the walking kernel
-    std::vector<sk::SynthTask> walk_tasks, long_tasks;
-    std::vector<sk::SynthGroup> groups;
-    std::vector<uint32_t> group_tasks;
-    uint32_t n_pair_tasks = 0;  // long_tasks[0 .. n_pair_tasks) are pairs of equal count (2p, 2p + 1) for the two-channel kernel
+    // `tasks` again, by kernel (see the end of build_plan_host)
+    std::vector<sk::SynthTask> pair_tasks, spair_tasks, long_tasks, walk_tasks;
     uint32_t frames_ok = 0;
     uint64_t off1024 = 0;  // total packed size in units of 1024 f32
 };
@@ -744,58 +736,67 @@ int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, in
     if (bad_desc_channels || off > 0xffffffffull) return SK_ERR_INVALID_ARG;
     hp.frames_ok = frames_ok;
     hp.off1024 = off;
-    // Which kernel runs which task.  Tasks whose frames are all OnlyLong (when the host knows the windows) take the
-    // straight-line walking kernel (k_aac_synth<.., true>); the rest the general one.  SK_SYNTH_GROUPS=1 sends the OnlyLong
-    // tasks to the frames-in-parallel kernel instead (k_aac_synth_group: correct and tested but slower on this part,
-    // profiles/r02_ab_synth_groups.md).
-    static const bool use_groups = [] { const char *v = std::getenv("SK_SYNTH_GROUPS"); return v && v[0] == '1'; }();
-    hp.walk_tasks.clear();
-    hp.long_tasks.clear();
-    hp.groups.clear();
-    hp.group_tasks.clear();
-    const uint32_t per_group = sk::synth_group_frames();
-    for (uint32_t t = 0; t < tasks.size(); ++t) {
-        // "long" = no EightShort frame: OnlyLong, LongStart and LongStop are one code path (the transition windows are tables)
-        bool only_long = windows_known, pure_long = windows_known;
-        for (uint32_t k = 0; only_long && k < tasks[t].count; ++k) {
-            const uint32_t seq = entries[tasks[t].begin + k].win & 3u;
-            only_long = seq != 2;
-            pure_long = pure_long && seq == 0;
-        }
-        if (!only_long) {
-            hp.walk_tasks.push_back(tasks[t]);
-        } else if (!use_groups || !pure_long) {
-            hp.long_tasks.push_back(tasks[t]);
-        } else {
-            hp.group_tasks.push_back(t);
-            for (uint32_t first = 0; first < tasks[t].count; first += per_group)
-                hp.groups.push_back(sk::SynthGroup{t, first, std::min(per_group, tasks[t].count - first), 0});
-        }
-    }
-    // OnlyLong tasks with the same number of frames go two to a wave (k_aac_synth_pair); a task meets the nearest earlier
-    // task of its count that is still alone -- the other channel of its stream, when there is one.  SK_SYNTH_PAIRS=0: none.
+    // Which kernel runs which task (dsp.rs:230-338: OnlyLong, LongStart and LongStop are one code path here -- the transition
+    // windows are tables -- so only EightShort frames tell tasks apart):
+    //   pair_tasks   two tasks of equal length without an EightShort frame share a wave (k_aac_synth_pair): normally the L and
+    //                R of a stream; a task meets the nearest earlier task of its length that is still alone
+    //   spair_tasks  the same for two tasks whose EightShort frames fall on the SAME frame numbers (a channel pair coded with
+    //                a common window -- the usual case -- switches both channels together): the pair kernel with a wave-uniform
+    //                eight-short arm.  One EightShort frame no longer sends all of a channel's frames to the one-channel kernel
+    //   long_tasks   without EightShort frames, no partner: the straight-line one-channel kernel
+    //   walk_tasks   everything else (and every task when the windows are not known yet: the device front-end fills them in)
+    // SK_SYNTH_PAIRS=0: no pairs at all (A/B runs).
     static const bool use_pairs = [] { const char *v = std::getenv("SK_SYNTH_PAIRS"); return !(v && v[0] == '0'); }();
-    hp.n_pair_tasks = 0;
-    if (use_pairs && hp.long_tasks.size() > 1) {
-        std::vector<sk::SynthTask> paired, alone;
-        std::unordered_map<uint32_t, uint32_t> waiting;  // count -> index into long_tasks
-        std::vector<uint8_t> taken(hp.long_tasks.size(), 0);
-        for (uint32_t t = 0; t < hp.long_tasks.size(); ++t) {
-            auto it = waiting.find(hp.long_tasks[t].count);
+    hp.pair_tasks.clear();
+    hp.spair_tasks.clear();
+    hp.long_tasks.clear();
+    hp.walk_tasks.clear();
+    {
+        struct Key {
+            uint32_t count;
+            uint64_t shorts;  // hash of the frame numbers that are EightShort (0: none)
+            bool operator==(const Key &o) const { return count == o.count && shorts == o.shorts; }
+        };
+        struct KeyHash {
+            size_t operator()(const Key &k) const { return (size_t)(k.shorts * 0x9e3779b97f4a7c15ull ^ k.count); }
+        };
+        std::unordered_map<Key, uint32_t, KeyHash> waiting;  // -> task index, still alone
+        std::vector<Key> keys(tasks.size());
+        std::vector<int32_t> partner(tasks.size(), -1);
+        for (uint32_t t = 0; t < tasks.size(); ++t) {
+            uint64_t h = 0;
+            for (uint32_t k = 0; windows_known && k < tasks[t].count; ++k)
+                if ((entries[tasks[t].begin + k].win & 3u) == 2u) h = (h ^ (k + 1)) * 0x100000001b3ull + 0x9e3779b9u;
+            keys[t] = Key{tasks[t].count, h};
+            if (!windows_known || !use_pairs) continue;
+            auto it = waiting.find(keys[t]);
             if (it == waiting.end()) {
-                waiting.emplace(hp.long_tasks[t].count, t);
+                waiting.emplace(keys[t], t);
+                continue;
+            }
+            // equal hashes are not yet equal patterns: compare the frames themselves
+            const uint32_t u = it->second;
+            bool same = true;
+            for (uint32_t k = 0; same && keys[t].shorts && k < tasks[t].count; ++k)
+                same = ((entries[tasks[t].begin + k].win & 3u) == 2u) == ((entries[tasks[u].begin + k].win & 3u) == 2u);
+            if (!same) continue;
+            partner[t] = (int32_t)u;
+            partner[u] = (int32_t)t;
+            waiting.erase(it);
+        }
+        for (uint32_t t = 0; t < tasks.size(); ++t) {
+            const bool has_short = !windows_known || keys[t].shorts != 0;
+            if (partner[t] >= 0) {
+                if ((uint32_t)partner[t] < t) continue;  // listed with its partner
+                std::vector<sk::SynthTask> &dst = has_short ? hp.spair_tasks : hp.pair_tasks;
+                dst.push_back(tasks[t]);
+                dst.push_back(tasks[(uint32_t)partner[t]]);
+            } else if (has_short) {
+                hp.walk_tasks.push_back(tasks[t]);
             } else {
-                paired.push_back(hp.long_tasks[it->second]);
-                paired.push_back(hp.long_tasks[t]);
-                taken[it->second] = taken[t] = 1;
-                waiting.erase(it);
+                hp.long_tasks.push_back(tasks[t]);
             }
         }
-        for (uint32_t t = 0; t < hp.long_tasks.size(); ++t)
-            if (!taken[t]) alone.push_back(hp.long_tasks[t]);
-        hp.n_pair_tasks = (uint32_t)paired.size();
-        paired.insert(paired.end(), alone.begin(), alone.end());
-        hp.long_tasks.swap(paired);
     }
     return SK_OK;
 }
@@ -826,13 +827,12 @@ int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n,
         if (he == hipSuccess) he = upload(&p->d_spans, hp.spans);
         if (he == hipSuccess && !hp.walk_tasks.empty()) he = upload(&p->d_walk_tasks, hp.walk_tasks);
         if (he == hipSuccess && !hp.long_tasks.empty()) he = upload(&p->d_long_tasks, hp.long_tasks);
-        p->n_long_tasks = (uint32_t)hp.long_tasks.size();
-        p->n_pair_tasks = hp.n_pair_tasks;
-        if (he == hipSuccess && !hp.groups.empty()) he = upload(&p->d_groups, hp.groups);
-        if (he == hipSuccess && !hp.group_tasks.empty()) he = upload(&p->d_group_tasks, hp.group_tasks);
+        if (he == hipSuccess && !hp.pair_tasks.empty()) he = upload(&p->d_pair_tasks, hp.pair_tasks);
+        if (he == hipSuccess && !hp.spair_tasks.empty()) he = upload(&p->d_spair_tasks, hp.spair_tasks);
         p->n_walk_tasks = (uint32_t)hp.walk_tasks.size();
-        p->n_groups = (uint32_t)hp.groups.size();
-        p->n_group_tasks = (uint32_t)hp.group_tasks.size();
+        p->n_long_tasks = (uint32_t)hp.long_tasks.size();
+        p->n_pair_tasks = (uint32_t)hp.pair_tasks.size();
+        p->n_spair_tasks = (uint32_t)hp.spair_tasks.size();
         if (he != hipSuccess) {
             sk_aac_plan_destroy(p);
             return e->hip_fail(he, "upload plan");
@@ -851,16 +851,16 @@ static int run_plan(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, f
     a.prev_shape = e->d_prev_shape;
     a.entries = p->d_entries;
     a.t = e->synth_tables;
-    a.tasks = p->d_tasks;
-    SK_HIP(sk::launch_aac_synth_groups(a, p->d_groups, p->n_groups, p->d_group_tasks, p->n_group_tasks, e->d_delay_next,
-                                       e->d_shape_next, e->stream), "launch aac synth (groups)");
     a.only_long = 1;
-    a.tasks = p->d_long_tasks;
+    a.tasks = p->d_pair_tasks;
     a.n_tasks = p->n_pair_tasks;
-    SK_HIP(sk::launch_aac_synth_pairs(a, e->stream), "launch aac synth (OnlyLong tasks, two per wave)");
-    a.tasks = p->d_long_tasks + p->n_pair_tasks;
-    a.n_tasks = p->n_long_tasks - p->n_pair_tasks;
-    SK_HIP(sk::launch_aac_synth(a, e->stream), "launch aac synth (OnlyLong tasks)");
+    SK_HIP(sk::launch_aac_synth_pairs(a, false, e->stream), "launch aac synth (two channels per wave)");
+    a.tasks = p->d_spair_tasks;
+    a.n_tasks = p->n_spair_tasks;
+    SK_HIP(sk::launch_aac_synth_pairs(a, true, e->stream), "launch aac synth (two channels per wave, eight-short arm)");
+    a.tasks = p->d_long_tasks;
+    a.n_tasks = p->n_long_tasks;
+    SK_HIP(sk::launch_aac_synth(a, e->stream), "launch aac synth (one channel per wave, no EightShort)");
     a.tasks = p->d_walk_tasks;
     a.n_tasks = p->n_walk_tasks;
     a.only_long = 0;
@@ -2372,24 +2372,21 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             }
             return SK_OK;
         }
-        if (!hp.groups.empty()) {  // channels that are OnlyLong throughout this tick: frames in parallel
-            const sk::SynthGroup *d_groups = nullptr;
-            const uint32_t *d_group_tasks = nullptr;
-            SK_HIP(aux.put(hp.groups, e->stream, &d_groups), "upload tick groups");
-            SK_HIP(aux.put(hp.group_tasks, e->stream, &d_group_tasks), "upload tick group tasks");
-            SK_HIP(sk::launch_aac_synth_groups(a, d_groups, (uint32_t)hp.groups.size(), d_group_tasks, (uint32_t)hp.group_tasks.size(),
-                                               e->d_delay_next, e->d_shape_next, e->stream), "launch tick synth (groups)");
+        a.only_long = 1;
+        if (!hp.pair_tasks.empty()) {
+            SK_HIP(aux.put(hp.pair_tasks, e->stream, &a.tasks), "upload tick pair tasks");
+            a.n_tasks = (uint32_t)hp.pair_tasks.size();
+            SK_HIP(sk::launch_aac_synth_pairs(a, false, e->stream), "launch tick synth (two channels per wave)");
+        }
+        if (!hp.spair_tasks.empty()) {
+            SK_HIP(aux.put(hp.spair_tasks, e->stream, &a.tasks), "upload tick pair tasks with EightShort frames");
+            a.n_tasks = (uint32_t)hp.spair_tasks.size();
+            SK_HIP(sk::launch_aac_synth_pairs(a, true, e->stream), "launch tick synth (two channels per wave, eight-short arm)");
         }
         if (!hp.long_tasks.empty()) {
-            const sk::SynthTask *d_long = nullptr;
-            SK_HIP(aux.put(hp.long_tasks, e->stream, &d_long), "upload tick OnlyLong tasks");
-            a.only_long = 1;
-            a.tasks = d_long;
-            a.n_tasks = hp.n_pair_tasks;
-            SK_HIP(sk::launch_aac_synth_pairs(a, e->stream), "launch tick synth (OnlyLong tasks, two per wave)");
-            a.tasks = d_long + hp.n_pair_tasks;
-            a.n_tasks = (uint32_t)hp.long_tasks.size() - hp.n_pair_tasks;
-            SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth (OnlyLong tasks)");
+            SK_HIP(aux.put(hp.long_tasks, e->stream, &a.tasks), "upload tick tasks without EightShort frames");
+            a.n_tasks = (uint32_t)hp.long_tasks.size();
+            SK_HIP(sk::launch_aac_synth(a, e->stream), "launch tick synth (one channel per wave, no EightShort)");
         }
         if (!hp.walk_tasks.empty()) {
             SK_HIP(aux.put(hp.walk_tasks, e->stream, &a.tasks), "upload tick walk tasks");

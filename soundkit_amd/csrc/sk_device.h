@@ -21,11 +21,6 @@ struct SynthTask {
     uint32_t pad;
 };
 
-// One workgroup of the OnlyLong kernel: `count` (<= synth_group_frames()) consecutive entries of a task, from entry `first`
-struct SynthGroup {
-    uint32_t task, first, count, pad;
-};
-
 struct SynthTables {
     const float2 *tw_long;   // [512]  dsp.rs:99-106 twiddle, input_len 1024
     const float2 *tw_short;  // [64]   same, input_len 128
@@ -56,11 +51,9 @@ struct FrameSpan {
 
 hipError_t launch_aac_synth(const SynthArgs &a, hipStream_t s);
 // OnlyLong tasks two per wave: a.tasks[2p] and a.tasks[2p + 1] have the same count (a.n_tasks even)
-hipError_t launch_aac_synth_pairs(const SynthArgs &a, hipStream_t s);
-// tasks whose frames are all OnlyLong, cut into groups (a.tasks indexed by SynthGroup::task; task_ids lists those tasks)
-hipError_t launch_aac_synth_groups(const SynthArgs &a, const SynthGroup *groups, uint32_t n_groups, const uint32_t *task_ids,
-                                   uint32_t n_group_tasks, float *delay_next, uint8_t *shape_next, hipStream_t s);
-uint32_t synth_group_frames();
+// with_short: the tasks' EightShort frames coincide pairwise (both channels of a pair switch together): the kernel with the
+// wave-uniform eight-short arm; without: the caller vouches that no entry is EightShort
+hipError_t launch_aac_synth_pairs(const SynthArgs &a, bool with_short, hipStream_t s);
 hipError_t launch_reset_stream(float *delay2048, uint8_t *shape2, uint32_t *pns, hipStream_t s);
 hipError_t launch_frames_to_s16(const float *planar, int16_t *out, const FrameSpan *frames, uint32_t n, hipStream_t s);
 hipError_t launch_dequantize(const int16_t *q, const int16_t *sf, float *out, size_t n, const float *pow43,

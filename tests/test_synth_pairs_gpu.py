@@ -164,3 +164,63 @@ def test_random_plans_against_the_oracle(engine, oracle, seed):
         assert np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)) / den < 1.0e-6, (s, kind[s], chans[s])
     for sid in sids:
         engine.close_stream(sid)
+
+
+@pytest.mark.parametrize("out", ["f32", "s16"])
+def test_pairs_with_coinciding_eight_short_frames(engine, oracle, out):
+    """Two channels whose EightShort frames fall on the same frame numbers share a wave (k_aac_synth_pair<.., true>: the
+    long arm plus a wave-uniform eight-short arm, dsp.rs:284-338), whatever the rest of their sequences; a channel whose
+    short frames sit elsewhere, or that finds no partner, runs the one-channel kernel.  Per channel both do the same
+    operations in the same order: the stereo stream's L and R must equal, bit for bit, the same channels decoded as mono
+    streams that cannot pair -- and both match the oracle."""
+    import torch
+    n = 14
+    # L and R: EightShort at frames 3, 4, 9 in both, different transitions / shapes around them
+    seq_l = [0, 0, 1, 2, 2, 3, 0, 0, 1, 2, 3, 0, 1, 3]
+    seq_r = [0, 1, 3, 2, 2, 3, 1, 3, 1, 2, 3, 0, 0, 0]
+    shapes_l = [(f // 2) & 1 for f in range(n)]
+    shapes_r = [(f // 3) & 1 for f in range(n)]
+    left, right = spectra(oracle, n, 0x2468, 6000.0), spectra(oracle, n, 0x1357, 9000.0)
+    stereo = engine.open_stream(48000, 2)
+    mono_l = engine.open_stream(48000, 1)     # n frames: its only possible partner (mono_r) has its shorts elsewhere
+    mono_r = engine.open_stream(48000, 1)     # n - 1 frames: no partner of that length
+    streams, chans, seqs, shapes, chunks = [], [], [], [], []
+    for f in range(n):
+        streams.append(stereo); chans.append(2); seqs.append([seq_l[f], seq_r[f]]); shapes.append([shapes_l[f], shapes_r[f]])
+        chunks.append(np.stack([left[f], right[f]]))
+        streams.append(mono_l); chans.append(1); seqs.append([seq_l[f], 0]); shapes.append([shapes_l[f], 0]); chunks.append(left[f][None])
+        if f < n - 1:
+            streams.append(mono_r); chans.append(1); seqs.append([seq_r[f], 0]); shapes.append([shapes_r[f], 0]); chunks.append(right[f][None])
+    packed = np.concatenate([c.reshape(-1) for c in chunks]).astype(np.float32)
+    descs, cnt = soundkit_amd.descs_from_arrays(streams, np.array(chans, np.uint8), np.array(seqs, np.uint8), np.array(shapes, np.uint8))
+    plan = engine.plan(descs, cnt)
+    d_in = torch.from_numpy(packed).cuda()
+    d_out = torch.empty_like(d_in) if out == "f32" else torch.zeros(d_in.shape, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    (plan.run_f32 if out == "f32" else plan.run_s16_planar)(d_in, d_out)
+    engine.synchronize()
+    got = d_out.cpu().numpy()
+    per = {stereo: [], mono_l: [], mono_r: []}
+    at = 0
+    for sid, ch in zip(streams, chans):
+        per[sid].append(got[at:at + ch * 1024].reshape(ch, 1024))
+        at += ch * 1024
+    st = np.stack(per[stereo])
+    assert np.array_equal(np.stack(per[mono_l])[:, 0], st[:, 0])
+    assert np.array_equal(np.stack(per[mono_r])[:, 0], st[:n - 1, 1])
+    ds, ss = engine.get_state(stereo, 2)
+    dl, sl = engine.get_state(mono_l, 1)
+    assert np.array_equal(ds[0], dl[0]) and ss[0] == sl[0]
+    want, _ = oracle.synthesize_stream(np.stack([left, right], 1), np.array(list(zip(seq_l, seq_r)), np.uint8),
+                                       np.array(list(zip(shapes_l, shapes_r)), np.uint8))
+    if out == "f32":
+        den = np.sqrt(np.mean(want.astype(np.float64) ** 2))
+        assert np.sqrt(np.mean((st.astype(np.float64) - want) ** 2)) / den < 1.0e-6
+        assert np.abs(st - want).max() < 2e-6 * np.abs(want).max()
+    else:
+        exp = np.stack([oracle.planar_f32_to_s16_interleaved(w).reshape(1024, 2).T for w in want])
+        d = np.abs(st.astype(np.int32) - exp.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    plan.destroy()
+    for sid in (stereo, mono_l, mono_r):
+        engine.close_stream(sid)
