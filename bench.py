@@ -191,7 +191,7 @@ def cpu_baseline_pcm(target_s=10.0):
 CPU_BASELINES = {"pcm": cpu_baseline_pcm, "fir": cpu_baseline_fir, "aac_synth": cpu_baseline_synth, "pipeline": cpu_baseline_pipeline}
 
 
-def end_to_end(args, eng, torch, dist, world, rank, device):
+def end_to_end(args, eng, torch, dist, world, rank, device, emit=True):
     """SURVEY 8d config 5, scaled: `--streams` ADTS AAC-LC streams (the 48 access units of the reference's 48 kHz
     stereo TS sample, looped) through the batch scheduler: host entropy decode -> GPU ticks -> 16 kHz mono s16 out.
     One step = one pass of the clip through every stream.  Everything is inside the timed region: framing, Huffman,
@@ -322,7 +322,9 @@ def end_to_end(args, eng, torch, dist, world, rank, device):
         "roofline": None,
         "note": "host-bound: the entropy threads limit this number; the device-resident rooflines are the default workload's",
     }
-    print(json.dumps(out))
+    if emit:
+        print(json.dumps(out))
+    return out
 
 
 def self_launch(n):
@@ -397,6 +399,9 @@ def main():
     ap.add_argument("--chain", default="s16", choices=["s16", "f32"],
                     help="pipeline: what crosses HBM between synthesis and FIR -- s16 as in the reference worker (default), or the f32 "
                          "PCM (round 1's chain)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="pipeline: skip the two extra measurements the default line carries (the mixed-window synthesis launch and a "
+                         "few seconds of the whole decode through the scheduler)")
     ap.add_argument("--entropy-threads", type=int, default=0, help="end_to_end: host threads for the AAC front-end (0 = cores - 1, split over ranks)")
     ap.add_argument("--tick-wait-us", type=int, default=0, help="end_to_end: how long a non-empty batch waits for more frames (0 = library default 200)")
     ap.add_argument("--tick-frames", type=int, default=0, help="end_to_end: access units per GPU tick, whole batch (0 = library default)")
@@ -671,7 +676,9 @@ def main():
         }
         rl = {}
         if "k_aac_synth" in per_kernel:
-            out["x_realtime"] = value / 46.875  # aac-wasm-bench lib.rs:526-549: 1/rtf summed over the batch
+            # aac-wasm-bench lib.rs:526-549: 1/rtf summed over the batch -- of the decode TAIL this workload is (no entropy
+            # front-end in it); the whole decode's figure is in `end_to_end`
+            out["x_realtime_decode_tail"] = value / 46.875
             ms = per_kernel["k_aac_synth"]
             # algorithmic bytes of this variant: 4 KiB in + 4 KiB out per channel-frame, the overlap delay
             # crosses HBM once per channel per launch (in + out); canonical figure charges it every frame
@@ -752,6 +759,52 @@ def main():
             out["kernels"] = rl
         if mix_report:
             out["mix"] = mix_report
+        extras = (args.workload == "pipeline" and args.chain == "s16" and not args.separate_s16 and not args.mix and world == 1
+                  and not args.no_extras and args.layout == "frame")
+        if extras:
+            # (a) SURVEY 8d's mixed-window batch through the same synthesis launch (planar s16 out): per ten frames one
+            # LongStart, one EightShort, one LongStop, every stream shifted by its index
+            def ten_launches(shorts):  # the synthesis launch alone, back to back (inside the timed region it alternates with the FIR)
+                d2, n2 = soundkit_amd.descs_from_arrays(ids, ch, sequences(shorts), shapes)
+                p2 = eng.plan(d2, n2)
+                for _ in range(3):
+                    p2.run_s16_planar(coeffs, pcm16)
+                eng.synchronize()
+                a0, b0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record(ext)
+                for _ in range(10):
+                    p2.run_s16_planar(coeffs, pcm16)
+                b0.record(ext)
+                eng.synchronize()
+                p2.destroy()
+                return a0.elapsed_time(b0) / 10
+            long_ms, mixed_ms = ten_launches(0), ten_launches(1)
+            seq0 = sequences(1)[:, 0]
+            synth_bytes = streams * frames * ch * 6144 + streams * ch * 8192
+            out["mix"] = {"k_aac_synth_ms": {"only_long": long_ms, "mixed": mixed_ms, "only_long_in_the_timed_region": per_kernel["k_aac_synth"]},
+                          "eight_short_channel_frames": int((seq0 == 2).sum()) * ch, "transition_channel_frames": int(((seq0 == 1) | (seq0 == 3)).sum()) * ch,
+                          "channel_frames": streams * frames * ch,
+                          "frac_of_hbm_peak_mixed": synth_bytes / (mixed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "note": "planar s16 out; channel pairs whose EightShort frames coincide stay in the two-channel kernel "
+                                  "(k_aac_synth_pair<.., true>, synth_rare_pair); both figures: 10 launches back to back after the timed region"}
+            # (b) the whole decode (ADTS framing, entropy front-end on the GPU, synthesis, 48 -> 16 kHz, mono s16, delivery)
+            # through the batch scheduler for a few seconds, in this process: the x-realtime figure of north_star
+            del coeffs, pcm16, s16_out
+            torch.cuda.empty_cache()
+            for sid in sids:
+                eng.close_stream(int(sid))
+            import copy
+            a2 = copy.copy(args)
+            a2.workload, a2.front_end, a2.gpu_entropy = "end_to_end", "gpu", True
+            a2.steps, a2.warmup = 90, 4   # 4096 streams x 48 units x 90 = 17.7 M access units: 3-4 s at the measured rates
+            e2e = end_to_end(a2, eng, torch, dist, world, rank, device, emit=False)
+            out["end_to_end"] = {"value": e2e["value"], "unit": "frames/s", "x_realtime": e2e["x_realtime"], "front_end": e2e["config"]["front_end"],
+                                 "host_cores": e2e["config"]["host_cores"], "streams": args.streams, "access_units": args.streams * 48 * a2.steps,
+                                 "seconds": e2e["ms_per_step"] * a2.steps / 1000.0, "scheduler": e2e["scheduler"],
+                                 "workload": e2e["config"]["workload"],
+                                 "note": "everything in the timed region: ADTS framing on host threads, Huffman decode / stereo tools / TNS, "
+                                         "synthesis, streaming 48 -> 16 kHz resampler, mono downmix, s16 pack on the GPU, D2H, delivery; "
+                                         "host-fed (the 16-core share frames and delivers), not a kernel figure"}
         if world == 1 and not args.no_cpu_baseline:
             single = CPU_BASELINES[args.workload](6.0 if all_cores else 15.0)
             single["build"] = "-O2 -ffp-contract=off (portable oracle/libsk_oracle.so)"

@@ -989,20 +989,22 @@ __global__ __launch_bounds__(256) void k_dequantize(const int16_t *q, const int1
     }
 }
 
-// a stream's carried state back to "just opened": zero overlap, Sine as the previous window shape, the reference's PNS seed
-// (dsp.rs:162-163, spectral.rs:2459) -- one launch instead of three memsets per sk_stream_open
-__global__ __launch_bounds__(256) void k_reset_stream(float *delay2048, uint8_t *shape2, uint32_t *pns) {
-    f4 *d = reinterpret_cast<f4 *>(delay2048);
+// carried state back to "just opened" for a list of streams: zero overlap, Sine as the previous window shape, the reference's
+// PNS seed (dsp.rs:162-163, spectral.rs:2459) -- one workgroup per stream, one launch for all streams opened in a row
+__global__ __launch_bounds__(256) void k_reset_streams(float *delay, uint8_t *shape, uint32_t *pns, const uint32_t *ids) {
+    const uint32_t id = ids[blockIdx.x];
+    f4 *d = reinterpret_cast<f4 *>(delay + (size_t)id * 2048);
     d[threadIdx.x] = (f4){0.f, 0.f, 0.f, 0.f};
     d[threadIdx.x + 256] = (f4){0.f, 0.f, 0.f, 0.f};
-    if (threadIdx.x < 2) shape2[threadIdx.x] = 0;
-    if (threadIdx.x == 2) *pns = 0x1f2e3d4cu;
+    if (threadIdx.x < 2) shape[(size_t)id * 2 + threadIdx.x] = 0;
+    if (threadIdx.x == 2) pns[id] = 0x1f2e3d4cu;
 }
 
 }  // namespace
 
-hipError_t launch_reset_stream(float *delay2048, uint8_t *shape2, uint32_t *pns, hipStream_t s) {
-    hipLaunchKernelGGL(k_reset_stream, dim3(1), dim3(256), 0, s, delay2048, shape2, pns);
+hipError_t launch_reset_streams(float *delay, uint8_t *shape, uint32_t *pns, const uint32_t *ids, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_reset_streams, dim3(n), dim3(256), 0, s, delay, shape, pns, ids);
     return hipGetLastError();
 }
 

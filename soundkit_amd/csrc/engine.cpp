@@ -233,6 +233,10 @@ struct sk_engine {
     uint8_t *h_arena = nullptr;
     size_t h_arena_cap = 0;
     std::vector<uint32_t> state_count, state_task;  // plan construction scratch
+    // streams opened (or reset) since the last launch: their device state is cleared by ONE launch in front of the next call
+    // that touches the device (sk_stream_open used to cost a launch each: 4096 of them in front of a batch)
+    std::vector<uint32_t> pending_reset;
+    uint32_t *d_reset_ids = nullptr;
     // diagnostics: where the current tick stands (read by sk_pipeline_debug_dump without the engine's lock), the bound on
     // its waits for the device, and a failure-injection countdown for the error-path tests (sk_engine_debug_fail_after)
     std::atomic<const char *> where{"idle"};
@@ -270,9 +274,29 @@ namespace {
 
 struct DeviceGuard {
     explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); want = dev; }
+    // the usual form at an entry point (engine lock held): the engine's device, and the state of the streams opened since
+    // the last call is cleared before anything else is queued
+    explicit DeviceGuard(sk_engine *e);
     ~DeviceGuard() { if (prev != want && prev >= 0) (void)hipSetDevice(prev); }
     int prev = -1, want = -1;
 };
+
+void flush_stream_resets(sk_engine *e) {
+    if (e->pending_reset.empty()) return;
+    const uint32_t n = (uint32_t)e->pending_reset.size();
+    hipError_t he = hipSuccess;
+    if (!e->d_reset_ids) he = hipMalloc((void **)&e->d_reset_ids, (size_t)e->max_streams * sizeof(uint32_t));
+    // pageable source: the copy is staged before the call returns, the list can be reused at once
+    if (he == hipSuccess) he = hipMemcpyAsync(e->d_reset_ids, e->pending_reset.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) he = sk::launch_reset_streams(e->d_delay, e->d_prev_shape, e->d_pns, e->d_reset_ids, n, e->stream);
+    if (he == hipSuccess && e->d_mp3_state)
+        for (uint32_t id : e->pending_reset)  // the Layer III overlap and polyphase FIFO of both channels
+            (void)hipMemsetAsync(e->d_mp3_state + (size_t)id * 2 * sk::kMp3StateFloats, 0, 2 * sk::kMp3StateFloats * sizeof(float), e->stream);
+    if (he != hipSuccess) (void)e->hip_fail(he, "reset stream state");  // the launch that follows reports it
+    e->pending_reset.clear();
+}
+
+DeviceGuard::DeviceGuard(sk_engine *e) : DeviceGuard(e->device) { flush_stream_resets(e); }
 
 template <typename T>
 hipError_t upload(T **dst, const std::vector<T> &src) {
@@ -415,7 +439,7 @@ int host_roundtrip(sk_engine *e, const void *in, size_t in_bytes, void *out, siz
     if (!e || (in_bytes && !in) || (out_bytes && !out)) return SK_ERR_INVALID_ARG;
     if (out_bytes == 0) return SK_OK;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     SK_HIP(e->in_buf.reserve(in_bytes), "alloc staging");
     SK_HIP(e->out_buf.reserve(out_bytes), "alloc staging");
     SK_HIP(hipMemcpyAsync(e->in_buf.p, in, in_bytes, hipMemcpyHostToDevice, e->stream), "H2D pcm");
@@ -501,8 +525,9 @@ int sk_engine_create(int device, uint32_t max_streams, sk_engine **out) {
 void sk_engine_destroy(sk_engine *e) {
     if (!e) return;
     {
-        DeviceGuard guard(e->device);
+        DeviceGuard guard(e);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
+        if (e->d_reset_ids) (void)hipFree(e->d_reset_ids);
         for (void *p : {(void *)e->d_mp3_tables, (void *)e->d_mp3_state, (void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
                         (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag, (void *)e->d_afrag16, (void *)e->d_afrag_f16,
                         (void *)e->d_zeros})
@@ -548,7 +573,8 @@ int sk_engine_set_wait_bound(sk_engine *e, double seconds) {
 
 int sk_engine_synchronize(sk_engine *e) {
     if (!e) return SK_ERR_INVALID_ARG;
-    DeviceGuard guard(e->device);
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e);
     SK_HIP(hipStreamSynchronize(e->stream), "stream synchronize");
     return SK_OK;
 }
@@ -556,12 +582,10 @@ int sk_engine_synchronize(sk_engine *e) {
 // ---- streams --------------------------------------------------------------------------------
 
 static int reset_stream_state(sk_engine *e, uint32_t id) {
-    // overlap delay, previous window shape and PNS generator (spectral.rs:2459) in one small launch
-    SK_HIP(sk::launch_reset_stream(e->d_delay + (size_t)id * 2048, e->d_prev_shape + (size_t)id * 2, e->d_pns + id, e->stream),
-           "reset stream state");
-    if (e->d_mp3_state)  // the Layer III overlap and polyphase FIFO of both channels
-        SK_HIP(hipMemsetAsync(e->d_mp3_state + (size_t)id * 2 * sk::kMp3StateFloats, 0, 2 * sk::kMp3StateFloats * sizeof(float), e->stream),
-               "reset mp3 state");
+    // overlap delay, previous window shape and PNS generator (spectral.rs:2459): queued, cleared by one launch for all the
+    // streams opened in a row (flush_stream_resets, in front of the next call that touches the device)
+    e->pending_reset.push_back(id);
+    if (e->pending_reset.size() >= e->max_streams) flush_stream_resets(e);  // ids repeat only across open / close cycles
     return SK_OK;
 }
 
@@ -569,7 +593,6 @@ int sk_stream_open(sk_engine *e, uint32_t sample_rate, uint8_t channels, uint32_
     if (!e || !stream_out || channels < 1 || channels > SK_MAX_CHANNELS || sample_rate == 0) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     if (e->free_ids.empty()) return SK_ERR_CAPACITY;
-    DeviceGuard guard(e->device);
     const uint32_t id = e->free_ids.back();
     int rc = reset_stream_state(e, id);
     if (rc != SK_OK) return rc;
@@ -596,7 +619,7 @@ int sk_stream_reset(sk_engine *e, uint32_t id) {
     if (!e) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     StreamInfo &s = e->streams[id];
     s.rs_fill = 0;
     s.rs_chunks = 0;
@@ -610,7 +633,7 @@ int sk_stream_get_state(sk_engine *e, uint32_t id, float *delay_out, uint8_t *pr
     if (!e || !delay_out || !prev_shape_out) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     const uint32_t ch = e->streams[id].channels;
     SK_HIP(hipMemcpyAsync(delay_out, e->d_delay + (size_t)id * 2048, ch * 1024 * sizeof(float), hipMemcpyDeviceToHost,
                           e->stream), "get delay");
@@ -627,7 +650,7 @@ int sk_stream_set_state(sk_engine *e, uint32_t id, const float *delay, const uin
     const uint32_t ch = e->streams[id].channels;
     for (uint32_t c = 0; c < ch; ++c)
         if (prev_shape[c] > 1) return SK_ERR_INVALID_ARG;
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     SK_HIP(hipMemcpyAsync(e->d_delay + (size_t)id * 2048, delay, ch * 1024 * sizeof(float), hipMemcpyHostToDevice,
                           e->stream), "set delay");
     SK_HIP(hipMemcpyAsync(e->d_prev_shape + (size_t)id * 2, prev_shape, ch, hipMemcpyHostToDevice, e->stream),
@@ -809,7 +832,7 @@ int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n,
     if (!e || !out || (n && !descs)) return SK_ERR_INVALID_ARG;
     *out = nullptr;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     HostPlan hp;
     int rc = build_plan_host(e, descs, n, status, hp);
     if (rc != SK_OK) return rc;
@@ -873,7 +896,7 @@ int sk_aac_plan_run_f32_dev(sk_engine *e, const sk_aac_plan *p, const float *d_c
     if (p->n_tasks == 0) return SK_OK;
     if (!d_coeffs || !d_pcm) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     return run_plan(e, p, d_coeffs, d_pcm);
 }
 
@@ -882,7 +905,7 @@ int sk_aac_plan_run_s16_planar_dev(sk_engine *e, const sk_aac_plan *p, const flo
     if (p->n_tasks == 0) return SK_OK;
     if (!d_coeffs || !d_pcm16 || ((uintptr_t)d_pcm16 & 7)) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     return run_plan(e, p, d_coeffs, nullptr, d_pcm16);
 }
 
@@ -891,7 +914,7 @@ int sk_aac_plan_run_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_c
     if (p->n_tasks == 0) return SK_OK;
     if (!d_coeffs || !d_pcm) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     SK_HIP(e->aux_buf.reserve(p->elements * sizeof(float)), "alloc planar scratch");
     int rc = run_plan(e, p, d_coeffs, (float *)e->aux_buf.p);
     if (rc != SK_OK) return rc;
@@ -909,7 +932,7 @@ static int synthesize_host(sk_engine *e, const sk_aac_frame_desc *descs, const f
     if (rc != SK_OK) return rc;
     {
         std::lock_guard<std::mutex> lock(e->mu);
-        DeviceGuard guard(e->device);
+        DeviceGuard guard(e);
         const size_t elems = (size_t)p->elements;
         do {
             hipError_t he = e->in_buf.reserve(elems * sizeof(float));
@@ -959,7 +982,7 @@ int sk_aac_synthesize_s16(sk_engine *e, const sk_aac_frame_desc *descs, const fl
 int sk_aac_dequantize_dev(sk_engine *e, const int16_t *d_quant, const int16_t *d_sf, float *d_out, size_t n) {
     if (!e || (n && (!d_quant || !d_sf || !d_out))) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     SK_HIP(sk::launch_dequantize(d_quant, d_sf, d_out, n, e->d_pow43, e->d_sftab, e->stream), "launch dequantize");
     return SK_OK;
 }
@@ -968,7 +991,7 @@ int sk_aac_dequantize(sk_engine *e, const int16_t *quant, const int16_t *sf, flo
     if (!e || (n && (!quant || !sf || !out))) return SK_ERR_INVALID_ARG;
     if (n == 0) return SK_OK;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     SK_HIP(e->in_buf.reserve(n * 4), "alloc staging");
     SK_HIP(e->out_buf.reserve(n * 4), "alloc staging");
     int16_t *dq = (int16_t *)e->in_buf.p, *dsf = dq + n;
@@ -1000,7 +1023,7 @@ int sk_pcm_fmt_bytes(int fmt) {
 int sk_pcm_convert_dev(sk_engine *e, int op, const void *d_in, void *d_out, size_t n) {
     if (!e || op < 0 || op >= SK_PCM_OP_COUNT || (n && (!d_in || !d_out))) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     SK_HIP(sk::launch_pcm_convert(op, d_in, d_out, n, e->stream), "launch pcm convert");
     return SK_OK;
 }
@@ -1015,7 +1038,7 @@ int sk_pcm_convert(sk_engine *e, int op, const void *in, void *out, size_t n) {
 #define SK_DEV_ENTRY(call)                              \
     do {                                                \
         std::lock_guard<std::mutex> lock(e->mu);        \
-        DeviceGuard guard(e->device);                   \
+        DeviceGuard guard(e);                   \
         SK_HIP(call, "launch pcm kernel");              \
         return SK_OK;                                   \
     } while (0)
@@ -1169,7 +1192,7 @@ int sk_downsample_48k_16k_f32_dev(sk_engine *e, const float *d_in, size_t in_str
     if (rows == 0 || n_out == 0) return SK_OK;
     if (!d_in || !d_out || in_stride < frames || out_stride < n_out) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     sk::FirArgs a = fir_base(e);
     a.in = d_in;
     a.out = d_out;
@@ -1196,7 +1219,7 @@ int sk_downsample_48k_16k_frames_dev(sk_engine *e, const float *d_pcm, size_t st
     if (!d_pcm || !d_out || out_stride < n_out || frame_stride < (size_t)channels * SK_AAC_FRAME_LEN)
         return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     sk::FirArgs a = fir_base(e);
     a.in = d_pcm;
     a.out = d_out;
@@ -1227,7 +1250,7 @@ int sk_downsample_48k_16k_frames_s16_dev(sk_engine *e, const float *d_pcm, size_
     if (!d_pcm || !d_out || out_stride < n_out || frame_stride < (size_t)channels * SK_AAC_FRAME_LEN)
         return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     sk::FirArgs a = fir_base(e);
     a.in = d_pcm;
     a.out = nullptr;
@@ -1280,7 +1303,7 @@ static int fir_from_s16(sk_engine *e, const int16_t *d_pcm16, size_t stream_stri
         stream_stride % 4 || frame_stride % 4 || ((uintptr_t)d_pcm16 & 7))
         return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     sk::FirArgs a = fir_base(e);
     a.in16 = d_pcm16;
     if (d_out) {
@@ -1312,7 +1335,7 @@ int sk_downsample_48k_16k_f32(sk_engine *e, const float *in, uint32_t rows, uint
     const size_t in_stride = ((size_t)frames + 3) & ~(size_t)3, out_stride = ((size_t)n_out + 3) & ~(size_t)3;
     {
         std::lock_guard<std::mutex> lock(e->mu);
-        DeviceGuard guard(e->device);
+        DeviceGuard guard(e);
         SK_HIP(e->in_buf.reserve(rows * in_stride * 4), "alloc staging");
         SK_HIP(e->out_buf.reserve(rows * out_stride * 4), "alloc staging");
         SK_HIP(hipMemcpy2DAsync(e->in_buf.p, in_stride * 4, in, (size_t)frames * 4, (size_t)frames * 4, rows,
@@ -1322,7 +1345,7 @@ int sk_downsample_48k_16k_f32(sk_engine *e, const float *in, uint32_t rows, uint
                                            out_stride, nullptr);
     if (rc != SK_OK) return rc;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     SK_HIP(hipMemcpy2DAsync(out, (size_t)n_out * 4, e->out_buf.p, out_stride * 4, (size_t)n_out * 4, rows,
                             hipMemcpyDeviceToHost, e->stream), "D2H fir output");
     SK_HIP(hipStreamSynchronize(e->stream), "fir sync");
@@ -1417,7 +1440,7 @@ int sk_downsample_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uin
     if (rows == 0 || n_out == 0) return SK_OK;
     if (!d_in || !d_out || in_stride < frames || out_stride < n_out) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     int table = -1;
     int rc = ratio_table_for(e, in_hz, out_hz, &table);
     if (rc != SK_OK) return rc;
@@ -1462,7 +1485,7 @@ int sk_downsample_f32(sk_engine *e, const float *in, uint32_t rows, uint32_t fra
     const size_t in_stride = ((size_t)frames + 3) & ~(size_t)3, out_stride = ((size_t)n_out + 3) & ~(size_t)3;
     {
         std::lock_guard<std::mutex> lock(e->mu);
-        DeviceGuard guard(e->device);
+        DeviceGuard guard(e);
         SK_HIP(e->in_buf.reserve(rows * in_stride * 4), "alloc staging");
         SK_HIP(e->out_buf.reserve(rows * out_stride * 4), "alloc staging");
         SK_HIP(hipMemcpy2DAsync(e->in_buf.p, in_stride * 4, in, (size_t)frames * 4, (size_t)frames * 4, rows,
@@ -1472,7 +1495,7 @@ int sk_downsample_f32(sk_engine *e, const float *in, uint32_t rows, uint32_t fra
                                    (float *)e->out_buf.p, out_stride, nullptr);
     if (rc != SK_OK) return rc;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     SK_HIP(hipMemcpy2DAsync(out, (size_t)out_cap * 4, e->out_buf.p, out_stride * 4, (size_t)n_out * 4, rows,
                             hipMemcpyDeviceToHost, e->stream), "D2H resample output");
     SK_HIP(hipStreamSynchronize(e->stream), "resample sync");
@@ -1531,7 +1554,7 @@ int mp3_synthesize(sk_engine *e, const sk_mp3_granule_desc *descs, const float *
     if (!e || (n && (!descs || !xr || !pcm_out))) return SK_ERR_INVALID_ARG;
     if (n == 0) return SK_OK;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     int rc = ensure_mp3(e);
     if (rc != SK_OK) return rc;
     if (!e->mp3_window_set) return SK_ERR_UNSUPPORTED;  // no synthesis window: sk_mp3_set_synthesis_window first
@@ -1619,7 +1642,7 @@ int mp3_synthesize(sk_engine *e, const sk_mp3_granule_desc *descs, const float *
 int sk_mp3_set_synthesis_window(sk_engine *e, const float *d512) {
     if (!e || !d512) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     const int rc = ensure_mp3(e);
     if (rc != SK_OK) return rc;
     SK_HIP(hipMemcpy(e->d_mp3_tables + kMp3Imdct + kMp3Matrix, d512, kMp3Window * sizeof(float), hipMemcpyHostToDevice), "upload mp3 window");
@@ -1647,7 +1670,7 @@ int sk_resampler_open(sk_engine *e, uint32_t id, uint32_t in_hz, uint32_t out_hz
     std::lock_guard<std::mutex> lock(e->mu);
     if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
     if (!common_rate(in_hz) || !common_rate(out_hz)) return SK_ERR_UNSUPPORTED;  // as downsample_audio rejects them
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     if (!e->d_rs) {
         const size_t bytes = (size_t)e->max_streams * 2 * kRsRow * sizeof(float);
         SK_HIP(hipMalloc((void **)&e->d_rs, bytes), "alloc resampler history");
@@ -1909,7 +1932,7 @@ int sk_resampler_process_f32(sk_engine *e, const uint32_t *streams, uint32_t n_s
                              float *out, uint32_t out_cap, uint32_t *out_frames) {
     if (!e || (n_streams && (!streams || !out_frames)) || (frames && n_streams && !in)) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     std::vector<RsCall> calls;
     size_t total_rows = 0;
     int rc = rs_collect(e, streams, n_streams, calls, &total_rows);
@@ -1971,7 +1994,7 @@ int sk_resampler_flush_f32(sk_engine *e, const uint32_t *streams, uint32_t n_str
                            uint32_t *out_frames) {
     if (!e || (n_streams && (!streams || !out_frames || !out))) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     std::vector<RsCall> calls;
     size_t total_rows = 0;
     int rc = rs_collect(e, streams, n_streams, calls, &total_rows);
@@ -2183,7 +2206,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     *n_outs = 0;
     if (out_bytes) *out_bytes = 0;
     if (n_streams == 0) return n_frames == 0 ? SK_OK : SK_ERR_INVALID_ARG;
-    DeviceGuard guard(e->device);
+    DeviceGuard guard(e);
     if (au_mode) {  // the descs are implied: every unit of a stream carries that stream's channel count
         uint64_t total = 0;
         for (uint32_t i = 0; i < n_streams; ++i) total += ts[i].n_frames;

@@ -54,7 +54,7 @@ hipError_t launch_aac_synth(const SynthArgs &a, hipStream_t s);
 // with_short: the tasks' EightShort frames coincide pairwise (both channels of a pair switch together): the kernel with the
 // wave-uniform eight-short arm; without: the caller vouches that no entry is EightShort
 hipError_t launch_aac_synth_pairs(const SynthArgs &a, bool with_short, hipStream_t s);
-hipError_t launch_reset_stream(float *delay2048, uint8_t *shape2, uint32_t *pns, hipStream_t s);
+hipError_t launch_reset_streams(float *delay, uint8_t *shape, uint32_t *pns, const uint32_t *ids, uint32_t n, hipStream_t s);
 hipError_t launch_frames_to_s16(const float *planar, int16_t *out, const FrameSpan *frames, uint32_t n, hipStream_t s);
 hipError_t launch_dequantize(const int16_t *q, const int16_t *sf, float *out, size_t n, const float *pow43,
                              const float *sftab, hipStream_t s);
