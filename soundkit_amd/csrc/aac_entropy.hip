@@ -1,81 +1,17 @@
-// aac_entropy.hip -- the AAC-LC access-unit front-end on gfx950, one stream per lane (SURVEY 8f ranks 1 + 4).
+// aac_entropy.hip -- the AAC-LC access-unit front-end on gfx950, one access unit per lane (SURVEY 8f ranks 1 + 4).
 //
-// A lane walks the access units of its stream in order (the PNS generator and the synthesis overlap make them
-// sequential anyway) through aac_entropy_core.h -- the same source that tests/entropy_core_check.cpp proves equal to
-// the host front-end under AddressSanitizer -- and writes the dequantised, stereo- and TNS-processed spectra straight
-// into the synthesis kernel's input buffer, plus the window fields into the synthesis schedule.  A unit that fails
-// gets its status recorded, zero spectra and a plain long window (so the synthesis launch that follows needs no
-// special case), and ends its stream for this launch: later units of the stream are marked skipped.
+// aac_entropy_core.h -- the same source that tests/entropy_core_check.cpp proves equal to the host front-end under
+// AddressSanitizer -- decodes the units and writes the dequantised, stereo- and TNS-processed spectra straight into the
+// synthesis kernel's input buffer, plus the window fields into the synthesis schedule.  A unit that fails gets its
+// status recorded, zero spectra and a plain long window (so the synthesis launch that follows needs no special case),
+// and ends its stream for this launch: later units of the stream are marked skipped.
 #include "aac_entropy_core.h"
 #include "sk_device.h"
 
-#ifdef SK_EC_PROFILE  // timing build only: per-wave clock stamps of the parse kernel's phases, read back by tools/entropy_phases.py
-__device__ unsigned long long g_ec_stamp[8192][24];
-namespace sk_ec {
-__device__ void sk_ec_mark(int slot) {
-    const unsigned long long now = __builtin_readcyclecounter();
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (wave < 8192 && slot >= 0) g_ec_stamp[wave][slot] = now;  // every active lane writes the same wave's slot: last one wins
-}
-}  // namespace sk_ec
-__device__ unsigned g_ec_count[8192][10][64];
-namespace sk_ec {
-__device__ void sk_ec_count(int what, unsigned n) {
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (wave < 8192) g_ec_count[wave][what][threadIdx.x & 63] = n;
-}
-}  // namespace sk_ec
-extern "C" int sk_debug_ec_counts(unsigned *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ec_count), sizeof(g_ec_count)); }
-extern "C" int sk_debug_ec_stamps(unsigned long long *out, int clear) {
-    if (clear) {
-        static unsigned long long zeros[8192][24];
-        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ec_stamp), zeros, sizeof(zeros));
-    }
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ec_stamp), sizeof(g_ec_stamp));
-}
-#endif
 
 namespace sk {
 
 namespace {
-
-__global__ __launch_bounds__(256) void k_aac_entropy(EntropyArgs a) {
-    // Every codeword costs two dependent table lookups: the Huffman tables and the tuple table live in LDS (~60 KB per
-    // workgroup of four waves), addressed through the same flat pointers the host build uses.
-    extern __shared__ uint4 lds_raw[];
-    uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
-    for (uint32_t i = threadIdx.x; i < a.lds_bytes / 16; i += blockDim.x)
-        lds_raw[i] = reinterpret_cast<const uint4 *>(a.lds_blob)[i];
-    __syncthreads();
-    sk_ec::Tables t = a.t;
-    t.meta = reinterpret_cast<const uint32_t *>(lds + a.lds_meta_off);
-    t.lut = reinterpret_cast<const uint32_t *>(lds + a.lds_lut_off);
-    t.tuples = reinterpret_cast<const uint64_t *>(lds + a.lds_tuple_off);
-    t.sf_mult = reinterpret_cast<const float *>(lds + a.lds_sf_off);
-    t.swb = reinterpret_cast<const uint16_t *>(lds + a.lds_swb_off);
-    t.pow43_lo = reinterpret_cast<const float *>(lds + a.lds_pow_off);
-    const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
-    if (task >= a.n_tasks) return;
-    const EntropyTask tk = a.tasks[task];
-    sk_ec::Stream st{tk.sf_index, (int)tk.channels, a.pns_state[tk.stream]};
-    sk_ec::Scratch scratch;
-    bool dead = false;
-    for (uint32_t k = 0; k < tk.count; ++k) {
-        const EntropyUnit u = a.units[tk.first + k];
-        float *coef = a.coeffs + (size_t)u.off1024 * 1024;
-        uint8_t seq[2] = {0, 0}, shape[2] = {0, 0};
-        int status = EC_SKIPPED;
-        if (!dead) status = sk_ec::decode_access_unit(t, st, a.words + u.word_offset, u.byte_len, coef, seq, shape, scratch);
-        if (status != sk_ec::EC_OK) {
-            dead = true;
-            for (uint32_t i = 0; i < tk.channels * 1024u; ++i) coef[i] = 0.0f;
-            seq[0] = seq[1] = shape[0] = shape[1] = 0;
-        }
-        a.status[tk.first + k] = status;
-        for (uint32_t c = 0; c < tk.channels; ++c) a.entries[u.entry[c]].win = (uint32_t)seq[c] | ((uint32_t)shape[c] << 2);
-    }
-    a.pns_state[tk.stream] = st.pns_state;
-}
 
 // ---- frame-parallel form ---------------------------------------------------------------------------------------------
 // The only thing that orders the access units of a stream is the PNS generator.  Phase 1 decodes every unit in its own
@@ -122,15 +58,8 @@ __device__ __forceinline__ void wave_zero_spectra(const EntropyArgs &a) {
         const EntropyUnit u = a.units[a.order ? a.order[slot] : slot];
         const uint32_t quads = a.tasks[u.task].channels * 256u;
         float4 *dst = reinterpret_cast<float4 *>(a.coeffs + (size_t)u.off1024 * 1024);
-#ifdef SK_EC_ABLATE_FILL  // timing experiment: stale spectra
-        if (quads == 12345u)
-#endif
         for (uint32_t i = lane; i < quads; i += 64) {
-#ifdef SK_EC_NT_FILL
-            __builtin_nontemporal_store(0.0f, &dst[i].x);
-#else
             dst[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#endif
         }
     }
     // a lane's own stores to these addresses come later in the same wave's store stream; wait all the same
@@ -139,31 +68,20 @@ __device__ __forceinline__ void wave_zero_spectra(const EntropyArgs &a) {
 
 __global__ __launch_bounds__(512) void k_aac_entropy_parse(EntropyArgs a) {
     extern __shared__ uint4 lds_raw[];
-    EC_MARK(0);
     const sk_ec::Tables t = lds_tables(a, lds_raw);
     wave_zero_spectra(a);
-    EC_MARK(1);
     uint32_t k;
     if (!unit_of_lane(a, k)) return;
-#ifdef SK_EC_PROFILE_SAMEUNIT  // timing experiment: every lane decodes the bitstream of unit 0 (into its own output)
-    EntropyUnit u = a.units[k];
-    u.word_offset = a.units[0].word_offset;
-    u.byte_len = a.units[0].byte_len;
-#else
     const EntropyUnit u = a.units[k];
-#endif
     const EntropyTask tk = a.tasks[u.task];
     sk_ec::Stream st{tk.sf_index, (int)tk.channels, 0u, true};
-    if (tk.channels) EC_MARK(12);  // after the unit and task records have arrived
     sk_ec::Scratch side;
     uint8_t seq[2] = {0, 0}, shape[2] = {0, 0};
     const int status = sk_ec::parse_unit(t, st, a.words + u.word_offset, u.byte_len, a.coeffs + (size_t)u.off1024 * 1024, seq, shape, side,
                                          sk_ec::PNS_COUNT);
-    EC_MARK(6);
     a.status[k] = status;
     a.side[k] = side;
     for (uint32_t c = 0; c < tk.channels; ++c) a.entries[u.entry[c]].win = (uint32_t)seq[c] | ((uint32_t)shape[c] << 2);
-    EC_MARK(7);
 }
 
 // Phase one of the quantised hand-over: the host has done the Huffman decode; a lane rebuilds its unit's side
@@ -244,7 +162,6 @@ __global__ __launch_bounds__(512) void k_aac_entropy_finish(EntropyArgs a) {
     const EntropyTask tk = a.tasks[u.task];
     float *coef = a.coeffs + (size_t)u.off1024 * 1024;
     int status = a.status[k];
-    EC_MARK(16);
     if (status == sk_ec::EC_OK) {
         sk_ec::Stream st{tk.sf_index, (int)tk.channels, a.pns_start[k]};
         // the side record is read where parse left it (global memory): a private copy is 3.1 KB per lane through scratch
@@ -252,7 +169,6 @@ __global__ __launch_bounds__(512) void k_aac_entropy_finish(EntropyArgs a) {
         if (status == sk_ec::EC_OK && a.wire) status = a.wire[k].tail_status;  // the host has looked at the rest of the unit
         a.status[k] = status;
     }
-    EC_MARK(22);
     if (status != sk_ec::EC_OK) {  // failed or skipped: silence for the synthesis launch that follows
         for (uint32_t i = 0; i < tk.channels * 1024u; ++i) coef[i] = 0.0f;
         for (uint32_t c = 0; c < tk.channels; ++c) a.entries[u.entry[c]].win = 0;
@@ -268,18 +184,9 @@ hipError_t launch_aac_entropy_parallel(const EntropyArgs &a, hipStream_t s) {
     const uint32_t per_wave = 64u >> a.lane_shift, waves = (a.n_units + per_wave - 1) / per_wave, blocks = (waves + 7) / 8;
     if (a.wire) hipLaunchKernelGGL(k_aac_expand_q, dim3(blocks), dim3(512), a.lds_bytes, s, a);
     else hipLaunchKernelGGL(k_aac_entropy_parse, dim3(blocks), dim3(512), a.lds_bytes, s, a);
-#ifdef SK_EC_PROFILE_TWICE  // timing build: the same launch again, everything it reads now warm; the stamps are the second launch's
-    if (!a.wire) hipLaunchKernelGGL(k_aac_entropy_parse, dim3(blocks), dim3(512), a.lds_bytes, s, a);
-#endif
     hipLaunchKernelGGL(k_aac_entropy_link, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_aac_entropy_finish, dim3(blocks), dim3(512), a.lds_bytes, s, a);
     hipLaunchKernelGGL(k_aac_entropy_seal, dim3((a.n_tasks + 63) / 64), dim3(64), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_aac_entropy(const EntropyArgs &a, hipStream_t s) {
-    if (a.n_tasks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_aac_entropy, dim3((a.n_tasks + 255) / 256), dim3(256), a.lds_bytes, s, a);
     return hipGetLastError();
 }
 

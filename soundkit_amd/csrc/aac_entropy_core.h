@@ -36,17 +36,6 @@ enum : int {
     EC_INVALID_BITSTREAM = -108,    // SK_AAC_ERR_INVALID_BITSTREAM
 };
 
-// SK_EC_PROFILE (a timing build, tools/build_ab.sh): the device kernels stamp the clock at these points per wave
-#if defined(SK_EC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-__device__ void sk_ec_mark(int slot);
-__device__ void sk_ec_count(int what, unsigned n);
-#define EC_MARK(slot) ::sk_ec::sk_ec_mark(slot)
-#define EC_COUNT(what, n) ::sk_ec::sk_ec_count(what, n)
-#else
-#define EC_MARK(slot) ((void)0)
-#define EC_COUNT(what, n) ((void)0)
-#endif
-
 #define EC_TRY(expr)            \
     do {                        \
         const int _st = (expr); \
@@ -350,11 +339,8 @@ SKE int read_channel(const Tables &t, Bits &b, Channel &ch, const Ics *common, i
     ch.global_gain = (uint8_t)v;
     if (common) ch.ics = *common;
     else EC_TRY(read_ics(b, ch.ics));
-    EC_MARK(mark);
     EC_TRY(read_sections(b, ch));
-    EC_MARK(mark + 1);
     EC_TRY(read_scalefactors(t, b, ch, sf_out));
-    EC_MARK(mark + 2);
     bool flag;
     EC_TRY(read_flag(b, &flag));
     ch.pulse_present = flag;
@@ -730,9 +716,6 @@ SKE int decode_spectrum_nested(const Tables &t, Stream &st, Bits &bits, const Ch
 // flat, every lane that still has codewords left decodes one per pass whatever band, book or window it is in.  Per lane
 // the operations, their order and therefore every result and every error code are those of the nested form
 // (tests/entropy_core_check.cpp runs both on every unit it sees; SK_EC_FLAT selects this form in a host build).
-#ifdef SK_EC_COUNT_PASSES
-static unsigned long g_flat_passes = 0, g_flat_codewords = 0;
-#endif
 template <bool QUANT>
 SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Channel &ch, bool allow_intensity, float *__restrict__ coef,
                              PnsMode mode, uint32_t *noise_samples, int16_t *__restrict__ quant, WideList *wide = nullptr, int wide_base = 0) {
@@ -779,29 +762,11 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
     float scale = 0.0f;
     BookRef br = BookRef{t.lut, t.tuples, 1};
     int q[4];
-    unsigned n_passes = 0, n_codewords = 0;  // read by the timing build only
-#if defined(SK_EC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long t_open = 0, t_tuple = 0, t_rest = 0, t_prev = __builtin_readcyclecounter();
-#define EC_LAP(acc)                                                  \
-    do {                                                             \
-        const unsigned long long _now = __builtin_readcyclecounter(); \
-        acc += _now - t_prev;                                        \
-        t_prev = _now;                                               \
-    } while (0)
-#else
-#define EC_LAP(acc) ((void)0)
-#endif
     while (phase != DONE) {
-        ++n_passes;
-        if (phase == IN_BAND) ++n_codewords;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SK_EC_THREADED_PHASES)
+#if defined(__HIP_DEVICE_COMPILE__)
         // keep this ONE loop: left alone, jump threading turns the state machine back into a loop per state, and a wave
         // whose lanes are in different states runs those loops one after the other
         asm volatile("" : "+v"(phase));
-#endif
-#ifdef SK_EC_COUNT_PASSES
-        ++g_flat_passes;
-        if (phase == IN_BAND) ++g_flat_codewords;
 #endif
         if (phase == OPEN_GROUP) {
             if (g >= groups) {
@@ -853,10 +818,8 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
                 }
             }
         }
-        EC_LAP(t_open);
         if (phase == IN_BAND) {
             status = read_tuple(br, b, q);
-            EC_LAP(t_tuple);
             if (status != EC_OK) {
                 phase = DONE;
             } else {
@@ -865,7 +828,7 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
                     if (k >= 0 && k < dim) q[k] += q[k] > 0 ? amp[p] : -amp[p];
                 }
                 const int at = (is_short ? w * 128 : 0) + i;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SK_EC_SCALAR_STORES)
+#if defined(__HIP_DEVICE_COMPILE__)
                 // device: a codeword's values leave in ONE store (16 bytes for the four-value books, 8 for the others; bands
                 // start on multiples of four lines): a scalar store is a separate partial cache line per lane and value
                 if (!QUANT && (((uintptr_t)coef) & 15u) == 0 && (at & (dim - 1)) == 0) {
@@ -885,12 +848,7 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
                     if (QUANT) {
                         quant[at + k] = quant_store(q[k], wide_base + at + k, wide, &status);
                     } else {
-#ifdef SK_EC_ABLATE_STORE  // timing experiment: the spectrum is computed but (almost) never stored
-                        const float dq = dequantize(t, q[k], scale);
-                        if (dq == 1.2345e30f) coef[at + k] = dq;
-#else
                         coef[at + k] = dequantize(t, q[k], scale);
-#endif
                     }
                 }
                 if (QUANT && status != EC_OK) {
@@ -908,17 +866,8 @@ SKE int decode_spectrum_flat(const Tables &t, Stream &st, Bits &bits, const Chan
                 }
             }
         }
-        EC_LAP(t_rest);
     }
     if (is_short && status == EC_OK && w0 != 8) status = EC_INVALID_BITSTREAM;
-#if defined(SK_EC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-    EC_COUNT(allow_intensity ? 7 : 4, (unsigned)(t_open >> 4));
-    EC_COUNT(allow_intensity ? 8 : 5, (unsigned)(t_tuple >> 4));
-    EC_COUNT(allow_intensity ? 9 : 6, (unsigned)(t_rest >> 4));
-#endif
-    EC_COUNT(allow_intensity ? 2 : 0, n_passes);
-    EC_COUNT(allow_intensity ? 3 : 1, n_codewords);
-    (void)n_passes, (void)n_codewords;
     bits = b;
     st.pns_state = pns;
     if (is_short || status != EC_OK || !pulse_present) return status;
@@ -1256,10 +1205,6 @@ SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len
                    Scratch &s, PnsMode mode, const QuantCapture *qc = nullptr) {
     Bits b = make_bits(au, len_bytes);
     s.noise_samples = 0;
-#if defined(SK_EC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the first scratch stores to the phase that issues them
-#endif
-    EC_MARK(15);
     // The element loop only steps over leading fill elements; the channel element is parsed BEHIND it.  Inside the loop a
     // wave whose lanes reach their channel element in different passes (one unit opens with a fill element -- FFmpeg's
     // encoder string in the first unit of a stream -- the other 31 do not) would run the whole parse once per pass, one
@@ -1268,7 +1213,6 @@ SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len
     bool found = false;
     while (b.total - b.pos >= 3) {  // each pass consumes >= 3 bits: bounded by the length of the access unit
         EC_TRY(read_bits(b, 3, &id));
-        EC_MARK(13);
         if (id <= 5) EC_TRY(read_bits(b, 4, &tag));  // syntax.rs:54-63
         if (id != 6) {
             found = true;
@@ -1315,21 +1259,15 @@ SKE int parse_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len
     s.mask.mode = 0;
     if (common_window) {
         EC_TRY(read_ics(b, common));
-        EC_MARK(14);
         EC_TRY(read_ms_mask(b, common, s.mask));
     }
     Channel &left = s.ch[0], &right = s.ch[1];
-    EC_MARK(8);
     EC_TRY(read_channel(t, b, left, common_window ? &common : nullptr, qc ? qc->sf[0] : nullptr, 9));
-    EC_MARK(2);
     if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, left, false, nullptr, PNS_COUNT, &s.noise_samples, qc->quant, qc->wide, 0));
     else EC_TRY(decode_spectrum(t, st, b, left, false, coef, mode, &s.noise_samples));
-    EC_MARK(3);
     EC_TRY(read_channel(t, b, right, common_window ? &common : nullptr, qc ? qc->sf[1] : nullptr));
-    EC_MARK(4);
     if (qc) EC_TRY(decode_spectrum_t<true>(t, st, b, right, true, nullptr, PNS_COUNT, &s.noise_samples, qc->quant + 1024, qc->wide, 1024));
     else EC_TRY(decode_spectrum(t, st, b, right, true, coef + 1024, mode, &s.noise_samples));
-    EC_MARK(5);
     s.is_pair = 1;
     s.common_window = common_window;
     sequence[0] = left.ics.sequence;
@@ -1346,19 +1284,11 @@ SKE int unit_tail(const uint32_t *au, uint32_t len_bytes, uint32_t resume_pos);
 // unit (fill elements, END, the trailing-zero rule) from where the first phase stopped.
 SKE int finish_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t len_bytes, float *coef, Scratch &s, bool fill) {
     Channel &left = s.ch[0], &right = s.ch[1];
-    EC_MARK(17);
-#ifndef SK_EC_ABLATE_NOISE  // the SK_EC_ABLATE_* switches are timing experiments (tools/build_ab.sh); results are wrong with them
     if (fill) {
         EC_TRY(fill_noise(t, st, left, coef));
         if (s.is_pair) EC_TRY(fill_noise(t, st, right, coef + 1024));
     }
-#endif
-    EC_MARK(18);
-#ifdef SK_EC_ABLATE_STEREO
-    if (false) {
-#else
     if (s.is_pair) {
-#endif
         if (!s.common_window) {  // decoder.rs:275-285
             const int stride = band_stride(right.ics);
             for (int g = 0; g < right.ics.num_groups; ++g)
@@ -1370,16 +1300,8 @@ SKE int finish_unit(const Tables &t, Stream &st, const uint32_t *au, uint32_t le
             EC_TRY(stereo_tools(t, st, s.mask, left.ics, left, right, coef, coef + 1024));
         }
     }
-    EC_MARK(19);
-#ifndef SK_EC_ABLATE_TNS
     if (left.tns_present) EC_TRY(apply_tns(t, st, left, coef));
-    EC_MARK(20);
     if (s.is_pair && right.tns_present) EC_TRY(apply_tns(t, st, right, coef + 1024));
-#endif
-    EC_MARK(21);
-#ifdef SK_EC_ABLATE_TAIL
-    return EC_OK;
-#endif
     return unit_tail(au, len_bytes, s.resume_pos);
 }
 

@@ -19,22 +19,10 @@
 // post-twiddled spectrum crosses LDS once (8 x ds_write_b64, 4 x ds_read_b128 per lane).
 #include "sk_device.h"
 
-// streaming accesses of the main path: spectra are read once, PCM written once.  SK_SYNTH_NT_LOAD / SK_SYNTH_NT_STORE
-// build the non-temporal forms for A/B runs (tools/build_ab.sh aac_synth SK_SYNTH_NT_LOAD ...).
-#ifdef SK_SYNTH_NT_BOTH
-#define SK_SYNTH_NT_LOAD
-#define SK_SYNTH_NT_STORE
-#endif
-#ifdef SK_SYNTH_NT_LOAD
-#define SK_SYNTH_LOAD(p) __builtin_nontemporal_load(p)
-#else
+// streaming accesses of the main path: spectra are read once, PCM written once.  Plain loads and stores: the non-temporal
+// forms measured no better (profiles/r01_ab_aac_synth.md)
 #define SK_SYNTH_LOAD(p) (*(p))
-#endif
-#ifdef SK_SYNTH_NT_STORE
-#define SK_SYNTH_STORE(v, p) __builtin_nontemporal_store(v, p)
-#else
 #define SK_SYNTH_STORE(v, p) (*(p) = (v))
-#endif
 
 namespace sk {
 
@@ -49,9 +37,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kWavesPerBlock = SK_SYNTH_BLOCK_WAVES;
 #ifndef SK_WAVES_PER_SIMD
 #define SK_WAVES_PER_SIMD 3
-#endif
-#ifndef SK_WIN_EARLY
-#define SK_WIN_EARLY 1
 #endif
 #ifndef SK_PREFETCH_DEPTH
 #define SK_PREFETCH_DEPTH 1
@@ -112,13 +97,7 @@ typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 // float_sample_to_i16 in its shortest exact form (through f64, sk_device.h; tools/check_f32_rounding.c sweeps all 2^32
 // inputs): the s16 variant of the kernel is bound by vector issue, and with the f32 form a third of it was these conversions
 __device__ __forceinline__ u2 pack4_s16(const f4 &v) {
-#ifdef SK_SYNTH_ABLATE_CVT  // timing experiment: a wrong, two-instruction conversion
-    typedef short s2v __attribute__((ext_vector_type(2)));
-    return (u2){__builtin_bit_cast(uint32_t, (s2v)__builtin_amdgcn_cvt_pk_i16((int)(v.x * 32768.0f), (int)(v.y * 32768.0f))),
-                __builtin_bit_cast(uint32_t, (s2v)__builtin_amdgcn_cvt_pk_i16((int)(v.z * 32768.0f), (int)(v.w * 32768.0f)))};
-#else
     return (u2){dev_pack2_s16(v.x, v.y), dev_pack2_s16(v.z, v.w)};
-#endif
 }
 
 // first-half and second-half window of a long-transform frame (dsp.rs:353-387): the long window of the previous / current
@@ -352,15 +331,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
     auto load_spectrum = [&](f2 (&xin)[8], uint32_t e) {
         const float *src = a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e].off1024) * 1024 + 2 * lane;
 #pragma unroll
-#ifdef SK_SYNTH_ABLATE_F4LOAD  // timing experiment only (wrong data order): the same bytes as four 16-byte loads per lane
-        for (int r = 0; r < 4; ++r) {
-            const f4 v = *reinterpret_cast<const f4 *>(src + 2 * lane + 256 * r);
-            xin[2 * r] = (f2){v.x, v.y};
-            xin[2 * r + 1] = (f2){v.z, v.w};
-        }
-#else
         for (int r = 0; r < 8; ++r) xin[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
-#endif
     };
     auto frame = [&](f2 (&xin)[8], uint32_t e) __attribute__((always_inline)) {
         const uint32_t ent_off = entries[e].off1024, ent_win = entries[e].win;
@@ -394,7 +365,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
         if (ONLY_LONG || seq != 2) {
             const float *w1 = first_half_window(a.t.win, seq, prev_shape);
             const float *w2 = second_half_window(a.t.win, seq, shape);
-#if SK_WIN_EARLY
             // Window loads go out BEFORE the prefetch: vector-memory results return in issue order, so
             // windows queued behind the next spectrum would make the epilogue wait for that HBM fetch.
             f4 w1f[2], w1m[2], w2f[2], w2m[2];
@@ -406,30 +376,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
                 w2f[r] = *reinterpret_cast<const f4 *>(w2 + j);
                 w2m[r] = *reinterpret_cast<const f4 *>(w2 + 1020 - j);
             }
-#endif
             // next spectrum in flight while this one is transformed.  Unconditional (the last frames re-read the task's
             // last spectrum): with a branch around these loads the compiler can no longer count what is outstanding when
             // the epilogue needs its windows, and waits for the prefetch itself before every store.
-#ifdef SK_SYNTH_ABLATE_LOAD  // timing experiment: the first spectrum is transformed over and over
-            if (e == 0x7fffffffu)
-#endif
             {
                 const uint32_t ahead = e + kDepth < count ? e + kDepth : count - 1;
                 const float *src = a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[ahead].off1024) * 1024 + 2 * lane;
 #pragma unroll
-#ifdef SK_SYNTH_ABLATE_F4LOAD
-                for (int r = 0; r < 4; ++r) {
-                    const f4 v = *reinterpret_cast<const f4 *>(src + 2 * lane + 256 * r);
-                    xin[2 * r] = (f2){v.x, v.y};
-                    xin[2 * r + 1] = (f2){v.z, v.w};
-                }
-#else
                 for (int r = 0; r < 8; ++r) xin[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
-#endif
             }
-#if !defined(SK_ABLATE_FFT)
             fft512(z, ex, t64, base2, lane);
-#endif
             // ---- post-twiddle: value = twiddle * conj(fft) (dsp.rs:512, 523) --------
 #pragma unroll
             for (int j = 0; j < 8; ++j) ex[lane + 64 * j] = cmul(tw_lds[lane + 64 * j], (f2){z[j].x, -z[j].y});
@@ -440,14 +396,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
                 const int q = 2 * lane + 128 * r, j = 2 * q;
                 const f4 F = *reinterpret_cast<const lds_f4 *>(&ex[256 + q]);
                 const f4 M = *reinterpret_cast<const lds_f4 *>(&ex[254 - q]);
-#if SK_WIN_EARLY
                 const f4 W1f = w1f[r], W1m = w1m[r], W2f = w2f[r], W2m = w2m[r];
-#else
-                const f4 W1f = *reinterpret_cast<const f4 *>(w1 + j);
-                const f4 W1m = *reinterpret_cast<const f4 *>(w1 + 1020 - j);
-                const f4 W2f = *reinterpret_cast<const f4 *>(w2 + j);
-                const f4 W2m = *reinterpret_cast<const f4 *>(w2 + 1020 - j);
-#endif
                 f4 f, m;
                 // out0[j..j+3] = -F0.re, -M1.im, -F1.re, -M0.im   (dsp.rs:516, 528)
                 f.x = -F.x * W1f.x + dly[8 * r + 0]; f.y = -M.w * W1f.y + dly[8 * r + 1];
@@ -455,9 +404,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
                 // out1[508-j..511-j] = M0.im, F1.re, M1.im, F0.re (dsp.rs:517, 529)
                 m.x = M.y * W1m.x + dly[8 * r + 4]; m.y = F.z * W1m.y + dly[8 * r + 5];
                 m.z = M.w * W1m.z + dly[8 * r + 6]; m.w = F.x * W1m.w + dly[8 * r + 7];
-#ifdef SK_SYNTH_ABLATE_STORE  // timing experiment: the PCM is computed but (almost) never stored
-                if (f.x == 1.2345e30f)
-#endif
                 if (OUT16) {
                     SK_SYNTH_STORE(pack4_s16(f), reinterpret_cast<u2 *>(out16_ptr + j));
                     SK_SYNTH_STORE(pack4_s16(m), reinterpret_cast<u2 *>(out16_ptr + 1020 - j));

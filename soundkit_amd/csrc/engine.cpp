@@ -215,7 +215,7 @@ struct sk_engine {
     // tables
     float *d_tables = nullptr;
     sk::SynthTables synth_tables{};
-    float *d_pow43 = nullptr, *d_sftab = nullptr, *d_taps = nullptr, *d_afrag = nullptr, *d_zeros = nullptr;
+    float *d_pow43 = nullptr, *d_sftab = nullptr, *d_taps = nullptr, *d_zeros = nullptr;
     uint32_t *d_afrag16 = nullptr, *d_afrag_f16 = nullptr;
     std::vector<float> h_taps;
     std::vector<RatioTable> ratio_tables;
@@ -383,15 +383,6 @@ int build_tables(sk_engine *e) {
     e->h_taps.resize(256);
     make_taps_48k_16k(e->h_taps.data());
     SK_HIP(upload(&e->d_taps, e->h_taps), "upload taps");
-    // MFMA A-operand fragments: step s, lane l (i = l & 15, q = l >> 4):
-    //   tap p = 16 (s >> 2) + 4 q + (s & 3) - 3 i - 3, zero outside [0, 255]
-    std::vector<float> afrag(76 * 64, 0.0f);
-    for (int s = 0; s < 76; ++s)
-        for (int l = 0; l < 64; ++l) {
-            const int p = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3) - 3 * (l & 15) - 3;
-            if (p >= 0 && p < 256) afrag[s * 64 + l] = e->h_taps[p];
-        }
-    SK_HIP(upload(&e->d_afrag, afrag), "upload tap fragments");
     // bf16 A fragments (fir_bf16.hip): h = h1 + h2 + h3 exactly, each the top 16 bits of an f32 (truncation);
     // window s, plane k, lane l (i = l & 15, q = l >> 4), element e: tap p = 32 s + 8 q + e - 3 i - 3
     std::vector<uint32_t> afrag16((size_t)10 * 3 * 64 * 4, 0u);
@@ -529,7 +520,7 @@ void sk_engine_destroy(sk_engine *e) {
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         if (e->d_reset_ids) (void)hipFree(e->d_reset_ids);
         for (void *p : {(void *)e->d_mp3_tables, (void *)e->d_mp3_state, (void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
-                        (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag, (void *)e->d_afrag16, (void *)e->d_afrag_f16,
+                        (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag16, (void *)e->d_afrag_f16,
                         (void *)e->d_zeros})
             if (p) (void)hipFree(p);
         for (RatioTable &t : e->ratio_tables)
@@ -1177,7 +1168,6 @@ int sk_downsample_48k_16k_taps(sk_engine *e, float *taps256) {
 static sk::FirArgs fir_base(sk_engine *e) {
     sk::FirArgs a{};
     a.zeros = e->d_zeros;
-    a.afrag = e->d_afrag;
     a.afrag16 = e->d_afrag16;
     a.afrag_f16 = e->d_afrag_f16;
     a.taps = e->d_taps;
@@ -1404,7 +1394,7 @@ static void make_index_set(double ratio, double last_index, uint32_t chunk, Inde
     set.last_in = last_index;
     set.count = (uint32_t)idx.size();
     set.starts.clear();
-    for (size_t k = 0; k < idx.size(); k += 128) set.starts.push_back(idx[k]);
+    for (size_t k = 0; k < idx.size(); k += 32) set.starts.push_back(idx[k]);  // every 32nd output: SincArgs::set_starts
 }
 
 // set of streaming chunk number n of a ratio (memoised: chunk n starts where chunk n - 1 ended)
@@ -1463,9 +1453,10 @@ int sk_downsample_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uin
     a.in_frames = frames;
     a.out_count = n_out;
     a.in_origin = 0;
-    for (uint32_t r0 = 0; r0 < rows; r0 += 65535) {
+    const uint32_t rows_per_launch = 65535u * sk::sinc_rows_per_block();  // grid.y limit
+    for (uint32_t r0 = 0; r0 < rows; r0 += rows_per_launch) {
         sk::SincArgs part = a;
-        part.rows = std::min<uint32_t>(65535, rows - r0);
+        part.rows = std::min<uint32_t>(rows_per_launch, rows - r0);
         part.in = d_in + (size_t)r0 * in_stride;
         part.out = d_out + (size_t)r0 * out_stride;
         SK_HIP(sk::launch_sinc_resample(part, e->stream), "launch sinc resample");
@@ -1823,9 +1814,10 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
         }
         if (max_count) {
             const uint32_t *d_map = nullptr, *d_off = nullptr;
-            SK_HIP(aux.put(row_map, e->stream, &d_map), "upload row map");
-            SK_HIP(aux.put(out_off, e->stream, &d_off), "upload out offsets");
+            uint32_t n_launch_rows = (uint32_t)row_map.size();
             if (fir) {
+                SK_HIP(aux.put(row_map, e->stream, &d_map), "upload row map");
+                SK_HIP(aux.put(out_off, e->stream, &d_off), "upload out offsets");
                 // integer time base: output m sits at index 3m - 125.  Any origin works as long as output
                 // out_first + j reads the row at chunk-relative index idx[0] + 3j (+ kRsHist of history in front)
                 // ... and the origin that makes the row's sample 0 fall on a multiple of four lets the kernel stage with
@@ -1856,6 +1848,30 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
                     std::copy(sets[i]->starts.begin(), sets[i]->starts.end(), starts.begin() + (ptrdiff_t)(i * stride));
                     set_count.push_back(sets[i]->count);
                 }
+                // the generic kernel's workgroups take 64 consecutive rows that share their index set: rows ordered by set,
+                // each set's rows padded to a multiple of that with rows that read and write nothing (row_map 0xffffffff)
+                {
+                    const uint32_t per_block = sk::sinc_rows_per_block();
+                    std::vector<uint32_t> order(row_map.size());
+                    for (uint32_t r = 0; r < order.size(); ++r) order[r] = r;
+                    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return row_set[x] < row_set[y]; });
+                    std::vector<uint32_t> g_map, g_off, g_set;
+                    for (size_t k = 0; k < order.size(); ++k) {
+                        if (k > 0 && row_set[order[k]] != row_set[order[k - 1]])
+                            while (g_map.size() % per_block) {
+                                g_map.push_back(0xffffffffu);
+                                g_off.push_back(0);
+                                g_set.push_back(g_set.back());
+                            }
+                        g_map.push_back(row_map[order[k]]);
+                        g_off.push_back(out_off[order[k]]);
+                        g_set.push_back(row_set[order[k]]);
+                    }
+                    SK_HIP(aux.put(g_map, e->stream, &d_map), "upload row map (grouped by index set)");
+                    SK_HIP(aux.put(g_off, e->stream, &d_off), "upload out offsets (grouped by index set)");
+                    row_set.swap(g_set);  // uploaded below; row_map stays the list of real rows (the history slide uses it)
+                    n_launch_rows = (uint32_t)g_map.size();
+                }
                 const double *d_starts = nullptr;
                 const uint32_t *d_count = nullptr, *d_set = nullptr;
                 SK_HIP(aux.put(starts, e->stream, &d_starts), "upload time indices");
@@ -1874,13 +1890,14 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
                 a.step = 1.0 / tab.ratio;
                 a.row_map = d_map;
                 a.out_off = d_off;
-                a.rows = (uint32_t)row_map.size();
+                a.rows = n_launch_rows;
                 a.in_frames = kRsRow;
                 a.out_count = max_count;
                 a.in_origin = -(int32_t)kRsHist;  // indices are relative to the chunk start; the row starts 512 earlier
-                for (uint32_t r0 = 0; r0 < a.rows; r0 += 65535) {  // grid.y limit
+                const uint32_t rows_per_launch = 65535u * sk::sinc_rows_per_block();  // grid.y limit; a multiple of the block's rows
+                for (uint32_t r0 = 0; r0 < a.rows; r0 += rows_per_launch) {
                     sk::SincArgs part = a;
-                    part.rows = std::min<uint32_t>(65535, a.rows - r0);
+                    part.rows = std::min<uint32_t>(rows_per_launch, a.rows - r0);
                     part.row_map = d_map + r0;
                     part.out_off = d_off + r0;
                     part.row_set = d_set + r0;
@@ -2344,10 +2361,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             ea.coeffs = (float *)e->in_buf.p;
             ea.entries = const_cast<sk::SynthEntry *>(a.entries);
             ea.status = const_cast<int32_t *>(d_status);
-            static const bool serial = std::getenv("SK_ENTROPY_SERIAL") != nullptr;  // the one-lane-per-stream form, for A/B runs
-            if (serial && !q_mode) {
-                SK_HIP(sk::launch_aac_entropy(ea, e->stream), "launch entropy decode");
-            } else {
+            {
                 SK_HIP(e->tick_side.reserve((size_t)n_frames * (sizeof(sk_ec::Scratch) + sizeof(uint32_t)) + 128),
                        "alloc entropy side information");
                 ea.n_units = n_frames;

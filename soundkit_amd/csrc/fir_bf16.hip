@@ -147,11 +147,6 @@ template <bool ALIGNED, bool PACKED, bool INTERIOR = false, bool IN16 = false>
 __device__ __forceinline__ void stage_issue(const FirArgs &a, int lane, uint32_t row0, int64_t n, Stage<IN16> &st, int half, int slot) {
     using Vec = typename Stage<IN16>::Vec;
     using Elem = typename Stage<IN16>::Elem;
-#ifdef SK_BF_ABLATE_LOAD
-#pragma unroll
-    for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(st.v[2 * slot + e]));
-    return;
-#endif
     if (ALIGNED) {
         const int64_t c0 = n - a.in_origin;  // the chunk's first sample in the row
         // the usual chunk lies inside the row (and inside one 1024-sample block of the frame-packed layout): one scalar
@@ -179,7 +174,7 @@ __device__ __forceinline__ void stage_issue(const FirArgs &a, int lane, uint32_t
                 st.v[sl] = *reinterpret_cast<const Vec *>(src);
             }
         }
-    } else if constexpr (!IN16) {  // s16 rows are only taken aligned (launch_fir_48k_16k_bf16 checks)
+    } else if constexpr (!IN16) {  // s16 rows are only taken aligned (launch_fir_48k_16k checks)
         const int64_t idx = n + lane - a.in_origin;
         const bool in_range = idx >= 0 && idx < (int64_t)a.in_frames;
         const size_t off = time_offset<PACKED>(a, (uint32_t)idx);
@@ -217,13 +212,8 @@ __device__ __forceinline__ void stage_commit(unsigned char *lds, int lane, int r
             *reinterpret_cast<u32x2 *>(dst + kPlaneBytes) = (u32x2){p2a, p2b};
         } else if (ALIGNED) {
             uint32_t p1a, p2a, p3a, p1b, p2b, p3b;
-#ifdef SK_BF_ABLATE_SPLIT
-            p1a = p2a = p3a = __float_as_uint(st.v[sl][0]) ^ __float_as_uint(st.v[sl][1]);
-            p1b = p2b = p3b = __float_as_uint(st.v[sl][2]) ^ __float_as_uint(st.v[sl][3]);
-#else
             split_pair(st.v[sl][0], st.v[sl][1], p1a, p2a, p3a);
             split_pair(st.v[sl][2], st.v[sl][3], p1b, p2b, p3b);
-#endif
             unsigned char *dst = lds + (4 * ld + (lane >> 4)) * kRowBytes + 2 * (ring_at + 4 * (lane & 15));
             *reinterpret_cast<u32x2 *>(dst) = (u32x2){p1a, p1b};
             *reinterpret_cast<u32x2 *>(dst + kPlaneBytes) = (u32x2){p2a, p2b};
@@ -271,14 +261,7 @@ __global__ __launch_bounds__(64, F16 ? SK_FIR_F16_WAVES : 2) void k_fir_48k_16k_
 
     const int lane = threadIdx.x;
     const int j = lane & 15, q = lane >> 4;
-    // SK_FIR_TIME_MAJOR experiment: blocks ordered by time segment first, so that short-lived blocks sweep the
-    // frame-packed PCM in address order
-#ifdef SK_FIR_TIME_MAJOR
-    const uint32_t n_groups = gridDim.x / n_segs;
-    const uint32_t group = blockIdx.x % n_groups, seg = blockIdx.x / n_groups;
-#else
     const uint32_t group = blockIdx.x / n_segs, seg = blockIdx.x % n_segs;
-#endif
     const uint32_t row0 = group * 16;
     // tile pair u = absolute outputs 32 u .. 32 u + 31 (even tile 2u, odd tile 2u + 1); segments start at multiples of 4
     const int32_t p_begin = pair0 + (int32_t)seg * pairs_per_seg;
@@ -341,9 +324,6 @@ __global__ __launch_bounds__(64, F16 ? SK_FIR_F16_WAVES : 2) void k_fir_48k_16k_
         // vector stores -- no branch, so a whole body is one scheduling region
         constexpr bool INTERIOR = decltype(itag)::value;
         if (!INTERIOR && (pair < p_begin || pair >= p_end)) return;  // wave-uniform
-#ifdef SK_BF_ABLATE_STORE
-        if (v[0] != 1.2345e30f) return;
-#endif
         const int32_t rel_tile = 32 * pair + 16 * parity - (int32_t)a.out_first;  // wave-uniform
         const bool whole = INTERIOR || (out_vec && rel_tile >= 0 && rel_tile + 16 <= (int32_t)a.out_count);
         const bool row_ok = INTERIOR || row_exists;
@@ -443,19 +423,13 @@ __global__ __launch_bounds__(64, F16 ? SK_FIR_F16_WAVES : 2) void k_fir_48k_16k_
                     }
                 }
                 // the tile that took its last step (s = 9, wi = 0) one half-step ago is stored now, behind 20 MFMAs
-#ifdef SK_BF_STORE_SPLIT
-                if (wi == 0 && par == 1) store_tile(itag, acc[0][(K + 1) & 3], P - 3, 0);
-                if (wi == 1 && par == 0) store_tile(itag, acc[1][(K + 1) & 3], P - 3, 1);
-#else
                 // both halves of each row's 128-byte line leave together
                 if (wi == 1 && par == 0) {
                     store_tile(itag, acc[0][(K + 1) & 3], P - 3, 0);
                     store_tile(itag, acc[1][(K + 1) & 3], P - 3, 1);
                 }
-#endif
                 bcur = bnext;
             }
-#ifndef SK_BF_NO_SCHED_GROUPS
             // a matrix instruction holds the vector issue port for half of its 16 cycles: two ordinary vector
             // instructions per MFMA ride along free, a longer run between two MFMAs stalls the matrix pipe
             if (INTERIOR) {
@@ -469,7 +443,6 @@ __global__ __launch_bounds__(64, F16 ? SK_FIR_F16_WAVES : 2) void k_fir_48k_16k_
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
                 }
             }
-#endif
         }
     };
 
@@ -510,14 +483,15 @@ __global__ __launch_bounds__(64, F16 ? SK_FIR_F16_WAVES : 2) void k_fir_48k_16k_
 
 }  // namespace
 
-bool fir_bf16_supported(const FirArgs &a) {
+static bool fir_bf16_supported(const FirArgs &a) {
     // tile and sample indices are 32-bit inside the kernel; longer rows (> ~2^31 / 3 outputs) stay on the f32 kernel
     const int64_t end_pair = ((int64_t)a.out_first + a.out_count + 31) / 32;
     return a.afrag16 != nullptr && end_pair <= 0x7ffffff0ll / 96 && a.out_count <= 0x7fffff00u;
 }
 
-hipError_t launch_fir_48k_16k_bf16(const FirArgs &a, hipStream_t s) {
+hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s) {
     if (a.rows == 0 || a.out_count == 0) return hipSuccess;
+    if (!fir_bf16_supported(a)) return hipErrorInvalidValue;
     const uint32_t groups = (a.rows + 15) / 16;
     const int64_t first_pair = ((int64_t)a.out_first / 32) & ~(int64_t)3;
     const int64_t end_pair = ((int64_t)a.out_first + a.out_count + 31) / 32;
@@ -532,9 +506,6 @@ hipError_t launch_fir_48k_16k_bf16(const FirArgs &a, hipStream_t s) {
     if (n_segs > max_segs) n_segs = max_segs;
     uint32_t pps = (pairs + n_segs - 1) / n_segs;
     pps = (pps + 3) & ~3u;
-#ifdef SK_FIR_PPS
-    pps = SK_FIR_PPS;  // experiment: short segments (many short-lived blocks)
-#endif
     n_segs = (pairs + pps - 1) / pps;
 
     const bool strides_ok = a.in_block ? (a.in_block % 4 == 0 && a.in_block_stride % 4 == 0 && a.in_group_stride % 4 == 0)

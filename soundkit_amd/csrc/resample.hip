@@ -7,85 +7,124 @@
 //     index = floor(idx), sub = floor((idx - index) * 256), frac = idx*256 - floor(idx*256)
 //     out   = p0 + frac * (p1 - p0),  p_k = sum_i buf[index_k + i] * sincs[sub_k][i]
 // The time index of every output comes from the host (the exact f64 accumulation rubato does), so
-// output counts and sub-filter choices match the restated reference bit for bit.
-// The 256 x 256 tap table (256 KiB) lives in L2; the input window of a block of outputs in LDS.
+// output counts and sub-filter choices match the restated reference bit for bit; the sums keep rubato's
+// order (eight running sums per dot product, separate multiplies and adds).
+//
+// Mapping (round 3; the first form gave every lane its own output of one row, so that the 64 lanes of a wave read 64
+// different 1 KiB sub-filters from L2 for every tap: 4.6 G outputs/s, 6 % of the vector peak):
+//   the rows of a launch that sit at the same point of the walk ask for the SAME sub-filters at the same output, so a
+//   wave takes ONE output of 64 rows.  The taps are then wave-uniform: they arrive by scalar loads and enter the
+//   multiplies as scalar operands -- no vector-memory or LDS traffic for 512 of the 770 operands of an output.  The
+//   inputs of the block's 64 rows sit in LDS transposed ([sample][row], pitch 65: lane = row reads and lane = sample
+//   writes are both conflict-free); the sixteen waves of a block share that tile (109 KB: one block per CU, so the block
+//   itself has to bring the four waves per SIMD that hide the scalar loads' and the LDS reads' latency -- with four waves
+//   per block the same kernel ran at 6.9 G outputs/s) and take every sixteenth of its (up to 32) outputs; results leave
+//   through a small transposed tile so that every row is written in runs.
 #include "sk_device.h"
 
 namespace sk {
 
 namespace {
 
-constexpr int kOutPerBlock = 128;   // outputs per workgroup (one per thread)
-constexpr int kSpan = 1024;         // input samples staged per block: covers 128 outputs at ratios >= 1/6
+constexpr int kRows = 64;        // rows per workgroup (one per lane)
+constexpr int kMaxOuts = 32;     // outputs per workgroup at most (the index sets carry the index of every 32nd output)
+constexpr int kSpanMax = 384;    // input samples staged per row: covers kMaxOuts outputs down to ratio ~1/4, fewer outputs below
+constexpr int kPitch = kRows + 1;
+constexpr int kWaves = 16;       // waves per workgroup
 
-__global__ __launch_bounds__(kOutPerBlock) void k_sinc_resample(SincArgs a) {
-    __shared__ float win[kSpan + 8];
-    const uint32_t row = blockIdx.y;
-    const uint32_t m0 = blockIdx.x * kOutPerBlock;
-    const uint32_t m = m0 + threadIdx.x;
-    const uint32_t phys = a.row_map ? a.row_map[row] : row;
-    const float *src = a.in + (size_t)phys * a.in_stride;
+typedef const __attribute__((address_space(4))) float *const_floats;
 
-    // this lane's time index: the set gives the index of the block's first output, the rest is rubato's own
-    // sequence of additions (f64 addition is not associative, so no shortcut)
-    __shared__ double sidx[kOutPerBlock];
-    const uint32_t set = a.row_set ? a.row_set[row] : 0;
-    const uint32_t count = a.set_count[set];
-    if (m0 >= count) return;  // block-uniform
-    double idx = a.set_starts[(size_t)set * a.starts_stride + blockIdx.x];
-    for (uint32_t i = 0; i < threadIdx.x; ++i) idx += a.step;
-    sidx[threadIdx.x] = idx;
-    __syncthreads();
-
-    // input window of this block: from floor(idx[m0]) to floor(idx[last]) + 257
-    const uint32_t m_last = min(m0 + kOutPerBlock, count) - 1;
-    const long base = (long)floor(sidx[0]);
-    const long need = (long)floor(sidx[m_last - m0]) + 257 - base + 1;
-    const bool staged = need <= kSpan;
-    if (staged) {
-        for (int i = threadIdx.x; i < (int)need; i += kOutPerBlock) {
-            const long n = base + i - a.in_origin;  // element of the row
-            win[i] = (n >= 0 && n < (long)a.in_frames) ? src[n] : 0.0f;
-        }
-    }
-    __syncthreads();
-    if (m >= count) return;
-
-    const double fl = floor(idx);
-    long index0 = (long)fl;
-    long sub0 = (long)floor((idx - fl) * 256.0);
-    long index1 = index0, sub1 = sub0 + 1;
-    if (sub1 >= 256) { sub1 -= 256; index1 += 1; }
-    const double scaled = idx * 256.0;
-    const float frac = (float)(scaled - floor(scaled));
-    const float *s0 = a.sincs + sub0 * 256, *s1 = a.sincs + sub1 * 256;
-
+// one output of 64 rows: SHIFT = index1 - index0 (1 only when the second sub-filter wraps to the next input sample)
+template <int SHIFT>
+__device__ __forceinline__ float dot_pair(const float *x /* tile + (index0 - base) * kPitch + lane */, const_floats s0, const_floats s1,
+                                          float frac) {
     float acc0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc1[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // rubato's 8 running sums
-    if (staged) {
-        const float *w0 = win + (index0 - base), *w1 = win + (index1 - base);
-        for (int i = 0; i < 256; i += 8) {
+    float carry = x[0];
+    for (int i = 0; i < 256; i += 8) {
+        float xs[9];
+        xs[0] = carry;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                acc0[j] += w0[i + j] * s0[i + j];
-                acc1[j] += w1[i + j] * s1[i + j];
-            }
-        }
-    } else {  // very low ratios: read the row directly
-        for (int i = 0; i < 256; i += 8) {
+        for (int j = 1; j < 9; ++j) xs[j] = x[(i + j) * kPitch];
+        carry = xs[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const long n0 = index0 + i + j - a.in_origin, n1 = index1 + i + j - a.in_origin;
-                const float x0 = (n0 >= 0 && n0 < (long)a.in_frames) ? src[n0] : 0.0f;
-                const float x1 = (n1 >= 0 && n1 < (long)a.in_frames) ? src[n1] : 0.0f;
-                acc0[j] += x0 * s0[i + j];
-                acc1[j] += x1 * s1[i + j];
-            }
+        for (int j = 0; j < 8; ++j) {
+            acc0[j] += xs[j] * s0[i + j];
+            acc1[j] += xs[j + SHIFT] * s1[i + j];
         }
     }
     const float p0 = acc0[0] + acc0[1] + acc0[2] + acc0[3] + acc0[4] + acc0[5] + acc0[6] + acc0[7];
     const float p1 = acc1[0] + acc1[1] + acc1[2] + acc1[3] + acc1[4] + acc1[5] + acc1[6] + acc1[7];
-    float *dst = a.out + (size_t)row * a.out_stride + (a.out_off ? a.out_off[row] : 0);
-    dst[m] = p0 + frac * (p1 - p0);
+    return p0 + frac * (p1 - p0);
+}
+
+__global__ __launch_bounds__(kWaves * 64) void k_sinc_resample(SincArgs a, uint32_t outs_per_block) {
+    // dynamic LDS (109 KB: above the static limit): [sample][row] input tile with one more sample row for the rolling read's
+    // look-ahead, the [output][row] result tile, the outputs' time indices
+    extern __shared__ double lds_raw[];
+    double *sidx = lds_raw;
+    float *tile = reinterpret_cast<float *>(lds_raw + kMaxOuts);
+    float *otile = tile + (kSpanMax + 1) * kPitch;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t row0 = blockIdx.y * kRows;
+    const uint32_t m0 = blockIdx.x * outs_per_block;
+    // the rows of a workgroup share their index set (the host groups them)
+    const uint32_t set = a.row_set ? a.row_set[row0] : 0;
+    const uint32_t count = a.set_count[set];
+    if (m0 >= count) return;  // block-uniform
+    const uint32_t n_here = min(outs_per_block, count - m0);
+
+    // rubato's own sequence of additions from the nearest index the host sent (f64 addition is not associative: no shortcut)
+    if (threadIdx.x < n_here) {
+        double idx = a.set_starts[(size_t)set * a.starts_stride + (m0 >> 5)];
+        const uint32_t steps = (m0 & 31u) + threadIdx.x;
+        for (uint32_t i = 0; i < steps; ++i) idx += a.step;
+        sidx[threadIdx.x] = idx;
+    }
+    __syncthreads();
+
+    // the block's input window, 64 rows x [floor(idx first), floor(idx last) + 257], transposed into LDS
+    const long base = (long)floor(sidx[0]);
+    const int need = (int)((long)floor(sidx[n_here - 1]) + 258 - base);  // <= kSpanMax by the host's choice of outs_per_block
+    for (int r = wave * (kRows / kWaves); r < (wave + 1) * (kRows / kWaves); ++r) {
+        const uint32_t row = row0 + (uint32_t)r;
+        uint32_t phys = 0xffffffffu;
+        if (row < a.rows) phys = a.row_map ? a.row_map[row] : row;
+        const float *src = a.in + (size_t)(phys == 0xffffffffu ? 0 : phys) * a.in_stride;
+        for (int c = lane; c <= need; c += 64) {
+            const long n = base + c - a.in_origin;  // element of the row
+            tile[c * kPitch + r] = (phys != 0xffffffffu && n >= 0 && n < (long)a.in_frames) ? src[n] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t o = (uint32_t)wave; o < n_here; o += kWaves) {  // wave-uniform
+        const double idx = sidx[o];
+        const double fl = floor(idx);
+        const long index0 = (long)fl;
+        long sub0 = (long)floor((idx - fl) * 256.0);
+        long sub1 = sub0 + 1;
+        const int shift = sub1 >= 256 ? 1 : 0;
+        if (shift) sub1 -= 256;
+        const double scaled = idx * 256.0;
+        const float frac = (float)(scaled - floor(scaled));
+        const int off = __builtin_amdgcn_readfirstlane((int)(index0 - base));
+        const const_floats s0 = reinterpret_cast<const_floats>(reinterpret_cast<uintptr_t>(a.sincs)) + __builtin_amdgcn_readfirstlane((int)sub0) * 256;
+        const const_floats s1 = reinterpret_cast<const_floats>(reinterpret_cast<uintptr_t>(a.sincs)) + __builtin_amdgcn_readfirstlane((int)sub1) * 256;
+        const float *x = tile + off * kPitch + lane;
+        const float v = __builtin_amdgcn_readfirstlane(shift) ? dot_pair<1>(x, s0, s1, frac) : dot_pair<0>(x, s0, s1, frac);
+        otile[o * kPitch + lane] = v;
+    }
+    __syncthreads();
+
+    // rows leave in runs of n_here consecutive outputs: lane = output, 32 rows per pass of the block
+    for (int r = (int)(threadIdx.x >> 5); r < kRows; r += kWaves * 2) {
+        const uint32_t row = row0 + (uint32_t)r, o = threadIdx.x & 31u;
+        if (row >= a.rows || o >= n_here) continue;
+        if (a.row_map && a.row_map[row] == 0xffffffffu) continue;  // a padding row of the host's grouping
+        float *dst = a.out + (size_t)row * a.out_stride + (a.out_off ? a.out_off[row] : 0);
+        dst[m0 + o] = otile[o * kPitch + r];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_row_copies(const float *src_base, float *dst_base, const RowCopy *jobs,
@@ -108,11 +147,23 @@ __global__ __launch_bounds__(256) void k_row_copies(const float *src_base, float
 
 }  // namespace
 
+uint32_t sinc_rows_per_block() { return kRows; }
+
 hipError_t launch_sinc_resample(const SincArgs &a, hipStream_t s) {
     if (a.rows == 0 || a.out_count == 0) return hipSuccess;
-    if (a.rows > 65535) return hipErrorInvalidValue;
-    const dim3 grid((a.out_count + kOutPerBlock - 1) / kOutPerBlock, a.rows);
-    hipLaunchKernelGGL(k_sinc_resample, grid, dim3(kOutPerBlock), 0, s, a);
+    const uint32_t row_blocks = (a.rows + kRows - 1) / kRows;
+    if (row_blocks > 65535) return hipErrorInvalidValue;
+    // outputs per workgroup: as many as the staged span allows at this step (a power of two, so that blocks never
+    // straddle the 32-output grid of the index sets)
+    uint32_t outs = kMaxOuts;
+    while (outs > 1 && (double)outs * a.step + 260.0 > (double)kSpanMax) outs >>= 1;
+    if ((double)outs * a.step + 260.0 > (double)kSpanMax) return hipErrorInvalidValue;  // step > ~120: no common rate pair
+    const dim3 grid((a.out_count + outs - 1) / outs, row_blocks);
+    constexpr size_t lds_bytes = kMaxOuts * sizeof(double) + ((size_t)(kSpanMax + 1) * kPitch + (size_t)kMaxOuts * kPitch) * sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sinc_resample), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)lds_bytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(k_sinc_resample, grid, dim3(kWaves * 64), lds_bytes, s, a, outs);
     return hipGetLastError();
 }
 

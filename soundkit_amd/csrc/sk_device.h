@@ -144,8 +144,7 @@ struct FirArgs {
     size_t out16_stride;
     uint32_t out16_ch;
     const float *zeros;   // >= 1 KiB of zeros (source for out-of-range input)
-    const float *afrag;   // [76][64] MFMA A-operand fragments of the Toeplitz tap matrix
-    const uint32_t *afrag16;  // [10][3][64][4] bf16 A-operand fragments (fir_bf16.hip); null = f32 kernel only
+    const uint32_t *afrag16;  // [10][3][64][4] bf16 A-operand fragments of the Toeplitz tap matrix
     const uint32_t *afrag_f16;  // [10][2][64][4] f16 A-operand fragments of the taps times 2^16 (s16 rows)
     const float *taps;    // [256]
     size_t in_stride, out_stride;
@@ -161,10 +160,9 @@ struct FirArgs {
     uint32_t out_first;   // first output index m to produce
     uint32_t out_count;   // outputs per row
 };
+// fir_bf16.hip: the 48 -> 16 kHz filter on the bf16 / f16 matrix cores (exact split of both operands).  Rows of more than
+// ~7e8 outputs in one call are refused (32-bit tile indices inside the kernel): hipErrorInvalidValue.
 hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s);
-// fir_bf16.hip: the same filter on the bf16 matrix cores (three-way exact split of both operands, six products)
-bool fir_bf16_supported(const FirArgs &a);
-hipError_t launch_fir_48k_16k_bf16(const FirArgs &a, hipStream_t s);
 
 // resample.hip -- generic-ratio windowed-sinc resampling (rubato SincFixedIn<f32>, Linear interpolation)
 struct SincArgs {
@@ -172,9 +170,11 @@ struct SincArgs {
     float *out;               // [rows][out_stride]
     const float *sincs;       // [256][256] sub-filter table of this ratio
     // Time indices: rubato advances an f64 index by `step` before every output.  Rows may sit at different points of
-    // that walk (streams of different ages), so indices come as "sets": set s holds the index of every 128th output
-    // (starts[s * starts_stride + b] = index of output 128 b) and its output count; a lane reproduces the additions
-    // in between.  row_set picks the set of a row (null: set 0 for every row).
+    // that walk (streams of different ages), so indices come as "sets": set s holds the index of every 32nd output
+    // (starts[s * starts_stride + b] = index of output 32 b) and its output count; a lane reproduces the additions
+    // in between.  row_set picks the set of a row (null: set 0 for every row).  A workgroup takes sinc_rows_per_block()
+    // consecutive rows, which must share their set: the host orders the rows by set and pads each set's rows to a multiple
+    // of that with rows whose row_map entry is 0xffffffff (nothing read, nothing written).
     const double *set_starts;
     const uint32_t *set_count;
     const uint32_t *row_set;
@@ -187,6 +187,7 @@ struct SincArgs {
     int32_t in_origin;        // sample index of in[r][0] in the index time base (history rows: negative)
 };
 hipError_t launch_sinc_resample(const SincArgs &a, hipStream_t s);
+uint32_t sinc_rows_per_block();
 
 // batched row copies (streaming resampler bookkeeping): job j copies count floats
 struct RowCopy {
@@ -258,7 +259,6 @@ struct EntropyArgs {
     const sk_ec::WireUnit *wire;  // [n_units], null in the other modes
     const int16_t *quant;         // packed like coeffs
 };
-hipError_t launch_aac_entropy(const EntropyArgs &a, hipStream_t s);           // one lane per stream, units in sequence
 hipError_t launch_aac_entropy_parallel(const EntropyArgs &a, hipStream_t s);  // parse | link | finish
 
 // pcm.hip -- the output stage of apply_output_options (soundkit-decoder lib.rs:3324-3456) for a batch of

@@ -303,6 +303,13 @@ class Engine:
                                                 C.byref(got)), "sk_downsample_48k_16k_f32_dev", self._h)
         return got.value
 
+    def downsample_dev(self, d_in, in_stride, rows, frames, in_hz, out_hz, d_out, out_stride):
+        """sk_downsample_f32_dev: one-shot downsample_audio of device rows, any pair of the reference's common rates"""
+        got = C.c_uint32()
+        check(lib.sk_downsample_f32_dev(self._h, _ptr(d_in), in_stride, rows, frames, in_hz, out_hz, _ptr(d_out), out_stride, C.byref(got)),
+              "sk_downsample_f32_dev", self._h)
+        return got.value
+
     def downsample(self, rows, in_hz, out_hz):
         """rows: [n_rows][frames] f32 -> [n_rows][out_frames], any pair of the reference's common rates."""
         rows = np.ascontiguousarray(rows, np.float32)
