@@ -399,6 +399,9 @@ def main():
     ap.add_argument("--chain", default="s16", choices=["s16", "f32"],
                     help="pipeline: what crosses HBM between synthesis and FIR -- s16 as in the reference worker (default), or the f32 "
                          "PCM (round 1's chain)")
+    ap.add_argument("--tail", default="separate", choices=["separate", "fused"],
+                    help="pipeline, s16 chain: the two launches (synthesis to planar s16, then the FIR) or sk_aac_plan_run_tail_s16_dev, "
+                         "the same work as one launch with the PCM kept in LDS")
     ap.add_argument("--no-extras", action="store_true",
                     help="pipeline: skip the two extra measurements the default line carries (the mixed-window synthesis launch and a "
                          "few seconds of the whole decode through the scheduler)")
@@ -542,10 +545,14 @@ def main():
                 del pcm
                 pcm16 = torch.empty(coeffs.shape, dtype=torch.int16, device=device)
 
-                def step():
+                def separate_step():
                     timed("k_aac_synth", lambda: plan.run_s16_planar(coeffs, pcm16))
                     timed("k_fir_48k_16k", lambda: eng.downsample_48k_16k_frames_s16_to_s16_dev(pcm16, stream_stride, frame_stride, ch,
                                                                                                 streams, frames, s16_out, s16_stride))
+
+                def fused_step():
+                    timed("k_aac_tail", lambda: plan.run_tail_s16(coeffs, stream_stride, ch, frames, s16_out, s16_stride))
+                step = fused_step if args.tail == "fused" else separate_step
             chain_note = {"f32": "f32 PCM between the kernels (not the reference's data flow: it narrows to s16 before resampling)",
                           "s16": "s16 PCM between the kernels as in the reference worker (decode_aac_access_unit -> "
                                  "audio_data_to_f32_channels: s / 32768)"}["f32" if args.separate_s16 else args.chain]
@@ -718,6 +725,20 @@ def main():
                     rl["k_aac_synth"]["same_kernel_f32_out"] = {"avg_launch_ms": synth_f32_ms, "achieved": f32_bytes / (synth_f32_ms * 1e-3) / 1e9,
                                                                 "frac": f32_bytes / (synth_f32_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
                                                                 "measured": "5 launches after the timed region, same batch"}
+        if "k_aac_tail" in per_kernel:
+            out["x_realtime_decode_tail"] = value / 46.875
+            ms = per_kernel["k_aac_tail"]
+            n_tail_out = eng.downsample_out_frames(frames * 1024)
+            # algorithmic bytes of the fused launch: spectra in (4 KiB per channel-frame), 16 kHz interleaved s16 out, the overlap
+            # delay once per channel per launch each way -- the s16 PCM between the two stages never leaves the CU
+            tail_bytes = streams * frames * ch * 4096 + streams * ch * n_tail_out * 2 + streams * ch * 8192
+            rl["k_aac_tail"] = {
+                "kernel": "k_aac_tail (synthesis + s16 + 48k->16k MFMA FIR + interleave in one launch)", "bound": "hbm",
+                "achieved": tail_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tail_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": None, "avg_launch_ms": ms,
+                "variant": "4096 B in per channel-frame + 2 B per 16 kHz output sample + 8192 B per channel per launch (delay in/out)",
+                "bytes_of_the_two_kernel_chain_it_replaces": streams * frames * ch * 6144 + streams * ch * 8192 + streams * ch * (frames * 1024 * 2 + n_tail_out * 2),
+                "matrix_form": "f16, 24 MFMAs per 256 outputs of a channel"}
         if "k_fir_48k_16k" in per_kernel:
             ms = per_kernel["k_fir_48k_16k"]
             fir_in = frames * 1024 if args.workload == "pipeline" else 48000

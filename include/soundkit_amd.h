@@ -363,6 +363,17 @@ int sk_downsample_48k_16k_frames_s16_to_f32_dev(sk_engine *, const int16_t *d_pc
                                                 uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream,
                                                 float *d_out, size_t out_stride, uint32_t *out_frames);
 
+/* sk_aac_plan_run_s16_planar_dev + sk_downsample_48k_16k_frames_s16_to_s16_dev over all frames of a plan as ONE launch
+ * (decode_aac_access_unit + apply_output_options, lib.rs:1793-1813, 3324-3456): the s16 PCM between the two never crosses
+ * HBM -- each channel's wave keeps its last 2048 samples as the FIR's two f16 planes in LDS and runs the FIR on them as
+ * they complete.  Same results bit for bit (same arithmetic in the same order).  For plans whose channels are all free of
+ * EightShort frames and pair up (two channels of equal length), every stream with `channels` channels and
+ * `frames_per_stream` frames from its frame 0; anything else returns SK_ERR_UNSUPPORTED: use the two calls.
+ * stream_stride: samples between the first frames of consecutive streams in the spectra's packing (as above);
+ * d_out[s][m][c] interleaved s16, out_stride frames per stream (a multiple of 4), 8-byte aligned. */
+int sk_aac_plan_run_tail_s16_dev(sk_engine *, const sk_aac_plan *, const float *d_coeffs, size_t stream_stride, uint32_t channels,
+                                 uint32_t frames_per_stream, int16_t *d_out, size_t out_stride, uint32_t *out_frames);
+
 /* StreamingResampler (soundkit-decoder lib.rs:1917-2060), any pair of COMMON_SAMPLE_RATES, fixed 4096-frame
  * chunks, history kept per stream on the device.  in: n_streams x channels x frames planar
  * (stream-major); out: capacity out_cap frames per channel row; out_frames[s] receives the

@@ -199,6 +199,7 @@ _sig = {
     "sk_mp3_hybrid_synthesize_s16": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "sk_mp3_hybrid_synthesize_f32_dev": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "sk_aac_entropy_decode": (_i, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _sz, _vp, _vp, _vp]),
+    "sk_aac_plan_run_tail_s16_dev": (_i, [_vp, _vp, _vp, _sz, _u32, _u32, _vp, _sz, C.POINTER(_u32)]),
     "sk_aac_expand_q_decode": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "sk_engine_where": (C.c_char_p, [_vp]),
     "sk_engine_set_wait_bound": (_i, [_vp, C.c_double]),

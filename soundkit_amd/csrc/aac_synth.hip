@@ -883,6 +883,228 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(Synth
     }
 }
 
+// ---- the decode tail in one kernel: synthesis -> s16 -> 48 to 16 kHz FIR -> interleaved s16 ----------------------------------
+// decode_aac_access_unit + apply_output_options (soundkit-decoder lib.rs:1793-1813, 3324-3456) for every frame of a launch
+// without the s16 PCM ever crossing HBM: what k_aac_synth<true, true> stores (float_sample_to_i16 of every sample) goes,
+// split into the FIR's two f16 planes, into a 2048-sample ring in LDS instead, and the wave runs the FIR on its own
+// channel whenever 768 more samples (256 outputs) are complete.  Same arithmetic as the two kernels it replaces, in the
+// same order -- the synthesis is k_aac_synth's code, the FIR fir_bf16.hip's f16 form (tap fragments, sample split and the
+// order of the matrix instructions per output: windows ascending, x1h1 | x1h2, x2h1) -- so the result is theirs bit for bit.
+//
+//   D[i][j] += A[i][k] * B[k][j]   v_mfma_f32_16x16x32_f16:  i = output within a block of 16, k = 32 samples of a window,
+//   j = sixteen blocks of 16 outputs, 48 samples apart, of the SAME channel (fir_bf16.hip: sixteen channel rows): a tile is
+//   256 consecutive outputs of one channel, its B operand a gather from the ring (sample 768 T - 128 + 48 j + 32 s + 8 q).
+//
+// One workgroup = the two tasks of a pair (k_aac_synth_pair's pairing: L and R of a stream, or two mono streams of equal
+// length), one wave each.  For a stereo stream the two waves swap their packed results through LDS behind a barrier and
+// each stores one half of the tile's interleaved frames (512 contiguous bytes); mono streams store their own.
+constexpr int kTailRing = 2048;  // samples per plane and wave: 255 of history + at most 767 waiting + one new frame
+constexpr int kTailDepth = 2;  // spectra in flight per wave (1 and 3 measured the same within 2 %)
+
+__global__ __launch_bounds__(128, 2) void k_aac_tail(TailArgs ta) {
+    const SynthArgs &a = ta.s;
+    __shared__ f2 lds[2][kExchange];
+    __shared__ f2 tw_tab[512];
+    __shared__ f2 t64_tab[64];
+    __shared__ __attribute__((aligned(16))) uint16_t ring_lds[2][2][kTailRing];  // [wave][plane][sample & 2047]
+    __shared__ __attribute__((aligned(16))) uint32_t xchg[2][2][128];            // [tile parity][wave][2 x lane]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int i = threadIdx.x; i < 512; i += 128) tw_tab[i] = reinterpret_cast<const f2 *>(a.t.tw_long)[i];
+    if (threadIdx.x < 64) t64_tab[threadIdx.x] = reinterpret_cast<const f2 *>(a.t.w64)[((threadIdx.x >> 3) * (threadIdx.x & 7)) & 63];
+    // the ring starts as silence: the filter's history in front of the launch's first sample
+    for (int i = threadIdx.x; i < 2 * 2 * kTailRing / 8; i += 128) reinterpret_cast<sk_u32x4 *>(&ring_lds[0][0][0])[i] = (sk_u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    const uint32_t pair_id = blockIdx.x;  // a.n_tasks is even: tasks 2p and 2p + 1 have the same count
+    lds_f2 *ex = (lds_f2 *)lds[wave];
+    const lds_f2 *tw_lds = (const lds_f2 *)tw_tab;
+    const lds_f2 *t64 = (const lds_f2 *)t64_tab;
+    unsigned char *ring = reinterpret_cast<unsigned char *>(&ring_lds[wave][0][0]);  // plane 1 at + 2 * kTailRing bytes
+
+    const SynthTask task_v = a.tasks[2 * pair_id + (uint32_t)wave];
+    const SynthTask other_v = a.tasks[2 * pair_id + (uint32_t)(wave ^ 1)];
+    const uint32_t count = __builtin_amdgcn_readfirstlane(task_v.count);
+    const uint32_t state = __builtin_amdgcn_readfirstlane(task_v.state);
+    const uint32_t other_state = __builtin_amdgcn_readfirstlane(other_v.state);
+    if (count == 0) return;  // both waves of the pair: the counts are equal
+    const const_entries entries = as_constant(a.entries + __builtin_amdgcn_readfirstlane(task_v.begin));
+    const bool stereo = (state ^ other_state) == 1u;  // L and R of one stream: interleaved output
+    // where this channel's output goes: its stream's row in the caller's layout, from the position of its first frame
+    const uint64_t first_elem = (uint64_t)__builtin_amdgcn_readfirstlane(entries[0].off1024) * 1024u;
+    const uint32_t out_row = (uint32_t)(first_elem / ta.stream_stride);
+    const uint32_t n_out = (1024u * count - 130u) / 3u;  // sk_downsample_48k_16k_out_frames(1024 * count): one-shot rubato SincFixedIn
+    uint32_t *dst32 = reinterpret_cast<uint32_t *>(ta.out16 + (size_t)out_row * ta.out_stride * 2);  // stereo rows
+    int16_t *dst16 = ta.out16 + (size_t)out_row * ta.out_stride;                                      // mono rows
+
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const f2 base2 = reinterpret_cast<const f2 *>(a.t.w512)[hi3 * lo3];
+
+    // the FIR's tap fragments (fir_bf16.hip: window s, plane k, this lane), held in registers for the whole launch: 68 VGPRs
+    // that cost the third wave per SIMD -- fetched from the CU's L1 for every tile instead (168 VGPRs, three waves) the launch
+    // took 1.75 ms against 1.22, at two waves 1.38 (profiles/r03_ab_fused.md)
+    sk_u32x4 af[10][2];
+    {
+        const sk_u32x4 *af_src = reinterpret_cast<const sk_u32x4 *>(ta.afrag_f16) + lane;
+#pragma unroll
+        for (int sidx = 0; sidx < 10; ++sidx)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) af[sidx][k] = af_src[(sidx * 2 + k) * 64];
+    }
+
+    float *delay_ptr = a.delay + (size_t)state * 1024;
+    int prev_shape = __builtin_amdgcn_readfirstlane((int)a.prev_shape[state]);
+    float dly[16];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 4 * lane + 256 * r;
+        const f4 f = *reinterpret_cast<const f4 *>(delay_ptr + j);
+        const f4 m = *reinterpret_cast<const f4 *>(delay_ptr + 1020 - j);
+        dly[8 * r + 0] = f.x; dly[8 * r + 1] = f.y; dly[8 * r + 2] = f.z; dly[8 * r + 3] = f.w;
+        dly[8 * r + 4] = m.x; dly[8 * r + 5] = m.y; dly[8 * r + 6] = m.z; dly[8 * r + 7] = m.w;
+    }
+
+    // four samples of the frame at position pos (a multiple of 4) -> s16 -> the two f16 planes -> ring
+    auto to_ring = [&](const f4 &v, int ring_pos) __attribute__((always_inline)) {
+        const u2 p = pack4_s16(v);
+        uint32_t p1a, p2a, p1b, p2b;
+        dev_split_pair16_f16(p.x, p1a, p2a);
+        dev_split_pair16_f16(p.y, p1b, p2b);
+        *reinterpret_cast<u2 *>(ring + 2 * ring_pos) = (u2){p1a, p1b};
+        *reinterpret_cast<u2 *>(ring + 2 * kTailRing + 2 * ring_pos) = (u2){p2a, p2b};
+    };
+
+    // one tile: outputs 256 T .. 256 T + 255 of this channel
+    const int jq_off = 48 * (lane & 15) + 8 * (lane >> 4);
+    auto fir_tile = [&](uint32_t T) __attribute__((always_inline)) {
+        const int base = (int)(768u * T) - 128 + jq_off;
+        sk_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < 10; ++sidx) {
+            const int at = 2 * ((base + 32 * sidx) & (kTailRing - 1));
+            const sk_u32x4 b1 = *reinterpret_cast<const sk_u32x4 *>(ring + at);
+            acc = dev_mfma_f16(af[sidx][0], b1, acc);                                  // x1 h1
+            if (kFirProductsF16[sidx] == 3) {
+                const sk_u32x4 b2 = *reinterpret_cast<const sk_u32x4 *>(ring + 2 * kTailRing + at);
+                acc = dev_mfma_f16(af[sidx][1], b1, acc);                              // x1 h2
+                acc = dev_mfma_f16(af[sidx][0], b2, acc);                              // x2 h1
+            }
+        }
+        // the samples went in as integers and the taps times 2^16: powers of two, they commute with every rounding
+        const sk_f32x4 v = acc * (1.0f / 2147483648.0f);
+        const uint32_t lo = dev_pack2_s16(v[0], v[1]), hi = dev_pack2_s16(v[2], v[3]);  // outputs 256 T + 16 j + 4 q + (0..3)
+        if (!stereo) {
+            const uint32_t m0 = 256u * T + 16u * (uint32_t)(lane & 15) + 4u * (uint32_t)(lane >> 4);
+            if (m0 + 3 < n_out) {
+                *reinterpret_cast<u2 *>(dst16 + m0) = (u2){lo, hi};
+            } else {
+                if (m0 + 0 < n_out) dst16[m0 + 0] = (int16_t)(lo & 0xffffu);
+                if (m0 + 1 < n_out) dst16[m0 + 1] = (int16_t)(lo >> 16);
+                if (m0 + 2 < n_out) dst16[m0 + 2] = (int16_t)(hi & 0xffffu);
+            }
+            return;
+        }
+        // stereo: both waves leave their tile in LDS (lane (j, q): 8 bytes at 8 * (16 q + j)), then wave w stores frames
+        // 128 w .. 128 w + 127 of the tile, two per lane: frame m of the tile sits at bytes 8 * (16 q + j) + 2 r of a wave's
+        // block with j = m >> 4, q = (m >> 2) & 3, r = m & 3
+        uint32_t *mine = &xchg[T & 1u][wave][0];
+        *reinterpret_cast<u2 *>(mine + 2 * lane) = (u2){lo, hi};
+        __syncthreads();
+        const uint32_t fm = 128u * (uint32_t)wave + 2u * (uint32_t)lane;  // this lane's first frame within the tile
+        const uint32_t word = 2u * (16u * ((fm >> 2) & 3u) + (fm >> 4)) + ((fm >> 1) & 1u);
+        const uint32_t l2 = xchg[T & 1u][(state & 1u) ? (wave ^ 1) : wave][word];  // two frames of the left channel
+        const uint32_t r2 = xchg[T & 1u][(state & 1u) ? wave : (wave ^ 1)][word];
+        const uint32_t f0 = __builtin_amdgcn_perm(r2, l2, 0x05040100u), f1 = __builtin_amdgcn_perm(r2, l2, 0x07060302u);
+        const uint32_t m0 = 256u * T + fm;
+        if (m0 + 1 < n_out) *reinterpret_cast<u2 *>(dst32 + m0) = (u2){f0, f1};
+        else if (m0 < n_out) dst32[m0] = f0;
+    };
+
+    auto load_spectrum = [&](f2 (&xin)[8], uint32_t e) {
+        const float *src = a.coeffs + (size_t)__builtin_amdgcn_readfirstlane(entries[e].off1024) * 1024 + 2 * lane;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xin[r] = SK_SYNTH_LOAD(reinterpret_cast<const f2 *>(src + 128 * r));
+    };
+
+    uint32_t next_tile = 0;
+    // one frame; `xin` holds its spectrum and is refilled with the spectrum kTailDepth frames on (two waves per SIMD: one
+    // spectrum in flight per wave left the memory pipeline idle a third of the time)
+    auto frame = [&](f2 (&xin)[8], uint32_t e) __attribute__((always_inline)) {
+        const uint32_t win = __builtin_amdgcn_readfirstlane(entries[e].win);
+        const int seq = (int)(win & 3);  // never 2: the host sends only tasks without EightShort frames here
+        const int shape = (win >> 2) & 1;
+        // ---- k_aac_synth<true, true>'s frame, its stores redirected into the ring ----
+        f2 z[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float even = xin[r].x;
+            const float odd = -__shfl(xin[7 - r].y, 63 - lane);
+            const f2 t = tw_lds[lane + 64 * r];
+            z[r] = (f2){odd * t.y - even * t.x, odd * t.x + even * t.y};
+        }
+        const float *w1 = first_half_window(a.t.win, seq, prev_shape);
+        const float *w2 = second_half_window(a.t.win, seq, shape);
+        f4 w1f[2], w1m[2], w2f[2], w2m[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 4 * lane + 256 * r;
+            w1f[r] = *reinterpret_cast<const f4 *>(w1 + j);
+            w1m[r] = *reinterpret_cast<const f4 *>(w1 + 1020 - j);
+            w2f[r] = *reinterpret_cast<const f4 *>(w2 + j);
+            w2m[r] = *reinterpret_cast<const f4 *>(w2 + 1020 - j);
+        }
+        load_spectrum(xin, e + kTailDepth < count ? e + kTailDepth : count - 1);
+        fft512(z, ex, t64, base2, lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ex[lane + 64 * j] = cmul(tw_lds[lane + 64 * j], (f2){z[j].x, -z[j].y});
+        wave_sync();
+        const int frame_at = (int)((e & 1u) * 1024u);  // the frame's first sample in the ring: 1024 e mod 2048
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int q = 2 * lane + 128 * r, j = 2 * q;
+            const f4 F = *reinterpret_cast<const lds_f4 *>(&ex[256 + q]);
+            const f4 M = *reinterpret_cast<const lds_f4 *>(&ex[254 - q]);
+            const f4 W1f = w1f[r], W1m = w1m[r], W2f = w2f[r], W2m = w2m[r];
+            f4 f, m;
+            f.x = -F.x * W1f.x + dly[8 * r + 0]; f.y = -M.w * W1f.y + dly[8 * r + 1];
+            f.z = -F.z * W1f.z + dly[8 * r + 2]; f.w = -M.y * W1f.w + dly[8 * r + 3];
+            m.x = M.y * W1m.x + dly[8 * r + 4]; m.y = F.z * W1m.y + dly[8 * r + 5];
+            m.z = M.w * W1m.z + dly[8 * r + 6]; m.w = F.x * W1m.w + dly[8 * r + 7];
+            to_ring(f, frame_at + j);
+            to_ring(m, frame_at + 1020 - j);
+            dly[8 * r + 0] = F.y * W2f.x; dly[8 * r + 1] = M.z * W2f.y;
+            dly[8 * r + 2] = F.w * W2f.z; dly[8 * r + 3] = M.x * W2f.w;
+            dly[8 * r + 4] = M.x * W2m.x; dly[8 * r + 5] = F.w * W2m.y;
+            dly[8 * r + 6] = M.z * W2m.z; dly[8 * r + 7] = F.y * W2m.w;
+        }
+        wave_sync();
+        prev_shape = shape;
+        // ---- every tile whose last sample (768 T + 895) has arrived; after the last frame, every tile that holds an output ----
+        const uint32_t have = 1024u * (e + 1);
+        while (256u * next_tile < n_out && (768u * next_tile + 896u <= have || e + 1 == count)) {
+            fir_tile(next_tile);
+            ++next_tile;
+        }
+    };
+    f2 ring_x[kTailDepth][8];
+#pragma unroll
+    for (int d = 0; d < kTailDepth; ++d) load_spectrum(ring_x[d], (uint32_t)d < count ? (uint32_t)d : count - 1);
+    for (uint32_t e0 = 0; e0 < count; e0 += kTailDepth) {
+#pragma unroll
+        for (int d = 0; d < kTailDepth; ++d)
+            if (e0 + (uint32_t)d < count) frame(ring_x[d], e0 + (uint32_t)d);
+    }
+
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = 4 * lane + 256 * r;
+        *reinterpret_cast<f4 *>(delay_ptr + j) = (f4){dly[8 * r + 0], dly[8 * r + 1], dly[8 * r + 2], dly[8 * r + 3]};
+        *reinterpret_cast<f4 *>(delay_ptr + 1020 - j) = (f4){dly[8 * r + 4], dly[8 * r + 5], dly[8 * r + 6], dly[8 * r + 7]};
+    }
+    if (lane == 0) a.prev_shape[state] = (uint8_t)prev_shape;
+}
+
 // planar f32 [ch][1024] -> interleaved i16 [1024][ch] with float_sample_to_i16
 // (soundkit-decoder/src/lib.rs:1793-1827): non-finite -> 0, clamp +-1, f64 scale by 32768
 // (negative) or 32767, round half away from zero, clamp.
@@ -979,6 +1201,13 @@ hipError_t launch_aac_synth_pairs(const SynthArgs &a, bool with_short, hipStream
         if (a.pcm16) hipLaunchKernelGGL((k_aac_synth_pair<true, false>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_aac_synth_pair<false, false>), grid, block, 0, s, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_aac_tail(const TailArgs &ta, hipStream_t s) {
+    if (ta.s.n_tasks < 2) return hipSuccess;
+    if ((ta.s.n_tasks & 1) || !ta.afrag_f16 || !ta.out16 || ta.stream_stride == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_aac_tail, dim3(ta.s.n_tasks / 2), dim3(128), 0, s, ta);
     return hipGetLastError();
 }
 

@@ -260,6 +260,8 @@ struct sk_aac_plan {
     // one channel per wave without / with them
     sk::SynthTask *d_pair_tasks = nullptr, *d_spair_tasks = nullptr, *d_long_tasks = nullptr, *d_walk_tasks = nullptr;
     uint32_t n_pair_tasks = 0, n_spair_tasks = 0, n_long_tasks = 0, n_walk_tasks = 0;
+    uint32_t uniform_count = 0;     // frames of every task when they all have the same number (else 0)
+    uint32_t uniform_channels = 0;  // channels of every stream in the plan when they all agree (else 0)
 };
 
 #define SK_HIP(expr, what)                               \
@@ -681,6 +683,7 @@ struct HostPlan {
     std::vector<uint32_t> entry_of;  // [frame * 2 + channel] -> index into entries (valid frames only)
     // `tasks` again, by kernel (see the end of build_plan_host)
     std::vector<sk::SynthTask> pair_tasks, spair_tasks, long_tasks, walk_tasks;
+    uint32_t uniform_count = 0, uniform_channels = 0;  // see sk_aac_plan
     uint32_t frames_ok = 0;
     uint64_t off1024 = 0;  // total packed size in units of 1024 f32
 };
@@ -750,6 +753,18 @@ int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, in
     if (bad_desc_channels || off > 0xffffffffull) return SK_ERR_INVALID_ARG;
     hp.frames_ok = frames_ok;
     hp.off1024 = off;
+    hp.uniform_count = tasks.empty() ? 0 : tasks[0].count;
+    for (const sk::SynthTask &t : tasks)
+        if (t.count != hp.uniform_count) hp.uniform_count = 0;
+    hp.uniform_channels = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (ok[i]) {
+            if (!hp.uniform_channels) hp.uniform_channels = descs[i].channels;
+            else if (hp.uniform_channels != descs[i].channels) {
+                hp.uniform_channels = 0xffu;  // mixed
+            }
+        }
+    if (hp.uniform_channels == 0xffu) hp.uniform_channels = 0;
     // Which kernel runs which task (dsp.rs:230-338: OnlyLong, LongStart and LongStop are one code path here -- the transition
     // windows are tables -- so only EightShort frames tell tasks apart):
     //   pair_tasks   two tasks of equal length without an EightShort frame share a wave (k_aac_synth_pair): normally the L and
@@ -847,6 +862,8 @@ int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n,
         p->n_long_tasks = (uint32_t)hp.long_tasks.size();
         p->n_pair_tasks = (uint32_t)hp.pair_tasks.size();
         p->n_spair_tasks = (uint32_t)hp.spair_tasks.size();
+        p->uniform_count = hp.uniform_count;
+        p->uniform_channels = hp.uniform_channels;
         if (he != hipSuccess) {
             sk_aac_plan_destroy(p);
             return e->hip_fail(he, "upload plan");
@@ -898,6 +915,44 @@ int sk_aac_plan_run_s16_planar_dev(sk_engine *e, const sk_aac_plan *p, const flo
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e);
     return run_plan(e, p, d_coeffs, nullptr, d_pcm16);
+}
+
+// The decode tail as one launch (k_aac_tail): sk_aac_plan_run_s16_planar_dev followed by the one-shot
+// sk_downsample_48k_16k_frames_s16_to_s16_dev over all frames of the plan, same results bit for bit, without the s16 PCM in
+// HBM.  For plans the fused kernel covers -- every channel free of EightShort frames and paired (two channels of equal
+// length: build_plan_host), every stream with the same channel count and the same number of frames, each stream's frames
+// `frames_per_stream` consecutive entries from its frame 0; anything else: SK_ERR_UNSUPPORTED, use the two calls.
+int sk_aac_plan_run_tail_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, size_t stream_stride, uint32_t channels,
+                                 uint32_t frames_per_stream, int16_t *d_out, size_t out_stride, uint32_t *out_frames) {
+    if (!e || !p || p->eng != e || channels < 1 || channels > SK_MAX_CHANNELS) return SK_ERR_INVALID_ARG;
+    const uint64_t samples = (uint64_t)frames_per_stream * SK_AAC_FRAME_LEN;
+    if (samples > 0xfffffffcull) return SK_ERR_INVALID_ARG;
+    const uint32_t n_out = sk_downsample_48k_16k_out_frames((uint32_t)samples);
+    if (out_frames) *out_frames = n_out;
+    if (p->n_tasks == 0) return SK_OK;
+    if (p->n_spair_tasks || p->n_long_tasks || p->n_walk_tasks || p->uniform_count != frames_per_stream || p->uniform_channels != channels ||
+        frames_per_stream == 0)
+        return SK_ERR_UNSUPPORTED;
+    if (!d_coeffs || !d_out || out_stride < n_out || out_stride % 4 || stream_stride < (size_t)channels * SK_AAC_FRAME_LEN ||
+        ((uintptr_t)d_out & 7))
+        return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e);
+    sk::TailArgs ta{};
+    ta.s.coeffs = d_coeffs;
+    ta.s.delay = e->d_delay;
+    ta.s.prev_shape = e->d_prev_shape;
+    ta.s.entries = p->d_entries;
+    ta.s.t = e->synth_tables;
+    ta.s.tasks = p->d_pair_tasks;
+    ta.s.n_tasks = p->n_pair_tasks;
+    ta.s.only_long = 1;
+    ta.afrag_f16 = e->d_afrag_f16;
+    ta.out16 = d_out;
+    ta.out_stride = out_stride;
+    ta.stream_stride = stream_stride;
+    SK_HIP(sk::launch_aac_tail(ta, e->stream), "launch decode tail (fused synthesis + fir)");
+    return SK_OK;
 }
 
 int sk_aac_plan_run_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, int16_t *d_pcm) {

@@ -60,7 +60,8 @@ __host__ __device__ constexpr int products_of(int s, bool in16) { return in16 &&
 // so that x1h1 + x1h2 + x2h1 leaves out only x2h2 < 2^-22 |x||h| and r -- measured against an f64 evaluation 1.0e-7 relative
 // RMS (tests/fir_split_model.py; the bf16 form with five products: 1.4e-7).  Eleven significand bits per value instead of eight: three products where bf16 needs five, and a
 // window whose largest tap is below 2^-13 of the peak needs only x1h1.  24 MFMAs per tile instead of 36.
-__device__ constexpr int kProductsF16[kWindows] = {1, 3, 3, 3, 3, 3, 3, 3, 1, 1};
+__device__ constexpr int kProductsF16[kWindows] = {kFirProductsF16[0], kFirProductsF16[1], kFirProductsF16[2], kFirProductsF16[3], kFirProductsF16[4],
+                                                     kFirProductsF16[5], kFirProductsF16[6], kFirProductsF16[7], kFirProductsF16[8], kFirProductsF16[9]};
 __host__ __device__ constexpr int products_of(int s, bool in16, bool f16) { return f16 ? kProductsF16[s] : products_of(s, in16); }
 #ifndef SK_BF_AHEAD
 #define SK_BF_AHEAD 2
@@ -103,16 +104,8 @@ __device__ __forceinline__ void split_pair16(uint32_t u, uint32_t &p1, uint32_t 
     p2 = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(b0), 0x07060302u);
 }
 
-// two s16 samples in one dword (the earlier one low) -> their two f16 planes: p1 = the sample rounded TOWARD ZERO to f16 (eleven
-// significand bits; no overflow at 32767), p2 = the rest (same sign, below 32: exact).  Three and a half vector instructions per sample.
-__device__ __forceinline__ void split_pair16_f16(uint32_t u, uint32_t &p1, uint32_t &p2) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 f = {(float)(short)(u & 0xffffu), (float)((int)u >> 16)};
-    const auto a = __builtin_amdgcn_cvt_pkrtz(f.x, f.y);
-    const f32x2 r = f - (f32x2){(float)a[0], (float)a[1]};  // exact; one packed subtraction
-    p1 = __builtin_bit_cast(uint32_t, a);
-    p2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r.x, r.y));
-}
+// (the f16 planes of s16 samples: dev_split_pair16_f16, sk_device.h -- shared with the fused decode-tail kernel)
+__device__ __forceinline__ void split_pair16_f16(uint32_t u, uint32_t &p1, uint32_t &p2) { dev_split_pair16_f16(u, p1, p2); }
 
 template <bool IN16>
 struct Stage {
@@ -240,10 +233,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 &av, const u32x4 &bv, con
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ f32x4 mfma_f16(const u32x4 &av, const u32x4 &bv, const f32x4 &c) {
-    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
-}
+__device__ __forceinline__ f32x4 mfma_f16(const u32x4 &av, const u32x4 &bv, const f32x4 &c) { return dev_mfma_f16(av, bv, c); }
 
 // OUT16: 0 = f32 rows out.  F16 (with IN16): f16 planes and the f16 matrix instruction instead of bf16.
 template <bool ALIGNED, bool PACKED, int OUT16, bool IN16 = false, bool F16 = false>

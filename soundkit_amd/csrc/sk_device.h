@@ -50,6 +50,17 @@ struct FrameSpan {
 };
 
 hipError_t launch_aac_synth(const SynthArgs &a, hipStream_t s);
+// The decode tail in one kernel (aac_synth.hip k_aac_tail): s.tasks are pairs as for launch_aac_synth_pairs(.., false, ..) --
+// no EightShort frame anywhere, tasks 2p / 2p + 1 of equal length -- every task's entries are ALL frames of its channel in
+// this launch, the first one frame 0 (the FIR is one-shot over them: silence in front, as downsample_audio).
+struct TailArgs {
+    SynthArgs s;
+    const uint32_t *afrag_f16;      // FirArgs::afrag_f16
+    int16_t *out16;                 // [stream row][out_stride frames][channels] interleaved s16; every stream of the launch has the same channel count
+    size_t out_stride;              // frames per stream row
+    size_t stream_stride;           // samples between the first frames of consecutive streams in the spectra's packing
+};
+hipError_t launch_aac_tail(const TailArgs &ta, hipStream_t s);
 // OnlyLong tasks two per wave: a.tasks[2p] and a.tasks[2p + 1] have the same count (a.n_tasks even)
 // with_short: the tasks' EightShort frames coincide pairwise (both channels of a pair switch together): the kernel with the
 // wave-uniform eight-short arm; without: the caller vouches that no entry is EightShort
@@ -132,6 +143,26 @@ __device__ __forceinline__ uint32_t dev_pack2_s16(float lo, float hi) {
     const s16x2_t p = __builtin_amdgcn_cvt_pk_i16(dev_float_sample_to_i16_presat(lo), dev_float_sample_to_i16_presat(hi));
     return __builtin_bit_cast(uint32_t, p);
 }
+
+// ---- shared by fir_bf16.hip and the fused decode-tail kernel (aac_synth.hip): the f16 form of the 48 -> 16 kHz FIR on s16 samples
+typedef uint32_t sk_u32x4 __attribute__((ext_vector_type(4)));
+typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
+// two s16 samples in one dword (the earlier one low) -> their two f16 planes: p1 = the sample rounded TOWARD ZERO to f16 (eleven
+// significand bits; no overflow at 32767), p2 = the rest (same sign, below 32: exact).  Three and a half vector instructions per sample.
+__device__ __forceinline__ void dev_split_pair16_f16(uint32_t u, uint32_t &p1, uint32_t &p2) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 f = {(float)(short)(u & 0xffffu), (float)((int)u >> 16)};
+    const auto a = __builtin_amdgcn_cvt_pkrtz(f.x, f.y);
+    const f32x2 r = f - (f32x2){(float)a[0], (float)a[1]};  // exact; one packed subtraction
+    p1 = __builtin_bit_cast(uint32_t, a);
+    p2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r.x, r.y));
+}
+__device__ __forceinline__ sk_f32x4 dev_mfma_f16(const sk_u32x4 &av, const sk_u32x4 &bv, const sk_f32x4 &c) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
+}
+// products kept per window of 32 samples, in the order x1h1 | x1h2, x2h1 (fir_bf16.hip explains the budget)
+__device__ constexpr int kFirProductsF16[10] = {1, 3, 3, 3, 3, 3, 3, 3, 1, 1};
 #endif
 
 struct FirArgs {

@@ -93,6 +93,14 @@ class Plan:
         check(lib.sk_aac_plan_run_s16_planar_dev(self.engine._h, self._h, _ptr(d_coeffs), _ptr(d_pcm16)),
               "sk_aac_plan_run_s16_planar_dev", self.engine._h)
 
+    def run_tail_s16(self, d_coeffs, stream_stride, channels, frames_per_stream, d_out, out_stride):
+        """sk_aac_plan_run_tail_s16_dev: run_s16_planar + the one-shot 48k->16k FIR to interleaved s16 as one launch (raises
+        SoundkitError -6 for plans the fused kernel does not cover)"""
+        got = C.c_uint32()
+        check(lib.sk_aac_plan_run_tail_s16_dev(self.engine._h, self._h, _ptr(d_coeffs), stream_stride, channels, frames_per_stream,
+                                               _ptr(d_out), out_stride, C.byref(got)), "sk_aac_plan_run_tail_s16_dev", self.engine._h)
+        return got.value
+
     def run_s16(self, d_coeffs, d_pcm):
         check(lib.sk_aac_plan_run_s16_dev(self.engine._h, self._h, _ptr(d_coeffs), _ptr(d_pcm)),
               "sk_aac_plan_run_s16_dev", self.engine._h)

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extras $*"
 # (pass --separate-s16 to profile the chain with the separate conversion kernel)
 # the stats pass runs the bench's own default step counts, so its per-kernel averages are those of the bench line
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline $* > "$OUT/bench_stats.json" 2> "$OUT/stats.err"

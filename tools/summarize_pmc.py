@@ -18,9 +18,11 @@ def find(root, pattern):
 def short(name):
     # the synthesis kernels are templates on the output type: <true, ...> writes s16, <false, ...> f32.  The s16 chain's bench
     # also times the f32 instance once (roofline.same_kernel_f32_out): keep the two apart
+    if "k_aac_tail" in name:
+        return "k_aac_tail"
     if "k_aac_synth" in name:
         return "k_aac_synth" if "<true" in name else "k_aac_synth_f32out"
-    for key in ("k_aac_synth", "k_fir_48k_16k", "k_f32_planar_stereo_to_s16le_batch", "k_pack_jobs", "k_sinc_resample"):
+    for key in ("k_aac_tail", "k_aac_synth", "k_fir_48k_16k", "k_f32_planar_stereo_to_s16le_batch", "k_pack_jobs", "k_sinc_resample"):
         if key in name:
             return key
     return name
