@@ -24,8 +24,9 @@ def test_f16_planes_of_s16_rows_stay_inside_the_bound():
     """the f16 form (two planes per operand, products x1h1 | x1h2, x2h1, 24 per tile): <= 2e-7 relative RMS against f64 at
     full scale and at small amplitudes alike (the remainder plane scales with the sample, not with full scale)"""
     import fir_split_model as model
-    src = open(os.path.join(HERE, "..", "soundkit_amd", "csrc", "fir_bf16.hip")).read()
-    table = re.search(r"kProductsF16\[kWindows\] = \{([0-9, ]+)\}", src).group(1)
+    # the table is shared by fir_bf16.hip and the fused decode-tail kernel: it lives in sk_device.h
+    src = open(os.path.join(HERE, "..", "soundkit_amd", "csrc", "sk_device.h")).read()
+    table = re.search(r"kFirProductsF16\[10\] = \{([0-9, ]+)\}", src).group(1)
     assert [int(v) for v in table.split(",")] == model.F16_SETS["f16, 24 (kProductsF16)"]
     r = model.errors_f16(n=12000)
     for (label, amp), (rms, _) in r.items():
