@@ -232,6 +232,10 @@ struct sk_engine {
     bool ec_ready = false;
     uint8_t *h_arena = nullptr;
     size_t h_arena_cap = 0;
+    uint8_t *h_out = nullptr;     // pinned bounce buffer for a tick whose caller passed a pageable output buffer
+    size_t h_out_cap = 0;
+    int32_t *h_status = nullptr;  // pinned: the front-end's per-unit statuses come back here (a pageable destination would make
+    size_t h_status_cap = 0;      // the "asynchronous" copy wait for the kernels inside the call, outside the tick's bounded wait)
     std::vector<uint32_t> state_count, state_task;  // plan construction scratch
     // streams opened (or reset) since the last launch: their device state is cleared by ONE launch in front of the next call
     // that touches the device (sk_stream_open used to cost a launch each: 4096 of them in front of a batch)
@@ -539,6 +543,8 @@ void sk_engine_destroy(sk_engine *e) {
         e->tick_side.release();
         e->tick_q.release();
         if (e->h_arena) (void)hipHostFree(e->h_arena);
+        if (e->h_status) (void)hipHostFree(e->h_status);
+        if (e->h_out) (void)hipHostFree(e->h_out);
         if (e->stream) (void)hipStreamDestroy(e->stream);
     }
     delete e;
@@ -2244,8 +2250,7 @@ int wait_stream(sk_engine *e, const char *what) {
             continue;
         }
         std::this_thread::sleep_for(std::chrono::microseconds(20));
-        if ((spins & 1023u) == 0 &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > e->sync_timeout_s) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > e->sync_timeout_s) {
             e->last_hip_error = std::string(what) + ": the device did not finish within the engine's wait bound";
             return SK_ERR_TIMEOUT;
         }
@@ -2334,6 +2339,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
 
     // ---- synthesis of the whole batch ----
     std::vector<int32_t> status(n_frames, 0);
+    bool status_pinned = false;  // the device front-ends' statuses arrive in e->h_status and are copied over after the wait
     HostPlan hp;
     int rc = build_plan_host(e, descs, n_frames, status.data(), hp, !au_mode);  // au mode: the windows are not known yet
     if (rc != SK_OK) return rc;
@@ -2444,8 +2450,17 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 ea.pns_start = (uint32_t *)((uint8_t *)e->tick_side.p + (((size_t)n_frames * sizeof(sk_ec::Scratch) + 15) & ~(size_t)15));
                 SK_HIP(sk::launch_aac_entropy_parallel(ea, e->stream), "launch entropy decode");
             }
-            SK_HIP(hipMemcpyAsync(status.data(), d_status, (size_t)n_frames * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream),
+            if (e->h_status_cap < n_frames) {
+                if (e->h_status) (void)hipHostFree(e->h_status);
+                e->h_status = nullptr;
+                e->h_status_cap = 0;
+                const size_t want = (size_t)n_frames + (size_t)n_frames / 2 + 1024;
+                SK_HIP(hipHostMalloc((void **)&e->h_status, want * sizeof(int32_t), hipHostMallocDefault), "alloc pinned status");
+                e->h_status_cap = want;
+            }
+            SK_HIP(hipMemcpyAsync(e->h_status, d_status, (size_t)n_frames * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream),
                    "D2H entropy status");
+            status_pinned = true;
         }
         if (probe) {  // the front-end alone: spectra, window fields and statuses back to the caller, nothing synthesised
             std::vector<sk::SynthEntry> got(hp.entries.size());
@@ -2453,6 +2468,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                    "D2H entropy window fields");
             SK_HIP(hipMemcpyAsync(probe->spectra, e->in_buf.p, elems * 4, hipMemcpyDeviceToHost, e->stream), "D2H entropy spectra");
             SK_HIP(hipStreamSynchronize(e->stream), "entropy sync");
+            if (status_pinned) std::memcpy(status.data(), e->h_status, (size_t)n_frames * sizeof(int32_t));
             for (uint32_t k = 0; k < n_frames; ++k) {
                 probe->status[k] = status[k];
                 probe->descs[k] = descs[k];
@@ -2491,6 +2507,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             t_au[0] = std::chrono::duration<double, std::milli>(q0 - t_mark).count();
             rc = wait_stream(e, "tick: waiting for the front-end kernels and the synthesis (mid-tick status read-back)");
             if (rc != SK_OK) return rc;
+            if (status_pinned) std::memcpy(status.data(), e->h_status, (size_t)n_frames * sizeof(int32_t));
             e->where.store("tick: resampler rounds, pack");
             t_au[1] = std::chrono::duration<double, std::milli>(TClock::now() - q0).count();
             for (uint32_t i = 0; i < n_streams; ++i) {
@@ -2681,15 +2698,33 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             d_out = (uint8_t *)e->tick_out.p;
         }
     }
+    uint8_t *bounce = nullptr;
     if (!packs.empty()) {
         const sk::PackJob *d_packs = nullptr;
         SK_HIP(aux.put(packs, e->stream, &d_packs), "upload pack jobs");
         SK_HIP(sk::launch_pack_jobs(d_packs, (uint32_t)packs.size(), max_pack_frames, e->stream), "launch pack");
-        SK_HIP(hipMemcpyAsync(out, d_out, cursor, hipMemcpyDeviceToHost, e->stream), "D2H tick output");
+        // Into pinned memory the copy is queued like a kernel and the bounded wait below is the tick's only wait.  A caller's
+        // pageable buffer would make hipMemcpyAsync itself wait for everything queued so far, unbounded: such a buffer (the
+        // scheduler's are pinned; a test's numpy array is not) gets the bytes through the engine's pinned bounce buffer.
+        hipPointerAttribute_t pa{};
+        const bool pinned = hipPointerGetAttributes(&pa, out) == hipSuccess && pa.type == hipMemoryTypeHost;
+        if (!pinned) (void)hipGetLastError();
+        if (!pinned) {
+            if (e->h_out_cap < cursor) {
+                if (e->h_out) (void)hipHostFree(e->h_out);
+                e->h_out = nullptr;
+                e->h_out_cap = 0;
+                SK_HIP(hipHostMalloc((void **)&e->h_out, cursor + cursor / 4 + 4096, hipHostMallocDefault), "alloc pinned output bounce");
+                e->h_out_cap = cursor + cursor / 4 + 4096;
+            }
+            bounce = e->h_out;
+        }
+        SK_HIP(hipMemcpyAsync(bounce ? bounce : out, d_out, cursor, hipMemcpyDeviceToHost, e->stream), "D2H tick output");
     }
     lap(3);
     rc = wait_stream(e, "tick: waiting for the device at the end of the tick");
     if (rc != SK_OK) return rc;
+    if (bounce) std::memcpy(out, bounce, cursor);
     lap(4);
     if (trace)
         std::fprintf(stderr, "sk_tick_run: %u streams %u frames | plan %.2f  h2d+synth %.2f  resample %.2f  pack %.2f  sync %.2f ms | au: queue %.2f wait %.2f\n",

@@ -180,3 +180,46 @@ def test_a_failed_launch_does_not_run_the_bookkeeping_ahead(engine):
     finally:
         engine.debug_fail_after(0)
         engine.close_stream(sid)
+
+
+def test_a_tick_that_outlasts_the_wait_bound_is_an_error_not_a_parked_thread(engine):
+    """sk_engine_set_wait_bound: with a bound of 100 ns a tick of 256 streams x 8 access units cannot finish in time -- the
+    call returns SK_ERR_TIMEOUT (-8) with the stage in the engine's error text instead of blocking, the engine reports idle,
+    and with the bound back at its default the engine works: fresh streams decode to what fresh streams decoded before."""
+    from soundkit_amd._lib import SoundkitError
+    rate, ch, frames = parsed("aac-stereo-48k.adts")
+    n_streams, per = 256, 8
+
+    def run(sids):
+        table = [{"stream": sid, "n_frames": per, "out_bits": 16, "out_channels": 1, "resample": True} for sid in sids]
+        descs, n = make_descs([(sid, ch, list(seqs), list(shapes)) for sid in sids for _, seqs, shapes in frames[:per]])
+        coeffs = np.concatenate([c.ravel() for _ in sids for c, _, _ in frames[:per]])
+        return engine.tick_run(table, descs, n, coeffs)
+
+    def fresh():
+        sids = [engine.open_stream(rate, ch) for _ in range(n_streams)]
+        for sid in sids:
+            engine.resampler_open(sid, rate, 16000)
+        return sids
+    first = fresh()
+    want = run(first)
+    assert len(want) == 2 * n_streams and all(r[1] == 0 for r in want)
+    for sid in first:
+        engine.close_stream(sid)
+    second = fresh()
+    engine.set_wait_bound(1e-7)
+    try:
+        with pytest.raises(SoundkitError) as exc:
+            run(second)
+        assert exc.value.status == -8 and "did not finish" in str(exc.value), str(exc.value)
+        assert engine.where() == "idle"
+    finally:
+        engine.set_wait_bound(120.0)
+    engine.synchronize()            # whatever that tick had queued is done now; its streams are in no defined state: drop them
+    for sid in second:
+        engine.close_stream(sid)
+    third = fresh()
+    got = run(third)
+    assert [(r[1], r[2], r[5]) for r in got] == [(r[1], r[2], r[5]) for r in want]
+    for sid in third:
+        engine.close_stream(sid)
