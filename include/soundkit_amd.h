@@ -228,6 +228,66 @@ int sk_mp3_hybrid_synthesize_s16(sk_engine *, const sk_mp3_granule_desc *descs, 
 int sk_mp3_hybrid_synthesize_f32_dev(sk_engine *, const sk_mp3_granule_desc *descs, const float *d_xr, float *d_pcm, uint32_t n,
                                      int32_t *status_per_granule);
 
+/* ---- MPEG Layer III: the fixed-syntax front of the bitstream half, and requantisation / stereo / reorder -------------
+ * What nanomp3::Decoder::decode (soundkit-mp3/src/lib.rs:284) does between the bytes and its Huffman stage, and between that
+ * stage and the hybrid synthesis above -- the parts that are closed-form syntax and arithmetic of ISO/IEC 11172-3 /
+ * 13818-3.  The Huffman stage itself needs Table B.7, the band tables B.8: data that exists nowhere in this tree or
+ * container; the band tables (and the pre-emphasis table) are caller-supplied like the synthesis window.  Parity of the MP3
+ * row stays unpinned; the reference's two MP3 fixtures pin the framing (tests/test_mp3_bitstream.py). */
+enum sk_mp3_status {
+    SK_MP3_NEED_MORE = -301,   /* not enough bytes for the header / side information / frame / reservoir */
+    SK_MP3_NO_SYNC = -302,     /* not a frame header */
+    SK_MP3_UNSUPPORTED = -303, /* Layer I / II, free format; LSF intensity stereo in sk_mp3_requantize */
+    SK_MP3_INVALID = -304      /* a field combination the syntax forbids */
+};
+typedef struct sk_mp3_frame_info { /* nanomp3::FrameInfo (lib.rs:188-215 reads sample_rate, channels, bitrate) + framing */
+    uint32_t offset;             /* sk_mp3_scan: position of the frame in the scanned buffer */
+    uint32_t frame_bytes;        /* header to the next header */
+    uint32_t sample_rate;
+    uint16_t bitrate_kbps, samples_per_channel; /* 1152 (MPEG-1) or 576 (MPEG-2 / 2.5) */
+    uint8_t version;             /* 1, 2 or 25 (= MPEG-2.5) */
+    uint8_t channels, mode, mode_ext, has_crc, padding, granules, side_info_bytes;
+} sk_mp3_frame_info;
+typedef struct sk_mp3_granule_side { /* 11172-3 2.4.1.7 / 13818-3 2.4.1.7, one granule of one channel */
+    uint16_t part2_3_length, big_values, scalefac_compress;
+    uint8_t global_gain, window_switching, block_type, mixed_block_flag, table_select[3], subblock_gain[3], region0_count,
+        region1_count, preflag, scalefac_scale, count1table_select, reserved;
+} sk_mp3_granule_side;
+typedef struct sk_mp3_side_info {
+    uint16_t main_data_begin;
+    uint8_t granules, channels;
+    uint8_t scfsi[2][4];
+    sk_mp3_granule_side gr[2][2]; /* [granule][channel] */
+} sk_mp3_side_info;
+int sk_mp3_parse_header(const uint8_t *data, size_t len, sk_mp3_frame_info *out);
+int sk_mp3_parse_side_info(const uint8_t *frame, size_t len, const sk_mp3_frame_info *header, sk_mp3_side_info *out);
+/* every frame of a byte stream (an ID3v2 tag in front is stepped over, garbage skipped, a header counts only if the next
+ * frame's header follows it); *consumed = bytes up to the first incomplete frame */
+int sk_mp3_scan(const uint8_t *data, size_t len, sk_mp3_frame_info *frames, uint32_t cap, uint32_t *n_frames, size_t *consumed);
+/* the bytes parts 2 + 3 of a frame are read from: main_data_begin bytes of the reservoir + the frame's own main data */
+int sk_mp3_main_data(const uint8_t *frame, size_t frame_len, const sk_mp3_frame_info *header, const sk_mp3_side_info *side,
+                     const uint8_t *prev_main_data, size_t prev_len, uint8_t *out, size_t out_cap, size_t *out_len);
+
+/* Requantisation (2.4.3.4.7.1), mid/side and MPEG-1 intensity stereo (2.4.3.4.9-10) and the short-block reorder
+ * (2.4.3.4.8) for a batch of granules on the GPU: is = the Huffman stage's integers, [granule][channel][576] in bitstream
+ * order; xr = what sk_mp3_hybrid_synthesize_* takes.  Band tables (Table B.8: 23 long and 14 short offsets per sampling
+ * rate) and the pre-emphasis table (22 entries) come from the caller, once per engine and sampling rate. */
+typedef struct sk_mp3_requant_channel {
+    uint8_t global_gain, scalefac_scale, preflag, block_type, mixed_block_flag, subblock_gain[3];
+    uint8_t scalefac_l[22];    /* long bands (also the long part of a mixed block) */
+    uint8_t scalefac_s[13][3]; /* short bands x windows */
+    uint8_t reserved;
+} sk_mp3_requant_channel;
+typedef struct sk_mp3_requant_granule {
+    uint32_t sample_rate;
+    uint8_t channels, ms_stereo, intensity_stereo, lsf; /* mode_ext bits of a joint-stereo frame; lsf: MPEG-2 / 2.5 */
+    sk_mp3_requant_channel ch[2];
+} sk_mp3_requant_granule;
+int sk_mp3_set_band_tables(sk_engine *, uint32_t sample_rate, const uint16_t long_offsets[23], const uint16_t short_offsets[14],
+                           const uint8_t pretab[22]);
+int sk_mp3_requantize(sk_engine *, const sk_mp3_requant_granule *granules, const int16_t *is, float *xr, uint32_t n,
+                      int32_t *status_per_granule);
+
 /* ---- sample-width / interleave conversion: soundkit::audio_bytes -------- */
 /* Elementwise ops; n = number of OUTPUT samples.  Citations: soundkit/src/audio_bytes.rs
  * unless noted. */

@@ -18,6 +18,7 @@ ERR_NAMES = {0: "SK_OK", -1: "SK_ERR_INVALID_ARG", -2: "SK_ERR_NO_DEVICE", -3: "
              -101: "UnexpectedEof", -102: "InvalidAudioObjectType", -103: "UnsupportedAudioObjectType",
              -104: "UnsupportedSamplingFrequencyIndex", -105: "UnsupportedChannelConfig", -106: "UnsupportedFeature",
              -107: "InvalidConfig", -108: "InvalidBitstream",
+             -301: "Mp3NeedMore", -302: "Mp3NoSync", -303: "Mp3Unsupported", -304: "Mp3Invalid",
              -201: "InputBufferFull", -202: "PipelineClosed", -203: "InputChunkTooLarge"}
 
 
@@ -31,6 +32,40 @@ class Mp3GranuleDesc(C.Structure):
     """sk_mp3_granule_desc"""
     _fields_ = [("stream", C.c_uint32), ("channels", C.c_uint8), ("block_type", C.c_uint8 * 2), ("mixed_block_flag", C.c_uint8 * 2),
                 ("reserved", C.c_uint8 * 3)]
+
+
+class Mp3FrameInfo(C.Structure):
+    """sk_mp3_frame_info"""
+    _fields_ = [("offset", C.c_uint32), ("frame_bytes", C.c_uint32), ("sample_rate", C.c_uint32), ("bitrate_kbps", C.c_uint16),
+                ("samples_per_channel", C.c_uint16)] + [(n, C.c_uint8) for n in ("version", "channels", "mode", "mode_ext", "has_crc",
+                                                                                  "padding", "granules", "side_info_bytes")]
+
+
+class Mp3GranuleSide(C.Structure):
+    """sk_mp3_granule_side"""
+    _fields_ = [("part2_3_length", C.c_uint16), ("big_values", C.c_uint16), ("scalefac_compress", C.c_uint16), ("global_gain", C.c_uint8),
+                ("window_switching", C.c_uint8), ("block_type", C.c_uint8), ("mixed_block_flag", C.c_uint8), ("table_select", C.c_uint8 * 3),
+                ("subblock_gain", C.c_uint8 * 3), ("region0_count", C.c_uint8), ("region1_count", C.c_uint8), ("preflag", C.c_uint8),
+                ("scalefac_scale", C.c_uint8), ("count1table_select", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class Mp3SideInfo(C.Structure):
+    """sk_mp3_side_info"""
+    _fields_ = [("main_data_begin", C.c_uint16), ("granules", C.c_uint8), ("channels", C.c_uint8), ("scfsi", (C.c_uint8 * 4) * 2),
+                ("gr", (Mp3GranuleSide * 2) * 2)]
+
+
+class Mp3RequantChannel(C.Structure):
+    """sk_mp3_requant_channel"""
+    _fields_ = [("global_gain", C.c_uint8), ("scalefac_scale", C.c_uint8), ("preflag", C.c_uint8), ("block_type", C.c_uint8),
+                ("mixed_block_flag", C.c_uint8), ("subblock_gain", C.c_uint8 * 3), ("scalefac_l", C.c_uint8 * 22),
+                ("scalefac_s", (C.c_uint8 * 3) * 13), ("reserved", C.c_uint8)]
+
+
+class Mp3RequantGranule(C.Structure):
+    """sk_mp3_requant_granule"""
+    _fields_ = [("sample_rate", C.c_uint32), ("channels", C.c_uint8), ("ms_stereo", C.c_uint8), ("intensity_stereo", C.c_uint8),
+                ("lsf", C.c_uint8), ("ch", Mp3RequantChannel * 2)]
 
 
 class TickStream(C.Structure):
@@ -198,6 +233,12 @@ _sig = {
     "sk_mp3_hybrid_synthesize_f32": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "sk_mp3_hybrid_synthesize_s16": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "sk_mp3_hybrid_synthesize_f32_dev": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    "sk_mp3_parse_header": (_i, [_vp, _sz, _vp]),
+    "sk_mp3_parse_side_info": (_i, [_vp, _sz, _vp, _vp]),
+    "sk_mp3_scan": (_i, [_vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
+    "sk_mp3_main_data": (_i, [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "sk_mp3_set_band_tables": (_i, [_vp, _u32, _vp, _vp, _vp]),
+    "sk_mp3_requantize": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "sk_aac_entropy_decode": (_i, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _sz, _vp, _vp, _vp]),
     "sk_aac_plan_run_tail_s16_dev": (_i, [_vp, _vp, _vp, _sz, _u32, _u32, _vp, _sz, C.POINTER(_u32)]),
     "sk_aac_expand_q_decode": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),

@@ -211,6 +211,10 @@ struct sk_engine {
     // MP3 hybrid synthesis (mp3_hybrid.hip): tables and per-(stream, channel) state, allocated on first use
     float *d_mp3_tables = nullptr, *d_mp3_state = nullptr;
     bool mp3_window_set = false;
+    // mp3_requant.hip: pow43 | root4 | is_k as floats, then the caller's band tables per sampling-rate slot
+    uint8_t *d_mp3_rq = nullptr;
+    uint16_t mp3_bands[sk::kMp3Rates][sk::kMp3BandRow] = {};  // [37] = long bands below line 36 (mixed blocks), 0xffff: none
+    bool mp3_bands_set[sk::kMp3Rates] = {};
 
     // tables
     float *d_tables = nullptr;
@@ -473,6 +477,10 @@ const char *sk_strerror(int status) {
     case SK_AAC_ERR_UNSUPPORTED_SF_INDEX: return "unsupported AAC sampling frequency index";
     case SK_AAC_ERR_UNSUPPORTED_CHANNEL_CONFIG: return "unsupported AAC channel configuration";
     case SK_ERR_TIMEOUT: return "the device did not finish in time";
+    case SK_MP3_NEED_MORE: return "more MP3 input needed";
+    case SK_MP3_NO_SYNC: return "not an MPEG audio frame header";
+    case SK_MP3_UNSUPPORTED: return "unsupported MPEG audio layer or feature";
+    case SK_MP3_INVALID: return "invalid MP3 side information";
     case SK_AAC_ERR_UNSUPPORTED_FEATURE: return "unsupported AAC feature";
     case SK_AAC_ERR_INVALID_CONFIG: return "invalid AAC config";
     case SK_AAC_ERR_INVALID_BITSTREAM: return "invalid AAC bitstream";
@@ -525,7 +533,7 @@ void sk_engine_destroy(sk_engine *e) {
         DeviceGuard guard(e);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         if (e->d_reset_ids) (void)hipFree(e->d_reset_ids);
-        for (void *p : {(void *)e->d_mp3_tables, (void *)e->d_mp3_state, (void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
+        for (void *p : {(void *)e->d_mp3_rq, (void *)e->d_mp3_tables, (void *)e->d_mp3_state, (void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
                         (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag16, (void *)e->d_afrag_f16,
                         (void *)e->d_zeros})
             if (p) (void)hipFree(p);
@@ -1715,6 +1723,137 @@ int sk_mp3_hybrid_synthesize_s16(sk_engine *e, const sk_mp3_granule_desc *descs,
 int sk_mp3_hybrid_synthesize_f32_dev(sk_engine *e, const sk_mp3_granule_desc *descs, const float *d_xr, float *d_pcm, uint32_t n,
                                      int32_t *status) {
     return mp3_synthesize(e, descs, d_xr, d_pcm, n, status, false, true);
+}
+
+// ---- Layer III requantisation / stereo / reorder (mp3_requant.hip) -----------------------------------------------------------
+namespace {
+
+constexpr size_t kRqFloats = sk::kMp3Pow43 + 4 + 8;
+constexpr size_t kRqBandsAt = kRqFloats * sizeof(float), kRqPretabAt = kRqBandsAt + sk::kMp3Rates * sk::kMp3BandRow * sizeof(uint16_t),
+                 kRqBytes = kRqPretabAt + sk::kMp3Rates * 24;
+
+int mp3_rate_slot(uint32_t hz) {
+    static const uint32_t rates[sk::kMp3Rates] = {44100, 48000, 32000, 22050, 24000, 16000, 11025, 12000, 8000};
+    for (uint32_t i = 0; i < sk::kMp3Rates; ++i)
+        if (rates[i] == hz) return (int)i;
+    return -1;
+}
+
+int ensure_mp3_requant(sk_engine *e) {
+    if (e->d_mp3_rq) return SK_OK;
+    const double pi = 3.14159265358979323846;
+    std::vector<uint8_t> blob(kRqBytes, 0);
+    float *f = (float *)blob.data();
+    for (uint32_t v = 0; v < sk::kMp3Pow43; ++v) f[v] = (float)std::pow((double)v, 4.0 / 3.0);
+    for (int i = 0; i < 4; ++i) f[sk::kMp3Pow43 + i] = (float)std::pow(2.0, i / 4.0);
+    for (int i = 0; i < 7; ++i) {
+        const double t = i == 6 ? 0.0 : std::tan(i * pi / 12);
+        f[sk::kMp3Pow43 + 4 + i] = i == 6 ? 1.0f : (float)(t / (1.0 + t));  // is_pos 6: tan = infinity, all of it goes left
+    }
+    SK_HIP(hipMalloc((void **)&e->d_mp3_rq, kRqBytes), "alloc mp3 requantisation tables");
+    SK_HIP(hipMemcpy(e->d_mp3_rq, blob.data(), kRqBytes, hipMemcpyHostToDevice), "upload mp3 requantisation tables");
+    return SK_OK;
+}
+
+}  // namespace
+
+int sk_mp3_set_band_tables(sk_engine *e, uint32_t sample_rate, const uint16_t *long_offsets, const uint16_t *short_offsets,
+                           const uint8_t *pretab) {
+    if (!e || !long_offsets || !short_offsets || !pretab) return SK_ERR_INVALID_ARG;
+    const int slot = mp3_rate_slot(sample_rate);
+    if (slot < 0) return SK_ERR_UNSUPPORTED;
+    // a partition of the 576 lines (long) / of the 192 lines of one window (short): the kernel's searches rely on it
+    if (long_offsets[0] != 0 || long_offsets[22] != 576 || short_offsets[0] != 0 || short_offsets[13] != 192) return SK_ERR_INVALID_ARG;
+    for (int i = 0; i < 22; ++i)
+        if (long_offsets[i] >= long_offsets[i + 1]) return SK_ERR_INVALID_ARG;
+    for (int i = 0; i < 13; ++i)
+        if (short_offsets[i] >= short_offsets[i + 1]) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e);
+    const int rc = ensure_mp3_requant(e);
+    if (rc != SK_OK) return rc;
+    uint16_t *row = e->mp3_bands[slot];
+    std::memset(row, 0, sizeof e->mp3_bands[slot]);
+    std::memcpy(row, long_offsets, 23 * sizeof(uint16_t));
+    std::memcpy(row + 23, short_offsets, 14 * sizeof(uint16_t));
+    // a mixed block is long below line 36 and short from there on: possible only if both tables have a boundary there
+    row[37] = 0xffff;
+    bool short_at_36 = false;
+    for (int i = 0; i < 14; ++i) short_at_36 |= 3 * short_offsets[i] == 36;
+    for (int i = 0; i < 23; ++i)
+        if (long_offsets[i] == 36 && short_at_36) row[37] = (uint16_t)i;
+    uint8_t pre[24] = {};
+    std::memcpy(pre, pretab, 22);
+    SK_HIP(hipMemcpy(e->d_mp3_rq + kRqBandsAt + (size_t)slot * sk::kMp3BandRow * sizeof(uint16_t), row, sk::kMp3BandRow * sizeof(uint16_t),
+                     hipMemcpyHostToDevice),
+           "upload mp3 band table");
+    SK_HIP(hipMemcpy(e->d_mp3_rq + kRqPretabAt + (size_t)slot * 24, pre, 24, hipMemcpyHostToDevice), "upload mp3 pre-emphasis table");
+    e->mp3_bands_set[slot] = true;
+    return SK_OK;
+}
+
+int sk_mp3_requantize(sk_engine *e, const sk_mp3_requant_granule *granules, const int16_t *is, float *xr, uint32_t n, int32_t *status) {
+    if (!e || (n && (!granules || !is || !xr))) return SK_ERR_INVALID_ARG;
+    if (n == 0) return SK_OK;
+    for (uint32_t i = 0; i < n; ++i)
+        if (granules[i].channels < 1 || granules[i].channels > 2) return SK_ERR_INVALID_ARG;  // the layout of is / xr depends on it
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e);
+    int rc = ensure_mp3_requant(e);
+    if (rc != SK_OK) return rc;
+    std::vector<sk::Mp3RequantRecord> records(n);
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const sk_mp3_requant_granule &g = granules[i];
+        sk::Mp3RequantRecord &r = records[i];
+        std::memset(&r, 0, sizeof r);
+        r.off = (uint32_t)off;
+        r.channels = g.channels;
+        off += g.channels;
+        const int slot = mp3_rate_slot(g.sample_rate);
+        const bool joint = g.channels == 2 && (g.ms_stereo || g.intensity_stereo);
+        int32_t st = SK_OK;
+        if (slot < 0 || !e->mp3_bands_set[slot]) st = SK_MP3_UNSUPPORTED;  // no band table for this rate: sk_mp3_set_band_tables first
+        for (uint32_t c = 0; c < g.channels && st == SK_OK; ++c) {
+            const sk_mp3_requant_channel &ch = g.ch[c];
+            if (ch.block_type > 3 || ch.mixed_block_flag > 1 || ch.scalefac_scale > 1 || ch.preflag > 1 || (ch.mixed_block_flag && ch.block_type != 2))
+                st = SK_MP3_INVALID;
+            else if (ch.mixed_block_flag && e->mp3_bands[slot][37] == 0xffff) st = SK_MP3_UNSUPPORTED;
+        }
+        if (st == SK_OK && joint) {
+            // the stereo step pairs line i of one channel with line i of the other: both must be cut up the same way
+            if ((g.ch[0].block_type == 2) != (g.ch[1].block_type == 2) || g.ch[0].mixed_block_flag != g.ch[1].mixed_block_flag) st = SK_MP3_INVALID;
+            // 13818-3 intensity positions (two scale-factor-dependent ratios) and intensity in mixed blocks are not built
+            else if (g.intensity_stereo && (g.lsf || g.ch[0].mixed_block_flag)) st = SK_MP3_UNSUPPORTED;
+        }
+        if (status) status[i] = st;
+        r.slot = st == SK_OK ? (uint8_t)slot : 0xff;
+        r.flags = joint ? (uint8_t)((g.ms_stereo ? 1 : 0) | (g.intensity_stereo ? 2 : 0)) : 0;
+        r.ch[0] = g.ch[0];
+        if (g.channels == 2) r.ch[1] = g.ch[1];
+    }
+    if (off * 576 > 0xffffffffull) return SK_ERR_INVALID_ARG;
+    const size_t lines = (size_t)off * 576, rec_bytes = (size_t)n * sizeof(sk::Mp3RequantRecord);
+    const size_t is_at = (rec_bytes + 255) & ~(size_t)255;
+    SK_HIP(e->in_buf.reserve(is_at + lines * sizeof(int16_t) + 16), "alloc mp3 requantisation input");
+    SK_HIP(e->out_buf.reserve(lines * sizeof(float) + 16), "alloc mp3 requantisation output");
+    uint8_t *d_in = (uint8_t *)e->in_buf.p;
+    SK_HIP(hipMemcpyAsync(d_in, records.data(), rec_bytes, hipMemcpyHostToDevice, e->stream), "H2D mp3 granule records");
+    SK_HIP(hipMemcpyAsync(d_in + is_at, is, lines * sizeof(int16_t), hipMemcpyHostToDevice, e->stream), "H2D mp3 quantised lines");
+    sk::Mp3RequantArgs a{};
+    a.records = (const sk::Mp3RequantRecord *)d_in;
+    a.is = (const int16_t *)(d_in + is_at);
+    a.xr = (float *)e->out_buf.p;
+    a.n = n;
+    a.pow43 = (const float *)e->d_mp3_rq;
+    a.root4 = a.pow43 + sk::kMp3Pow43;
+    a.is_k = a.root4 + 4;
+    a.bands = (const uint16_t *)(e->d_mp3_rq + kRqBandsAt);
+    a.pretab = e->d_mp3_rq + kRqPretabAt;
+    SK_HIP(sk::launch_mp3_requant(a, e->stream), "launch mp3 requantisation");
+    SK_HIP(hipMemcpyAsync(xr, e->out_buf.p, lines * sizeof(float), hipMemcpyDeviceToHost, e->stream), "D2H mp3 lines");
+    SK_HIP(hipStreamSynchronize(e->stream), "mp3 requantisation sync");
+    return SK_OK;
 }
 
 int sk_resampler_open(sk_engine *e, uint32_t id, uint32_t in_hz, uint32_t out_hz) {

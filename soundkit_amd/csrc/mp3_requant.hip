@@ -1,0 +1,181 @@
+// mp3_requant.hip -- Layer III requantisation, joint-stereo processing and the short-block reorder for gfx950, batched
+// over granules: what sits between the Huffman stage of nanomp3::Decoder::decode (soundkit-mp3/src/lib.rs:284; the
+// crate's source is not in the reference tree) and the hybrid synthesis of mp3_hybrid.hip.  ISO/IEC 11172-3 in closed form:
+//   2.4.3.4.7.1  xr = sign(is) |is|^(4/3) 2^(q / 4),
+//                q = global_gain - 210 - 8 subblock_gain[w] - (scalefac_scale ? 4 : 2) (scalefac + preflag pretab)
+//   2.4.3.4.9    mid/side: L = (M + S) / sqrt 2, R = (M - S) / sqrt 2
+//   2.4.3.4.9.3  MPEG-1 intensity: in the bands above the last one where the right channel holds anything (per window for
+//                short blocks) the right channel's scale factor is a position is_pos; L = xr k, R = xr (1 - k),
+//                k = t / (1 + t), t = tan(is_pos pi / 12); is_pos 7 = "not intensity coded"
+//   2.4.3.4.8    short blocks: band-by-band [window][line] -> [line][window]
+// The scale-factor band offsets (Table B.8) and the pre-emphasis table are caller-supplied (sk_mp3_set_band_tables): this
+// tree does not hold them.  oracle/mp3_requant.py is the f64 checker; parity of the MP3 row is unpinned.
+//
+// One wavefront per granule, four per block.  A lane takes the lines lane + 64 k (k < 9) of both channels in bitstream
+// order: band and window by a 5-step search in the LDS copy of the band table, requantised into registers; the highest
+// occupied band of the right channel is a wave maximum; the stereo step works on the lane's own pair of values; the
+// reorder goes through LDS so that the 576 lines of a channel leave as coalesced rows.  Traffic per granule-channel:
+// 1152 B in, 2304 B out; the kernel is HBM-bound like everything else on this path.
+#include "sk_device.h"
+
+namespace sk {
+
+namespace {
+
+constexpr int kWaves = 4;
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int d = 32; d; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+
+struct Line {  // where a bitstream-order line sits
+    int band;  // long band 0..21 or short band 0..12
+    int win;   // -1: long
+    int dest;  // its position after the reorder
+};
+
+__device__ __forceinline__ Line locate(int i, bool short_lines, const uint16_t *tab) {
+    Line r;
+    if (!short_lines) {
+        int l = 0;
+#pragma unroll
+        for (int step = 16; step; step >>= 1)
+            if (l + step <= 21 && tab[l + step] <= i) l += step;
+        r.band = l;
+        r.win = -1;
+        r.dest = i;
+    } else {
+        const uint16_t *st = tab + 23;
+        int s = 0;
+#pragma unroll
+        for (int step = 8; step; step >>= 1)
+            if (s + step <= 12 && 3 * st[s + step] <= i) s += step;
+        const int begin = st[s], width = st[s + 1] - begin, rel = i - 3 * begin;
+        const int w = rel >= 2 * width ? 2 : (rel >= width ? 1 : 0);
+        r.band = s;
+        r.win = w;
+        r.dest = 3 * (begin + rel - w * width) + w;
+    }
+    return r;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[kWaves][2][576];
+    __shared__ uint32_t rec[kWaves][sizeof(Mp3RequantRecord) / 4];
+    __shared__ uint16_t tabs[kWaves][kMp3BandRow];
+    __shared__ uint8_t pre[kWaves][24];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gi = blockIdx.x * kWaves + wave;
+    if (gi >= a.n) return;
+    {
+        const uint32_t *src = (const uint32_t *)(a.records + gi);
+        if (lane < (int)(sizeof(Mp3RequantRecord) / 4)) rec[wave][lane] = src[lane];
+    }
+    wave_sync();
+    const Mp3RequantRecord &g = *(const Mp3RequantRecord *)rec[wave];
+    const int channels = g.channels;
+    float *out = a.xr + (size_t)g.off * 576;
+    if (g.slot >= kMp3Rates) {  // rejected on the host: silence, so that the synthesis after it stays defined
+        for (int c = 0; c < channels; ++c)
+            for (int k = 0; k < 9; ++k) out[c * 576 + lane + 64 * k] = 0.0f;
+        return;
+    }
+    if (lane < kMp3BandRow) tabs[wave][lane] = a.bands[g.slot * kMp3BandRow + lane];
+    if (lane < 24) pre[wave][lane] = a.pretab[g.slot * 24 + lane];
+    wave_sync();
+    const uint16_t *tab = tabs[wave];
+    const int16_t *is = a.is + (size_t)g.off * 576;
+
+    const bool is_short = g.ch[0].block_type == 2;  // both channels agree whenever the stereo step looks at it (host check)
+    float v[2][9];
+    Line where[2][9];
+    int top[3] = {-1, -1, -1};  // highest band of the right channel holding a non-zero line: long -> [0], short -> per window
+    for (int c = 0; c < channels; ++c) {
+        const sk_mp3_requant_channel &ch = g.ch[c];
+        const bool sh = ch.block_type == 2;
+        const int mult = ch.scalefac_scale ? 4 : 2;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int i = lane + 64 * k;
+            const Line at = locate(i, sh && !(ch.mixed_block_flag && i < 36), tab);
+            where[c][k] = at;
+            const int q_in = is[c * 576 + i];
+            int q = (int)ch.global_gain - 210;
+            if (at.win < 0) q -= mult * ((int)ch.scalefac_l[at.band] + (ch.preflag ? (int)pre[wave][at.band] : 0));
+            else q -= 8 * (int)ch.subblock_gain[at.win] + mult * (int)ch.scalefac_s[at.band][at.win];
+            const int mag = min(abs(q_in), (int)kMp3Pow43 - 1);
+            const float m = a.pow43[mag] * a.root4[q & 3];  // 2^(q / 4) = 2^floor(q / 4) * 2^((q mod 4) / 4): one rounding here,
+            const float x = ldexpf(m, q >> 2);              // the power of two is exact
+            v[c][k] = q_in < 0 ? -x : x;
+            if (c == 1 && q_in != 0) {
+                if (at.win < 0) top[0] = max(top[0], at.band);
+                else top[at.win] = max(top[at.win], at.band);
+            }
+        }
+    }
+
+    if (channels == 2 && (g.flags & 3)) {
+        const bool ms = g.flags & 1, intensity = g.flags & 2;
+        if (intensity) {
+            top[0] = wave_max(top[0]);
+            if (is_short) {
+                top[1] = wave_max(top[1]);
+                top[2] = wave_max(top[2]);
+            }
+        }
+        const sk_mp3_requant_channel &right = g.ch[1];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const Line at = where[0][k];
+            bool done = false;
+            if (intensity) {
+                const int bound = at.win < 0 ? top[0] : top[at.win];
+                if (at.band > bound) {
+                    // the last band has no scale factor of its own: it takes the position of the one below
+                    const int pos = at.win < 0 ? right.scalefac_l[min(at.band, 20)] : right.scalefac_s[min(at.band, 11)][at.win];
+                    if (pos < 7) {
+                        const float kl = a.is_k[pos];
+                        const float x = v[0][k];
+                        v[0][k] = x * kl;
+                        v[1][k] = x * (1.0f - kl);
+                        done = true;
+                    }
+                }
+            }
+            if (!done && ms) {
+                const float m = v[0][k], s = v[1][k];
+                v[0][k] = (m + s) * 0.70710678118654752440f;
+                v[1][k] = (m - s) * 0.70710678118654752440f;
+            }
+        }
+    }
+
+    for (int c = 0; c < channels; ++c) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) xs[wave][c][where[c][k].dest] = v[c][k];
+    }
+    wave_sync();
+    for (int c = 0; c < channels; ++c) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out[c * 576 + lane + 64 * k] = xs[wave][c][lane + 64 * k];
+    }
+}
+
+hipError_t launch_mp3_requant(const Mp3RequantArgs &a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    k_mp3_requant<<<(a.n + kWaves - 1) / kWaves, kWaves * 64, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace sk

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/soundkit_amd.h"  // sk_mp3_requant_channel
+
 namespace sk {
 
 // One schedule entry = one channel-frame.  off1024: index (in units of 1024 f32) of this
@@ -245,6 +247,29 @@ struct Mp3Args {
     const float *cs_ca;    // [16]: alias-reduction cs[8] | ca[8]
 };
 hipError_t launch_mp3_hybrid(const Mp3Args &a, hipStream_t s);
+
+// mp3_requant.hip -- Layer III requantisation + joint stereo + short-block reorder, one wave per granule
+constexpr uint32_t kMp3Rates = 9;      // 44.1 / 48 / 32 / 22.05 / 24 / 16 / 11.025 / 12 / 8 kHz: one band-table slot each
+constexpr uint32_t kMp3BandRow = 40;   // u16 per slot: 23 long offsets | 14 short offsets | padding
+constexpr uint32_t kMp3Pow43 = 8208;   // |is| <= 15 + 2^13 - 1 (the widest linbits escape)
+struct Mp3RequantRecord {              // what the host makes of one sk_mp3_requant_granule
+    uint32_t off;                      // index of the granule's first channel, in 576-line rows of is / xr
+    uint8_t slot, channels, flags, reserved;  // slot >= kMp3Rates: rejected, the kernel writes silence; flags = ms | intensity << 1
+    sk_mp3_requant_channel ch[2];
+};
+static_assert(sizeof(Mp3RequantRecord) % 4 == 0 && sizeof(Mp3RequantRecord) <= 256, "one word per lane");
+struct Mp3RequantArgs {
+    const Mp3RequantRecord *records;
+    const int16_t *is;
+    float *xr;
+    uint32_t n;
+    const float *pow43;     // [kMp3Pow43]
+    const float *root4;     // 2^(0/4) .. 2^(3/4)
+    const float *is_k;      // [8]: t / (1 + t), t = tan(i pi / 12), i < 7
+    const uint16_t *bands;  // [kMp3Rates][kMp3BandRow]
+    const uint8_t *pretab;  // [kMp3Rates][24]
+};
+hipError_t launch_mp3_requant(const Mp3RequantArgs &a, hipStream_t s);
 
 // aac_entropy.hip -- the AAC-LC front-end on the device, one stream per lane
 }  // namespace sk

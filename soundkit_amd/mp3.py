@@ -1,12 +1,14 @@
-"""Host-side mirror of the transform half of soundkit-mp3's decoder (soundkit-mp3/src/lib.rs:147-374): the Layer III
-hybrid synthesis filterbank that `nanomp3::Decoder::decode` ends with, batched on the GPU (csrc/mp3_hybrid.hip), and the
-reference's `f32_to_i16` tail.  The bitstream side and the standard's synthesis window D are not part of this tree
-(include/soundkit_amd.h); the window is supplied by the caller."""
+"""Host-side mirror of soundkit-mp3's decoder (soundkit-mp3/src/lib.rs:147-374) as far as this tree builds it: frame sync,
+header, side information and the bit reservoir (csrc/mp3_bitstream.cpp, host); requantisation, joint stereo and the
+short-block reorder (csrc/mp3_requant.hip) and the hybrid synthesis filterbank (csrc/mp3_hybrid.hip) on the GPU; the
+reference's `f32_to_i16` tail.  Between the two halves sits the Huffman stage of `nanomp3::Decoder::decode`, which needs
+ISO/IEC 11172-3 Table B.7 -- data this tree does not hold (include/soundkit_amd.h).  The synthesis window D and the
+scale-factor band tables are supplied by the caller."""
 import ctypes as C
 
 import numpy as np
 
-from ._lib import Mp3GranuleDesc, check, lib
+from ._lib import (Mp3FrameInfo, Mp3GranuleDesc, Mp3RequantGranule, Mp3SideInfo, check, lib)
 from .engine import _ptr, default_engine
 
 
@@ -41,3 +43,92 @@ def hybrid_synthesize(granules, xr, engine=None, s16=False):
     fn = lib.sk_mp3_hybrid_synthesize_s16 if s16 else lib.sk_mp3_hybrid_synthesize_f32
     check(fn(engine._h, descs, _ptr(xr), _ptr(out), n, _ptr(status)), "sk_mp3_hybrid_synthesize", engine._h)
     return out, status[:n]
+
+
+# ---- the fixed-syntax front (host) ----------------------------------------------------------------------------------------
+
+def _as_dict(struct):
+    out = {}
+    for name, _ in struct._fields_:
+        v = getattr(struct, name)
+        out[name] = v if isinstance(v, int) else np.ctypeslib.as_array(v).tolist()
+    return out
+
+
+def _bytes(data):
+    return np.frombuffer(bytes(data), np.uint8) if len(data) else np.zeros(1, np.uint8)
+
+
+def parse_header(data):
+    """4 bytes -> (status, Mp3FrameInfo)"""
+    info = Mp3FrameInfo()
+    b = _bytes(data)
+    return lib.sk_mp3_parse_header(_ptr(b), len(data), C.byref(info)), info
+
+
+def parse_side_info(frame, info):
+    side = Mp3SideInfo()
+    b = _bytes(frame)
+    return lib.sk_mp3_parse_side_info(_ptr(b), len(frame), C.byref(info), C.byref(side)), side
+
+
+def scan(data, cap=1 << 16):
+    """every frame of a byte string -> ([Mp3FrameInfo], bytes consumed)"""
+    frames = (Mp3FrameInfo * cap)()
+    n, used = C.c_uint32(0), C.c_size_t(0)
+    b = _bytes(data)
+    check(lib.sk_mp3_scan(_ptr(b), len(data), frames, cap, C.byref(n), C.byref(used)), "sk_mp3_scan")
+    return [frames[i] for i in range(min(n.value, cap))], used.value
+
+
+def main_data(frame, info, side, reservoir):
+    """(status, the bytes parts 2 + 3 of this frame are read from)"""
+    out = np.zeros(len(reservoir) + len(frame) + 16, np.uint8)
+    n = C.c_size_t(0)
+    f, r = _bytes(frame), _bytes(reservoir)
+    rc = lib.sk_mp3_main_data(_ptr(f), len(frame), C.byref(info), C.byref(side), _ptr(r), len(reservoir), _ptr(out), out.size, C.byref(n))
+    return rc, out[:n.value].tobytes()
+
+
+# ---- requantisation / joint stereo / reorder (GPU) -------------------------------------------------------------------------
+
+def set_band_tables(sample_rate, long_offsets, short_offsets, pretab, engine=None):
+    """ISO/IEC 11172-3 Table B.8 (23 long, 14 short offsets) and the pre-emphasis table (22), once per engine and rate"""
+    engine = engine or default_engine()
+    lo, so, pt = (np.ascontiguousarray(long_offsets, np.uint16), np.ascontiguousarray(short_offsets, np.uint16),
+                  np.ascontiguousarray(pretab, np.uint8))
+    assert lo.shape == (23,) and so.shape == (14,) and pt.shape == (22,)
+    return lib.sk_mp3_set_band_tables(engine._h, sample_rate, _ptr(lo), _ptr(so), _ptr(pt))
+
+
+def make_requant_granules(granules):
+    """granules: dicts as oracle/mp3_bitstream.py requantize_granule takes them, plus sample_rate and lsf"""
+    arr = (Mp3RequantGranule * max(len(granules), 1))()
+    for i, g in enumerate(granules):
+        a = arr[i]
+        a.sample_rate, a.channels = g["sample_rate"], g["channels"]
+        a.ms_stereo, a.intensity_stereo, a.lsf = g.get("ms_stereo", 0), g.get("intensity_stereo", 0), g.get("lsf", 0)
+        for c in range(min(g["channels"], 2)):
+            src, dst = g["ch"][c], a.ch[c]
+            for name in ("global_gain", "scalefac_scale", "preflag", "block_type", "mixed_block_flag"):
+                setattr(dst, name, src[name])
+            for w in range(3):
+                dst.subblock_gain[w] = src["subblock_gain"][w]
+            for b in range(22):
+                dst.scalefac_l[b] = src["scalefac_l"][b]
+            for b in range(13):
+                for w in range(3):
+                    dst.scalefac_s[b][w] = src["scalefac_s"][b][w]
+    return arr
+
+
+def requantize(granules, quant, engine=None):
+    """quant: int16, the granules' channels one after another, 576 lines each, bitstream order -> (xr f32 same shape, status)"""
+    engine = engine or default_engine()
+    arr = make_requant_granules(granules)
+    n = len(granules)
+    q = np.ascontiguousarray(quant, np.int16)
+    xr = np.zeros(q.shape, np.float32)
+    status = np.zeros(max(n, 1), np.int32)
+    check(lib.sk_mp3_requantize(engine._h, arr, _ptr(q), _ptr(xr), n, _ptr(status)), "sk_mp3_requantize", engine._h)
+    return xr, status[:n]

@@ -1,0 +1,257 @@
+"""The fixed-syntax front of the MP3 path (csrc/mp3_bitstream.cpp: header, side information, frame scan, bit reservoir)
+against oracle/mp3_bitstream.py and the reference's own MP3 fixtures (testdata/mp3 and golden/mp3, copied as data).
+
+What the fixtures pin: the reference's tests decode the mono file as 16 kHz, 1 channel (soundkit-mp3/src/lib.rs:551-552)
+and write the stereo one from the 16 kHz stereo WAV (lib.rs:482-518), so every frame must parse as MPEG-2 Layer III at
+16 kHz with that channel count, frames must chain header to header to the last byte of the file, and the side information of every frame must fit
+what the frame plus the reservoir hold.  Host code only: no GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mp3_bitstream as ref
+from soundkit_amd import mp3
+from soundkit_amd._lib import SK_OK
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "mp3")
+FIXTURES = {"stereo16k_A_Tusk_encoded.mp3": 2, "mono16k_A_Tusk.mp3": 1}
+NEED_MORE, NO_SYNC, UNSUPPORTED, INVALID = -301, -302, -303, -304
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name), "rb") as f:
+        return f.read()
+
+
+HEADER_FIELDS = ("frame_bytes", "sample_rate", "bitrate_kbps", "samples_per_channel", "version", "channels", "mode", "mode_ext",
+                 "has_crc", "padding", "granules", "side_info_bytes")
+SIDE_FIELDS = ("part2_3_length", "big_values", "global_gain", "scalefac_compress", "window_switching", "block_type",
+               "mixed_block_flag", "preflag", "scalefac_scale", "count1table_select", "region0_count", "region1_count")
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+def test_fixture_frames_chain_to_the_end_of_the_file(name):
+    data = load(name)
+    frames, used = mp3.scan(data)
+    want, want_used = ref.scan(data)
+    assert used == want_used == len(data), "the last frame ends with the file"
+    assert len(frames) == len(want) > 50
+    first = frames[0].offset
+    assert first == want[0][0] and (first == 0 or data[:3] == b"ID3")
+    at = first
+    for f, (off, h) in zip(frames, want):
+        assert f.offset == off == at
+        for k in HEADER_FIELDS:
+            assert getattr(f, k) == h[k], k
+        assert (f.sample_rate, f.channels, f.version, f.samples_per_channel) == (16000, FIXTURES[name], 2, 576)
+        at += f.frame_bytes
+    # 576 samples a frame at 16 kHz: the clip lengths the reference's tests expect of these files are consistent with that
+    assert len(frames) * 576 / 16000 == pytest.approx(2.95 if FIXTURES[name] == 2 else 3.1, abs=0.2)
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+def test_fixture_side_information_adds_up(name):
+    data = load(name)
+    frames, _ = mp3.scan(data)
+    want_main = ref.main_data([(f.offset, ref.parse_header(data[f.offset:f.offset + 4])) for f in frames], data)
+    kept = b""
+    block_types = set()
+    for k, f in enumerate(frames):
+        frame = data[f.offset:f.offset + f.frame_bytes]
+        rc, side = mp3.parse_side_info(frame, f)
+        assert rc == SK_OK
+        want = ref.parse_side_info(frame, ref.parse_header(frame[:4]))
+        assert side.main_data_begin == want["main_data_begin"] and side.granules == 1 and side.channels == f.channels
+        bits = 0
+        for c in range(f.channels):
+            got, w = side.gr[0][c], want["gr"][0][c]
+            for field in SIDE_FIELDS:
+                assert getattr(got, field) == w[field], (k, c, field)
+            assert list(got.table_select) == w["table_select"] and list(got.subblock_gain) == w["subblock_gain"]
+            assert got.big_values <= 288 and got.block_type <= 3
+            assert got.window_switching == (got.block_type != 0)
+            block_types.add(got.block_type)
+            bits += got.part2_3_length
+        rc, main = mp3.main_data(frame, f, side, kept)
+        if want_main[k] is None:
+            assert rc == NEED_MORE
+        else:
+            assert rc == SK_OK and main == want_main[k]
+            assert bits <= 8 * len(main), "parts 2 + 3 fit in the reservoir plus the frame's own main data"
+        head = 4 + 2 * f.has_crc + f.side_info_bytes
+        kept = (kept + frame[head:])[-1024:]
+    assert 0 in block_types
+    # an encoder that fills frames: the reservoir is in use somewhere in the clip
+    assert any(mp3.parse_side_info(data[f.offset:f.offset + f.frame_bytes], f)[1].main_data_begin for f in frames)
+
+
+def test_header_fields_of_all_versions_and_rejections():
+    rng = np.random.default_rng(5)
+    seen = set()
+    for _ in range(20000):
+        b = bytes([0xFF]) + bytes(rng.integers(0, 256, 3, dtype=np.uint8))
+        if rng.random() < 0.8:
+            b = bytes([0xFF, b[1] | 0xE0]) + b[2:]
+        rc, info = mp3.parse_header(b)
+        want = ref.parse_header(b)
+        if want is None or want["frame_bytes"] < 4 + 2 * want["has_crc"] + want["side_info_bytes"]:
+            assert rc in (NO_SYNC, UNSUPPORTED)
+            continue
+        assert rc == SK_OK
+        for k in HEADER_FIELDS:
+            assert getattr(info, k) == want[k], (b.hex(), k)
+        seen.add((info.version, info.channels))
+    assert seen == {(v, c) for v in (1, 2, 25) for c in (1, 2)}
+    assert mp3.parse_header(b"\xff\xfb\x90")[0] == NEED_MORE
+    assert mp3.parse_header(b"\xff\xfd\x90\x00")[0] == UNSUPPORTED  # Layer II
+    assert mp3.parse_header(b"\xff\xfb\x00\x00")[0] == UNSUPPORTED  # free format
+    assert mp3.parse_header(b"\xff\xfb\xf0\x00")[0] == NO_SYNC      # bitrate index 15
+    assert mp3.parse_header(b"\xff\xeb\x90\x00")[0] == NO_SYNC      # version bits 01
+
+
+def pack_side_info(h, side):
+    """the inverse of parse_side_info, for synthetic MPEG-1 / LSF frames"""
+    out = []
+
+    def put(v, n):
+        out.extend((v >> (n - 1 - i)) & 1 for i in range(n))
+    mpeg1, ch = h["version"] == 1, h["channels"]
+    put(side["main_data_begin"], 9 if mpeg1 else 8)
+    put(0, (5 if ch == 1 else 3) if mpeg1 else (1 if ch == 1 else 2))
+    if mpeg1:
+        for c in range(ch):
+            for v in side["scfsi"][c]:
+                put(v, 1)
+    for g in range(h["granules"]):
+        for c in range(ch):
+            s = side["gr"][g][c]
+            put(s["part2_3_length"], 12), put(s["big_values"], 9), put(s["global_gain"], 8)
+            put(s["scalefac_compress"], 4 if mpeg1 else 9), put(s["window_switching"], 1)
+            if s["window_switching"]:
+                put(s["block_type"], 2), put(s["mixed_block_flag"], 1)
+                put(s["table_select"][0], 5), put(s["table_select"][1], 5)
+                for w in range(3):
+                    put(s["subblock_gain"][w], 3)
+            else:
+                for r in range(3):
+                    put(s["table_select"][r], 5)
+                put(s["region0_count"], 4), put(s["region1_count"], 3)
+            if mpeg1:
+                put(s["preflag"], 1)
+            put(s["scalefac_scale"], 1), put(s["count1table_select"], 1)
+    assert len(out) == 8 * h["side_info_bytes"]
+    return bytes(int("".join(map(str, out[i:i + 8])), 2) for i in range(0, len(out), 8))
+
+
+@pytest.mark.parametrize("header", [b"\xff\xfb\x90\x40", b"\xff\xfb\x90\xc0", b"\xff\xf3\x80\x40", b"\xff\xe3\x80\xc0", b"\xff\xfa\x90\x00"])
+def test_side_information_round_trip_on_synthetic_frames(header):
+    """MPEG-1 stereo / mono, MPEG-2 stereo, MPEG-2.5 mono, MPEG-1 with CRC: random legal side information, packed by the test"""
+    rng = np.random.default_rng(list(header))
+    h = ref.parse_header(header)
+    assert h is not None
+    for _ in range(200):
+        side = {"main_data_begin": int(rng.integers(0, 512 if h["version"] == 1 else 256)),
+                "scfsi": [[int(v) for v in rng.integers(0, 2, 4)] for _ in range(2)], "gr": []}
+        for _g in range(h["granules"]):
+            row = []
+            for _c in range(h["channels"]):
+                ws = int(rng.integers(0, 2))
+                row.append({"part2_3_length": int(rng.integers(0, 4096)), "big_values": int(rng.integers(0, 289)),
+                            "global_gain": int(rng.integers(0, 256)), "scalefac_compress": int(rng.integers(0, 16 if h["version"] == 1 else 512)),
+                            "window_switching": ws, "block_type": int(rng.integers(1, 4)) if ws else 0,
+                            "mixed_block_flag": int(rng.integers(0, 2)) if ws else 0, "table_select": [int(v) for v in rng.integers(0, 32, 3)],
+                            "subblock_gain": [int(v) for v in rng.integers(0, 8, 3)], "region0_count": int(rng.integers(0, 16)),
+                            "region1_count": int(rng.integers(0, 8)), "preflag": int(rng.integers(0, 2)) if h["version"] == 1 else 0,
+                            "scalefac_scale": int(rng.integers(0, 2)), "count1table_select": int(rng.integers(0, 2))})
+            side["gr"].append(row)
+        frame = header + (b"\x12\x34" if h["has_crc"] else b"") + pack_side_info(h, side)
+        rc, info = mp3.parse_header(frame)
+        assert rc == SK_OK
+        assert mp3.parse_side_info(frame[:-1], info)[0] == NEED_MORE
+        rc, got = mp3.parse_side_info(frame, info)
+        assert rc == SK_OK and got.main_data_begin == side["main_data_begin"]
+        want = ref.parse_side_info(frame, h)
+        for g in range(h["granules"]):
+            for c in range(h["channels"]):
+                s, w = got.gr[g][c], want["gr"][g][c]
+                for field in SIDE_FIELDS:
+                    assert getattr(s, field) == w[field], field
+                if s.window_switching:
+                    assert list(s.table_select)[:2] == side["gr"][g][c]["table_select"][:2]
+                    assert list(s.subblock_gain) == side["gr"][g][c]["subblock_gain"]
+                else:
+                    assert list(s.table_select) == side["gr"][g][c]["table_select"]
+        if h["version"] == 1:
+            assert [list(r) for r in got.scfsi][:h["channels"]] == side["scfsi"][:h["channels"]]
+
+
+def test_forbidden_side_information_is_rejected():
+    header = b"\xff\xfb\x90\xc0"
+    h = ref.parse_header(header)
+    base = {"part2_3_length": 0, "big_values": 0, "global_gain": 0, "scalefac_compress": 0, "window_switching": 1, "block_type": 0,
+            "mixed_block_flag": 0, "table_select": [0, 0, 0], "subblock_gain": [0, 0, 0], "region0_count": 0, "region1_count": 0,
+            "preflag": 0, "scalefac_scale": 0, "count1table_select": 0}
+    side = {"main_data_begin": 0, "scfsi": [[0] * 4] * 2, "gr": [[dict(base)], [dict(base, window_switching=0)]]}
+    frame = header + pack_side_info(h, side)
+    rc, info = mp3.parse_header(frame)
+    assert rc == SK_OK and mp3.parse_side_info(frame, info)[0] == INVALID  # window switching with block type 0
+    side["gr"][0][0] = dict(base, window_switching=0, big_values=289)
+    frame = header + pack_side_info(h, side)
+    assert mp3.parse_side_info(frame, info)[0] == INVALID  # 578 lines in a granule of 576
+
+
+def test_scan_skips_garbage_and_false_syncs_and_stops_at_a_partial_frame():
+    data = load("stereo16k_A_Tusk_encoded.mp3")
+    frames, _ = mp3.scan(data)
+    body = data[:frames[10].offset]
+    # a sync word inside garbage whose "next header" is not one
+    junk = b"\x00\x01\xff\xf3\xc8\x44" + bytes(range(7, 90))
+    got, used = mp3.scan(junk + body + data[frames[10].offset:frames[10].offset + 100])
+    assert [f.offset for f in got] == [len(junk) + f.offset for f in frames[:10]]
+    assert used == len(junk) + len(body), "the partial eleventh frame is left for the next call"
+    want, want_used = ref.scan(junk + body + data[frames[10].offset:frames[10].offset + 100])
+    assert [o for o, _ in want] == [f.offset for f in got] and want_used == used
+    assert mp3.scan(b"")[0] == [] and mp3.scan(b"\xff")[0] == []
+    capped, _ = mp3.scan(data, cap=5)
+    assert len(capped) == 5
+
+
+def test_oracle_requantisation_known_values():
+    """the checker of tests/test_mp3_requant_gpu.py on values that can be worked out by hand"""
+    long_o = list(range(0, 22 * 26, 26))[:22] + [576]
+    short_o = list(range(0, 13 * 14, 14))[:13] + [192]
+    flat = {"global_gain": 210, "scalefac_scale": 0, "preflag": 0, "block_type": 0, "mixed_block_flag": 0, "subblock_gain": [0, 0, 0],
+            "scalefac_l": [0] * 22, "scalefac_s": [[0, 0, 0] for _ in range(13)]}
+    q = np.zeros((1, 576), np.int64)
+    q[0, :4] = [8, -27, 1, 64]
+    g = {"channels": 1, "ms_stereo": 0, "intensity_stereo": 0, "ch": [dict(flat)]}
+    assert np.allclose(ref.requantize_granule(g, q, long_o, short_o, [0] * 22)[0, :4], [16, -81, 1, 256], rtol=1e-14)
+    # global_gain 214 doubles; scale factor 2 at scalefac_scale 0 halves; preflag adds the table entry; scalefac_scale 1 squares the step
+    g["ch"][0] = dict(flat, global_gain=214, scalefac_l=[2] * 22, preflag=1)
+    assert np.allclose(ref.requantize_granule(g, q, long_o, short_o, [2] * 22)[0, :4], np.array([16, -81, 1, 256]) * 2 / 4, rtol=1e-14)
+    g["ch"][0] = dict(flat, scalefac_scale=1, scalefac_l=[3] * 22)
+    assert np.allclose(ref.requantize_granule(g, q, long_o, short_o, [0] * 22)[0, :4], np.array([16, -81, 1, 256]) / 8, rtol=1e-14)
+    # short block: window 1 of band 0 with subblock_gain 1 -> a quarter, landing at 3 j + 1
+    g["ch"][0] = dict(flat, block_type=2, subblock_gain=[0, 1, 0])
+    q[:] = 0
+    q[0, 14:28] = 8
+    out = ref.requantize_granule(g, q, long_o, short_o, [0] * 22)[0]
+    assert np.allclose(out[1:42:3], 4.0) and np.count_nonzero(out) == 14
+    # mid/side is its own inverse up to the factor: (M, S) -> (L, R) -> back
+    rng = np.random.default_rng(0)
+    q2 = rng.integers(-30, 31, (2, 576))
+    g2 = {"channels": 2, "ms_stereo": 1, "intensity_stereo": 0, "ch": [dict(flat), dict(flat)]}
+    lr = ref.requantize_granule(g2, q2, long_o, short_o, [0] * 22)
+    plain = ref.requantize_granule(dict(g2, ms_stereo=0), q2, long_o, short_o, [0] * 22)
+    assert np.allclose((lr[0] + lr[1]) / np.sqrt(2), plain[0]) and np.allclose((lr[0] - lr[1]) / np.sqrt(2), plain[1])
+    # intensity: right channel empty from band 3 on, position 3 (tan(pi / 4) = 1) splits evenly; position 7 leaves the band alone
+    q2[1, long_o[3]:] = 0
+    q2[1, :long_o[3]] = 1
+    right = dict(flat, scalefac_l=[0, 0, 0] + [3] * 9 + [7] * 9 + [0])
+    g3 = {"channels": 2, "ms_stereo": 0, "intensity_stereo": 1, "ch": [dict(flat), right]}
+    out = ref.requantize_granule(g3, q2, long_o, short_o, [0] * 22)
+    plain = ref.requantize_granule(dict(g3, intensity_stereo=0), q2, long_o, short_o, [0] * 22)
+    a, b = long_o[3], long_o[12]
+    assert np.allclose(out[0, a:b], plain[0, a:b] / 2) and np.allclose(out[1, a:b], plain[0, a:b] / 2)
+    assert np.array_equal(out[:, :a], plain[:, :a]) and np.array_equal(out[:, b:long_o[21]], plain[:, b:long_o[21]])
