@@ -288,6 +288,67 @@ int sk_mp3_set_band_tables(sk_engine *, uint32_t sample_rate, const uint16_t lon
 int sk_mp3_requantize(sk_engine *, const sk_mp3_requant_granule *granules, const int16_t *is, float *xr, uint32_t n,
                       int32_t *status_per_granule);
 
+/* ---- MPEG Layer III: scale factors, the Huffman stage and a decoder handle in Mp3Decoder's shape ----------------------
+ * Parts 2 and 3 of the main data are syntax too, but syntax over data tables of the standard that this tree does not hold.
+ * The caller hands them over once (nanomp3 has them all) in the standard's own presentation -- for every code its length
+ * and its bits -- and the library builds its decoding structures from that.  Nothing in here was written down from
+ * memory of the standard's annexes; the tests run on synthetic code books and an encoder of their own. */
+typedef struct sk_mp3_code_table { /* one table of ISO/IEC 11172-3 Table B.7 */
+    uint8_t xlen;                  /* values 0 .. xlen-1 for x and for y; 0 = table carries no codes (tables 0, 4, 14) */
+    uint8_t linbits;
+    const uint8_t *hlen;           /* [xlen * xlen], index x * xlen + y: code length in bits, 1..32 */
+    const uint32_t *hcod;          /* the code, right-aligned */
+} sk_mp3_code_table;
+typedef struct sk_mp3_tables {
+    sk_mp3_code_table big_values[32];
+    uint8_t count1_hlen[2][16];    /* tables A and B of the count1 region, index v << 3 | w << 2 | x << 1 | y */
+    uint8_t count1_hcod[2][16];
+    uint8_t slen[16][2];           /* 11172-3 2.4.2.7: scalefac_compress -> slen1, slen2 */
+    uint8_t lsf_partitions[6][3][4]; /* 13818-3 2.4.3.2: scale factors per partition, [row][long | short | mixed][partition] */
+    uint16_t long_offsets[9][23];  /* Table B.8 by sampling rate: 44100 48000 32000 22050 24000 16000 11025 12000 8000 */
+    uint16_t short_offsets[9][14];
+    uint8_t rates_present[9];      /* which rows of the two arrays above are filled in */
+    uint8_t pretab[22];
+    float window[512];             /* Table B.3 */
+} sk_mp3_tables;
+typedef struct sk_mp3_codebook sk_mp3_codebook; /* host-side: validated copies + prefix-decoding tables; no GPU involved */
+int sk_mp3_codebook_create(const sk_mp3_tables *, sk_mp3_codebook **out); /* SK_MP3_INVALID: a code set that is no prefix code */
+void sk_mp3_codebook_destroy(sk_mp3_codebook *);
+
+/* One granule of one channel out of parts 2 + 3: the scale factors in sk_mp3_requantize's layout and the 576 integers. */
+typedef struct sk_mp3_granule_data {
+    int16_t is[576];
+    uint8_t scalefac_l[22];
+    uint8_t scalefac_s[13][3];
+    uint8_t preflag;     /* MPEG-1: the side information's; LSF: implied by scalefac_compress */
+    uint8_t intensity_scale; /* LSF intensity channel: scalefac_compress & 1 (not used: such granules are rejected later) */
+    uint16_t part2_bits; /* what the scale factors took of part2_3_length */
+    uint16_t nonzero_lines; /* lines up to and including the last decoded pair / quadruple */
+    int32_t status;      /* SK_OK | SK_MP3_INVALID (a bit pattern that is no code, values past line 576) | SK_MP3_UNSUPPORTED */
+} sk_mp3_granule_data;
+/* main = what sk_mp3_main_data assembled.  out[granule][channel]; previous = the same frame's granule-0 scale factors are
+ * taken from out itself (scfsi). */
+int sk_mp3_decode_main_data(const sk_mp3_codebook *, const sk_mp3_frame_info *header, const sk_mp3_side_info *side, const uint8_t *main,
+                            size_t main_len, sk_mp3_granule_data out[2][2]);
+
+/* Mp3Decoder (soundkit-mp3/src/lib.rs:147-374): bytes in at any chunking, interleaved PCM out.  One call decodes every
+ * complete frame its input buffer holds -- framing, reservoir, scale factors and Huffman on the host, then ONE
+ * requantisation launch and ONE hybrid-synthesis launch over all their granules -- subject to the reference's output rule:
+ * it stops once fewer than SK_MP3_MAX_SAMPLES_PER_FRAME samples of room are left (lib.rs:300-302) and fails with
+ * SK_ERR_CAPACITY if a frame does not fit (lib.rs:237-243).  Input beyond 4 MiB buffered: SK_PIPE_CHUNK_TOO_LARGE
+ * (lib.rs:155, 219-227).  A frame whose main data reaches further back than the reservoir holds (a stream joined in the
+ * middle) is consumed without output, as are frames the later stages reject. */
+#define SK_MP3_MAX_SAMPLES_PER_FRAME 2304u
+typedef struct sk_mp3_decoder sk_mp3_decoder;
+int sk_mp3_decoder_create(sk_engine *, const sk_mp3_codebook *, sk_mp3_decoder **out); /* Mp3Decoder::new, lib.rs:157 */
+void sk_mp3_decoder_destroy(sk_mp3_decoder *);
+int sk_mp3_decoder_reset(sk_mp3_decoder *);                                           /* lib.rs:180-185 */
+/* sample_rate / channels are 0 until the first frame was decoded (Option::None, lib.rs:167-173); buffer_len: lib.rs:176 */
+int sk_mp3_decoder_info(const sk_mp3_decoder *, uint32_t *sample_rate, uint8_t *channels, size_t *buffer_len, uint64_t *frames_decoded);
+int sk_mp3_decoder_decode_i16(sk_mp3_decoder *, const uint8_t *input, size_t len, int16_t *out, size_t out_cap, size_t *written);
+int sk_mp3_decoder_decode_i32(sk_mp3_decoder *, const uint8_t *input, size_t len, int32_t *out, size_t out_cap, size_t *written);
+int sk_mp3_decoder_decode_f32(sk_mp3_decoder *, const uint8_t *input, size_t len, float *out, size_t out_cap, size_t *written);
+
 /* ---- sample-width / interleave conversion: soundkit::audio_bytes -------- */
 /* Elementwise ops; n = number of OUTPUT samples.  Citations: soundkit/src/audio_bytes.rs
  * unless noted. */

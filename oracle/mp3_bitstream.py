@@ -219,3 +219,241 @@ def requantize_granule(g, quant, long_offsets, short_offsets, pretab):
         for i in range(576):
             out[c][where[c][i][2]] = vals[c][i]
     return out
+
+
+# ---- parts 2 and 3 of the main data: scale factors and the Huffman stage, over caller-supplied tables --------------------
+# `tables` is a dict in the shape of sk_mp3_tables: big_values[32] = None | dict(xlen, linbits, hlen[], hcod[]),
+# count1[2] = dict(hlen[16], hcod[16]), slen[16][2], lsf_partitions[6][3][4], bands{rate: (long23, short14)}, pretab[22],
+# window[512].  Codes are matched by reading bits until (length, value) is a code of the table.
+
+def _code_map(hlen, hcod):
+    return {(int(n), int(c)): s for s, (n, c) in enumerate(zip(hlen, hcod))}
+
+
+def _read_code(bits, code_map):
+    value = 0
+    for n in range(1, 33):
+        value = (value << 1) | bits.take1()
+        if (n, value) in code_map:
+            return code_map[(n, value)]
+    return None
+
+
+class MainBits:
+    """bit reader that returns zeros past the end and keeps counting (like the product's)"""
+
+    def __init__(self, data, pos=0):
+        self.data, self.pos = data, pos
+
+    def take1(self):
+        byte = self.pos >> 3
+        v = (self.data[byte] >> (7 - (self.pos & 7))) & 1 if byte < len(self.data) else 0
+        self.pos += 1
+        return v
+
+    def take(self, n):
+        v = 0
+        for _ in range(n):
+            v = (v << 1) | self.take1()
+        return v
+
+
+def scale_factors(tables, h, side, gr, ch, bits, first_granule):
+    """-> (scalefac_l[22], scalefac_s[13][3], preflag); first_granule: granule 0's scalefac_l of this channel (scfsi)"""
+    s = side["gr"][gr][ch]
+    sl, ss = [0] * 22, [[0, 0, 0] for _ in range(13)]
+    short = s["window_switching"] and s["block_type"] == 2
+    if h["version"] == 1:
+        slen1, slen2 = tables["slen"][s["scalefac_compress"]]
+        if short:
+            first = 0
+            if s["mixed_block_flag"]:
+                for band in range(8):
+                    sl[band] = bits.take(slen1)
+                first = 3
+            for band in range(first, 12):
+                for w in range(3):
+                    ss[band][w] = bits.take(slen1 if band < 6 else slen2)
+        else:
+            for group, (a, b) in enumerate(((0, 6), (6, 11), (11, 16), (16, 21))):
+                for band in range(a, b):
+                    if gr == 1 and side["scfsi"][ch][group]:
+                        sl[band] = first_granule[band]
+                    else:
+                        sl[band] = bits.take(slen1 if group < 2 else slen2)
+        return sl, ss, s["preflag"]
+    sfc, preflag = s["scalefac_compress"], 0
+    if not (h["mode"] == 1 and (h["mode_ext"] & 1) and ch == 1):
+        if sfc < 400:
+            lens, row = [(sfc >> 4) // 5, (sfc >> 4) % 5, (sfc % 16) >> 2, sfc % 4], 0
+        elif sfc < 500:
+            sfc -= 400
+            lens, row = [(sfc >> 2) // 5, (sfc >> 2) % 5, sfc % 4, 0], 1
+        else:
+            sfc -= 500
+            lens, row, preflag = [sfc // 3, sfc % 3, 0, 0], 2, 1
+    else:
+        sfc >>= 1
+        if sfc < 180:
+            lens, row = [sfc // 36, (sfc % 36) // 6, (sfc % 36) % 6, 0], 3
+        elif sfc < 244:
+            sfc -= 180
+            lens, row = [(sfc % 64) >> 4, (sfc % 16) >> 2, sfc % 4, 0], 4
+        else:
+            sfc -= 244
+            lens, row = [sfc // 3, sfc % 3, 0, 0], 5
+    column = (2 if s["mixed_block_flag"] else 1) if short else 0
+    values = []
+    for part, count in enumerate(tables["lsf_partitions"][row][column]):
+        values += [bits.take(lens[part]) for _ in range(count)]
+    if column == 0:
+        sl[:len(values)] = values
+    else:
+        n_long = 6 if column == 2 else 0
+        sl[:n_long] = values[:n_long]
+        for k, v in enumerate(values[n_long:]):
+            band, w = divmod(k + (9 if column == 2 else 0), 3)
+            ss[band][w] = v
+    return sl, ss, preflag
+
+
+def region_bounds(s, long_offsets, short_offsets):
+    """line numbers where regions 1 and 2 of the big values begin"""
+    short = s["window_switching"] and s["block_type"] == 2
+    if not short:
+        widths = [long_offsets[b + 1] - long_offsets[b] for b in range(22)]
+    else:
+        widths, first = [], 0
+        if s["mixed_block_flag"]:
+            widths = [long_offsets[b + 1] - long_offsets[b] for b in range(22) if long_offsets[b + 1] <= 36]
+            first = min(b for b in range(14) if 3 * short_offsets[b] >= 36)
+        for band in range(first, 13):
+            widths += [short_offsets[band + 1] - short_offsets[band]] * 3
+    r1 = min(576, sum(widths[:s["region0_count"] + 1]))
+    r2 = 576 if s["window_switching"] else min(576, sum(widths[:s["region0_count"] + s["region1_count"] + 2]))
+    return r1, r2
+
+
+def huffman_granule(tables, h, s, bits, end):
+    """-> 576 integers or None (a bit pattern that is no code, or an overrun)"""
+    long_offsets, short_offsets = tables["bands"][h["sample_rate"]]
+    out = [0] * 576
+    big_end = 2 * s["big_values"]
+    if big_end > 576:
+        return None
+    r1, r2 = region_bounds(s, long_offsets, short_offsets)
+    bounds = [0, min(r1, big_end), min(r2, big_end), big_end]
+    line = 0
+    for region in range(3):
+        select = s["table_select"][region]
+        table = tables["big_values"][select]
+        code_map = _code_map(table["hlen"], table["hcod"]) if table else None
+        while line < bounds[region + 1]:
+            x = y = 0
+            if table:
+                symbol = _read_code(bits, code_map)
+                if symbol is None:
+                    return None
+                x, y = divmod(symbol, table["xlen"])
+                if table["linbits"] and x == table["xlen"] - 1:
+                    x += bits.take(table["linbits"])
+                if x and bits.take1():
+                    x = -x
+                if table["linbits"] and y == table["xlen"] - 1:
+                    y += bits.take(table["linbits"])
+                if y and bits.take1():
+                    y = -y
+            elif select != 0:
+                return None
+            out[line], out[line + 1] = x, y
+            line += 2
+    if bits.pos > end:
+        return None
+    quad = tables["count1"][s["count1table_select"]]
+    code_map = _code_map(quad["hlen"], quad["hcod"])
+    while bits.pos < end and line + 4 <= 576:
+        symbol = _read_code(bits, code_map)
+        if symbol is None:
+            return None
+        v = [(symbol >> (3 - k)) & 1 for k in range(4)]
+        for k in range(4):
+            if v[k] and bits.take1():
+                v[k] = -1
+        if bits.pos > end:
+            break
+        out[line:line + 4] = v
+        line += 4
+    return out
+
+
+def decode_main_data(tables, h, side, main):
+    """-> [granule][channel] dict(is, scalefac_l, scalefac_s, preflag, part2_bits) or None where the granule is undecodable"""
+    out, start = [], 0
+    first_granule = [[0] * 22, [0] * 22]  # granule 0's long scale factors stand for scfsi even if its Huffman data is damaged
+    for gr in range(h["granules"]):
+        row = []
+        for ch in range(h["channels"]):
+            s = side["gr"][gr][ch]
+            end = start + s["part2_3_length"]
+            bits = MainBits(main, start)
+            g = None
+            if end <= 8 * len(main):
+                sl, ss, preflag = scale_factors(tables, h, side, gr, ch, bits, first_granule[ch])
+                if gr == 0:
+                    first_granule[ch] = sl
+                part2 = bits.pos - start
+                if bits.pos <= end:
+                    values = huffman_granule(tables, h, s, bits, end)
+                    if values is not None:
+                        g = {"is": values, "scalefac_l": sl, "scalefac_s": ss, "preflag": preflag, "part2_bits": part2}
+            row.append(g)
+            start = end
+        out.append(row)
+    return out
+
+
+class Decoder:
+    """the whole decode in f64: frames -> interleaved PCM; mirrors what sk_mp3_decoder_* does with a frame it cannot decode
+    (consumed without output).  hybrid: oracle/mp3_hybrid.py's Channel class."""
+
+    def __init__(self, tables):
+        from . import mp3_hybrid
+        self.tables, self.hybrid = tables, mp3_hybrid
+        self.kept, self.channels, self.state = b"", 0, []
+        self.window = np.asarray(tables["window"], np.float32).astype(np.float64)
+
+    def frame(self, data, off, h):
+        """-> [samples_per_channel][channels] f64 or None"""
+        frame = data[off:off + h["frame_bytes"]]
+        side = parse_side_info(frame, h)
+        head = 4 + (2 if h["has_crc"] else 0) + h["side_info_bytes"]
+        back, own = side["main_data_begin"], frame[head:]
+        main = (self.kept[len(self.kept) - back:] if back else b"") + own if back <= len(self.kept) else None
+        self.kept = (self.kept + own)[-2048:]
+        if main is None:
+            return None
+        joint = h["mode"] == 1
+        if h["version"] != 1 and joint and (h["mode_ext"] & 1):
+            return None
+        grs = decode_main_data(self.tables, h, side, main)
+        if any(g is None for row in grs for g in row):
+            return None
+        if self.channels != h["channels"]:
+            self.channels, self.state = h["channels"], [self.hybrid.Channel() for _ in range(h["channels"])]
+        long_offsets, short_offsets = self.tables["bands"][h["sample_rate"]]
+        out = []
+        for gr in range(h["granules"]):
+            g = {"channels": h["channels"], "ms_stereo": int(joint and bool(h["mode_ext"] & 2)),
+                 "intensity_stereo": int(joint and bool(h["mode_ext"] & 1)), "ch": []}
+            for ch in range(h["channels"]):
+                s, d = side["gr"][gr][ch], grs[gr][ch]
+                g["ch"].append({"global_gain": s["global_gain"], "scalefac_scale": s["scalefac_scale"], "preflag": d["preflag"],
+                                "block_type": s["block_type"], "mixed_block_flag": s["mixed_block_flag"],
+                                "subblock_gain": s["subblock_gain"], "scalefac_l": d["scalefac_l"], "scalefac_s": d["scalefac_s"]})
+            xr = requantize_granule(g, [grs[gr][ch]["is"] for ch in range(h["channels"])], long_offsets, short_offsets, self.tables["pretab"])
+            # the product hands f32 lines from one GPU stage to the next
+            xr = xr.astype(np.float32).astype(np.float64)
+            pcm = [self.state[ch].granule(xr[ch], side["gr"][gr][ch]["block_type"], side["gr"][gr][ch]["mixed_block_flag"], self.window)
+                   for ch in range(h["channels"])]
+            out.append(np.stack(pcm, axis=1))
+        return np.concatenate(out)

@@ -68,6 +68,25 @@ class Mp3RequantGranule(C.Structure):
                 ("lsf", C.c_uint8), ("ch", Mp3RequantChannel * 2)]
 
 
+class Mp3CodeTable(C.Structure):
+    """sk_mp3_code_table"""
+    _fields_ = [("xlen", C.c_uint8), ("linbits", C.c_uint8), ("hlen", C.POINTER(C.c_uint8)), ("hcod", C.POINTER(C.c_uint32))]
+
+
+class Mp3Tables(C.Structure):
+    """sk_mp3_tables"""
+    _fields_ = [("big_values", Mp3CodeTable * 32), ("count1_hlen", (C.c_uint8 * 16) * 2), ("count1_hcod", (C.c_uint8 * 16) * 2),
+                ("slen", (C.c_uint8 * 2) * 16), ("lsf_partitions", ((C.c_uint8 * 4) * 3) * 6), ("long_offsets", (C.c_uint16 * 23) * 9),
+                ("short_offsets", (C.c_uint16 * 14) * 9), ("rates_present", C.c_uint8 * 9), ("pretab", C.c_uint8 * 22),
+                ("window", C.c_float * 512)]
+
+
+class Mp3GranuleData(C.Structure):
+    """sk_mp3_granule_data"""
+    _fields_ = [("is_", C.c_int16 * 576), ("scalefac_l", C.c_uint8 * 22), ("scalefac_s", (C.c_uint8 * 3) * 13), ("preflag", C.c_uint8),
+                ("intensity_scale", C.c_uint8), ("part2_bits", C.c_uint16), ("nonzero_lines", C.c_uint16), ("status", C.c_int32)]
+
+
 class TickStream(C.Structure):
     """sk_tick_stream"""
     _fields_ = [("stream", C.c_uint32), ("n_frames", C.c_uint32), ("out_bits", C.c_uint8), ("out_channels", C.c_uint8),
@@ -237,6 +256,16 @@ _sig = {
     "sk_mp3_parse_side_info": (_i, [_vp, _sz, _vp, _vp]),
     "sk_mp3_scan": (_i, [_vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
     "sk_mp3_main_data": (_i, [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "sk_mp3_codebook_create": (_i, [_vp, C.POINTER(_vp)]),
+    "sk_mp3_codebook_destroy": (None, [_vp]),
+    "sk_mp3_decode_main_data": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "sk_mp3_decoder_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "sk_mp3_decoder_destroy": (None, [_vp]),
+    "sk_mp3_decoder_reset": (_i, [_vp]),
+    "sk_mp3_decoder_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(C.c_uint8), C.POINTER(_sz), C.POINTER(C.c_uint64)]),
+    "sk_mp3_decoder_decode_i16": (_i, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "sk_mp3_decoder_decode_i32": (_i, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "sk_mp3_decoder_decode_f32": (_i, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "sk_mp3_set_band_tables": (_i, [_vp, _u32, _vp, _vp, _vp]),
     "sk_mp3_requantize": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "sk_aac_entropy_decode": (_i, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _sz, _vp, _vp, _vp]),

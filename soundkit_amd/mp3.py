@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (Mp3FrameInfo, Mp3GranuleDesc, Mp3RequantGranule, Mp3SideInfo, check, lib)
+from ._lib import (Mp3FrameInfo, Mp3GranuleData, Mp3GranuleDesc, Mp3RequantGranule, Mp3SideInfo, SoundkitError, check, lib)
 from .engine import _ptr, default_engine
 
 
@@ -132,3 +132,88 @@ def requantize(granules, quant, engine=None):
     status = np.zeros(max(n, 1), np.int32)
     check(lib.sk_mp3_requantize(engine._h, arr, _ptr(q), _ptr(xr), n, _ptr(status)), "sk_mp3_requantize", engine._h)
     return xr, status[:n]
+
+
+# ---- parts 2 + 3 over caller-supplied tables, and the decoder handle -----------------------------------------------------------
+
+class Codebook:
+    """sk_mp3_codebook: host-side decoding structures built from an Mp3Tables (Table B.7 and friends, from the caller)"""
+
+    def __init__(self, tables):
+        self._h = C.c_void_p()
+        check(lib.sk_mp3_codebook_create(C.byref(tables), C.byref(self._h)), "sk_mp3_codebook_create")
+
+    def close(self):
+        if self._h:
+            lib.sk_mp3_codebook_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+
+def decode_main_data(codebook, info, side, main):
+    """(status, [granule][channel] Mp3GranuleData) -- scale factors and the 576 integers of every granule of one frame"""
+    out = ((Mp3GranuleData * 2) * 2)()
+    b = _bytes(main)
+    rc = lib.sk_mp3_decode_main_data(codebook._h, C.byref(info), C.byref(side), _ptr(b), len(main), out)
+    return rc, out
+
+
+MAX_SAMPLES_PER_FRAME = 2304
+
+
+class Mp3Decoder:
+    """soundkit-mp3's Mp3Decoder (soundkit-mp3/src/lib.rs:147-374): new / sample_rate / channels / buffer_len / reset /
+    decode_i16 / decode_i32 / decode_f32, bytes in at any chunking, interleaved samples out; errors raise SoundkitError"""
+
+    def __init__(self, codebook, engine=None):
+        self._engine = engine or default_engine()
+        self._codebook = codebook
+        self._h = C.c_void_p()
+        check(lib.sk_mp3_decoder_create(self._engine._h, codebook._h, C.byref(self._h)), "sk_mp3_decoder_create", self._engine._h)
+
+    def close(self):
+        if self._h:
+            lib.sk_mp3_decoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def _info(self):
+        rate, ch, n, frames = C.c_uint32(0), C.c_uint8(0), C.c_size_t(0), C.c_uint64(0)
+        check(lib.sk_mp3_decoder_info(self._h, C.byref(rate), C.byref(ch), C.byref(n), C.byref(frames)), "sk_mp3_decoder_info")
+        return rate.value, ch.value, n.value, frames.value
+
+    def sample_rate(self):
+        return self._info()[0] or None
+
+    def channels(self):
+        return self._info()[1] or None
+
+    def buffer_len(self):
+        return self._info()[2]
+
+    def frames_decoded(self):
+        return self._info()[3]
+
+    def reset(self):
+        check(lib.sk_mp3_decoder_reset(self._h), "sk_mp3_decoder_reset")
+
+    def _decode(self, fn, data, out):
+        b = _bytes(data)
+        n = C.c_size_t(0)
+        rc = fn(self._h, _ptr(b), len(data), _ptr(out), out.size, C.byref(n))
+        if rc != 0:
+            raise SoundkitError(rc, "sk_mp3_decoder_decode", lib.sk_engine_last_hip_error(self._engine._h).decode() if rc in (-3, -4, -8) else "")
+        return n.value
+
+    def decode_i16(self, data, out, fec=False):
+        assert out.dtype == np.int16
+        return self._decode(lib.sk_mp3_decoder_decode_i16, data, out)
+
+    def decode_i32(self, data, out, fec=False):
+        assert out.dtype == np.int32
+        return self._decode(lib.sk_mp3_decoder_decode_i32, data, out)
+
+    def decode_f32(self, data, out, fec=False):
+        assert out.dtype == np.float32
+        return self._decode(lib.sk_mp3_decoder_decode_f32, data, out)

@@ -1,0 +1,219 @@
+"""Parts 2 and 3 of the Layer III main data on the host (csrc/mp3_decoder.cpp: scale factors, big-value regions with
+escapes and signs, count1 quadruples, all over caller-supplied code books) against what tests/mp3_builder.py wrote and
+against oracle/mp3_bitstream.py's own reading of the same bytes.  Bit-exact (integers).  The code books are synthetic
+(module docstring of mp3_builder): this pins the syntax, not Table B.7.  No GPU."""
+import numpy as np
+import pytest
+
+import mp3_builder as B
+from oracle import mp3_bitstream as ref
+from soundkit_amd import mp3
+from soundkit_amd._lib import SK_OK, SoundkitError
+
+NEED_MORE, INVALID = -301, -304
+TABLES = B.make_tables(3)
+CTABLES, _KEEP = B.to_ctypes(TABLES)
+
+
+@pytest.fixture(scope="module")
+def codebook():
+    cb = mp3.Codebook(CTABLES)
+    yield cb
+    cb.close()
+
+
+STREAMS = [dict(version=1, rate=44100, channels=2, mode=1, joint_modes=(0, 2)), dict(version=1, rate=48000, channels=1),
+           dict(version=1, rate=32000, channels=2, mode=0, crc=True), dict(version=1, rate=44100, channels=2, mode=1, joint_modes=(1, 3)),
+           dict(version=2, rate=22050, channels=2, mode=1, joint_modes=(0, 2), bitrate_indices=(8, 10, 13)),
+           dict(version=2, rate=16000, channels=1, bitrate_indices=(6, 9, 12)), dict(version=25, rate=11025, channels=2, mode=2, bitrate_indices=(8, 11)),
+           dict(version=25, rate=8000, channels=1, bitrate_indices=(7, 8), crc=True)]
+
+
+@pytest.mark.parametrize("k", range(len(STREAMS)))
+def test_main_data_decodes_to_what_the_writer_encoded(codebook, k):
+    data, frames = B.build_stream(TABLES, 100 + k, n_frames=36, **STREAMS[k])
+    found, used = mp3.scan(data)
+    assert used == len(data) and len(found) == len(frames)
+    kept = b""
+    seen = {"escape": 0, "quads": 0, "short": 0, "mixed": 0, "scfsi": 0, "reservoir": 0, "negative": 0}
+    for f, src in zip(found, frames):
+        frame = data[f.offset:f.offset + f.frame_bytes]
+        h = ref.parse_header(frame[:4])
+        rc, side = mp3.parse_side_info(frame, f)
+        assert rc == SK_OK and side.main_data_begin == src["side"]["main_data_begin"]
+        rc, main = mp3.main_data(frame, f, side, kept)
+        assert rc == SK_OK
+        seen["reservoir"] += side.main_data_begin > 0
+        rc, got = mp3.decode_main_data(codebook, f, side, main)
+        assert rc == SK_OK
+        want_ref = ref.decode_main_data(TABLES, h, ref.parse_side_info(frame, h), main)
+        at = 0
+        for gr in range(f.granules):
+            for ch in range(f.channels):
+                g, w, o, s = got[gr][ch], src["granules"][gr][ch], want_ref[gr][ch], src["side"]["gr"][gr][ch]
+                assert g.status == SK_OK and o is not None
+                assert list(g.is_) == w["is"] == o["is"]
+                assert list(g.scalefac_l) == w["scalefac_l"] == o["scalefac_l"]
+                assert [list(r) for r in g.scalefac_s] == w["scalefac_s"] == o["scalefac_s"]
+                assert g.preflag == w["preflag"] == o["preflag"]
+                assert g.part2_bits == o["part2_bits"] <= s["part2_3_length"]
+                assert g.nonzero_lines >= max([i + 1 for i, v in enumerate(w["is"]) if v] + [0])
+                seen["escape"] += any(abs(v) > 15 for v in w["is"])
+                seen["negative"] += any(v < 0 for v in w["is"])
+                seen["quads"] += g.nonzero_lines > 2 * s["big_values"]
+                seen["short"] += s["block_type"] == 2
+                seen["mixed"] += s["mixed_block_flag"]
+                seen["scfsi"] += any(s["scfsi"])
+                at += s["part2_3_length"]
+        assert at <= 8 * len(main)
+        head = 4 + 2 * f.has_crc + f.side_info_bytes
+        kept = (kept + frame[head:])[-1024:]
+    assert seen["escape"] and seen["quads"] and seen["short"] and seen["negative"] and seen["reservoir"]
+    if STREAMS[k].get("version") == 1:
+        assert seen["scfsi"]
+
+
+def test_every_table_and_long_escapes(codebook):
+    """one granule per big-value table, values up to the table's own maximum (15 + 2^linbits - 1 for the widest)"""
+    rng = np.random.default_rng(9)
+    hb = B.header_bytes(1, 44100, 14, 1, 3, 0, False)
+    h = ref.parse_header(hb)
+    rc, info = mp3.parse_header(hb)
+    assert rc == SK_OK
+    for t in range(32):
+        table = TABLES["big_values"][t]
+        if not table:
+            continue
+        top = min(8206, table["xlen"] - 1 + ((1 << table["linbits"]) - 1 if table["linbits"] else 0))
+        w = B.BitWriter()
+        values = [0] * 576
+        for line in range(0, 120, 2):
+            x, y = (int(rng.integers(-top, top + 1)) for _ in range(2))
+            if line == 0:
+                x, y = top, -top
+            B.put_pair(w, table, x, y)
+            values[line], values[line + 1] = x, y
+        if len(w) > 4095:
+            continue
+        s = {"part2_3_length": len(w), "big_values": 60, "global_gain": 100, "scalefac_compress": 0, "window_switching": 0, "block_type": 0,
+             "mixed_block_flag": 0, "table_select": [t, t, t], "subblock_gain": [0, 0, 0], "region0_count": 3, "region1_count": 2, "preflag": 0,
+             "scalefac_scale": 0, "count1table_select": 0}
+        empty = dict(s, part2_3_length=0, big_values=0)
+        side_bytes = B.pack_side_info(h, {"main_data_begin": 0, "scfsi": [[0] * 4] * 2, "gr": [[s], [empty]]})
+        rc, side = mp3.parse_side_info(hb + side_bytes, info)
+        assert rc == SK_OK
+        rc, got = mp3.decode_main_data(codebook, info, side, w.tobytes())
+        assert rc == SK_OK and list(got[0][0].is_) == values and got[0][0].nonzero_lines == 120
+        assert not any(got[1][0].is_)
+        # one bit short: the frame's bytes do not hold what part2_3_length promises
+        if len(w) % 8 == 1:
+            rc, got = mp3.decode_main_data(codebook, info, side, w.tobytes()[:-1])
+            assert rc == NEED_MORE and got[0][0].status == NEED_MORE and not any(got[0][0].is_)
+
+
+def test_damaged_main_data_is_reported_not_followed(codebook):
+    """bit flips in the main data: every granule either decodes (to something) or reports SK_MP3_INVALID / NEED_MORE with
+    its lines cleared; the product and the oracle agree on which, and on every value"""
+    rng = np.random.default_rng(17)
+    data, frames = B.build_stream(TABLES, 55, version=1, rate=44100, channels=2, mode=0, n_frames=6, bitrate_indices=(9,))
+    found, _ = mp3.scan(data)
+    kept, checked, failed = b"", 0, 0
+    for f in found:
+        frame = data[f.offset:f.offset + f.frame_bytes]
+        h = ref.parse_header(frame[:4])
+        rc, side = mp3.parse_side_info(frame, f)
+        rc, main = mp3.main_data(frame, f, side, kept)
+        assert rc == SK_OK
+        for trial in range(40):
+            bad = bytearray(main)
+            rc, hurt = mp3.parse_side_info(frame, f)   # a fresh copy to damage
+            ref_side = ref.parse_side_info(frame, h)
+            if trial % 3 == 0:
+                for _flip in range(int(rng.integers(1, 6))):
+                    bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            elif trial % 3 == 1:    # part2_3_length cut short: the big values run past it
+                gr, ch = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+                cut = int(rng.integers(1, 300))
+                n = max(0, hurt.gr[gr][ch].part2_3_length - cut)
+                hurt.gr[gr][ch].part2_3_length = ref_side["gr"][gr][ch]["part2_3_length"] = n
+            else:                   # a region names a table that has no codes
+                gr, ch, region = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+                hurt.gr[gr][ch].table_select[region] = ref_side["gr"][gr][ch]["table_select"][region] = int(rng.choice([4, 14]))
+            rc, got = mp3.decode_main_data(codebook, f, hurt, bytes(bad))
+            want = ref.decode_main_data(TABLES, h, ref_side, bytes(bad))
+            for gr in range(2):
+                for ch in range(2):
+                    g, o = got[gr][ch], want[gr][ch]
+                    checked += 1
+                    if o is None:
+                        failed += 1
+                        assert g.status in (INVALID, NEED_MORE) and not any(g.is_)
+                    else:
+                        assert g.status == SK_OK and list(g.is_) == o["is"] and list(g.scalefac_l) == o["scalefac_l"]
+            assert (rc == SK_OK) == all(o is not None for row in want for o in row)
+        head = 4 + 2 * f.has_crc + f.side_info_bytes
+        kept = (kept + frame[head:])[-1024:]
+    assert checked > 500 and failed > 20
+
+
+def test_codebook_rejects_what_is_no_prefix_code():
+    import copy
+    for damage in ("duplicate", "prefix", "length", "slen", "bands"):
+        t = copy.deepcopy(TABLES)
+        if damage == "duplicate":
+            t["big_values"][7]["hcod"][3], t["big_values"][7]["hlen"][3] = t["big_values"][7]["hcod"][4], t["big_values"][7]["hlen"][4]
+        elif damage == "prefix":
+            # the shortest code of a table becomes the start of a longer one
+            tab = t["count1"][0]
+            short = int(np.argmin(tab["hlen"]))
+            longer = int(np.argmax(tab["hlen"]))
+            n = tab["hlen"][longer] - tab["hlen"][short]
+            tab["hcod"][longer] = (tab["hcod"][short] << n) | (tab["hcod"][longer] & ((1 << n) - 1))
+        elif damage == "length":
+            t["big_values"][1]["hlen"][0] = 0
+        elif damage == "slen":
+            t["slen"] = [[5, 0]] + t["slen"][1:]
+        else:
+            lo, so = t["bands"][44100]
+            t["bands"][44100] = (lo[:5] + [lo[4]] + lo[6:], so)
+        ct, keep = B.to_ctypes(t)
+        with pytest.raises(SoundkitError) as exc:
+            mp3.Codebook(ct)
+        assert exc.value.status in (INVALID, -1), damage
+
+
+def test_lsf_scale_factor_lengths_fit_the_reference_fixtures(codebook):
+    """The reference's MP3 files are MPEG-2: for every granule the scale factors that scalefac_compress announces
+    (13818-3 2.4.3.2, partition rows 0-2) must fit inside part2_3_length.  (Their Huffman data cannot be read: the code
+    books here are synthetic.)  A weak pin, but it is on real data."""
+    import os
+    golden = os.path.join(os.path.dirname(__file__), "golden", "mp3")
+    checked = 0
+    for name in sorted(os.listdir(golden)):
+        with open(os.path.join(golden, name), "rb") as fh:
+            data = fh.read()
+        found, _ = mp3.scan(data)
+        kept = b""
+        for f in found:
+            frame = data[f.offset:f.offset + f.frame_bytes]
+            h = ref.parse_header(frame[:4])
+            rc, side = mp3.parse_side_info(frame, f)
+            rc, main = mp3.main_data(frame, f, side, kept)
+            if rc == SK_OK:
+                bits = ref.MainBits(main, 0)
+                start = 0
+                ref_side = ref.parse_side_info(frame, h)
+                for ch in range(f.channels):
+                    s = side.gr[0][ch]
+                    bits.pos = start
+                    ref.scale_factors(TABLES, h, ref_side, 0, ch, bits, [0] * 22)
+                    part2 = bits.pos - start
+                    assert part2 <= s.part2_3_length, (name, f.offset, ch)
+                    # an empty granule carries no scale factors worth bits either
+                    if s.part2_3_length == 0:
+                        assert part2 == 0
+                    start += s.part2_3_length
+                    checked += 1
+            head = 4 + 2 * f.has_crc + f.side_info_bytes
+            kept = (kept + frame[head:])[-1024:]
+    assert checked > 200

@@ -138,7 +138,16 @@ def test_mid_side_and_intensity_stereo(engine, block_type):
     assert np.array_equal(xr[0], plain[0])
 
 
-def test_rejected_granules_are_silent_and_do_not_disturb_the_others(engine):
+def test_rejected_granules_are_silent_and_do_not_disturb_the_others():
+    import soundkit_amd
+    engine = soundkit_amd.Engine(0, 4)  # its own: which rates have band tables is engine state
+    try:
+        rejected_granules(engine)
+    finally:
+        engine.close()
+
+
+def rejected_granules(engine):
     rng = np.random.default_rng(30)
     long_o, short_o, pretab = tables(5)
     plain_long, plain_short, _ = tables(6, mixed_boundary=False)
