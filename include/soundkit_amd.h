@@ -287,6 +287,13 @@ int sk_mp3_set_band_tables(sk_engine *, uint32_t sample_rate, const uint16_t lon
                            const uint8_t pretab[22]);
 int sk_mp3_requantize(sk_engine *, const sk_mp3_requant_granule *granules, const int16_t *is, float *xr, uint32_t n,
                       int32_t *status_per_granule);
+/* The two GPU stages back to back -- sk_mp3_requantize then sk_mp3_hybrid_synthesize_* with descs[i] describing the same
+ * granule as granules[i] -- the frequency lines staying on the device: integers in, interleaved PCM out, one
+ * synchronisation.  What sk_mp3_decoder_decode_* runs per call. */
+int sk_mp3_decode_granules_f32(sk_engine *, const sk_mp3_requant_granule *granules, const sk_mp3_granule_desc *descs, const int16_t *is,
+                               float *pcm_out, uint32_t n, int32_t *status_per_granule);
+int sk_mp3_decode_granules_s16(sk_engine *, const sk_mp3_requant_granule *granules, const sk_mp3_granule_desc *descs, const int16_t *is,
+                               int16_t *pcm_out, uint32_t n, int32_t *status_per_granule);
 
 /* ---- MPEG Layer III: scale factors, the Huffman stage and a decoder handle in Mp3Decoder's shape ----------------------
  * Parts 2 and 3 of the main data are syntax too, but syntax over data tables of the standard that this tree does not hold.

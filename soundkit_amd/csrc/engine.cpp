@@ -1609,12 +1609,9 @@ int ensure_mp3(sk_engine *e) {
     return SK_OK;
 }
 
-int mp3_synthesize(sk_engine *e, const sk_mp3_granule_desc *descs, const float *xr, void *pcm_out, uint32_t n, int32_t *status,
-                   bool s16, bool device_ptrs) {
-    if (!e || (n && (!descs || !xr || !pcm_out))) return SK_ERR_INVALID_ARG;
-    if (n == 0) return SK_OK;
-    std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+// e->mu held, device selected
+int mp3_synthesize_locked(sk_engine *e, const sk_mp3_granule_desc *descs, const float *xr, void *pcm_out, uint32_t n, int32_t *status,
+                          bool s16, bool device_ptrs) {
     int rc = ensure_mp3(e);
     if (rc != SK_OK) return rc;
     if (!e->mp3_window_set) return SK_ERR_UNSUPPORTED;  // no synthesis window: sk_mp3_set_synthesis_window first
@@ -1695,6 +1692,15 @@ int mp3_synthesize(sk_engine *e, const sk_mp3_granule_desc *descs, const float *
     SK_HIP(hipMemcpyAsync(pcm_out, e->out_buf.p, out_bytes, hipMemcpyDeviceToHost, e->stream), "D2H mp3 pcm");
     SK_HIP(hipStreamSynchronize(e->stream), "mp3 sync");
     return SK_OK;
+}
+
+int mp3_synthesize(sk_engine *e, const sk_mp3_granule_desc *descs, const float *xr, void *pcm_out, uint32_t n, int32_t *status,
+                   bool s16, bool device_ptrs) {
+    if (!e || (n && (!descs || !xr || !pcm_out))) return SK_ERR_INVALID_ARG;
+    if (n == 0) return SK_OK;
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e);
+    return mp3_synthesize_locked(e, descs, xr, pcm_out, n, status, s16, device_ptrs);
 }
 
 }  // namespace
@@ -1792,13 +1798,13 @@ int sk_mp3_set_band_tables(sk_engine *e, uint32_t sample_rate, const uint16_t *l
     return SK_OK;
 }
 
-int sk_mp3_requantize(sk_engine *e, const sk_mp3_requant_granule *granules, const int16_t *is, float *xr, uint32_t n, int32_t *status) {
-    if (!e || (n && (!granules || !is || !xr))) return SK_ERR_INVALID_ARG;
-    if (n == 0) return SK_OK;
-    for (uint32_t i = 0; i < n; ++i)
-        if (granules[i].channels < 1 || granules[i].channels > 2) return SK_ERR_INVALID_ARG;  // the layout of is / xr depends on it
-    std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+namespace {
+
+// e->mu held, device selected: records + integers up, the kernel; the lines stay on the device in e->out_buf.  pcm_bytes: room
+// the caller wants in e->in_buf afterwards (the kernel is done with it by then in stream order) -- reserved HERE, before
+// anything is enqueued, because DevBuf::reserve frees what it replaces.
+int mp3_requantize_locked(sk_engine *e, const sk_mp3_requant_granule *granules, const int16_t *is, uint32_t n, int32_t *status, size_t pcm_bytes,
+                          size_t *lines_out) {
     int rc = ensure_mp3_requant(e);
     if (rc != SK_OK) return rc;
     std::vector<sk::Mp3RequantRecord> records(n);
@@ -1835,11 +1841,12 @@ int sk_mp3_requantize(sk_engine *e, const sk_mp3_requant_granule *granules, cons
     if (off * 576 > 0xffffffffull) return SK_ERR_INVALID_ARG;
     const size_t lines = (size_t)off * 576, rec_bytes = (size_t)n * sizeof(sk::Mp3RequantRecord);
     const size_t is_at = (rec_bytes + 255) & ~(size_t)255;
-    SK_HIP(e->in_buf.reserve(is_at + lines * sizeof(int16_t) + 16), "alloc mp3 requantisation input");
+    SK_HIP(e->in_buf.reserve(std::max(is_at + lines * sizeof(int16_t), pcm_bytes) + 16), "alloc mp3 requantisation input");
     SK_HIP(e->out_buf.reserve(lines * sizeof(float) + 16), "alloc mp3 requantisation output");
     uint8_t *d_in = (uint8_t *)e->in_buf.p;
     SK_HIP(hipMemcpyAsync(d_in, records.data(), rec_bytes, hipMemcpyHostToDevice, e->stream), "H2D mp3 granule records");
     SK_HIP(hipMemcpyAsync(d_in + is_at, is, lines * sizeof(int16_t), hipMemcpyHostToDevice, e->stream), "H2D mp3 quantised lines");
+    SK_HIP(hipStreamSynchronize(e->stream), "mp3 requantisation upload");  // the records go out of scope
     sk::Mp3RequantArgs a{};
     a.records = (const sk::Mp3RequantRecord *)d_in;
     a.is = (const int16_t *)(d_in + is_at);
@@ -1851,9 +1858,63 @@ int sk_mp3_requantize(sk_engine *e, const sk_mp3_requant_granule *granules, cons
     a.bands = (const uint16_t *)(e->d_mp3_rq + kRqBandsAt);
     a.pretab = e->d_mp3_rq + kRqPretabAt;
     SK_HIP(sk::launch_mp3_requant(a, e->stream), "launch mp3 requantisation");
+    *lines_out = lines;
+    return SK_OK;
+}
+
+// requantisation and hybrid synthesis back to back, the lines never leaving the device: what sk_mp3_decoder_decode_* runs
+int mp3_decode_granules(sk_engine *e, const sk_mp3_requant_granule *granules, const sk_mp3_granule_desc *descs, const int16_t *is, void *pcm_out,
+                        uint32_t n, int32_t *status, bool s16) {
+    if (!e || (n && (!granules || !descs || !is || !pcm_out))) return SK_ERR_INVALID_ARG;
+    if (n == 0) return SK_OK;
+    size_t rows = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (granules[i].channels < 1 || granules[i].channels > 2 || descs[i].channels != granules[i].channels) return SK_ERR_INVALID_ARG;
+        rows += granules[i].channels;
+    }
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e);
+    const size_t pcm_bytes = rows * 576 * (s16 ? sizeof(int16_t) : sizeof(float));
+    size_t lines = 0;
+    std::vector<int32_t> requant_status(n, 0);
+    int rc = mp3_requantize_locked(e, granules, is, n, requant_status.data(), pcm_bytes, &lines);
+    if (rc != SK_OK) return rc;
+    SK_HIP(hipMemsetAsync(e->in_buf.p, 0, pcm_bytes, e->stream), "clear mp3 output");  // granules the synthesis rejects stay silent
+    rc = mp3_synthesize_locked(e, descs, (const float *)e->out_buf.p, e->in_buf.p, n, status, s16, true);
+    if (rc != SK_OK) return rc;
+    SK_HIP(hipMemcpyAsync(pcm_out, e->in_buf.p, pcm_bytes, hipMemcpyDeviceToHost, e->stream), "D2H mp3 pcm");
+    SK_HIP(hipStreamSynchronize(e->stream), "mp3 decode sync");
+    if (status)
+        for (uint32_t i = 0; i < n; ++i)
+            if (status[i] == SK_OK) status[i] = requant_status[i];
+    return SK_OK;
+}
+
+}  // namespace
+
+int sk_mp3_requantize(sk_engine *e, const sk_mp3_requant_granule *granules, const int16_t *is, float *xr, uint32_t n, int32_t *status) {
+    if (!e || (n && (!granules || !is || !xr))) return SK_ERR_INVALID_ARG;
+    if (n == 0) return SK_OK;
+    for (uint32_t i = 0; i < n; ++i)
+        if (granules[i].channels < 1 || granules[i].channels > 2) return SK_ERR_INVALID_ARG;  // the layout of is / xr depends on it
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e);
+    size_t lines = 0;
+    const int rc = mp3_requantize_locked(e, granules, is, n, status, 0, &lines);
+    if (rc != SK_OK) return rc;
     SK_HIP(hipMemcpyAsync(xr, e->out_buf.p, lines * sizeof(float), hipMemcpyDeviceToHost, e->stream), "D2H mp3 lines");
     SK_HIP(hipStreamSynchronize(e->stream), "mp3 requantisation sync");
     return SK_OK;
+}
+
+int sk_mp3_decode_granules_f32(sk_engine *e, const sk_mp3_requant_granule *granules, const sk_mp3_granule_desc *descs, const int16_t *is,
+                               float *pcm_out, uint32_t n, int32_t *status) {
+    return mp3_decode_granules(e, granules, descs, is, pcm_out, n, status, false);
+}
+
+int sk_mp3_decode_granules_s16(sk_engine *e, const sk_mp3_requant_granule *granules, const sk_mp3_granule_desc *descs, const int16_t *is,
+                               int16_t *pcm_out, uint32_t n, int32_t *status) {
+    return mp3_decode_granules(e, granules, descs, is, pcm_out, n, status, true);
 }
 
 int sk_resampler_open(sk_engine *e, uint32_t id, uint32_t in_hz, uint32_t out_hz) {

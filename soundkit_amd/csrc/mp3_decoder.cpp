@@ -338,7 +338,7 @@ struct sk_mp3_decoder {
     std::vector<sk_mp3_requant_granule> granules;
     std::vector<sk_mp3_granule_desc> descs;
     std::vector<int16_t> is;
-    std::vector<float> xr, pcm;
+    std::vector<float> pcm;
     std::vector<int32_t> status;
 };
 
@@ -446,17 +446,14 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
 
     const uint32_t n = (uint32_t)d->granules.size();
     if (n) {
-        d->xr.resize(d->is.size());
         d->status.assign(n, 0);
-        rc = sk_mp3_requantize(d->engine, d->granules.data(), d->is.data(), d->xr.data(), n, d->status.data());
-        if (rc != SK_OK) return rc;
         if (kind == Out::I16) {
-            rc = sk_mp3_hybrid_synthesize_s16(d->engine, d->descs.data(), d->xr.data(), (int16_t *)out, n, d->status.data());
+            rc = sk_mp3_decode_granules_s16(d->engine, d->granules.data(), d->descs.data(), d->is.data(), (int16_t *)out, n, d->status.data());
         } else if (kind == Out::F32) {
-            rc = sk_mp3_hybrid_synthesize_f32(d->engine, d->descs.data(), d->xr.data(), (float *)out, n, d->status.data());
+            rc = sk_mp3_decode_granules_f32(d->engine, d->granules.data(), d->descs.data(), d->is.data(), (float *)out, n, d->status.data());
         } else {
             d->pcm.resize(d->is.size());
-            rc = sk_mp3_hybrid_synthesize_f32(d->engine, d->descs.data(), d->xr.data(), d->pcm.data(), n, d->status.data());
+            rc = sk_mp3_decode_granules_f32(d->engine, d->granules.data(), d->descs.data(), d->is.data(), d->pcm.data(), n, d->status.data());
             for (size_t i = 0; rc == SK_OK && i < samples; ++i) ((int32_t *)out)[i] = mp3_f32_to_i32(d->pcm[i]);
         }
         if (rc != SK_OK) return rc;
