@@ -992,8 +992,8 @@ __global__ __launch_bounds__(128, 2) void k_aac_tail(TailArgs ta) {
             }
         }
         // the samples went in as integers and the taps times 2^16: powers of two, they commute with every rounding
-        const sk_f32x4 v = acc * (1.0f / 2147483648.0f);
-        const uint32_t lo = dev_pack2_s16(v[0], v[1]), hi = dev_pack2_s16(v[2], v[3]);  // outputs 256 T + 16 j + 4 q + (0..3)
+        // fir_bf16.hip's epilogue: the factor 2^-31 (integer samples, taps times 2^16) rides in the conversion's constants
+        const uint32_t lo = dev_pack2_s16_scaled<31>(acc[0], acc[1]), hi = dev_pack2_s16_scaled<31>(acc[2], acc[3]);  // outputs 256 T + 16 j + 4 q + (0..3)
         if (!stereo) {
             const uint32_t m0 = 256u * T + 16u * (uint32_t)(lane & 15) + 4u * (uint32_t)(lane >> 4);
             if (m0 + 3 < n_out) {

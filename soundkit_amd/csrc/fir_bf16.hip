@@ -331,7 +331,15 @@ __global__ __launch_bounds__(64, F16 ? SK_FIR_F16_WAVES : 2) void k_fir_48k_16k_
         }
         // the worker's 16-bit output stage (float_sample_to_i16, interleave) on the four results a lane holds; the
         // conversions are ordinary vector work in the shadow of the matrix instructions
-        const uint32_t mine01 = dev_pack2_s16(v[0], v[1]), mine23 = dev_pack2_s16(v[2], v[3]);  // shortest exact form (sk_device.h)
+        // shortest exact form (sk_device.h); for s16 rows the power of two rides in the conversion's constants
+        uint32_t mine01, mine23;
+        if constexpr (IN16) {
+            mine01 = dev_pack2_s16_scaled<F16 ? 31 : 15>(vraw[0], vraw[1]);
+            mine23 = dev_pack2_s16_scaled<F16 ? 31 : 15>(vraw[2], vraw[3]);
+        } else {
+            mine01 = dev_pack2_s16(v[0], v[1]);
+            mine23 = dev_pack2_s16(v[2], v[3]);
+        }
         if (OUT16 == 2) {
             // the neighbouring row's lane (lane ^ 1) holds the other channel: two packed dwords cross by DPP quad_perm [1,0,3,2]
             const uint32_t other01 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine01, 0xB1, 0xF, 0xF, true);

@@ -146,6 +146,28 @@ __device__ __forceinline__ uint32_t dev_pack2_s16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, p);
 }
 
+// The same conversion for an accumulator that still carries a power-of-two factor 2^EXP (the FIR's s16 rows go in as integers,
+// its f16 taps times 2^16): x = acc * 2^-EXP is folded into the two f64 constants -- exact, a power of two -- which saves the
+// f32 multiply, and a sum of finite products needs no non-finite guard, which saves the fma(x, 0, x).  Same integer as
+// dev_float_sample_to_i16_presat(acc * 2^-EXP) for every finite acc (where that product is an f32 denormal both give 0).
+template <int EXP>
+__device__ __forceinline__ int dev_scaled_sample_to_i16_presat(float acc) {
+    constexpr double kScale = 1.0 / (double)(1ull << EXP);
+    const double X = (double)acc;
+    const double half = __builtin_copysign(0.5, X);
+    const double h = __builtin_fma(__builtin_fabs(X), -0.5 * kScale, half);
+    const double t = __builtin_fma(X, 32767.5 * kScale, h);
+    int k;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(k) : "v"(t));
+    return k;
+}
+template <int EXP>
+__device__ __forceinline__ uint32_t dev_pack2_s16_scaled(float lo, float hi) {
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
+    const s16x2_t p = __builtin_amdgcn_cvt_pk_i16(dev_scaled_sample_to_i16_presat<EXP>(lo), dev_scaled_sample_to_i16_presat<EXP>(hi));
+    return __builtin_bit_cast(uint32_t, p);
+}
+
 // ---- shared by fir_bf16.hip and the fused decode-tail kernel (aac_synth.hip): the f16 form of the 48 -> 16 kHz FIR on s16 samples
 typedef uint32_t sk_u32x4 __attribute__((ext_vector_type(4)));
 typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
