@@ -140,9 +140,22 @@ __device__ __forceinline__ int dev_float_sample_to_i16_presat(float x) {
     asm("v_cvt_i32_f64 %0, %1" : "=v"(k) : "v"(t));  // the instruction's own out-of-range rule, not C's undefined cast
     return k;
 }
+// the part behind the non-finite guard (y = x for finite x, NaN otherwise)
+__device__ __forceinline__ int dev_guarded_sample_to_i16_presat(float y) {
+    const double X = (double)y;
+    const double half = __builtin_copysign(0.5, X);
+    const double h = __builtin_fma(__builtin_fabs(X), -0.5, half);
+    const double t = __builtin_fma(X, 32767.5, h);
+    int k;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(k) : "v"(t));
+    return k;
+}
 __device__ __forceinline__ uint32_t dev_pack2_s16(float lo, float hi) {
     typedef short s16x2_t __attribute__((ext_vector_type(2)));
-    const s16x2_t p = __builtin_amdgcn_cvt_pk_i16(dev_float_sample_to_i16_presat(lo), dev_float_sample_to_i16_presat(hi));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t x = {lo, hi};
+    const f32x2_t y = __builtin_elementwise_fma(x, (f32x2_t){0.0f, 0.0f}, x);  // the guard of both samples in one v_pk_fma_f32
+    const s16x2_t p = __builtin_amdgcn_cvt_pk_i16(dev_guarded_sample_to_i16_presat(y.x), dev_guarded_sample_to_i16_presat(y.y));
     return __builtin_bit_cast(uint32_t, p);
 }
 
