@@ -27,17 +27,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")  # rocprofv3 --pmc passes of this same workload (tools/profile_bench.sh)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc.json")  # rocprofv3 --pmc passes of this same workload (tools/profile_bench.sh)
+PMC_KERNEL = {"aac_synth_s16out": "k_aac_synth", "aac_synth": "k_aac_synth_f32out", "fir_pipeline_s16in": "k_fir_48k_16k"}
 
 
 def pmc_traffic(kind, **config):
-    """HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB), if they were
-    taken on exactly this workload; otherwise None."""
+    """HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB: tools/summarize_pmc.py), if
+    they were taken on exactly this workload; otherwise None."""
     try:
-        entry = json.load(open(PMC_SUMMARY))[kind]
+        summary = json.load(open(PMC_SUMMARY))
+        entry = summary[PMC_KERNEL[kind]]
+        took = summary["_bench_line_under_profiler"]["config"]
     except (OSError, KeyError, ValueError):
         return None
-    return entry["traffic_bytes"] if entry.get("config") == config else None
+    rows = took["streams_per_gpu"] * took["channels"]
+    same = (config == {"streams": took["streams_per_gpu"], "frames": took["frames_per_stream"], "channels": took["channels"]} or
+            config == {"rows": rows, "frames": took["frames_per_stream"] * 1024})
+    return entry["traffic_bytes"] if same else None
 
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak
