@@ -13,8 +13,8 @@
 //
 // One wavefront per granule, four per block.  A lane takes the lines lane + 64 k (k < 9) of both channels in bitstream
 // order: band and window by a 5-step search in the LDS copy of the band table, requantised into registers; the highest
-// occupied band of the right channel is a wave maximum; the stereo step works on the lane's own pair of values; the
-// reorder goes through LDS so that the 576 lines of a channel leave as coalesced rows.  Traffic per granule-channel:
+// occupied band of the right channel is a wave maximum; the stereo step works on the lane's own pair of values; the integers
+// come in and the reordered lines go out through LDS, so that both cross HBM as whole 256-byte runs.  Traffic per granule-channel:
 // 1152 B in, 2304 B out; the kernel is HBM-bound like everything else on this path.
 #include "sk_device.h"
 
@@ -70,6 +70,7 @@ __device__ __forceinline__ Line locate(int i, bool short_lines, const uint16_t *
 
 __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[kWaves][2][576];
+    __shared__ __attribute__((aligned(16))) int16_t qs[kWaves][2 * 576];  // the granule's integers, brought in as whole dwords
     __shared__ uint32_t rec[kWaves][sizeof(Mp3RequantRecord) / 4];
     __shared__ uint16_t tabs[kWaves][kMp3BandRow];
     __shared__ uint8_t pre[kWaves][24];
@@ -93,9 +94,15 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
     }
     if (lane < kMp3BandRow) tabs[wave][lane] = a.bands[g.slot * kMp3BandRow + lane];
     if (lane < 24) pre[wave][lane] = a.pretab[g.slot * 24 + lane];
+    {
+        // 1152 bytes per channel in 256-byte runs (a lane's own lines are 64 apart: read one by one they are 2-byte gathers)
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.is + (size_t)g.off * 576);  // 1152-byte granularity: dword aligned
+        uint32_t *dst = reinterpret_cast<uint32_t *>(qs[wave]);
+        for (int d = lane; d < channels * 288; d += 64) dst[d] = src[d];
+    }
     wave_sync();
     const uint16_t *tab = tabs[wave];
-    const int16_t *is = a.is + (size_t)g.off * 576;
+    const int16_t *is = qs[wave];
 
     const bool is_short = g.ch[0].block_type == 2;  // both channels agree whenever the stereo step looks at it (host check)
     float v[2][9];
