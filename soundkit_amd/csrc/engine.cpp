@@ -79,7 +79,7 @@ struct IndexSet {
 struct RatioTable {
     uint32_t in_hz = 0, out_hz = 0;
     double ratio = 0.0;
-    float *d_sincs = nullptr;  // [256][256]
+    float *d_sincs = nullptr;  // [256][256], then [256][256][2]: {sub-filter, the next one} interleaved
     // streaming: every stream of this ratio walks the same index sequence from -128, so chunk n's set is shared
     std::vector<IndexSet> chunk_sets;
 };
@@ -1438,6 +1438,14 @@ static int ratio_table_for(sk_engine *e, uint32_t in_hz, uint32_t out_hz, int *i
     t.ratio = (double)out_hz / (double)in_hz;
     std::vector<float> sincs;
     make_sinc_table(t.ratio, sincs);
+    // behind the table, the same taps as pairs {sub-filter s, sub-filter s + 1} for the packed form of the two dot products
+    // of an output (resample.hip: dot_pair_packed)
+    sincs.resize(3 * 65536);
+    for (size_t sub = 0; sub < 256; ++sub)
+        for (size_t i = 0; i < 256; ++i) {
+            sincs[65536 + 2 * (sub * 256 + i)] = sincs[sub * 256 + i];
+            sincs[65536 + 2 * (sub * 256 + i) + 1] = sincs[((sub + 1) & 255) * 256 + i];
+        }
     SK_HIP(upload(&t.d_sincs, sincs), "upload sinc table");
     e->ratio_tables.push_back(t);
     *index = (int)e->ratio_tables.size() - 1;

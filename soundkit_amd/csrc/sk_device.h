@@ -236,7 +236,7 @@ hipError_t launch_fir_48k_16k(const FirArgs &a, hipStream_t s);
 struct SincArgs {
     const float *in;          // [phys rows][in_stride]
     float *out;               // [rows][out_stride]
-    const float *sincs;       // [256][256] sub-filter table of this ratio
+    const float *sincs;       // [256][256] sub-filter table of this ratio, followed by [256][256][2]: taps of sub-filters s and s + 1 interleaved
     // Time indices: rubato advances an f64 index by `step` before every output.  Rows may sit at different points of
     // that walk (streams of different ages), so indices come as "sets": set s holds the index of every 32nd output
     // (starts[s * starts_stride + b] = index of output 32 b) and its output count; a lane reproduces the additions
