@@ -424,7 +424,7 @@ def main():
                     help="end_to_end: where the AAC front-end runs -- host threads (f32 spectra over PCIe), host Huffman decode + device "
                          "dequantisation / PNS / stereo tools / TNS (i16 + side records over PCIe), or all of it on the GPU")
     ap.add_argument("--clip", default="aac-stereo-48k.adts", help="end_to_end: ADTS file under tests/golden/aac to loop")
-    ap.add_argument("--feeders", type=int, default=2, help="end_to_end: producer/consumer threads of the load generator")
+    ap.add_argument("--feeders", type=int, default=4, help="end_to_end: producer/consumer threads of the load generator (2 + 2 measured best on the 16-core share: profiles/r03_ab_feeders.md)")
     ap.add_argument("--out-rate", type=int, default=16000, help="end_to_end: DecodeOptions.output_sample_rate (0 = source rate)")
     ap.add_argument("--out-channels", type=int, default=1, help="end_to_end: DecodeOptions.output_channels (0 = source)")
     args = ap.parse_args()
