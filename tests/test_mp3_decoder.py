@@ -217,3 +217,41 @@ def test_lsf_scale_factor_lengths_fit_the_reference_fixtures(codebook):
             head = 4 + 2 * f.has_crc + f.side_info_bytes
             kept = (kept + frame[head:])[-1024:]
     assert checked > 200
+
+
+def test_mutated_streams_under_sanitizers(tmp_path):
+    """tests/fuzz_mp3.cpp: the reference's two MP3 files (and mutants: bit flips, overwritten bytes, cuts, insertions, foreign
+    headers, truncation) through sk_mp3_decoder_* in random chunkings with ASan + UBSan; the GPU stages are stubs that check
+    what reaches them."""
+    import os
+    import re
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "fuzz_mp3")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-Wno-subobject-linkage", "-o", exe, os.path.join(here, "fuzz_mp3.cpp")], cwd=here)
+    golden = os.path.join(here, "golden", "mp3")
+    files = [os.path.join(golden, n) for n in sorted(os.listdir(golden))]
+    # streams the harness can decode: written with ITS code book (fixed-length codes) and band tables, so that the mutants reach
+    # the stages behind the Huffman decoder too
+    fixed = dict(TABLES)
+    fixed["big_values"] = []
+    for t in range(32):
+        n = B.XLEN[t] ** 2
+        bits = max(1, (n - 1).bit_length())
+        fixed["big_values"].append({"xlen": B.XLEN[t], "linbits": B.LINBITS[t], "hlen": [bits] * n, "hcod": list(range(n))} if n else None)
+    fixed["count1"] = [{"hlen": [5] * 16, "hcod": list(range(16))}, {"hlen": [4] * 16, "hcod": list(range(16))}]
+    long_o = [4 * i for i in range(8)] + [36] + [36 + 41 * (i - 8) for i in range(9, 22)] + [576]
+    short_o = [0, 4, 8, 12] + [12 + 15 * (i - 3) for i in range(4, 13)] + [192]
+    fixed["bands"] = {r: (long_o, short_o) for r in B.RATES}
+    for k, params in enumerate((dict(version=1, rate=44100, channels=2, mode=1, joint_modes=(0, 2)), dict(version=2, rate=16000, channels=1, bitrate_indices=(8, 12)),
+                                dict(version=25, rate=11025, channels=2, mode=0, bitrate_indices=(9, 11), crc=True))):
+        data, _ = B.build_stream(fixed, 900 + k, n_frames=24, **params)
+        path = str(tmp_path / ("stream%d.mp3" % k))
+        with open(path, "wb") as fh:
+            fh.write(data)
+        files.append(path)
+    out = subprocess.run([exe, "1500"] + files, capture_output=True, text=True, cwd=here)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
+    calls, samples, errors, granules, gpu_calls = [int(x) for x in re.findall(r"\d+", out.stdout)]
+    assert calls > 50000 and samples > 10 ** 7 and granules > 30000 and errors > 0, out.stdout
