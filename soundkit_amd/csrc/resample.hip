@@ -80,74 +80,211 @@ __device__ __forceinline__ float dot_pair_packed(const float *x, const_pairs s01
     return p0 + frac * (p1 - p0);
 }
 
-__global__ __launch_bounds__(kWaves * 64) void k_sinc_resample(SincArgs a, uint32_t outs_per_block) {
+// Two consecutive outputs of the 64 rows in one pass over the samples: output B's window starts d samples after output A's,
+// so sample p is tap p of A and tap p - d of B -- every LDS read feeds four products instead of two (with sixteen waves per
+// CU the LDS reads weigh as much as the arithmetic).  B's eight running sums are kept under A's numbering (register j holds
+// B's sum (j - d) mod 8) and put back in rubato's order for the final additions; the first d samples belong to A alone, the
+// last d to B alone.  sBm = B's tap pairs moved back by d, so that sBm[p] is tap p - d.
+template <int D>
+__device__ __forceinline__ void sums_in_order(const f2 (&acc)[8], float &p0, float &p1) {
+    p0 = acc[D & 7].x + acc[(1 + D) & 7].x + acc[(2 + D) & 7].x + acc[(3 + D) & 7].x + acc[(4 + D) & 7].x + acc[(5 + D) & 7].x + acc[(6 + D) & 7].x +
+         acc[(7 + D) & 7].x;
+    p1 = acc[D & 7].y + acc[(1 + D) & 7].y + acc[(2 + D) & 7].y + acc[(3 + D) & 7].y + acc[(4 + D) & 7].y + acc[(5 + D) & 7].y + acc[(6 + D) & 7].y +
+         acc[(7 + D) & 7].y;
+}
+__device__ __forceinline__ void dot_two(const float *x, const_pairs sA, const_pairs sBm, int d /* 0..7, wave-uniform */, float frac_a, float frac_b,
+                                        float &out_a, float &out_b) {
+    f2 acc_a[8], acc_b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc_a[j] = acc_b[j] = (f2){0.0f, 0.0f};
+    {
+        float xs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[j] = x[j * kPitch];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc_a[j] += (f2){xs[j], xs[j]} * sA[j];
+            if (j >= d) acc_b[j] += (f2){xs[j], xs[j]} * sBm[j];
+        }
+    }
+    for (int i = 8; i < 256; i += 8) {
+        float xs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[j] = x[(i + j) * kPitch];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc_a[j] += (f2){xs[j], xs[j]} * sA[i + j];
+            acc_b[j] += (f2){xs[j], xs[j]} * sBm[i + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+        if (j < d) acc_b[j] += (f2){x[(256 + j) * kPitch], x[(256 + j) * kPitch]} * sBm[256 + j];
+    float p0, p1;
+    sums_in_order<0>(acc_a, p0, p1);
+    out_a = p0 + frac_a * (p1 - p0);
+    switch (d) {
+    case 0: sums_in_order<0>(acc_b, p0, p1); break;
+    case 1: sums_in_order<1>(acc_b, p0, p1); break;
+    case 2: sums_in_order<2>(acc_b, p0, p1); break;
+    case 3: sums_in_order<3>(acc_b, p0, p1); break;
+    case 4: sums_in_order<4>(acc_b, p0, p1); break;
+    case 5: sums_in_order<5>(acc_b, p0, p1); break;
+    case 6: sums_in_order<6>(acc_b, p0, p1); break;
+    default: sums_in_order<7>(acc_b, p0, p1); break;
+    }
+    out_b = p0 + frac_b * (p1 - p0);
+}
+
+// A workgroup walks `group` consecutive output blocks of its 64 rows.  While the waves work on one block's tile in LDS the
+// threads already hold the next block's input window in registers (its global loads were issued before the dot products
+// began), so the only time nothing is computed is the two barriers around the LDS refill.  With one 109 KB workgroup per CU
+// there is nobody else to cover that latency.
+constexpr int kStageRows = kRows / kWaves;               // rows a wave stages: 4
+constexpr int kStageCols = (kSpanMax + 1 + 63) / 64;     // samples per lane and row: 7
+
+struct OutputAt {  // where an output sits: first sample, sub-filter, blend weight (rubato's own expressions)
+    long index0;
+    int sub0, shift;
+    float frac;
+};
+__device__ __forceinline__ OutputAt output_at(double idx) {
+    OutputAt r;
+    const double fl = floor(idx);
+    r.index0 = (long)fl;
+    r.sub0 = (int)floor((idx - fl) * 256.0);
+    r.shift = r.sub0 + 1 >= 256 ? 1 : 0;
+    const double scaled = idx * 256.0;
+    r.frac = (float)(scaled - floor(scaled));
+    return r;
+}
+
+__global__ __launch_bounds__(kWaves * 64) void k_sinc_resample(SincArgs a, uint32_t outs_per_block, uint32_t group) {
     // dynamic LDS (109 KB: above the static limit): [sample][row] input tile with one more sample row for the rolling read's
-    // look-ahead, the [output][row] result tile, the outputs' time indices
+    // look-ahead, the [output][row] result tile, the outputs' time indices of this block and of the next
     extern __shared__ double lds_raw[];
-    double *sidx = lds_raw;
-    float *tile = reinterpret_cast<float *>(lds_raw + kMaxOuts);
+    double *sidx_buf = lds_raw;  // [2][kMaxOuts]
+    float *tile = reinterpret_cast<float *>(lds_raw + 2 * kMaxOuts);
     float *otile = tile + (kSpanMax + 1) * kPitch;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t row0 = blockIdx.y * kRows;
-    const uint32_t m0 = blockIdx.x * outs_per_block;
     // the rows of a workgroup share their index set (the host groups them)
     const uint32_t set = a.row_set ? a.row_set[row0] : 0;
     const uint32_t count = a.set_count[set];
-    if (m0 >= count) return;  // block-uniform
-    const uint32_t n_here = min(outs_per_block, count - m0);
+    const uint32_t m_first = blockIdx.x * group * outs_per_block;
+    if (m_first >= count) return;  // block-uniform
+    const uint32_t n_blocks = min(group, (count - m_first + outs_per_block - 1) / outs_per_block);
 
     // rubato's own sequence of additions from the nearest index the host sent (f64 addition is not associative: no shortcut)
-    if (threadIdx.x < n_here) {
-        double idx = a.set_starts[(size_t)set * a.starts_stride + (m0 >> 5)];
-        const uint32_t steps = (m0 & 31u) + threadIdx.x;
-        for (uint32_t i = 0; i < steps; ++i) idx += a.step;
-        sidx[threadIdx.x] = idx;
-    }
-    __syncthreads();
-
-    // the block's input window, 64 rows x [floor(idx first), floor(idx last) + 257], transposed into LDS
-    const long base = (long)floor(sidx[0]);
-    const int need = (int)((long)floor(sidx[n_here - 1]) + 258 - base);  // <= kSpanMax by the host's choice of outs_per_block
-    for (int r = wave * (kRows / kWaves); r < (wave + 1) * (kRows / kWaves); ++r) {
-        const uint32_t row = row0 + (uint32_t)r;
+    auto walk = [&](uint32_t m0, double *sidx) {
+        const uint32_t n_here = min(outs_per_block, count - m0);
+        if (threadIdx.x < n_here) {
+            double idx = a.set_starts[(size_t)set * a.starts_stride + (m0 >> 5)];
+            const uint32_t steps = (m0 & 31u) + threadIdx.x;
+            for (uint32_t i = 0; i < steps; ++i) idx += a.step;
+            sidx[threadIdx.x] = idx;
+        }
+    };
+    // the rows this wave stages
+    const float *src[kStageRows];
+    bool live[kStageRows];
+#pragma unroll
+    for (int k = 0; k < kStageRows; ++k) {
+        const uint32_t row = row0 + (uint32_t)(wave * kStageRows + k);
         uint32_t phys = 0xffffffffu;
         if (row < a.rows) phys = a.row_map ? a.row_map[row] : row;
-        const float *src = a.in + (size_t)(phys == 0xffffffffu ? 0 : phys) * a.in_stride;
-        for (int c = lane; c <= need; c += 64) {
-            const long n = base + c - a.in_origin;  // element of the row
-            tile[c * kPitch + r] = (phys != 0xffffffffu && n >= 0 && n < (long)a.in_frames) ? src[n] : 0.0f;
+        live[k] = phys != 0xffffffffu;
+        src[k] = a.in + (size_t)(live[k] ? phys : 0) * a.in_stride;
+    }
+    // a block's input window, 64 rows x [floor(idx first), floor(idx last) + 257], into registers / from registers into LDS
+    float pre[kStageRows][kStageCols];
+    auto fetch = [&](const double *sidx, uint32_t n_here) {
+        const long base = (long)floor(sidx[0]);
+        const int need = (int)((long)floor(sidx[n_here - 1]) + 258 - base);  // <= kSpanMax by the host's choice of outs_per_block
+#pragma unroll
+        for (int k = 0; k < kStageRows; ++k)
+#pragma unroll
+            for (int cc = 0; cc < kStageCols; ++cc) {
+                const int c = lane + 64 * cc;
+                const long n = base + c - a.in_origin;  // element of the row
+                pre[k][cc] = (live[k] && c <= need && n >= 0 && n < (long)a.in_frames) ? src[k][n] : 0.0f;
+            }
+    };
+    auto refill = [&]() {
+#pragma unroll
+        for (int k = 0; k < kStageRows; ++k)
+#pragma unroll
+            for (int cc = 0; cc < kStageCols; ++cc) {
+                const int c = lane + 64 * cc;
+                if (c <= kSpanMax) tile[c * kPitch + wave * kStageRows + k] = pre[k][cc];
+            }
+    };
+
+    walk(m_first, sidx_buf);
+    __syncthreads();
+    fetch(sidx_buf, min(outs_per_block, count - m_first));
+    refill();
+    if (n_blocks > 1) walk(m_first + outs_per_block, sidx_buf + kMaxOuts);
+    __syncthreads();
+
+    const const_floats sincs = reinterpret_cast<const_floats>(reinterpret_cast<uintptr_t>(a.sincs));
+    const const_pairs pairs = reinterpret_cast<const_pairs>(reinterpret_cast<uintptr_t>(a.sincs + 65536));
+    for (uint32_t blk = 0; blk < n_blocks; ++blk) {
+        const uint32_t m0 = m_first + blk * outs_per_block;
+        const uint32_t n_here = min(outs_per_block, count - m0);
+        const double *sidx = sidx_buf + (blk & 1u) * kMaxOuts;
+        const double *sidx_next = sidx_buf + ((blk + 1) & 1u) * kMaxOuts;
+        const bool more = blk + 1 < n_blocks;
+        if (more) fetch(sidx_next, min(outs_per_block, count - (m0 + outs_per_block)));  // in flight during the dot products
+        const long base = (long)floor(sidx[0]);
+
+        for (uint32_t o = 2u * (uint32_t)wave; o < n_here; o += 2 * kWaves) {  // wave-uniform: outputs o and o + 1
+            const OutputAt at = output_at(sidx[o]);
+            const int off = __builtin_amdgcn_readfirstlane((int)(at.index0 - base));
+            const int sub_a = __builtin_amdgcn_readfirstlane(at.sub0);
+            const float *x = tile + off * kPitch + lane;
+            bool paired = false;
+            if (o + 1 < n_here) {
+                const OutputAt bt = output_at(sidx[o + 1]);
+                const int d = __builtin_amdgcn_readfirstlane((int)(bt.index0 - at.index0));
+                const int sub_b = __builtin_amdgcn_readfirstlane(bt.sub0);
+                if (!__builtin_amdgcn_readfirstlane(at.shift | bt.shift) && d >= 0 && d <= 7) {
+                    float va, vb;
+                    dot_two(x, pairs + sub_a * 256, pairs + sub_b * 256 - d, d, at.frac, bt.frac, va, vb);
+                    otile[o * kPitch + lane] = va;
+                    otile[(o + 1) * kPitch + lane] = vb;
+                    paired = true;
+                } else {
+                    const int off_b = __builtin_amdgcn_readfirstlane((int)(bt.index0 - base));
+                    const float *xb = tile + off_b * kPitch + lane;
+                    const int sub_b1 = (sub_b + 1) & 255;
+                    otile[(o + 1) * kPitch + lane] = __builtin_amdgcn_readfirstlane(bt.shift)
+                                                         ? dot_pair<1>(xb, sincs + sub_b * 256, sincs + sub_b1 * 256, bt.frac)
+                                                         : dot_pair_packed(xb, pairs + sub_b * 256, bt.frac);
+                }
+            }
+            if (!paired) {
+                const int sub_a1 = (sub_a + 1) & 255;
+                otile[o * kPitch + lane] = __builtin_amdgcn_readfirstlane(at.shift) ? dot_pair<1>(x, sincs + sub_a * 256, sincs + sub_a1 * 256, at.frac)
+                                                                                    : dot_pair_packed(x, pairs + sub_a * 256, at.frac);
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();  // the tile has been read, the results are in otile
 
-    for (uint32_t o = (uint32_t)wave; o < n_here; o += kWaves) {  // wave-uniform
-        const double idx = sidx[o];
-        const double fl = floor(idx);
-        const long index0 = (long)fl;
-        long sub0 = (long)floor((idx - fl) * 256.0);
-        long sub1 = sub0 + 1;
-        const int shift = sub1 >= 256 ? 1 : 0;
-        if (shift) sub1 -= 256;
-        const double scaled = idx * 256.0;
-        const float frac = (float)(scaled - floor(scaled));
-        const int off = __builtin_amdgcn_readfirstlane((int)(index0 - base));
-        const const_floats s0 = reinterpret_cast<const_floats>(reinterpret_cast<uintptr_t>(a.sincs)) + __builtin_amdgcn_readfirstlane((int)sub0) * 256;
-        const const_floats s1 = reinterpret_cast<const_floats>(reinterpret_cast<uintptr_t>(a.sincs)) + __builtin_amdgcn_readfirstlane((int)sub1) * 256;
-        const float *x = tile + off * kPitch + lane;
-        const const_pairs s01 = reinterpret_cast<const_pairs>(reinterpret_cast<uintptr_t>(a.sincs + 65536)) + __builtin_amdgcn_readfirstlane((int)sub0) * 256;
-        const float v = __builtin_amdgcn_readfirstlane(shift) ? dot_pair<1>(x, s0, s1, frac) : dot_pair_packed(x, s01, frac);
-        otile[o * kPitch + lane] = v;
-    }
-    __syncthreads();
-
-    // rows leave in runs of n_here consecutive outputs: lane = output, 32 rows per pass of the block
-    for (int r = (int)(threadIdx.x >> 5); r < kRows; r += kWaves * 2) {
-        const uint32_t row = row0 + (uint32_t)r, o = threadIdx.x & 31u;
-        if (row >= a.rows || o >= n_here) continue;
-        if (a.row_map && a.row_map[row] == 0xffffffffu) continue;  // a padding row of the host's grouping
-        float *dst = a.out + (size_t)row * a.out_stride + (a.out_off ? a.out_off[row] : 0);
-        dst[m0 + o] = otile[o * kPitch + r];
+        // rows leave in runs of n_here consecutive outputs: lane = output, 32 rows per pass of the block
+        for (int r = (int)(threadIdx.x >> 5); r < kRows; r += kWaves * 2) {
+            const uint32_t row = row0 + (uint32_t)r, o = threadIdx.x & 31u;
+            if (row >= a.rows || o >= n_here) continue;
+            if (a.row_map && a.row_map[row] == 0xffffffffu) continue;  // a padding row of the host's grouping
+            float *dst = a.out + (size_t)row * a.out_stride + (a.out_off ? a.out_off[row] : 0);
+            dst[m0 + o] = otile[o * kPitch + r];
+        }
+        if (more) {
+            refill();
+            if (blk + 2 < n_blocks) walk(m0 + 2 * outs_per_block, sidx_buf + (blk & 1u) * kMaxOuts);  // this block's slot is free now
+        }
+        __syncthreads();
     }
 }
 
@@ -182,12 +319,15 @@ hipError_t launch_sinc_resample(const SincArgs &a, hipStream_t s) {
     uint32_t outs = kMaxOuts;
     while (outs > 1 && (double)outs * a.step + 260.0 > (double)kSpanMax) outs >>= 1;
     if ((double)outs * a.step + 260.0 > (double)kSpanMax) return hipErrorInvalidValue;  // step > ~120: no common rate pair
-    const dim3 grid((a.out_count + outs - 1) / outs, row_blocks);
-    constexpr size_t lds_bytes = kMaxOuts * sizeof(double) + ((size_t)(kSpanMax + 1) * kPitch + (size_t)kMaxOuts * kPitch) * sizeof(float);
+    // a workgroup takes `group` consecutive blocks of outputs, the next one's input prefetched while it works on the current
+    const uint32_t n_out_blocks = (a.out_count + outs - 1) / outs;
+    const uint32_t group = n_out_blocks >= 64 ? 8u : (n_out_blocks >= 8 ? 4u : 1u);
+    const dim3 grid((n_out_blocks + group - 1) / group, row_blocks);
+    constexpr size_t lds_bytes = 2 * kMaxOuts * sizeof(double) + ((size_t)(kSpanMax + 1) * kPitch + (size_t)kMaxOuts * kPitch) * sizeof(float);
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sinc_resample), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        (int)lds_bytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(k_sinc_resample, grid, dim3(kWaves * 64), lds_bytes, s, a, outs);
+    hipLaunchKernelGGL(k_sinc_resample, grid, dim3(kWaves * 64), lds_bytes, s, a, outs, group);
     return hipGetLastError();
 }
 

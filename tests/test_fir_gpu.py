@@ -307,3 +307,18 @@ def test_bf16_split_fir_is_f32_accurate(engine, oracle, amplitude):
     exact = np.stack([padded[r][idx] @ taps for r in range(16)])
     err_gpu, err_f32 = rel_rms(got, exact), rel_rms(want32, exact)
     assert err_f32 < 2e-7 and err_gpu < 3e-7, (err_gpu, err_f32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_hz,out_hz", [(44100, 16000), (22050, 16000), (16000, 48000), (96000, 8000), (44100, 48000), (32000, 44100)])
+def test_generic_ratios_are_bit_identical_to_the_restated_rubato(engine, oracle, in_hz, out_hz):
+    """k_sinc_resample keeps rubato's order of operations (eight running sums per dot product, separate multiplies and adds,
+    p0 + frac (p1 - p0)) through the packed form, the two-outputs-per-pass form (window offsets 0..7) and the fallbacks: the
+    result is the oracle's f32 restatement bit for bit, not merely within the float tolerance.  130 rows = two full row
+    blocks and a ragged one."""
+    rng = np.random.default_rng(in_hz + out_hz)
+    x = rng.uniform(-1, 1, (130, 30000)).astype(np.float32)
+    got = engine.downsample(x, in_hz, out_hz)
+    for rows in ((0, 3), (63, 66), (127, 130)):
+        want = oracle.downsample_planar(x[rows[0]:rows[1]], in_hz, out_hz)
+        assert got.shape[1] == want.shape[1] and np.array_equal(got[rows[0]:rows[1]], want)
