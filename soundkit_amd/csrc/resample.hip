@@ -13,13 +13,17 @@
 // Mapping (round 3; the first form gave every lane its own output of one row, so that the 64 lanes of a wave read 64
 // different 1 KiB sub-filters from L2 for every tap: 4.6 G outputs/s, 6 % of the vector peak):
 //   the rows of a launch that sit at the same point of the walk ask for the SAME sub-filters at the same output, so a
-//   wave takes ONE output of 64 rows.  The taps are then wave-uniform: they arrive by scalar loads and enter the
+//   wave takes outputs of 64 rows at a time.  The taps are then wave-uniform: they arrive by scalar loads and enter the
 //   multiplies as scalar operands -- no vector-memory or LDS traffic for 512 of the 770 operands of an output.  The
 //   inputs of the block's 64 rows sit in LDS transposed ([sample][row], pitch 65: lane = row reads and lane = sample
-//   writes are both conflict-free); the sixteen waves of a block share that tile (109 KB: one block per CU, so the block
-//   itself has to bring the four waves per SIMD that hide the scalar loads' and the LDS reads' latency -- with four waves
-//   per block the same kernel ran at 6.9 G outputs/s) and take every sixteenth of its (up to 32) outputs; results leave
-//   through a small transposed tile so that every row is written in runs.
+//   writes are both conflict-free); the sixteen waves of a block share that tile (134 KB: one block per CU, so the block
+//   itself has to bring the four waves per SIMD that hide the scalar loads' and the LDS reads' latency) and take its (up to
+//   64) outputs two at a time; results leave through a small transposed tile so that every row is written in runs.
+//   Three things on top (28.4 ms -> 6.8 -> 4.4 ms at 4096 x 2 rows x 1 s of 44.1 -> 16 kHz): the two dot
+//   products of an output share the packed f32 instructions; a wave computes two consecutive outputs in one pass over the
+//   samples (dot_two); a workgroup walks several consecutive output blocks and has the next block's input in registers
+//   while it works on the current one.  rubato's order of operations survives all three: the results are the oracle's bits
+//   (tests/test_fir_gpu.py::test_generic_ratios_are_bit_identical_to_the_restated_rubato).
 #include "sk_device.h"
 
 namespace sk {
@@ -27,8 +31,8 @@ namespace sk {
 namespace {
 
 constexpr int kRows = 64;        // rows per workgroup (one per lane)
-constexpr int kMaxOuts = 32;     // outputs per workgroup at most (the index sets carry the index of every 32nd output)
-constexpr int kSpanMax = 384;    // input samples staged per row: covers kMaxOuts outputs down to ratio ~1/4, fewer outputs below
+constexpr int kMaxOuts = 64;     // outputs per workgroup at most (the index sets carry the index of every 32nd output: a block starts at one)
+constexpr int kSpanMax = 448;    // input samples staged per row: 64 outputs down to ratio ~1/3 (44.1 -> 16 kHz needs 437), fewer outputs below
 constexpr int kPitch = kRows + 1;
 constexpr int kWaves = 16;       // waves per workgroup
 
@@ -138,7 +142,7 @@ __device__ __forceinline__ void dot_two(const float *x, const_pairs sA, const_pa
 
 // A workgroup walks `group` consecutive output blocks of its 64 rows.  While the waves work on one block's tile in LDS the
 // threads already hold the next block's input window in registers (its global loads were issued before the dot products
-// began), so the only time nothing is computed is the two barriers around the LDS refill.  With one 109 KB workgroup per CU
+// began), so the only time nothing is computed is the two barriers around the LDS refill.  With one 134 KB workgroup per CU
 // there is nobody else to cover that latency.
 constexpr int kStageRows = kRows / kWaves;               // rows a wave stages: 4
 constexpr int kStageCols = (kSpanMax + 1 + 63) / 64;     // samples per lane and row: 7
@@ -160,7 +164,7 @@ __device__ __forceinline__ OutputAt output_at(double idx) {
 }
 
 __global__ __launch_bounds__(kWaves * 64) void k_sinc_resample(SincArgs a, uint32_t outs_per_block, uint32_t group) {
-    // dynamic LDS (109 KB: above the static limit): [sample][row] input tile with one more sample row for the rolling read's
+    // dynamic LDS (134 KB: above the static limit): [sample][row] input tile with one more sample row for the rolling read's
     // look-ahead, the [output][row] result tile, the outputs' time indices of this block and of the next
     extern __shared__ double lds_raw[];
     double *sidx_buf = lds_raw;  // [2][kMaxOuts]
@@ -180,8 +184,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_sinc_resample(SincArgs a, uint3
     auto walk = [&](uint32_t m0, double *sidx) {
         const uint32_t n_here = min(outs_per_block, count - m0);
         if (threadIdx.x < n_here) {
-            double idx = a.set_starts[(size_t)set * a.starts_stride + (m0 >> 5)];
-            const uint32_t steps = (m0 & 31u) + threadIdx.x;
+            const uint32_t m = m0 + threadIdx.x;
+            double idx = a.set_starts[(size_t)set * a.starts_stride + (m >> 5)];
+            const uint32_t steps = m & 31u;
             for (uint32_t i = 0; i < steps; ++i) idx += a.step;
             sidx[threadIdx.x] = idx;
         }
@@ -272,9 +277,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_sinc_resample(SincArgs a, uint3
         }
         __syncthreads();  // the tile has been read, the results are in otile
 
-        // rows leave in runs of n_here consecutive outputs: lane = output, 32 rows per pass of the block
-        for (int r = (int)(threadIdx.x >> 5); r < kRows; r += kWaves * 2) {
-            const uint32_t row = row0 + (uint32_t)r, o = threadIdx.x & 31u;
+        // rows leave in runs of n_here consecutive outputs: lane = output, 16 rows per pass of the block
+        for (int r = (int)(threadIdx.x >> 6); r < kRows; r += kWaves) {
+            const uint32_t row = row0 + (uint32_t)r, o = threadIdx.x & 63u;
             if (row >= a.rows || o >= n_here) continue;
             if (a.row_map && a.row_map[row] == 0xffffffffu) continue;  // a padding row of the host's grouping
             float *dst = a.out + (size_t)row * a.out_stride + (a.out_off ? a.out_off[row] : 0);
