@@ -90,6 +90,10 @@ const char *sk_engine_last_hip_error(const sk_engine *);
  * sk_engine_debug_fail_after: the n-th HIP call from now fails as a launch failure (error-path tests; 0 disarms). */
 const char *sk_engine_where(const sk_engine *);
 int sk_engine_set_wait_bound(sk_engine *, double seconds);
+/* Generic-ratio resampling (every pair of soundkit's common rates other than 48 -> 16 kHz) runs on the matrix cores, held to
+ * the float tolerance like the 48 -> 16 kHz FIR.  exact = 1 selects the scalar form instead, whose sums keep rubato's order
+ * of operations: the restated reference bit for bit, about five times slower. */
+int sk_engine_set_resampler_exact(sk_engine *, int exact);
 int sk_engine_debug_fail_after(sk_engine *, int n_hip_calls);
 const char *sk_strerror(int status);
 const char *sk_version(void);

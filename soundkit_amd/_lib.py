@@ -275,6 +275,7 @@ _sig = {
     "sk_aac_expand_q_decode": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "sk_engine_where": (C.c_char_p, [_vp]),
     "sk_engine_set_wait_bound": (_i, [_vp, C.c_double]),
+    "sk_engine_set_resampler_exact": (_i, [_vp, _i]),
     "sk_engine_debug_fail_after": (_i, [_vp, _i]),
     "sk_pipeline_debug_dump": (_sz, [_vp, _vp, _sz]),
     "sk_tick_out_bound": (_sz, [_vp, _u32, C.POINTER(_u32)]),

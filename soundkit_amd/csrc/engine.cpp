@@ -226,6 +226,8 @@ struct sk_engine {
 
     // grow-only scratch
     DevBuf in_buf, out_buf, aux_buf, aux2_buf;
+    DevBuf sinc_scratch;      // tap fragments of the matrix-core resampler (resample.hip), sized per launch
+    bool sinc_exact = false;  // sk_engine_set_resampler_exact: the scalar form that keeps rubato's order of operations
     // sk_tick_run: synthesis output, resampler output, packed bytes, small-array arena (+ pinned host mirror)
     DevBuf tick_pcm, tick_res, tick_out, tick_arena, tick_au, tick_side, tick_q;
     // entropy decode on the device (sk_tick_run_au): per-stream PNS generator state and the front-end's tables
@@ -533,6 +535,7 @@ void sk_engine_destroy(sk_engine *e) {
         DeviceGuard guard(e);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         if (e->d_reset_ids) (void)hipFree(e->d_reset_ids);
+        e->sinc_scratch.release();
         for (void *p : {(void *)e->d_mp3_rq, (void *)e->d_mp3_tables, (void *)e->d_mp3_state, (void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
                         (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag16, (void *)e->d_afrag_f16,
                         (void *)e->d_zeros})
@@ -568,6 +571,13 @@ const char *sk_engine_where(const sk_engine *e) { return e ? e->where.load() : "
 int sk_engine_debug_fail_after(sk_engine *e, int n_hip_calls) {
     if (!e || n_hip_calls < 0) return SK_ERR_INVALID_ARG;
     e->fail_after.store(n_hip_calls);
+    return SK_OK;
+}
+
+int sk_engine_set_resampler_exact(sk_engine *e, int exact) {
+    if (!e) return SK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->sinc_exact = exact != 0;
     return SK_OK;
 }
 
@@ -1530,6 +1540,12 @@ int sk_downsample_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uin
     a.in_frames = frames;
     a.out_count = n_out;
     a.in_origin = 0;
+    a.n_sets = 1;
+    a.exact = e->sinc_exact;
+    if (!a.exact) {
+        const size_t want = sk::sinc_mfma_scratch_bytes(1, n_out, a.step);
+        if (want && e->sinc_scratch.reserve(want) == hipSuccess) a.scratch = e->sinc_scratch.p, a.scratch_bytes = e->sinc_scratch.cap;
+    }
     const uint32_t rows_per_launch = 65535u * sk::sinc_rows_per_block();  // grid.y limit
     for (uint32_t r0 = 0; r0 < rows; r0 += rows_per_launch) {
         sk::SincArgs part = a;
@@ -2163,6 +2179,12 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
                 a.in_frames = kRsRow;
                 a.out_count = max_count;
                 a.in_origin = -(int32_t)kRsHist;  // indices are relative to the chunk start; the row starts 512 earlier
+                a.n_sets = (uint32_t)sets.size();
+                a.exact = e->sinc_exact;
+                if (!a.exact) {
+                    const size_t want = sk::sinc_mfma_scratch_bytes(a.n_sets, max_count, a.step);
+                    if (want && e->sinc_scratch.reserve(want) == hipSuccess) a.scratch = e->sinc_scratch.p, a.scratch_bytes = e->sinc_scratch.cap;
+                }
                 const uint32_t rows_per_launch = 65535u * sk::sinc_rows_per_block();  // grid.y limit; a multiple of the block's rows
                 for (uint32_t r0 = 0; r0 < a.rows; r0 += rows_per_launch) {
                     sk::SincArgs part = a;

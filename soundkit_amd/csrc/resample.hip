@@ -293,6 +293,201 @@ __global__ __launch_bounds__(kWaves * 64) void k_sinc_resample(SincArgs a, uint3
     }
 }
 
+// ---- the same resampler on the matrix cores -------------------------------------------------------------------------------------
+// An output is a 256-tap (257 where the second sub-filter wraps) dot product of its row's samples with ONE effective filter,
+//     g[p] = (1 - frac) sincs[sub][p] + frac sincs[sub + 1][p - shift],
+// and the filter depends on the output's place in the walk only -- not on the row.  So per 16 consecutive outputs (a tile)
+// the sixteen filters, placed at their offsets from the tile's first sample, are the A operand of the FIR's matrix product
+// (fir_bf16.hip):  D[i][j] += A_s[i][k] B_s[k][j],  i = output of the tile, j = one of 16 rows, k = 32 samples of window s,
+//     A_s[i][k] = g_i[32 s + k - (index0_i - base)],   B_s[k][j] = x_j[base + 32 s + k],
+// both split exactly into three bf16 planes and multiplied as the six products  x1h1, x1h2, x2h1, x2h2, x1h3, x3h1  (what is
+// left out is below 2^-24 |x||h|: one f32 rounding; 2.2e-7 relative RMS against f64 on the 48 -> 16 kHz path that uses the same
+// products).  k_sinc_taps builds the A fragments of every tile of every index set once per launch (they are shared by all
+// rows of the set: thousands of them in a batch); k_sinc_mfma stages 32 rows x the span of eight tiles as bf16 planes in LDS,
+// one wave per tile, two row groups per wave.  This form does NOT keep rubato's order of operations (the scalar form above
+// does, bit for bit, and stays available: SincArgs::exact); it is held to the float tolerance like the 48 -> 16 kHz FIR.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMfmaRows = 32;                    // rows per workgroup: two row groups of 16
+constexpr int kMfmaTiles = 8;                    // tiles (of 16 outputs) per workgroup at most: one per wave
+constexpr int kMfmaSpan = 704;                   // samples staged per row
+constexpr int kMfmaPitch = 2 * kMfmaSpan + 16;   // bytes per row of a plane: 1424 = 16 * 89, odd multiple of 16: conflict-free b128 reads
+constexpr int kMfmaPlane = kMfmaRows * kMfmaPitch;
+constexpr int kMaxWindows = 12;                  // windows of a tile held in registers: steps up to ~6.9 (96 -> 16 kHz: 6); beyond: the scalar form
+
+struct TileMeta {
+    int32_t base;      // first sample of window 0 (a multiple of 8), in the index time base
+    int32_t windows;   // 32-sample windows of this tile; 0: no outputs
+};
+
+// x = p1 + p2 + p3 exactly, each a bf16 (the top half of an f32 word); two values per dword, the earlier one low
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
+    const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+// grid (tiles, sets), one wave: the A fragments [window][plane][lane] of tile t of index set `set`, and its TileMeta
+__global__ __launch_bounds__(64) void k_sinc_taps(SincArgs a, uint32_t n_tiles, uint32_t max_windows, u32x4 *frags, TileMeta *meta) {
+    const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
+    const uint32_t t = blockIdx.x, set = blockIdx.y;
+    const uint32_t count = a.set_count[set];
+    TileMeta *my_meta = meta + (size_t)set * n_tiles + t;
+    if (16u * t >= count) {
+        if (lane == 0) *my_meta = TileMeta{0, 0};
+        return;
+    }
+    const uint32_t last = min(15u, count - 1u - 16u * t);  // the tile's last output
+    const uint32_t m = 16u * t + min((uint32_t)i, last);
+    double idx = a.set_starts[(size_t)set * a.starts_stride + (m >> 5)];
+    for (uint32_t k = 0; k < (m & 31u); ++k) idx += a.step;  // rubato's own additions
+    const OutputAt at = output_at(idx);
+    const int index0 = (int)at.index0;
+    const int base = (__shfl(index0, 0) >> 3) << 3;  // floor to a multiple of 8: 16-byte aligned reads of the bf16 planes
+    const int windows = (__shfl(index0, (int)last) - base + 257 + 31) / 32;
+    if (lane == 0) *my_meta = TileMeta{base, windows <= (int)max_windows ? windows : 0};
+    if (windows > (int)max_windows) return;  // (the host sized max_windows for this step: not reached)
+    const bool valid = (uint32_t)i <= last;
+    const float *s0 = a.sincs + (size_t)at.sub0 * 256, *s1 = a.sincs + (size_t)((at.sub0 + 1) & 255) * 256;
+    const int delta = index0 - base;
+    u32x4 *out = frags + ((size_t)set * n_tiles + t) * max_windows * 3 * 64 + lane;
+    for (int s = 0; s < windows; ++s) {
+        float g[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int p = 32 * s + 8 * q + kk - delta, pb = p - at.shift;
+            const float ta = (valid && p >= 0 && p < 256) ? s0[p] : 0.0f;
+            const float tb = (valid && pb >= 0 && pb < 256) ? s1[pb] : 0.0f;
+            g[kk] = ta + at.frac * (tb - ta);
+        }
+        u32x4 pl[3];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            uint32_t p1, p2, p3;
+            split3(g[2 * h], g[2 * h + 1], p1, p2, p3);
+            pl[0][h] = p1, pl[1][h] = p2, pl[2][h] = p3;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[(size_t)(s * 3 + k) * 64] = pl[k];
+    }
+}
+
+__global__ __launch_bounds__(kMfmaTiles * 64, 1) void k_sinc_mfma(SincArgs a, uint32_t n_tiles, uint32_t max_windows, uint32_t tiles_per_block,
+                                                               const u32x4 *frags, const TileMeta *meta) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char planes[];  // [3][kMfmaRows][kMfmaPitch]
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // row blocks vary fastest: the workgroups that run together share their tiles' fragments (240 KB per block of eight tiles)
+    // in L2; with the tiles fastest every workgroup streamed its own 240 KB of a 30 MB table past a 4 MB cache
+    const uint32_t row0 = blockIdx.x * kMfmaRows;
+    const uint32_t set = a.row_set ? a.row_set[row0] : 0;  // 64 consecutive rows share their set (the host's grouping): so do 32
+    const uint32_t count = a.set_count[set];
+    const uint32_t t0 = blockIdx.y * tiles_per_block;
+    if (16u * t0 >= count) return;  // block-uniform
+    const uint32_t nt = min(tiles_per_block, (count - 16u * t0 + 15u) / 16u);
+    const TileMeta *tm = meta + (size_t)set * n_tiles + t0;
+    const int base_first = tm[0].base;
+    int span = 0;
+    for (uint32_t k = 0; k < nt; ++k) span = max(span, tm[k].base + 32 * tm[k].windows - base_first);
+    if (span > kMfmaSpan) return;  // (the host chose tiles_per_block for this step: not reached)
+
+    // The wave's tap fragments first: up to 16 windows x 3 planes in registers (two waves per SIMD: 256 registers each), so
+    // that their trip from L2 runs under the staging below instead of in front of every window's matrix instructions.
+    const bool has_tile = (uint32_t)wave < nt;
+    const uint32_t t = t0 + (uint32_t)wave;
+    const int off = has_tile ? __builtin_amdgcn_readfirstlane(tm[has_tile ? wave : 0].base - base_first) : 0;  // a multiple of 8
+    const int windows = has_tile ? __builtin_amdgcn_readfirstlane(tm[has_tile ? wave : 0].windows) : 0;
+    const u32x4 *fa = frags + ((size_t)set * n_tiles + t) * max_windows * 3 * 64 + lane;
+    u32x4 h[kMaxWindows][3];
+#pragma unroll
+    for (int s = 0; s < kMaxWindows; ++s)
+        if (s < windows) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)  // issued HERE by hand: an ordinary load is sunk to its use behind the barrier, a volatile one bypasses L2
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(h[s][k]) : "v"(fa + (size_t)(s * 3 + k) * 64) : "memory");
+        }
+
+    // stage: 32 rows x span samples from base_first, as three bf16 planes; a thread takes pairs of samples.  All of a wave's
+    // loads (4 rows x 6 pairs per lane) are issued before the first is used: one trip to memory per block, not one per pair.
+    constexpr int kStageR = kMfmaRows / kMfmaTiles, kStageC = (kMfmaSpan / 2 + 63) / 64;
+    float pre[kStageR][kStageC][2];
+#pragma unroll
+    for (int k = 0; k < kStageR; ++k) {
+        const uint32_t row = row0 + (uint32_t)(wave + kMfmaTiles * k);
+        uint32_t phys = 0xffffffffu;
+        if (row < a.rows) phys = a.row_map ? a.row_map[row] : row;
+        const float *src = a.in + (size_t)(phys == 0xffffffffu ? 0 : phys) * a.in_stride;
+#pragma unroll
+        for (int cc = 0; cc < kStageC; ++cc) {
+            const int c2 = lane + 64 * cc;
+            const long n = (long)base_first + 2 * c2 - a.in_origin;
+            const bool live = phys != 0xffffffffu && 2 * c2 < span;
+            pre[k][cc][0] = (live && n >= 0 && n < (long)a.in_frames) ? src[n] : 0.0f;
+            pre[k][cc][1] = (live && n + 1 >= 0 && n + 1 < (long)a.in_frames) ? src[n + 1] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kStageR; ++k) {
+        unsigned char *dst = planes + (wave + kMfmaTiles * k) * kMfmaPitch;
+#pragma unroll
+        for (int cc = 0; cc < kStageC; ++cc) {
+            const int c2 = lane + 64 * cc;
+            if (2 * c2 >= span) continue;
+            uint32_t p1, p2, p3;
+            split3(pre[k][cc][0], pre[k][cc][1], p1, p2, p3);
+            *reinterpret_cast<uint32_t *>(dst + 4 * c2) = p1;
+            *reinterpret_cast<uint32_t *>(dst + kMfmaPlane + 4 * c2) = p2;
+            *reinterpret_cast<uint32_t *>(dst + 2 * kMfmaPlane + 4 * c2) = p3;
+        }
+    }
+    __syncthreads();
+    if (!has_tile) return;
+    // the hand-issued loads have landed (the staging loads behind them were waited for above: vector memory returns in order);
+    // the registers pass through the statement so that nothing that reads them is scheduled in front of it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < kMaxWindows; ++s) asm volatile("" : "+v"(h[s][0]), "+v"(h[s][1]), "+v"(h[s][2]));
+
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < kMaxWindows; ++s) {
+        if (s >= windows) continue;  // (wave-uniform; no break: the loop must unroll for h[s] to stay in registers)
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            const unsigned char *bp = planes + (rg * 16 + j) * kMfmaPitch + 2 * (off + 32 * s + 8 * q);
+            const u32x4 x0 = *reinterpret_cast<const u32x4 *>(bp), x1 = *reinterpret_cast<const u32x4 *>(bp + kMfmaPlane),
+                        x2 = *reinterpret_cast<const u32x4 *>(bp + 2 * kMfmaPlane);
+            f32x4 c = acc[rg];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x1), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, x1), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][2]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x2), c, 0, 0, 0);
+            acc[rg] = c;
+        }
+    }
+    // D[i][j]: lane (j, q) holds outputs i = 4 q .. 4 q + 3 of row j of each row group
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) {
+        const uint32_t row = row0 + (uint32_t)(rg * 16 + j);
+        if (row >= a.rows) continue;
+        if (a.row_map && a.row_map[row] == 0xffffffffu) continue;  // a padding row of the host's grouping
+        float *dst = a.out + (size_t)row * a.out_stride + (a.out_off ? a.out_off[row] : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t mo = 16u * t + 4u * (uint32_t)q + (uint32_t)r;
+            if (mo < count) dst[mo] = acc[rg][r];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_row_copies(const float *src_base, float *dst_base, const RowCopy *jobs,
                                                     uint32_t n_jobs) {
     const uint32_t j = blockIdx.y;
@@ -315,8 +510,49 @@ __global__ __launch_bounds__(256) void k_row_copies(const float *src_base, float
 
 uint32_t sinc_rows_per_block() { return kRows; }
 
+// windows a tile can need at this step: 16 outputs spread over 15 steps, + up to 7 samples of alignment, + 257 taps
+static uint32_t sinc_mfma_windows(double step) { return (uint32_t)((15.0 * step + 1.0 + 7.0 + 257.0 + 31.0) / 32.0); }
+static uint32_t sinc_mfma_tiles_per_block(double step) {
+    uint32_t tiles = kMfmaTiles;
+    // span of `tiles` consecutive tiles: their bases spread over (tiles - 1) * 16 steps, the last one's windows behind it
+    while (tiles > 1 && (tiles - 1) * 16.0 * step + 8.0 + 32.0 * sinc_mfma_windows(step) > (double)kMfmaSpan) tiles >>= 1;
+    return tiles;
+}
+
+size_t sinc_mfma_scratch_bytes(uint32_t n_sets, uint32_t out_count, double step) {
+    if (n_sets == 0 || out_count == 0) return 0;
+    const uint32_t windows = sinc_mfma_windows(step);
+    if (windows > (uint32_t)kMaxWindows || 32.0 * windows + 8.0 > (double)kMfmaSpan) return 0;
+    const size_t tiles = (out_count + 15) / 16;
+    const size_t bytes = (size_t)n_sets * tiles * ((size_t)windows * 3 * 1024 + sizeof(TileMeta)) + 256;
+    return bytes > ((size_t)64 << 30) ? 0 : bytes;
+}
+
+static hipError_t launch_sinc_mfma(const SincArgs &a, hipStream_t s) {
+    const uint32_t windows = sinc_mfma_windows(a.step), tiles = (a.out_count + 15) / 16, tpb = sinc_mfma_tiles_per_block(a.step);
+    const size_t frag_bytes = (size_t)a.n_sets * tiles * windows * 3 * 1024;
+    u32x4 *frags = reinterpret_cast<u32x4 *>(a.scratch);
+    TileMeta *meta = reinterpret_cast<TileMeta *>(reinterpret_cast<unsigned char *>(a.scratch) + ((frag_bytes + 255) & ~(size_t)255));
+    const uint32_t row_blocks = (a.rows + kMfmaRows - 1) / kMfmaRows;
+    if ((tiles + tpb - 1) / tpb > 65535 || a.n_sets > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sinc_taps, dim3(tiles, a.n_sets), dim3(64), 0, s, a, tiles, windows, frags, meta);
+    constexpr size_t lds_bytes = 3 * (size_t)kMfmaPlane;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sinc_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)lds_bytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(k_sinc_mfma, dim3(row_blocks, (tiles + tpb - 1) / tpb), dim3(kMfmaTiles * 64), lds_bytes, s, a, tiles, windows, tpb, frags, meta);
+    return hipGetLastError();
+}
+
 hipError_t launch_sinc_resample(const SincArgs &a, hipStream_t s) {
     if (a.rows == 0 || a.out_count == 0) return hipSuccess;
+    // The matrix-core form whenever the caller lent scratch for it -- for ONE row as for thousands: a row's samples must not
+    // depend on how many other rows shared its launch (tests/test_scheduler_gpu.py compares a stream in a batch of many with
+    // the same stream alone, bit for bit), and the two forms differ in the last bits.
+    if (!a.exact && a.scratch && a.n_sets) {
+        const size_t need = sinc_mfma_scratch_bytes(a.n_sets, a.out_count, a.step);
+        if (need && need <= a.scratch_bytes) return launch_sinc_mfma(a, s);
+    }
     const uint32_t row_blocks = (a.rows + kRows - 1) / kRows;
     if (row_blocks > 65535) return hipErrorInvalidValue;
     // outputs per workgroup: as many as the staged span allows at this step (a power of two, so that blocks never

@@ -253,9 +253,16 @@ struct SincArgs {
     size_t in_stride, out_stride;
     uint32_t rows, in_frames, out_count;  // out_count: the largest count among the sets in use
     int32_t in_origin;        // sample index of in[r][0] in the index time base (history rows: negative)
+    // the matrix-core form (resample.hip, k_sinc_taps + k_sinc_mfma): taken when the caller lends scratch of
+    // sinc_mfma_scratch_bytes(n_sets, out_count, step) bytes and does not ask for rubato's own order of operations
+    uint32_t n_sets;          // index sets in set_starts / set_count (0: unknown -> the scalar form)
+    void *scratch;
+    size_t scratch_bytes;
+    int exact;                // 1: the scalar form, whose sums are rubato's bit for bit
 };
 hipError_t launch_sinc_resample(const SincArgs &a, hipStream_t s);
 uint32_t sinc_rows_per_block();
+size_t sinc_mfma_scratch_bytes(uint32_t n_sets, uint32_t out_count, double step);  // 0: this shape stays on the scalar form
 
 // batched row copies (streaming resampler bookkeeping): job j copies count floats
 struct RowCopy {

@@ -541,6 +541,11 @@ class Engine:
         """sk_engine_where: the stage of the engine's current tick ("idle" outside one)"""
         return lib.sk_engine_where(self._h).decode()
 
+    def set_resampler_exact(self, exact=True):
+        """generic-ratio resampling in rubato's own order of operations (bit-identical to the restated reference) instead of
+        the matrix-core form"""
+        check(lib.sk_engine_set_resampler_exact(self._h, 1 if exact else 0), "sk_engine_set_resampler_exact", self._h)
+
     def set_wait_bound(self, seconds):
         check(lib.sk_engine_set_wait_bound(self._h, float(seconds)), "sk_engine_set_wait_bound")
 

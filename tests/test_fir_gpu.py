@@ -309,16 +309,45 @@ def test_bf16_split_fir_is_f32_accurate(engine, oracle, amplitude):
     assert err_f32 < 2e-7 and err_gpu < 3e-7, (err_gpu, err_f32)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("in_hz,out_hz", [(44100, 16000), (22050, 16000), (16000, 48000), (96000, 8000), (44100, 48000), (32000, 44100)])
+RATIOS = [(44100, 16000), (22050, 16000), (16000, 48000), (96000, 8000), (44100, 48000), (32000, 44100), (8000, 96000), (48000, 44100)]
+
+
+@pytest.mark.parametrize("in_hz,out_hz", RATIOS)
 def test_generic_ratios_are_bit_identical_to_the_restated_rubato(engine, oracle, in_hz, out_hz):
-    """k_sinc_resample keeps rubato's order of operations (eight running sums per dot product, separate multiplies and adds,
-    p0 + frac (p1 - p0)) through the packed form, the two-outputs-per-pass form (window offsets 0..7) and the fallbacks: the
-    result is the oracle's f32 restatement bit for bit, not merely within the float tolerance.  130 rows = two full row
-    blocks and a ragged one."""
+    """The scalar form of k_sinc_resample (sk_engine_set_resampler_exact) keeps rubato's order of operations (eight running
+    sums per dot product, separate multiplies and adds, p0 + frac (p1 - p0)) through the packed form, the two-outputs-per-pass
+    form (window offsets 0..7) and the fallbacks: the result is the oracle's f32 restatement bit for bit, not merely within the
+    float tolerance.  130 rows = two full row blocks and a ragged one."""
     rng = np.random.default_rng(in_hz + out_hz)
     x = rng.uniform(-1, 1, (130, 30000)).astype(np.float32)
-    got = engine.downsample(x, in_hz, out_hz)
+    engine.set_resampler_exact(True)
+    try:
+        got = engine.downsample(x, in_hz, out_hz)
+    finally:
+        engine.set_resampler_exact(False)
     for rows in ((0, 3), (63, 66), (127, 130)):
         want = oracle.downsample_planar(x[rows[0]:rows[1]], in_hz, out_hz)
         assert got.shape[1] == want.shape[1] and np.array_equal(got[rows[0]:rows[1]], want)
+
+
+@pytest.mark.parametrize("in_hz,out_hz", RATIOS)
+@pytest.mark.parametrize("amplitude", [1.0, 1e-3])
+def test_generic_ratios_on_the_matrix_cores(engine, oracle, in_hz, out_hz, amplitude):
+    """The default form for batches (k_sinc_taps + k_sinc_mfma: the outputs' blended filters as the A operand, bf16 x 3 planes,
+    six products): within the float tolerance of the restated rubato -- 1e-6 relative RMS, 4e-6 of full scale at most -- at
+    full scale and on a quiet signal alike, with the scalar form's output count.  130 rows: four full 32-row blocks and a ragged
+    one; the last tile of a row is partial for most ratios."""
+    rng = np.random.default_rng(in_hz * 3 + out_hz)
+    x = (rng.uniform(-1, 1, (130, 20000)) * amplitude).astype(np.float32)
+    x[5] = (np.sin(2 * np.pi * 440.0 * np.arange(20000) / in_hz) * 0.5 * amplitude).astype(np.float32)  # soundkit-decoder lib.rs:5192-5197
+    got = engine.downsample(x, in_hz, out_hz)
+    worst = 0.0
+    for rows in ((0, 8), (60, 68), (126, 130)):
+        want = oracle.downsample_planar(x[rows[0]:rows[1]], in_hz, out_hz)
+        assert got.shape[1] == want.shape[1]
+        mine = got[rows[0]:rows[1]]
+        if in_hz / out_hz <= 6.5:  # (steeper ratios need more than the twelve windows a tile keeps in registers: scalar form)
+            assert not np.array_equal(mine, want)  # a different order of operations: equal bits would mean the scalar form ran
+        worst = max(worst, rel_rms(mine, want))
+        assert np.abs(mine - want).max() < 4e-6 * amplitude
+    assert worst < 1e-6, worst

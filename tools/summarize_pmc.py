@@ -22,7 +22,7 @@ def short(name):
         return "k_aac_tail"
     if "k_aac_synth" in name:
         return "k_aac_synth" if "<true" in name else "k_aac_synth_f32out"
-    for key in ("k_aac_tail", "k_aac_synth", "k_fir_48k_16k", "k_f32_planar_stereo_to_s16le_batch", "k_pack_jobs", "k_sinc_resample"):
+    for key in ("k_aac_tail", "k_aac_synth", "k_fir_48k_16k", "k_f32_planar_stereo_to_s16le_batch", "k_pack_jobs", "k_sinc_resample", "k_sinc_mfma", "k_sinc_taps", "k_mp3_requant", "k_mp3_hybrid"):
         if key in name:
             return key
     return name
