@@ -378,113 +378,186 @@ __global__ __launch_bounds__(64) void k_sinc_taps(SincArgs a, uint32_t n_tiles, 
     }
 }
 
+// A workgroup = eight tiles (one per wave) x a run of consecutive 32-row blocks.  The waves keep their tiles' fragments in
+// registers for the whole run (rows of one index set share them; the host orders rows by set, so a reload is rare) and hold
+// the NEXT row block's samples in registers while the matrix instructions work on the current one out of LDS -- with 137 KB of
+// LDS there is one workgroup per CU and nobody else to cover a trip to memory (one block per launch of 12.7 us, 13 % of the
+// matrix pipe: profiles/r03_resample_pmc.json, the form before this loop).
+struct RowBlock {
+    uint32_t set, count, nt;
+    const TileMeta *tm;
+    int base_first, span;
+    bool live;  // this tile chunk has outputs for the block's index set
+};
+
 __global__ __launch_bounds__(kMfmaTiles * 64, 1) void k_sinc_mfma(SincArgs a, uint32_t n_tiles, uint32_t max_windows, uint32_t tiles_per_block,
-                                                               const u32x4 *frags, const TileMeta *meta) {
+                                                               uint32_t row_blocks_per_group, const u32x4 *frags, const TileMeta *meta) {
     extern __shared__ __attribute__((aligned(16))) unsigned char planes[];  // [3][kMfmaRows][kMfmaPitch]
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // row blocks vary fastest: the workgroups that run together share their tiles' fragments (240 KB per block of eight tiles)
-    // in L2; with the tiles fastest every workgroup streamed its own 240 KB of a 30 MB table past a 4 MB cache
-    const uint32_t row0 = blockIdx.x * kMfmaRows;
-    const uint32_t set = a.row_set ? a.row_set[row0] : 0;  // 64 consecutive rows share their set (the host's grouping): so do 32
-    const uint32_t count = a.set_count[set];
+    const uint32_t n_row_blocks = (a.rows + kMfmaRows - 1) / kMfmaRows;
+    const uint32_t rb_begin = blockIdx.x * row_blocks_per_group;
+    const uint32_t rb_end = min(n_row_blocks, rb_begin + row_blocks_per_group);
     const uint32_t t0 = blockIdx.y * tiles_per_block;
-    if (16u * t0 >= count) return;  // block-uniform
-    const uint32_t nt = min(tiles_per_block, (count - 16u * t0 + 15u) / 16u);
-    const TileMeta *tm = meta + (size_t)set * n_tiles + t0;
-    const int base_first = tm[0].base;
-    int span = 0;
-    for (uint32_t k = 0; k < nt; ++k) span = max(span, tm[k].base + 32 * tm[k].windows - base_first);
-    if (span > kMfmaSpan) return;  // (the host chose tiles_per_block for this step: not reached)
-
-    // The wave's tap fragments first: up to 16 windows x 3 planes in registers (two waves per SIMD: 256 registers each), so
-    // that their trip from L2 runs under the staging below instead of in front of every window's matrix instructions.
-    const bool has_tile = (uint32_t)wave < nt;
     const uint32_t t = t0 + (uint32_t)wave;
-    const int off = has_tile ? __builtin_amdgcn_readfirstlane(tm[has_tile ? wave : 0].base - base_first) : 0;  // a multiple of 8
-    const int windows = has_tile ? __builtin_amdgcn_readfirstlane(tm[has_tile ? wave : 0].windows) : 0;
-    const u32x4 *fa = frags + ((size_t)set * n_tiles + t) * max_windows * 3 * 64 + lane;
-    u32x4 h[kMaxWindows][3];
-#pragma unroll
-    for (int s = 0; s < kMaxWindows; ++s)
-        if (s < windows) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k)  // issued HERE by hand: an ordinary load is sunk to its use behind the barrier, a volatile one bypasses L2
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(h[s][k]) : "v"(fa + (size_t)(s * 3 + k) * 64) : "memory");
-        }
 
-    // stage: 32 rows x span samples from base_first, as three bf16 planes; a thread takes pairs of samples.  All of a wave's
-    // loads (4 rows x 6 pairs per lane) are issued before the first is used: one trip to memory per block, not one per pair.
+    // the index sets of the run's row blocks, read once up front (eight independent loads instead of one dependent chain per
+    // block); a block of the set its predecessor had takes over its description without touching memory again
+    constexpr uint32_t kMaxRun = 8;
+    uint32_t set_of[kMaxRun];
+#pragma unroll
+    for (uint32_t k = 0; k < kMaxRun; ++k)
+        set_of[k] = (a.row_set && rb_begin + k < rb_end) ? a.row_set[(rb_begin + k) * kMfmaRows] : 0;  // 64 consecutive rows share their set: so do 32
+    auto describe = [&](uint32_t rb, uint32_t set) {
+        RowBlock b;
+        b.set = set;
+        b.count = a.set_count[b.set];
+        b.tm = meta + (size_t)b.set * n_tiles + t0;
+        b.live = 16u * t0 < b.count;
+        b.nt = 0, b.base_first = 0, b.span = 0;
+        if (b.live) {
+            b.nt = min(tiles_per_block, (b.count - 16u * t0 + 15u) / 16u);
+            b.base_first = b.tm[0].base;
+            for (uint32_t k = 0; k < b.nt; ++k) b.span = max(b.span, b.tm[k].base + 32 * b.tm[k].windows - b.base_first);
+            if (b.span > kMfmaSpan || b.tm[0].windows == 0) b.live = false;  // (the host sized the launch for this step: not reached)
+        }
+        return b;
+    };
+
+    // the wave's tap fragments: up to 12 windows x 3 planes in registers (two waves per SIMD: 256 registers each)
+    u32x4 h[kMaxWindows][3];
+    uint32_t loaded_set = 0xffffffffu;
+    bool taps_pending = false, has_tile = false;
+    int off = 0, windows = 0;
+    auto load_taps = [&](const RowBlock &b) __attribute__((always_inline)) {
+        has_tile = (uint32_t)wave < b.nt;
+        off = has_tile ? __builtin_amdgcn_readfirstlane(b.tm[has_tile ? wave : 0].base - b.base_first) : 0;  // a multiple of 8
+        windows = has_tile ? __builtin_amdgcn_readfirstlane(b.tm[has_tile ? wave : 0].windows) : 0;
+        const u32x4 *fa = frags + ((size_t)b.set * n_tiles + t) * max_windows * 3 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < kMaxWindows; ++s)
+            if (s < windows) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)  // issued HERE by hand: an ordinary load is sunk to its use behind the barrier, a volatile one bypasses L2
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(h[s][k]) : "v"(fa + (size_t)(s * 3 + k) * 64) : "memory");
+            }
+        loaded_set = b.set;
+        taps_pending = true;
+    };
+
+    // a row block's samples: 32 rows x span from base_first; a thread takes pairs, all of a wave's loads (4 rows x 6 pairs per
+    // lane) issued before the first is used; then split into three bf16 planes and written to LDS
     constexpr int kStageR = kMfmaRows / kMfmaTiles, kStageC = (kMfmaSpan / 2 + 63) / 64;
     float pre[kStageR][kStageC][2];
+    auto fetch = [&](uint32_t rb, const RowBlock &b) __attribute__((always_inline)) {
+        const long n0 = (long)b.base_first - a.in_origin;  // element of the row at the block's first sample
+        // the usual block lies inside its rows and all 32 rows exist: no per-sample tests (wave-uniform branch)
+        const bool inside = n0 >= 0 && n0 + 2 * 64 * kStageC <= (long)a.in_frames && (rb + 1) * kMfmaRows <= a.rows;
 #pragma unroll
-    for (int k = 0; k < kStageR; ++k) {
-        const uint32_t row = row0 + (uint32_t)(wave + kMfmaTiles * k);
-        uint32_t phys = 0xffffffffu;
-        if (row < a.rows) phys = a.row_map ? a.row_map[row] : row;
-        const float *src = a.in + (size_t)(phys == 0xffffffffu ? 0 : phys) * a.in_stride;
+        for (int k = 0; k < kStageR; ++k) {
+            const uint32_t row = rb * kMfmaRows + (uint32_t)(wave + kMfmaTiles * k);
+            uint32_t phys = 0xffffffffu;
+            if (row < a.rows) phys = a.row_map ? a.row_map[row] : row;
+            const float *src = a.in + (size_t)(phys == 0xffffffffu ? 0 : phys) * a.in_stride;
+            if (inside && phys != 0xffffffffu) {
+                const float *at = src + n0 + 2 * lane;
 #pragma unroll
-        for (int cc = 0; cc < kStageC; ++cc) {
-            const int c2 = lane + 64 * cc;
-            const long n = (long)base_first + 2 * c2 - a.in_origin;
-            const bool live = phys != 0xffffffffu && 2 * c2 < span;
-            pre[k][cc][0] = (live && n >= 0 && n < (long)a.in_frames) ? src[n] : 0.0f;
-            pre[k][cc][1] = (live && n + 1 >= 0 && n + 1 < (long)a.in_frames) ? src[n + 1] : 0.0f;
+                for (int cc = 0; cc < kStageC; ++cc) __builtin_memcpy(pre[k][cc], at + 128 * cc, 8);  // (rows are 4-byte aligned only)
+                continue;
+            }
+#pragma unroll
+            for (int cc = 0; cc < kStageC; ++cc) {
+                const int c2 = lane + 64 * cc;
+                const long n = n0 + 2 * c2;
+                const bool live = phys != 0xffffffffu && 2 * c2 < b.span;
+                pre[k][cc][0] = (live && n >= 0 && n < (long)a.in_frames) ? src[n] : 0.0f;
+                pre[k][cc][1] = (live && n + 1 >= 0 && n + 1 < (long)a.in_frames) ? src[n + 1] : 0.0f;
+            }
         }
-    }
+    };
+    auto refill = [&](const RowBlock &b) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < kStageR; ++k) {
-        unsigned char *dst = planes + (wave + kMfmaTiles * k) * kMfmaPitch;
+        for (int k = 0; k < kStageR; ++k) {
+            unsigned char *dst = planes + (wave + kMfmaTiles * k) * kMfmaPitch;
 #pragma unroll
-        for (int cc = 0; cc < kStageC; ++cc) {
-            const int c2 = lane + 64 * cc;
-            if (2 * c2 >= span) continue;
-            uint32_t p1, p2, p3;
-            split3(pre[k][cc][0], pre[k][cc][1], p1, p2, p3);
-            *reinterpret_cast<uint32_t *>(dst + 4 * c2) = p1;
-            *reinterpret_cast<uint32_t *>(dst + kMfmaPlane + 4 * c2) = p2;
-            *reinterpret_cast<uint32_t *>(dst + 2 * kMfmaPlane + 4 * c2) = p3;
+            for (int cc = 0; cc < kStageC; ++cc) {
+                const int c2 = lane + 64 * cc;
+                if (2 * c2 >= b.span) continue;
+                uint32_t p1, p2, p3;
+                split3(pre[k][cc][0], pre[k][cc][1], p1, p2, p3);
+                *reinterpret_cast<uint32_t *>(dst + 4 * c2) = p1;
+                *reinterpret_cast<uint32_t *>(dst + kMfmaPlane + 4 * c2) = p2;
+                *reinterpret_cast<uint32_t *>(dst + 2 * kMfmaPlane + 4 * c2) = p3;
+            }
         }
+    };
+
+    RowBlock cur = describe(rb_begin, set_of[0]);
+    if (cur.live) {
+        load_taps(cur);
+        fetch(rb_begin, cur);
+        refill(cur);
     }
     __syncthreads();
-    if (!has_tile) return;
-    // the hand-issued loads have landed (the staging loads behind them were waited for above: vector memory returns in order);
-    // the registers pass through the statement so that nothing that reads them is scheduled in front of it
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t rb = rb_begin; rb < rb_end; ++rb) {
+        const bool more = rb + 1 < rb_end;
+        RowBlock nxt = cur;
+        if (more) {
+            uint32_t set_next = 0;
 #pragma unroll
-    for (int s = 0; s < kMaxWindows; ++s) asm volatile("" : "+v"(h[s][0]), "+v"(h[s][1]), "+v"(h[s][2]));
-
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int s = 0; s < kMaxWindows; ++s) {
-        if (s >= windows) continue;  // (wave-uniform; no break: the loop must unroll for h[s] to stay in registers)
-#pragma unroll
-        for (int rg = 0; rg < 2; ++rg) {
-            const unsigned char *bp = planes + (rg * 16 + j) * kMfmaPitch + 2 * (off + 32 * s + 8 * q);
-            const u32x4 x0 = *reinterpret_cast<const u32x4 *>(bp), x1 = *reinterpret_cast<const u32x4 *>(bp + kMfmaPlane),
-                        x2 = *reinterpret_cast<const u32x4 *>(bp + 2 * kMfmaPlane);
-            f32x4 c = acc[rg];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x1), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, x1), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][2]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x2), c, 0, 0, 0);
-            acc[rg] = c;
+            for (uint32_t k = 1; k < kMaxRun; ++k)
+                if (rb + 1 - rb_begin == k) set_next = set_of[k];
+            if (set_next != cur.set) nxt = describe(rb + 1, set_next);
+            if (nxt.live) fetch(rb + 1, nxt);  // in flight during the matrix instructions below
         }
-    }
-    // D[i][j]: lane (j, q) holds outputs i = 4 q .. 4 q + 3 of row j of each row group
+        if (cur.live && has_tile) {
+            if (taps_pending) {  // wave-uniform.  Vector memory returns in order: this also waits for the loads just issued, once per set
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                taps_pending = false;
+            }
+            // the registers pass through this statement so that nothing that reads them is scheduled in front of the wait
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg) {
-        const uint32_t row = row0 + (uint32_t)(rg * 16 + j);
-        if (row >= a.rows) continue;
-        if (a.row_map && a.row_map[row] == 0xffffffffu) continue;  // a padding row of the host's grouping
-        float *dst = a.out + (size_t)row * a.out_stride + (a.out_off ? a.out_off[row] : 0);
+            for (int s = 0; s < kMaxWindows; ++s) asm volatile("" : "+v"(h[s][0]), "+v"(h[s][1]), "+v"(h[s][2]));
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t mo = 16u * t + 4u * (uint32_t)q + (uint32_t)r;
-            if (mo < count) dst[mo] = acc[rg][r];
+            for (int s = 0; s < kMaxWindows; ++s) {
+                if (s >= windows) continue;  // (wave-uniform; no break: the loop must unroll for h[s] to stay in registers)
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) {
+                    const unsigned char *bp = planes + (rg * 16 + j) * kMfmaPitch + 2 * (off + 32 * s + 8 * q);
+                    const u32x4 x0 = *reinterpret_cast<const u32x4 *>(bp), x1 = *reinterpret_cast<const u32x4 *>(bp + kMfmaPlane),
+                                x2 = *reinterpret_cast<const u32x4 *>(bp + 2 * kMfmaPlane);
+                    f32x4 c = acc[rg];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x1), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, x1), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][2]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x2), c, 0, 0, 0);
+                    acc[rg] = c;
+                }
+            }
+            // D[i][j]: lane (j, q) holds outputs i = 4 q .. 4 q + 3 of row j of each row group
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) {
+                const uint32_t row = rb * kMfmaRows + (uint32_t)(rg * 16 + j);
+                if (row >= a.rows) continue;
+                if (a.row_map && a.row_map[row] == 0xffffffffu) continue;  // a padding row of the host's grouping
+                float *dst = a.out + (size_t)row * a.out_stride + (a.out_off ? a.out_off[row] : 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t mo = 16u * t + 4u * (uint32_t)q + (uint32_t)r;
+                    if (mo < cur.count) dst[mo] = acc[rg][r];
+                }
+            }
         }
+        __syncthreads();  // the planes have been read
+        if (more && nxt.live) {
+            refill(nxt);
+            if (nxt.set != loaded_set || !cur.live) load_taps(nxt);
+        }
+        cur = nxt;
+        __syncthreads();
     }
 }
 
@@ -540,7 +613,13 @@ static hipError_t launch_sinc_mfma(const SincArgs &a, hipStream_t s) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sinc_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        (int)lds_bytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(k_sinc_mfma, dim3(row_blocks, (tiles + tpb - 1) / tpb), dim3(kMfmaTiles * 64), lds_bytes, s, a, tiles, windows, tpb, frags, meta);
+    // runs of row blocks per workgroup: long enough to amortise the fragments and the pipeline's fill, short enough for >= 4
+    // workgroups per CU in the launch
+    const uint32_t tile_chunks = (tiles + tpb - 1) / tpb;
+    uint32_t run = 8;
+    while (run > 1 && (uint64_t)((row_blocks + run - 1) / run) * tile_chunks < 1024) run >>= 1;
+    hipLaunchKernelGGL(k_sinc_mfma, dim3((row_blocks + run - 1) / run, tile_chunks), dim3(kMfmaTiles * 64), lds_bytes, s, a, tiles, windows, tpb, run,
+                       frags, meta);
     return hipGetLastError();
 }
 
