@@ -594,6 +594,8 @@ def main():
         unit = "stream-seconds/s"
 
         def step():
+            if os.environ.get("SK_BENCH_RESAMPLER_EXACT") == "1":
+                eng.set_resampler_exact(True)
             timed("k_sinc_resample", lambda: eng.downsample_dev(x, frames_in, rows, frames_in, 44100, 16000, y, n_out))
         workload = "downsample_audio 44.1k->16k (generic ratio): %d streams x 2 ch x 1 s, f32" % streams
     else:
@@ -774,16 +776,19 @@ def main():
             n_rs_out = eng.downsample_out_frames(44100, 44100, 16000)
             outs = streams * ch * n_rs_out
             rs_bytes = streams * ch * (44100 * 4.0 + n_rs_out * 4.0)
-            # rubato's order of operations is kept: per output two 256-tap sums of separate multiplies and adds (8 running sums
-            # each), then the blend -- 1026 multiplies + adds; the launch is bound by the vector ALUs, not by its 6.7 B of HBM
-            # traffic per output.  `frac` is against the HBM peak all the same (the schema's choice); the vector figure is beside it.
+            # default: the matrix-core form (k_sinc_taps + k_sinc_mfma: the outputs' blended 257-tap filters as the A operand, bf16 x 3
+            # planes, six products per 32-sample window); SK_BENCH_RESAMPLER_EXACT=1: the scalar form that keeps rubato's order of
+            # operations.  Neither is bound by its 6.7 B of HBM traffic per output; `frac` is against the HBM peak all the same (the
+            # schema's choice), the arithmetic figures are beside it.
+            exact = os.environ.get("SK_BENCH_RESAMPLER_EXACT") == "1"
             rl["k_sinc_resample"] = {
-                "kernel": "k_sinc_resample", "bound": "hbm", "achieved": rs_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "kernel": "k_sinc_resample (scalar form)" if exact else "k_sinc_mfma (+ k_sinc_taps)", "bound": "hbm",
+                "achieved": rs_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rs_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
-                "outputs_per_s": outs / (ms * 1e-3), "vector_tflops": outs * 1026.0 / (ms * 1e-3) / 1e12,
-                "vector_f32_peak_tflops_unpacked": 78.6,
+                "outputs_per_s": outs / (ms * 1e-3), "algorithmic_tflops": outs * 1026.0 / (ms * 1e-3) / 1e12,
+                "vector_f32_peak_tflops_unpacked": 78.6, "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TF,
                 "note": "avg_launch_ms brackets sk_downsample_f32_dev: the host's walk of rubato's f64 time index, two small uploads, the "
-                        "launch and a stream synchronisation"}
+                        "launch(es) and a stream synchronisation"}
             out["metric"] = "stream-seconds/s through soundkit::downsample_audio 44.1 kHz -> 16 kHz (generic-ratio sinc resampler)"
         if "k_convert" in per_kernel:
             ms = per_kernel["k_convert"]

@@ -1,4 +1,5 @@
-// resample.hip -- generic-ratio windowed-sinc resampler for gfx950.
+// resample.hip -- generic-ratio windowed-sinc resampler for gfx950: a scalar form that keeps rubato's order of operations (this
+// comment and the first half of the file) and the matrix-core form that batches take by default (k_sinc_taps + k_sinc_mfma, below).
 //
 // Replaces rubato 0.14.1 SincFixedIn<f32>::process (Linear interpolation) as the reference drives it
 // for every ratio other than 48k->16k (soundkit/src/audio_pipeline.rs:474-491,
