@@ -307,15 +307,22 @@ __global__ __launch_bounds__(kWaves * 64) void k_sinc_resample(SincArgs a, uint3
 // rows of the set: thousands of them in a batch); k_sinc_mfma stages 32 rows x the span of eight tiles as bf16 planes in LDS,
 // one wave per tile, two row groups per wave.  This form does NOT keep rubato's order of operations (the scalar form above
 // does, bit for bit, and stays available: SincArgs::exact); it is held to the float tolerance like the 48 -> 16 kHz FIR.
+#ifndef SK_MFMA_ROWS
+#define SK_MFMA_ROWS 32
+#define SK_MFMA_TILES 8
+#define SK_MFMA_SPAN 704
+#define SK_MFMA_BLOCKS 1
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMfmaRows = 32;                    // rows per workgroup: two row groups of 16
-constexpr int kMfmaTiles = 8;                    // tiles (of 16 outputs) per workgroup at most: one per wave
-constexpr int kMfmaSpan = 704;                   // samples staged per row
+constexpr int kMfmaRows = SK_MFMA_ROWS;           // rows per workgroup: row groups of 16
+constexpr int kMfmaTiles = SK_MFMA_TILES;         // tiles (of 16 outputs) per workgroup at most: one per wave
+constexpr int kMfmaSpan = SK_MFMA_SPAN;           // samples staged per row
 constexpr int kMfmaPitch = 2 * kMfmaSpan + 16;   // bytes per row of a plane: 1424 = 16 * 89, odd multiple of 16: conflict-free b128 reads
 constexpr int kMfmaPlane = kMfmaRows * kMfmaPitch;
+static_assert((kMfmaPitch / 16) % 2 == 1 && kMfmaRows % 16 == 0 && kMfmaRows % kMfmaTiles == 0, "row pitch: an odd multiple of 16 bytes");
 constexpr int kMaxWindows = 12;                  // windows of a tile held in registers: steps up to ~6.9 (96 -> 16 kHz: 6); beyond: the scalar form
 
 struct TileMeta {
@@ -391,7 +398,7 @@ struct RowBlock {
     bool live;  // this tile chunk has outputs for the block's index set
 };
 
-__global__ __launch_bounds__(kMfmaTiles * 64, 1) void k_sinc_mfma(SincArgs a, uint32_t n_tiles, uint32_t max_windows, uint32_t tiles_per_block,
+__global__ __launch_bounds__(kMfmaTiles * 64, SK_MFMA_BLOCKS) void k_sinc_mfma(SincArgs a, uint32_t n_tiles, uint32_t max_windows, uint32_t tiles_per_block,
                                                                uint32_t row_blocks_per_group, const u32x4 *frags, const TileMeta *meta) {
     extern __shared__ __attribute__((aligned(16))) unsigned char planes[];  // [3][kMfmaRows][kMfmaPitch]
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
@@ -519,12 +526,15 @@ __global__ __launch_bounds__(kMfmaTiles * 64, 1) void k_sinc_mfma(SincArgs a, ui
             // the registers pass through this statement so that nothing that reads them is scheduled in front of the wait
 #pragma unroll
             for (int s = 0; s < kMaxWindows; ++s) asm volatile("" : "+v"(h[s][0]), "+v"(h[s][1]), "+v"(h[s][2]));
-            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            constexpr int kGroups = kMfmaRows / 16;
+            f32x4 acc[kGroups];
+#pragma unroll
+            for (int rg = 0; rg < kGroups; ++rg) acc[rg] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < kMaxWindows; ++s) {
                 if (s >= windows) continue;  // (wave-uniform; no break: the loop must unroll for h[s] to stay in registers)
 #pragma unroll
-                for (int rg = 0; rg < 2; ++rg) {
+                for (int rg = 0; rg < kGroups; ++rg) {
                     const unsigned char *bp = planes + (rg * 16 + j) * kMfmaPitch + 2 * (off + 32 * s + 8 * q);
                     const u32x4 x0 = *reinterpret_cast<const u32x4 *>(bp), x1 = *reinterpret_cast<const u32x4 *>(bp + kMfmaPlane),
                                 x2 = *reinterpret_cast<const u32x4 *>(bp + 2 * kMfmaPlane);
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(kMfmaTiles * 64, 1) void k_sinc_mfma(SincArgs a, ui
             }
             // D[i][j]: lane (j, q) holds outputs i = 4 q .. 4 q + 3 of row j of each row group
 #pragma unroll
-            for (int rg = 0; rg < 2; ++rg) {
+            for (int rg = 0; rg < kGroups; ++rg) {
                 const uint32_t row = rb * kMfmaRows + (uint32_t)(rg * 16 + j);
                 if (row >= a.rows) continue;
                 if (a.row_map && a.row_map[row] == 0xffffffffu) continue;  // a padding row of the host's grouping
