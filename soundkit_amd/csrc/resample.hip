@@ -320,7 +320,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMfmaRows = SK_MFMA_ROWS;           // rows per workgroup: row groups of 16
 constexpr int kMfmaTiles = SK_MFMA_TILES;         // tiles (of 16 outputs) per workgroup at most: one per wave
 constexpr int kMfmaSpan = SK_MFMA_SPAN;           // samples staged per row
-constexpr int kMfmaPitch = 2 * kMfmaSpan + 16;   // bytes per row of a plane: 1424 = 16 * 89, odd multiple of 16: conflict-free b128 reads
+constexpr int kMfmaPitch = 2 * (128 * ((kMfmaSpan + 127) / 128)) + 16;  // bytes per row of a plane: whole 128-sample groups + 16 = 1552 = 16 * 97, an odd multiple of 16 (conflict-free b128 reads)
 constexpr int kMfmaPlane = kMfmaRows * kMfmaPitch;
 static_assert((kMfmaPitch / 16) % 2 == 1 && kMfmaRows % 16 == 0 && kMfmaRows % kMfmaTiles == 0, "row pitch: an odd multiple of 16 bytes");
 constexpr int kMaxWindows = 12;                  // windows of a tile held in registers: steps up to ~6.9 (96 -> 16 kHz: 6); beyond: the scalar form
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(kMfmaTiles * 64, SK_MFMA_BLOCKS) void k_sinc_mfma(S
 #pragma unroll
             for (int cc = 0; cc < kStageC; ++cc) {
                 const int c2 = lane + 64 * cc;
-                if (2 * c2 >= b.span) continue;
+                if (128 * cc >= b.span) continue;  // wave-uniform: the row's pitch has room for whole 128-sample groups
                 uint32_t p1, p2, p3;
                 split3(pre[k][cc][0], pre[k][cc][1], p1, p2, p3);
                 *reinterpret_cast<uint32_t *>(dst + 4 * c2) = p1;
