@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64) void k_sinc_taps(SincArgs a, uint32_t n_tiles, 
 
 // A workgroup = eight tiles (one per wave) x a run of consecutive 32-row blocks.  The waves keep their tiles' fragments in
 // registers for the whole run (rows of one index set share them; the host orders rows by set, so a reload is rare) and hold
-// the NEXT row block's samples in registers while the matrix instructions work on the current one out of LDS -- with 137 KB of
+// the NEXT row block's samples in registers while the matrix instructions work on the current one out of LDS -- with 149 KB of
 // LDS there is one workgroup per CU and nobody else to cover a trip to memory (one block per launch of 12.7 us, 13 % of the
 // matrix pipe: profiles/r03_resample_pmc.json, the form before this loop).
 struct RowBlock {
