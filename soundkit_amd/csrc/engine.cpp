@@ -1760,7 +1760,7 @@ namespace {
 
 constexpr size_t kRqFloats = sk::kMp3Pow43 + 4 + 8;
 constexpr size_t kRqBandsAt = kRqFloats * sizeof(float), kRqPretabAt = kRqBandsAt + sk::kMp3Rates * sk::kMp3BandRow * sizeof(uint16_t),
-                 kRqBytes = kRqPretabAt + sk::kMp3Rates * 24;
+                 kRqMapAt = (kRqPretabAt + sk::kMp3Rates * 24 + 255) & ~(size_t)255, kRqBytes = kRqMapAt + sk::kMp3Rates * 3 * 576 * sizeof(uint32_t);
 
 int mp3_rate_slot(uint32_t hz) {
     static const uint32_t rates[sk::kMp3Rates] = {44100, 48000, 32000, 22050, 24000, 16000, 11025, 12000, 8000};
@@ -1818,6 +1818,25 @@ int sk_mp3_set_band_tables(sk_engine *e, uint32_t sample_rate, const uint16_t *l
                      hipMemcpyHostToDevice),
            "upload mp3 band table");
     SK_HIP(hipMemcpy(e->d_mp3_rq + kRqPretabAt + (size_t)slot * 24, pre, 24, hipMemcpyHostToDevice), "upload mp3 pre-emphasis table");
+    // where every bitstream-order line sits, for the three ways a granule can be cut up (mp3_requant.hip)
+    std::vector<uint32_t> map(3 * 576, 0);
+    for (int layout = 0; layout < 3; ++layout)
+        for (int i = 0; i < 576; ++i) {
+            const bool short_line = layout == 1 || (layout == 2 && i >= 36);
+            uint32_t band = 0, win = 0, dest = (uint32_t)i;
+            if (!short_line) {
+                while (band < 21 && long_offsets[band + 1] <= i) ++band;
+            } else {
+                while (band < 12 && 3 * short_offsets[band + 1] <= i) ++band;
+                const int begin = short_offsets[band], width = short_offsets[band + 1] - begin, rel = i - 3 * begin;
+                const int w = rel / width;
+                win = (uint32_t)w + 1;
+                dest = (uint32_t)(3 * (begin + rel - w * width) + w);
+            }
+            map[(size_t)layout * 576 + i] = dest | (band << 10) | (win << 15);
+        }
+    SK_HIP(hipMemcpy(e->d_mp3_rq + kRqMapAt + (size_t)slot * 3 * 576 * sizeof(uint32_t), map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice),
+           "upload mp3 line map");
     e->mp3_bands_set[slot] = true;
     return SK_OK;
 }
@@ -1881,6 +1900,7 @@ int mp3_requantize_locked(sk_engine *e, const sk_mp3_requant_granule *granules, 
     a.is_k = a.root4 + 4;
     a.bands = (const uint16_t *)(e->d_mp3_rq + kRqBandsAt);
     a.pretab = e->d_mp3_rq + kRqPretabAt;
+    a.line_map = (const uint32_t *)(e->d_mp3_rq + kRqMapAt);
     SK_HIP(sk::launch_mp3_requant(a, e->stream), "launch mp3 requantisation");
     *lines_out = lines;
     return SK_OK;

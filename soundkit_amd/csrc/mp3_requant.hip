@@ -12,7 +12,7 @@
 // tree does not hold them.  oracle/mp3_requant.py is the f64 checker; parity of the MP3 row is unpinned.
 //
 // One wavefront per granule, four per block.  A lane takes the lines lane + 64 k (k < 9) of both channels in bitstream
-// order: band and window by a 5-step search in the LDS copy of the band table, requantised into registers; the highest
+// order: band, window and destination from the engine's line map, requantised into registers; the highest
 // occupied band of the right channel is a wave maximum; the stereo step works on the lane's own pair of values; the integers
 // come in and the reordered lines go out through LDS, so that both cross HBM as whole 256-byte runs.  Traffic per granule-channel:
 // 1152 B in, 2304 B out; the kernel is HBM-bound like everything else on this path.
@@ -35,45 +35,30 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
-struct Line {  // where a bitstream-order line sits
+struct Line {  // where a bitstream-order line sits (unpacked from the engine's line map: dest | band << 10 | (win + 1) << 15)
     int band;  // long band 0..21 or short band 0..12
     int win;   // -1: long
     int dest;  // its position after the reorder
 };
-
-__device__ __forceinline__ Line locate(int i, bool short_lines, const uint16_t *tab) {
+__device__ __forceinline__ Line unpack_line(uint32_t m) {
     Line r;
-    if (!short_lines) {
-        int l = 0;
-#pragma unroll
-        for (int step = 16; step; step >>= 1)
-            if (l + step <= 21 && tab[l + step] <= i) l += step;
-        r.band = l;
-        r.win = -1;
-        r.dest = i;
-    } else {
-        const uint16_t *st = tab + 23;
-        int s = 0;
-#pragma unroll
-        for (int step = 8; step; step >>= 1)
-            if (s + step <= 12 && 3 * st[s + step] <= i) s += step;
-        const int begin = st[s], width = st[s + 1] - begin, rel = i - 3 * begin;
-        const int w = rel >= 2 * width ? 2 : (rel >= width ? 1 : 0);
-        r.band = s;
-        r.win = w;
-        r.dest = 3 * (begin + rel - w * width) + w;
-    }
+    r.dest = (int)(m & 1023u);
+    r.band = (int)((m >> 10) & 31u);
+    r.win = (int)((m >> 15) & 3u) - 1;
     return r;
 }
 
 }  // namespace
 
+// One wavefront per granule, four per block.  Where a line sits -- band, window, position after the reorder -- depends on the
+// sampling rate and on how the granule is cut up (long, short, mixed) only: the engine tabulates it once per rate
+// (Mp3RequantArgs::line_map, 3 x 576 words, read coalesced), and the exponent q of every band / window of the granule is
+// worked out once by 61 lanes into LDS; a line then costs one map word, one LDS read for q, one gather of |is|^(4/3).
 __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[kWaves][2][576];
     __shared__ __attribute__((aligned(16))) int16_t qs[kWaves][2 * 576];  // the granule's integers, brought in as whole dwords
     __shared__ uint32_t rec[kWaves][sizeof(Mp3RequantRecord) / 4];
-    __shared__ uint16_t tabs[kWaves][kMp3BandRow];
-    __shared__ uint8_t pre[kWaves][24];
+    __shared__ int16_t qtab[kWaves][2][64];  // [channel][long band 0..21 | 22 + 3 band + window]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -92,16 +77,21 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
             for (int k = 0; k < 9; ++k) out[c * 576 + lane + 64 * k] = 0.0f;
         return;
     }
-    if (lane < kMp3BandRow) tabs[wave][lane] = a.bands[g.slot * kMp3BandRow + lane];
-    if (lane < 24) pre[wave][lane] = a.pretab[g.slot * 24 + lane];
     {
         // 1152 bytes per channel in 256-byte runs (a lane's own lines are 64 apart: read one by one they are 2-byte gathers)
         const uint32_t *src = reinterpret_cast<const uint32_t *>(a.is + (size_t)g.off * 576);  // 1152-byte granularity: dword aligned
         uint32_t *dst = reinterpret_cast<uint32_t *>(qs[wave]);
         for (int d = lane; d < channels * 288; d += 64) dst[d] = src[d];
     }
+    for (int c = 0; c < channels; ++c) {  // q of every band (long) and band x window (short): 2.4.3.4.7.1
+        const sk_mp3_requant_channel &ch = g.ch[c];
+        const int mult = ch.scalefac_scale ? 4 : 2;
+        int q = (int)ch.global_gain - 210;
+        if (lane < 22) q -= mult * ((int)ch.scalefac_l[lane] + (ch.preflag ? (int)a.pretab[g.slot * 24 + lane] : 0));
+        else if (lane < 61) q -= 8 * (int)ch.subblock_gain[(lane - 22) % 3] + mult * (int)ch.scalefac_s[(lane - 22) / 3][(lane - 22) % 3];
+        qtab[wave][c][lane] = (int16_t)q;
+    }
     wave_sync();
-    const uint16_t *tab = tabs[wave];
     const int16_t *is = qs[wave];
 
     const bool is_short = g.ch[0].block_type == 2;  // both channels agree whenever the stereo step looks at it (host check)
@@ -110,17 +100,15 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
     int top[3] = {-1, -1, -1};  // highest band of the right channel holding a non-zero line: long -> [0], short -> per window
     for (int c = 0; c < channels; ++c) {
         const sk_mp3_requant_channel &ch = g.ch[c];
-        const bool sh = ch.block_type == 2;
-        const int mult = ch.scalefac_scale ? 4 : 2;
+        const int layout = ch.block_type == 2 ? (ch.mixed_block_flag ? 2 : 1) : 0;
+        const uint32_t *map = a.line_map + ((size_t)g.slot * 3 + layout) * 576;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int i = lane + 64 * k;
-            const Line at = locate(i, sh && !(ch.mixed_block_flag && i < 36), tab);
+            const Line at = unpack_line(map[i]);
             where[c][k] = at;
             const int q_in = is[c * 576 + i];
-            int q = (int)ch.global_gain - 210;
-            if (at.win < 0) q -= mult * ((int)ch.scalefac_l[at.band] + (ch.preflag ? (int)pre[wave][at.band] : 0));
-            else q -= 8 * (int)ch.subblock_gain[at.win] + mult * (int)ch.scalefac_s[at.band][at.win];
+            const int q = qtab[wave][c][at.win < 0 ? at.band : 22 + 3 * at.band + at.win];
             const int mag = min(abs(q_in), (int)kMp3Pow43 - 1);
             const float m = a.pow43[mag] * a.root4[q & 3];  // 2^(q / 4) = 2^floor(q / 4) * 2^((q mod 4) / 4): one rounding here,
             const float x = ldexpf(m, q >> 2);              // the power of two is exact

@@ -310,6 +310,7 @@ struct Mp3RequantArgs {
     const float *is_k;      // [8]: t / (1 + t), t = tan(i pi / 12), i < 7
     const uint16_t *bands;  // [kMp3Rates][kMp3BandRow]
     const uint8_t *pretab;  // [kMp3Rates][24]
+    const uint32_t *line_map;  // [kMp3Rates][long | short | mixed][576]: dest | band << 10 | (window + 1) << 15 of every bitstream-order line
 };
 hipError_t launch_mp3_requant(const Mp3RequantArgs &a, hipStream_t s);
 
