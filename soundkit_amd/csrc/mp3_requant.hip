@@ -55,8 +55,10 @@ __device__ __forceinline__ Line unpack_line(uint32_t m) {
 // (Mp3RequantArgs::line_map, 3 x 576 words, read coalesced), and the exponent q of every band / window of the granule is
 // worked out once by 61 lanes into LDS; a line then costs one map word, one LDS read for q, one gather of |is|^(4/3).
 __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
+    // the granule's integers (brought in as whole dwords) and, once they have all been read, its reordered lines share one buffer:
+    // 5 KB of LDS per wave instead of 7, 32 waves per CU instead of 20 -- the kernel lives on how many of its chains of
+    // dependent memory trips are in flight
     __shared__ __attribute__((aligned(16))) float xs[kWaves][2][576];
-    __shared__ __attribute__((aligned(16))) int16_t qs[kWaves][2 * 576];  // the granule's integers, brought in as whole dwords
     __shared__ uint32_t rec[kWaves][sizeof(Mp3RequantRecord) / 4];
     __shared__ int16_t qtab[kWaves][2][64];  // [channel][long band 0..21 | 22 + 3 band + window]
 
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
     {
         // 1152 bytes per channel in 256-byte runs (a lane's own lines are 64 apart: read one by one they are 2-byte gathers)
         const uint32_t *src = reinterpret_cast<const uint32_t *>(a.is + (size_t)g.off * 576);  // 1152-byte granularity: dword aligned
-        uint32_t *dst = reinterpret_cast<uint32_t *>(qs[wave]);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(xs[wave]);
         for (int d = lane; d < channels * 288; d += 64) dst[d] = src[d];
     }
     for (int c = 0; c < channels; ++c) {  // q of every band (long) and band x window (short): 2.4.3.4.7.1
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
         qtab[wave][c][lane] = (int16_t)q;
     }
     wave_sync();
-    const int16_t *is = qs[wave];
+    const int16_t *is = reinterpret_cast<const int16_t *>(xs[wave]);
 
     const bool is_short = g.ch[0].block_type == 2;  // both channels agree whenever the stereo step looks at it (host check)
     float v[2][9];
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
         }
     }
 
+    wave_sync();  // every integer has been read: the buffer changes hands
     for (int c = 0; c < channels; ++c) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) xs[wave][c][where[c][k].dest] = v[c][k];
