@@ -575,11 +575,13 @@ __device__ __forceinline__ void write_positions2(lds_f2 *buf, int lane, const f2
 //   in : ex[64 w + lane] = pre-twiddled element `lane` of short block w (slot = re A, re B, im A, im B);
 //        stage = the two overlap delays as pairs at this lane's 16 positions (write_positions2)
 //   out: ex, viewed as 1024 pairs, = PCM; stage = new delays (both at this lane's 16 positions)
-__device__ __attribute__((noinline)) void synth_rare_pair(lds_f4 *ex, lds_f2 *stage, const float *win, const f2 *w64, const f2 *tw_short,
+// short_win, w64, tw_short: the two 256-entry short windows (sine, KBD), the 64 roots and the 64 short twiddles in LDS, copied
+// there once per workgroup -- read from global memory here they were three trips to memory in the middle of every EightShort frame
+__device__ __attribute__((noinline)) void synth_rare_pair(lds_f4 *ex, lds_f2 *stage, const lds_f *short_win, const lds_f2 *w64, const lds_f2 *tw_short,
                                                           int prev_a, int shape_a, int prev_b, int shape_b, int lane) {
     const int hi3 = lane >> 3, lo3 = lane & 7;
-    const float *prev_short_a = win + 4096 + 256 * prev_a, *cur_short_a = win + 4096 + 256 * shape_a;
-    const float *prev_short_b = win + 4096 + 256 * prev_b, *cur_short_b = win + 4096 + 256 * shape_b;
+    const lds_f *prev_short_a = short_win + 256 * prev_a, *cur_short_a = short_win + 256 * shape_a;
+    const lds_f *prev_short_b = short_win + 256 * prev_b, *cur_short_b = short_win + 256 * shape_b;
     c2 z[8];
     f2 dly[16];
     read_positions2(stage, lane, dly);
@@ -665,11 +667,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(Synth
     __shared__ f2 stage_lds[WITH_SHORT ? kWavesPerBlock : 1][WITH_SHORT ? kStage : 2];  // eight-short arm only: 1024 (A, B) pairs per wave
     __shared__ f2 tw_tab[512];
     __shared__ f2 t64_tab[64];
+    __shared__ float short_win_tab[WITH_SHORT ? 512 : 2];  // the sine and the KBD short window (eight-short arm only)
+    __shared__ f2 short_tw_tab[WITH_SHORT ? 128 : 1];       // w64[64] | tw_short[64] (eight-short arm only)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < 512; i += kWavesPerBlock * 64) tw_tab[i] = reinterpret_cast<const f2 *>(a.t.tw_long)[i];
     if (threadIdx.x < 64) t64_tab[threadIdx.x] = reinterpret_cast<const f2 *>(a.t.w64)[((threadIdx.x >> 3) * (threadIdx.x & 7)) & 63];
+    if (WITH_SHORT) {
+        for (int i = threadIdx.x; i < 512; i += kWavesPerBlock * 64) short_win_tab[i] = a.t.win[4096 + i];
+        if (threadIdx.x < 128)
+            short_tw_tab[threadIdx.x] = threadIdx.x < 64 ? reinterpret_cast<const f2 *>(a.t.w64)[threadIdx.x] : reinterpret_cast<const f2 *>(a.t.tw_short)[threadIdx.x - 64];
+    }
     __syncthreads();
 
     const uint32_t pair_id = blockIdx.x * kWavesPerBlock + wave;
@@ -776,9 +785,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(Synth
                 // both channels' EightShort frame (dsp.rs:284-338) through synth_rare_pair: pre-twiddled blocks and the two
                 // overlaps in through the wave's LDS, PCM and new overlaps back the same way
                 {
-                    int opq = 0;  // keeps this rare-path table load inside the branch
-                    asm volatile("" : "+v"(opq));
-                    const f2 tws = reinterpret_cast<const f2 *>(a.t.tw_short)[lane + opq];
+                    const f2 tws = short_tw_tab[64 + lane];
                     const f2 tx = splat(tws.x), ty = splat(tws.y);
 #pragma unroll
                     for (int w = 0; w < 8; ++w) {  // z_w[lane] of short block w (dsp.rs:495-503 with input_len 128)
@@ -793,8 +800,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void k_aac_synth_pair(Synth
                     write_positions2(stage, lane, both);
                     wave_sync();
                 }
-                synth_rare_pair(ex, stage, a.t.win, reinterpret_cast<const f2 *>(a.t.w64), reinterpret_cast<const f2 *>(a.t.tw_short),
-                                prev_a, shape_a, prev_b, shape_b, lane);
+                synth_rare_pair(ex, stage, (const lds_f *)short_win_tab, (const lds_f2 *)short_tw_tab, (const lds_f2 *)short_tw_tab + 64, prev_a, shape_a, prev_b,
+                                shape_b, lane);
                 float pcm_a[16], pcm_b[16];
                 {
                     f2 both[16];
