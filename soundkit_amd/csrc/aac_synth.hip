@@ -172,13 +172,15 @@ __device__ __forceinline__ void fft512(f2 (&z)[8], lds_f2 *ex, const lds_f2 *t64
 //   out: PCM written to out_ptr; stage = new delay at this lane's 16 positions
 __device__ __attribute__((noinline)) void synth_rare_frame(lds_f2 *ex, lds_f *stage, const lds_f2 *tw_lds,
                                                             const lds_f2 *t64, float base2_re, float base2_im,
-                                                            const float *win, const f2 *w64, const f2 *tw_short,
+                                                            const lds_f *short_win, const lds_f2 *w64, const lds_f2 *tw_short,
                                                             float *out_ptr, int16_t *out16_ptr, int seq, int prev_shape,
                                                             int shape, int lane) {
     const int hi3 = lane >> 3, lo3 = lane & 7;
     (void)base2_re, (void)base2_im, (void)t64, (void)tw_lds, (void)seq;  // only the short transform is left here
-    const float *prev_short = win + 4096 + 256 * prev_shape;
-    const float *cur_short = win + 4096 + 256 * shape;
+    // short_win (the sine and the KBD short window), w64, tw_short: LDS copies made once per workgroup -- from global memory
+    // they were three trips to memory in the middle of every EightShort frame
+    const lds_f *prev_short = short_win + 256 * prev_shape;
+    const lds_f *cur_short = short_win + 256 * shape;
     f2 z[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) z[r] = ex[64 * r + lane];
@@ -283,11 +285,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
     __shared__ float stage_lds[ONLY_LONG ? 1 : kWavesPerBlock][ONLY_LONG ? 4 : kStage];  // rare-path staging only
     __shared__ f2 tw_tab[512];  // pre/post twiddle (dsp.rs:99-106), shared by the block's waves
     __shared__ f2 t64_tab[64];  // t64[k][n] = W64^{n k}
+    __shared__ float short_win_tab[ONLY_LONG ? 2 : 512];  // the sine and the KBD short window (eight-short frames only)
+    __shared__ f2 short_tw_tab[ONLY_LONG ? 1 : 128];       // w64[64] | tw_short[64]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < 512; i += kWavesPerBlock * 64) tw_tab[i] = reinterpret_cast<const f2 *>(a.t.tw_long)[i];
     if (threadIdx.x < 64) t64_tab[threadIdx.x] = reinterpret_cast<const f2 *>(a.t.w64)[((threadIdx.x >> 3) * (threadIdx.x & 7)) & 63];
+    if (!ONLY_LONG) {
+        for (int i = threadIdx.x; i < 512; i += kWavesPerBlock * 64) short_win_tab[i] = a.t.win[4096 + i];
+        if (threadIdx.x < 128)
+            short_tw_tab[threadIdx.x] = threadIdx.x < 64 ? reinterpret_cast<const f2 *>(a.t.w64)[threadIdx.x] : reinterpret_cast<const f2 *>(a.t.tw_short)[threadIdx.x - 64];
+    }
     __syncthreads();
 
     const uint32_t task_id = blockIdx.x * kWavesPerBlock + wave;
@@ -352,9 +361,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
                 z[r] = (f2){odd * t.y - even * t.x, odd * t.x + even * t.y};
             }
         } else {
-            int opq = 0;  // keeps this rare-path table load inside the branch (no hoisting out of the frame loop)
-            asm volatile("" : "+v"(opq));
-            const f2 tws = reinterpret_cast<const f2 *>(a.t.tw_short)[lane + opq];
+            const f2 tws = short_tw_tab[ONLY_LONG ? 0 : 64 + lane];
 #pragma unroll
             for (int w = 0; w < 8; ++w) {  // z_w[lane] of short block w
                 const float even = xin[w].x;
@@ -425,8 +432,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (ONLY_LONG && kDepth == 1) ? k
             for (int r = 0; r < 8; ++r) ex[64 * r + lane] = z[r];
             write_positions(stage, lane, dly);
             wave_sync();
-            synth_rare_frame(ex, stage, tw_lds, t64, base2.x, base2.y, a.t.win, reinterpret_cast<const f2 *>(a.t.w64),
-                             reinterpret_cast<const f2 *>(a.t.tw_short), out_ptr, out16_ptr, seq, prev_shape, shape, lane);
+            synth_rare_frame(ex, stage, tw_lds, t64, base2.x, base2.y, (const lds_f *)short_win_tab, (const lds_f2 *)short_tw_tab,
+                             (const lds_f2 *)short_tw_tab + 64, out_ptr, out16_ptr, seq, prev_shape, shape, lane);
             read_positions(stage, lane, dly);
             float pcm[16];
             read_positions((const lds_f *)ex, lane, pcm);
