@@ -64,10 +64,11 @@ __device__ constexpr int kProductsF16[kWindows] = {kFirProductsF16[0], kFirProdu
                                                      kFirProductsF16[5], kFirProductsF16[6], kFirProductsF16[7], kFirProductsF16[8], kFirProductsF16[9]};
 __host__ __device__ constexpr int products_of(int s, bool in16, bool f16) { return f16 ? kProductsF16[s] : products_of(s, in16); }
 #ifndef SK_BF_AHEAD
-#define SK_BF_AHEAD 2
+#define SK_BF_AHEAD 3
 #endif
-// half-chunks of input in flight per wave (2, 3, 4 or 6: a divisor of the 12 steps of the unrolled body).  Three made no
-// difference to the launch time (profiles/r01_ab_fir.md): the kernel moves bytes at the rate a copy does, latency is covered.
+// half-chunks of input in flight per wave (2, 3, 4 or 6: a divisor of the 12 steps of the unrolled body).  In round 1 three made
+// no difference (profiles/r01_ab_fir.md); with this round's shorter steps the loads of two half-chunks no longer land in time:
+// 2 -> 3 is 4 % of the launch (0.381-0.386 -> 0.364-0.370 ms on one box), 4 the same, 6 spills (profiles/r03_ab_fir.md).
 constexpr int kAhead = SK_BF_AHEAD;
 
 __host__ __device__ constexpr int ring_index(int rho) { return ((rho % kRing) + kRing) % kRing; }
