@@ -43,10 +43,11 @@ __device__ __forceinline__ int16_t mp3_to_i16(float x) {
 }
 
 template <bool OUT16>
-__global__ __launch_bounds__(kWaves * 64) void k_mp3_hybrid(Mp3Args a) {
+__global__ __launch_bounds__(kWaves * 64, 3) void k_mp3_hybrid(Mp3Args a) {
     __shared__ __attribute__((aligned(16))) float mat[4 * 36 * kRow];
+    // the granule's lines and, once every lane holds its eighteen of them, the hybrid samples share one buffer: 8.7 KB of LDS per
+    // wave instead of 11, three workgroups per CU instead of two (the kernel is a chain of LDS round trips: it lives on waves)
     __shared__ __attribute__((aligned(16))) float xs[kWaves][576];
-    __shared__ __attribute__((aligned(16))) float hyb[kWaves][576];
     __shared__ __attribute__((aligned(16))) float ovl[kWaves][576];
     __shared__ __attribute__((aligned(16))) float ring[kWaves][1024];
 
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_hybrid(Mp3Args a) {
     const SynthTask task = a.tasks[task_id];
     const uint32_t count = __builtin_amdgcn_readfirstlane(task.count), state = __builtin_amdgcn_readfirstlane(task.state);
     const SynthEntry *entries = a.entries + __builtin_amdgcn_readfirstlane(task.begin);
-    lds_f *x = (lds_f *)xs[wave], *h = (lds_f *)hyb[wave], *ov = (lds_f *)ovl[wave], *rg = (lds_f *)ring[wave];
+    lds_f *x = (lds_f *)xs[wave], *h = (lds_f *)xs[wave], *ov = (lds_f *)ovl[wave], *rg = (lds_f *)ring[wave];
     const lds_f *m = (const lds_f *)mat;
 
     // carried state in: overlap[576], ring[1024], position
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_hybrid(Mp3Args a) {
             out[i] = acc;
         }
         // ---- overlap-add, frequency inversion; the second half becomes the overlap ----
+        wave_sync();  // every lane has read its lines: the buffer changes hands
         if (half == 0) {
 #pragma unroll
             for (int i = 0; i < 18; ++i) {
