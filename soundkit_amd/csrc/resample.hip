@@ -27,6 +27,8 @@
 //   (tests/test_fir_gpu.py::test_generic_ratios_are_bit_identical_to_the_restated_rubato).
 #include "sk_device.h"
 
+#include <algorithm>
+
 namespace sk {
 
 namespace {
@@ -342,11 +344,11 @@ __device__ __forceinline__ void split3(float x0, float x1, uint32_t &p1, uint32_
 }
 
 // grid (tiles, sets), one wave: the A fragments [window][plane][lane] of tile t of index set `set`, and its TileMeta
-__global__ __launch_bounds__(64) void k_sinc_taps(SincArgs a, uint32_t n_tiles, uint32_t max_windows, u32x4 *frags, TileMeta *meta) {
+__global__ __launch_bounds__(64) void k_sinc_taps(SincArgs a, uint32_t n_tiles, uint32_t tile_first, uint32_t max_windows, u32x4 *frags, TileMeta *meta) {
     const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
-    const uint32_t t = blockIdx.x, set = blockIdx.y;
+    const uint32_t t = tile_first + blockIdx.x, set = blockIdx.y;  // t: tile of the row; storage is per pass (n_tiles of them)
     const uint32_t count = a.set_count[set];
-    TileMeta *my_meta = meta + (size_t)set * n_tiles + t;
+    TileMeta *my_meta = meta + (size_t)set * n_tiles + blockIdx.x;
     if (16u * t >= count) {
         if (lane == 0) *my_meta = TileMeta{0, 0};
         return;
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(64) void k_sinc_taps(SincArgs a, uint32_t n_tiles, 
     const bool valid = (uint32_t)i <= last;
     const float *s0 = a.sincs + (size_t)at.sub0 * 256, *s1 = a.sincs + (size_t)((at.sub0 + 1) & 255) * 256;
     const int delta = index0 - base;
-    u32x4 *out = frags + ((size_t)set * n_tiles + t) * max_windows * 3 * 64 + lane;
+    u32x4 *out = frags + ((size_t)set * n_tiles + blockIdx.x) * max_windows * 3 * 64 + lane;
     for (int s = 0; s < windows; ++s) {
         float g[8];
 #pragma unroll
@@ -398,15 +400,17 @@ struct RowBlock {
     bool live;  // this tile chunk has outputs for the block's index set
 };
 
-__global__ __launch_bounds__(kMfmaTiles * 64, SK_MFMA_BLOCKS) void k_sinc_mfma(SincArgs a, uint32_t n_tiles, uint32_t max_windows, uint32_t tiles_per_block,
-                                                               uint32_t row_blocks_per_group, const u32x4 *frags, const TileMeta *meta) {
+__global__ __launch_bounds__(kMfmaTiles * 64, SK_MFMA_BLOCKS) void k_sinc_mfma(SincArgs a, uint32_t n_tiles, uint32_t tile_first, uint32_t max_windows,
+                                                               uint32_t tiles_per_block, uint32_t row_blocks_per_group, const u32x4 *frags,
+                                                               const TileMeta *meta) {
     extern __shared__ __attribute__((aligned(16))) unsigned char planes[];  // [3][kMfmaRows][kMfmaPitch]
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n_row_blocks = (a.rows + kMfmaRows - 1) / kMfmaRows;
     const uint32_t rb_begin = blockIdx.x * row_blocks_per_group;
     const uint32_t rb_end = min(n_row_blocks, rb_begin + row_blocks_per_group);
-    const uint32_t t0 = blockIdx.y * tiles_per_block;
+    const uint32_t l0 = blockIdx.y * tiles_per_block;  // first tile of the workgroup within this pass (storage index)
+    const uint32_t t0 = tile_first + l0;               // ... and within the row
     const uint32_t t = t0 + (uint32_t)wave;
 
     // the index sets of the run's row blocks, read once up front (eight independent loads instead of one dependent chain per
@@ -420,11 +424,11 @@ __global__ __launch_bounds__(kMfmaTiles * 64, SK_MFMA_BLOCKS) void k_sinc_mfma(S
         RowBlock b;
         b.set = set;
         b.count = a.set_count[b.set];
-        b.tm = meta + (size_t)b.set * n_tiles + t0;
+        b.tm = meta + (size_t)b.set * n_tiles + l0;
         b.live = 16u * t0 < b.count;
         b.nt = 0, b.base_first = 0, b.span = 0;
         if (b.live) {
-            b.nt = min(tiles_per_block, (b.count - 16u * t0 + 15u) / 16u);
+            b.nt = min(min(tiles_per_block, n_tiles - l0), (b.count - 16u * t0 + 15u) / 16u);
             b.base_first = b.tm[0].base;
             for (uint32_t k = 0; k < b.nt; ++k) b.span = max(b.span, b.tm[k].base + 32 * b.tm[k].windows - b.base_first);
             if (b.span > kMfmaSpan || b.tm[0].windows == 0) b.live = false;  // (the host sized the launch for this step: not reached)
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(kMfmaTiles * 64, SK_MFMA_BLOCKS) void k_sinc_mfma(S
         has_tile = (uint32_t)wave < b.nt;
         off = has_tile ? __builtin_amdgcn_readfirstlane(b.tm[has_tile ? wave : 0].base - b.base_first) : 0;  // a multiple of 8
         windows = has_tile ? __builtin_amdgcn_readfirstlane(b.tm[has_tile ? wave : 0].windows) : 0;
-        const u32x4 *fa = frags + ((size_t)b.set * n_tiles + t) * max_windows * 3 * 64 + lane;
+        const u32x4 *fa = frags + ((size_t)b.set * n_tiles + l0 + (uint32_t)wave) * max_windows * 3 * 64 + lane;
 #pragma unroll
         for (int s = 0; s < kMaxWindows; ++s)
             if (s < windows) {
@@ -603,34 +607,42 @@ static uint32_t sinc_mfma_tiles_per_block(double step) {
     return tiles;
 }
 
+// The fragments are built and used in passes of at most kPassTiles tiles (64 K outputs) per index set, so the scratch does not
+// grow with the length of the rows and the form never depends on it.
+constexpr uint32_t kPassTiles = 4096;
+
 size_t sinc_mfma_scratch_bytes(uint32_t n_sets, uint32_t out_count, double step) {
     if (n_sets == 0 || out_count == 0) return 0;
     const uint32_t windows = sinc_mfma_windows(step);
     if (windows > (uint32_t)kMaxWindows || 32.0 * windows + 8.0 > (double)kMfmaSpan) return 0;
-    const size_t tiles = (out_count + 15) / 16;
+    const size_t tiles = std::min<size_t>((out_count + 15) / 16, kPassTiles);
     const size_t bytes = (size_t)n_sets * tiles * ((size_t)windows * 3 * 1024 + sizeof(TileMeta)) + 256;
     return bytes > ((size_t)64 << 30) ? 0 : bytes;
 }
 
 static hipError_t launch_sinc_mfma(const SincArgs &a, hipStream_t s) {
-    const uint32_t windows = sinc_mfma_windows(a.step), tiles = (a.out_count + 15) / 16, tpb = sinc_mfma_tiles_per_block(a.step);
-    const size_t frag_bytes = (size_t)a.n_sets * tiles * windows * 3 * 1024;
+    const uint32_t windows = sinc_mfma_windows(a.step), all_tiles = (a.out_count + 15) / 16, tpb = sinc_mfma_tiles_per_block(a.step);
+    const uint32_t pass_tiles = std::min(all_tiles, kPassTiles);
+    const size_t frag_bytes = (size_t)a.n_sets * pass_tiles * windows * 3 * 1024;
     u32x4 *frags = reinterpret_cast<u32x4 *>(a.scratch);
     TileMeta *meta = reinterpret_cast<TileMeta *>(reinterpret_cast<unsigned char *>(a.scratch) + ((frag_bytes + 255) & ~(size_t)255));
     const uint32_t row_blocks = (a.rows + kMfmaRows - 1) / kMfmaRows;
-    if ((tiles + tpb - 1) / tpb > 65535 || a.n_sets > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_sinc_taps, dim3(tiles, a.n_sets), dim3(64), 0, s, a, tiles, windows, frags, meta);
+    if (a.n_sets > 65535) return hipErrorInvalidValue;
     constexpr size_t lds_bytes = 3 * (size_t)kMfmaPlane;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sinc_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        (int)lds_bytes);
     if (attr != hipSuccess) return attr;
-    // runs of row blocks per workgroup: long enough to amortise the fragments and the pipeline's fill, short enough for >= 4
-    // workgroups per CU in the launch
-    const uint32_t tile_chunks = (tiles + tpb - 1) / tpb;
-    uint32_t run = 8;
-    while (run > 1 && (uint64_t)((row_blocks + run - 1) / run) * tile_chunks < 1024) run >>= 1;
-    hipLaunchKernelGGL(k_sinc_mfma, dim3((row_blocks + run - 1) / run, tile_chunks), dim3(kMfmaTiles * 64), lds_bytes, s, a, tiles, windows, tpb, run,
-                       frags, meta);
+    for (uint32_t tile_first = 0; tile_first < all_tiles; tile_first += pass_tiles) {
+        const uint32_t tiles = std::min(pass_tiles, all_tiles - tile_first);
+        hipLaunchKernelGGL(k_sinc_taps, dim3(tiles, a.n_sets), dim3(64), 0, s, a, pass_tiles, tile_first, windows, frags, meta);
+        // runs of row blocks per workgroup: long enough to amortise the fragments and the pipeline's fill, short enough for >= 4
+        // workgroups per CU in the launch
+        const uint32_t tile_chunks = (tiles + tpb - 1) / tpb;
+        uint32_t run = 8;
+        while (run > 1 && (uint64_t)((row_blocks + run - 1) / run) * tile_chunks < 1024) run >>= 1;
+        hipLaunchKernelGGL(k_sinc_mfma, dim3((row_blocks + run - 1) / run, tile_chunks), dim3(kMfmaTiles * 64), lds_bytes, s, a, pass_tiles, tile_first, windows,
+                           tpb, run, frags, meta);
+    }
     return hipGetLastError();
 }
 

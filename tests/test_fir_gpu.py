@@ -351,3 +351,18 @@ def test_generic_ratios_on_the_matrix_cores(engine, oracle, in_hz, out_hz, ampli
         worst = max(worst, rel_rms(mine, want))
         assert np.abs(mine - want).max() < 4e-6 * amplitude
     assert worst < 1e-6, worst
+
+
+def test_matrix_core_resampler_in_several_passes(engine, oracle):
+    """rows long enough for more than one pass of 4096 tiles (65 536 outputs): the tap fragments are rebuilt per pass in the same
+    scratch, and the seam between the passes is just another tile boundary"""
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-1, 1, (33, 200000)).astype(np.float32)
+    got = engine.downsample(x, 44100, 16000)
+    assert got.shape[1] > 70000
+    for rows in ((0, 2), (31, 33)):
+        want = oracle.downsample_planar(x[rows[0]:rows[1]], 44100, 16000)
+        assert got.shape[1] == want.shape[1]
+        assert rel_rms(got[rows[0]:rows[1]], want) < 1e-6 and np.abs(got[rows[0]:rows[1]] - want).max() < 4e-6
+        seam = slice(65536 - 64, 65536 + 64)
+        assert np.abs(got[rows[0]:rows[1], seam] - want[:, seam]).max() < 4e-6
