@@ -211,9 +211,11 @@ int sk_aac_dequantize(sk_engine *, const int16_t *quant, const int16_t *scalefac
  * IMDCT 36 or 3 x 12 with the block-type windows -> overlap-add -> frequency inversion -> 32-band polyphase synthesis
  * (ISO/IEC 11172-3 2.4.3.4), 576 PCM samples out, float in +-1.0 interleaved as nanomp3 emits them, or s16 through
  * f32_to_i16 (lib.rs:376-385).  Carried state (overlap, polyphase FIFO) is per engine stream, reset by sk_stream_open /
- * sk_stream_reset.  NOT here, because the data exists nowhere in this tree or container: the bitstream side (Huffman
- * tables, ISO 11172-3 Table B.7) and the synthesis window D (Table B.3), which the caller supplies once per engine --
- * until then the synthesis entry points return SK_ERR_UNSUPPORTED.  Parity of this row is unpinned.
+ * sk_stream_reset.  The synthesis window D (Table B.3) is set once per engine: sk_mp3_decoder_create does it (with the
+ * standard's table, csrc/mp3_iso_tables.h, unless the caller brings its own); callers of the bare stage call
+ * sk_mp3_set_synthesis_window -- until then the synthesis entry points return SK_ERR_UNSUPPORTED.  Sample parity with
+ * nanomp3 is unpinned (its source is absent); what pins this row is the decode of the reference's two MP3 fixtures against
+ * the source PCM the reference holds for them (tests/test_mp3_fixtures_gpu.py).
  * Lines of a short block (block_type 2) are window-interleaved: X_w[m] = xr[18 sb + 3 m + w]. */
 typedef struct sk_mp3_granule_desc {
     uint32_t stream;
@@ -235,9 +237,8 @@ int sk_mp3_hybrid_synthesize_f32_dev(sk_engine *, const sk_mp3_granule_desc *des
 /* ---- MPEG Layer III: the fixed-syntax front of the bitstream half, and requantisation / stereo / reorder -------------
  * What nanomp3::Decoder::decode (soundkit-mp3/src/lib.rs:284) does between the bytes and its Huffman stage, and between that
  * stage and the hybrid synthesis above -- the parts that are closed-form syntax and arithmetic of ISO/IEC 11172-3 /
- * 13818-3.  The Huffman stage itself needs Table B.7, the band tables B.8: data that exists nowhere in this tree or
- * container; the band tables (and the pre-emphasis table) are caller-supplied like the synthesis window.  Parity of the MP3
- * row stays unpinned; the reference's two MP3 fixtures pin the framing (tests/test_mp3_bitstream.py). */
+ * 13818-3.  The band tables (Table B.8) and the pre-emphasis table are set per engine and sampling rate like the synthesis
+ * window (sk_mp3_decoder_create does it).  The reference's two MP3 fixtures pin the framing (tests/test_mp3_bitstream.py). */
 enum sk_mp3_status {
     SK_MP3_NEED_MORE = -301,   /* not enough bytes for the header / side information / frame / reservoir */
     SK_MP3_NO_SYNC = -302,     /* not a frame header */
@@ -300,10 +301,11 @@ int sk_mp3_decode_granules_s16(sk_engine *, const sk_mp3_requant_granule *granul
                                int16_t *pcm_out, uint32_t n, int32_t *status_per_granule);
 
 /* ---- MPEG Layer III: scale factors, the Huffman stage and a decoder handle in Mp3Decoder's shape ----------------------
- * Parts 2 and 3 of the main data are syntax too, but syntax over data tables of the standard that this tree does not hold.
- * The caller hands them over once (nanomp3 has them all) in the standard's own presentation -- for every code its length
- * and its bits -- and the library builds its decoding structures from that.  Nothing in here was written down from
- * memory of the standard's annexes; the tests run on synthetic code books and an encoder of their own. */
+ * Parts 2 and 3 of the main data are syntax over data tables of the standard.  They enter in the standard's own
+ * presentation -- for every code its length and its bits -- and the library builds its decoding structures from that.
+ * sk_mp3_iso_tables hands out the standard's tables (csrc/mp3_iso_tables.h: normative constants of ISO/IEC 11172-3 B.3 /
+ * B.6 / B.7 / B.8 and 13818-3 2.4.3.2, written by tools/transcribe_iso_mp3_tables.py, which records where they were read
+ * and the checks that gate them); a caller may pass any other complete prefix code set instead (the syntax tests do). */
 typedef struct sk_mp3_code_table { /* one table of ISO/IEC 11172-3 Table B.7 */
     uint8_t xlen;                  /* values 0 .. xlen-1 for x and for y; 0 = table carries no codes (tables 0, 4, 14) */
     uint8_t linbits;
@@ -325,6 +327,8 @@ typedef struct sk_mp3_tables {
 typedef struct sk_mp3_codebook sk_mp3_codebook; /* host-side: validated copies + prefix-decoding tables; no GPU involved */
 int sk_mp3_codebook_create(const sk_mp3_tables *, sk_mp3_codebook **out); /* SK_MP3_INVALID: a code set that is no prefix code */
 void sk_mp3_codebook_destroy(sk_mp3_codebook *);
+int sk_mp3_iso_tables(sk_mp3_tables *out);            /* the standard's tables; hlen / hcod point to static storage */
+int sk_mp3_codebook_create_iso(sk_mp3_codebook **out); /* = sk_mp3_iso_tables + sk_mp3_codebook_create */
 
 /* One granule of one channel out of parts 2 + 3: the scale factors in sk_mp3_requantize's layout and the 576 integers. */
 typedef struct sk_mp3_granule_data {
@@ -335,6 +339,7 @@ typedef struct sk_mp3_granule_data {
     uint8_t intensity_scale; /* LSF intensity channel: scalefac_compress & 1 (not used: such granules are rejected later) */
     uint16_t part2_bits; /* what the scale factors took of part2_3_length */
     uint16_t nonzero_lines; /* lines up to and including the last decoded pair / quadruple */
+    uint16_t part3_bits; /* what the accepted pairs / quadruples took; a well-formed granule: part2_bits + part3_bits == part2_3_length */
     int32_t status;      /* SK_OK | SK_MP3_INVALID (a bit pattern that is no code, values past line 576) | SK_MP3_UNSUPPORTED */
 } sk_mp3_granule_data;
 /* main = what sk_mp3_main_data assembled.  out[granule][channel]; previous = the same frame's granule-0 scale factors are
@@ -351,7 +356,9 @@ int sk_mp3_decode_main_data(const sk_mp3_codebook *, const sk_mp3_frame_info *he
  * middle) is consumed without output, as are frames the later stages reject. */
 #define SK_MP3_MAX_SAMPLES_PER_FRAME 2304u
 typedef struct sk_mp3_decoder sk_mp3_decoder;
-int sk_mp3_decoder_create(sk_engine *, const sk_mp3_codebook *, sk_mp3_decoder **out); /* Mp3Decoder::new, lib.rs:157 */
+/* Mp3Decoder::new, lib.rs:157.  codebook NULL = the standard's tables (what nanomp3 has built in); the decoder installs the
+ * codebook's band tables and synthesis window on the engine. */
+int sk_mp3_decoder_create(sk_engine *, const sk_mp3_codebook *, sk_mp3_decoder **out);
 void sk_mp3_decoder_destroy(sk_mp3_decoder *);
 int sk_mp3_decoder_reset(sk_mp3_decoder *);                                           /* lib.rs:180-185 */
 /* sample_rate / channels are 0 until the first frame was decoded (Option::None, lib.rs:167-173); buffer_len: lib.rs:176 */

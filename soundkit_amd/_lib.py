@@ -84,7 +84,7 @@ class Mp3Tables(C.Structure):
 class Mp3GranuleData(C.Structure):
     """sk_mp3_granule_data"""
     _fields_ = [("is_", C.c_int16 * 576), ("scalefac_l", C.c_uint8 * 22), ("scalefac_s", (C.c_uint8 * 3) * 13), ("preflag", C.c_uint8),
-                ("intensity_scale", C.c_uint8), ("part2_bits", C.c_uint16), ("nonzero_lines", C.c_uint16), ("status", C.c_int32)]
+                ("intensity_scale", C.c_uint8), ("part2_bits", C.c_uint16), ("nonzero_lines", C.c_uint16), ("part3_bits", C.c_uint16), ("status", C.c_int32)]
 
 
 class TickStream(C.Structure):
@@ -260,6 +260,8 @@ _sig = {
     "sk_mp3_decode_granules_s16": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "sk_mp3_codebook_create": (_i, [_vp, C.POINTER(_vp)]),
     "sk_mp3_codebook_destroy": (None, [_vp]),
+    "sk_mp3_iso_tables": (_i, [C.POINTER(Mp3Tables)]),
+    "sk_mp3_codebook_create_iso": (_i, [C.POINTER(_vp)]),
     "sk_mp3_decode_main_data": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "sk_mp3_decoder_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
     "sk_mp3_decoder_destroy": (None, [_vp]),

@@ -8,6 +8,7 @@
 // binary decoding tries here.  Host code throughout; the arithmetic behind it (requantisation, stereo, reorder, hybrid
 // synthesis) runs on the GPU, one launch each per decode call (mp3_requant.hip, mp3_hybrid.hip).
 #include "../../include/soundkit_amd.h"
+#include "mp3_iso_tables.h"
 
 #include <cmath>
 #include <cstring>
@@ -177,6 +178,7 @@ int scale_factors_lsf(const sk_mp3_codebook &cb, const sk_mp3_frame_info &h, con
 
 // 2.4.3.4.6: big_values pairs in up to three regions, then count1 quadruples up to the end of part2_3_length
 int huffman(const sk_mp3_codebook &cb, const sk_mp3_frame_info &h, const sk_mp3_granule_side &s, Bits &b, size_t end_bit, sk_mp3_granule_data &g) {
+    const size_t start_bit = b.pos;
     const int row = rate_row(h.sample_rate);
     if (row < 0 || !cb.t.rates_present[row]) return SK_MP3_UNSUPPORTED;
     const uint16_t *lo = cb.t.long_offsets[row], *so = cb.t.short_offsets[row];
@@ -226,6 +228,8 @@ int huffman(const sk_mp3_codebook &cb, const sk_mp3_frame_info &h, const sk_mp3_
         }
     }
     if (b.pos > end_bit) return SK_MP3_INVALID;  // the big values alone overran part2_3_length
+    const size_t part3_begin = start_bit;
+    size_t accepted = b.pos;
     const sk_mp3_codebook::Trie &q = cb.count1[s.count1table_select & 1];
     while (b.pos < end_bit && line + 4 <= 576) {
         const int symbol = trie_read(q, b);
@@ -238,7 +242,9 @@ int huffman(const sk_mp3_codebook &cb, const sk_mp3_frame_info &h, const sk_mp3_
         if (b.pos > end_bit) break;  // a quadruple that reaches past the end is stuffing, not data
         for (int k = 0; k < 4; ++k) g.is[line + k] = (int16_t)v[k];
         line += 4;
+        accepted = b.pos;
     }
+    g.part3_bits = (uint16_t)(accepted - part3_begin);
     g.nonzero_lines = (uint16_t)line;
     return SK_OK;
 }
@@ -289,6 +295,34 @@ int sk_mp3_codebook_create(const sk_mp3_tables *t, sk_mp3_codebook **out) {
 
 void sk_mp3_codebook_destroy(sk_mp3_codebook *cb) { delete cb; }
 
+// The standard's own tables (csrc/mp3_iso_tables.h) in the caller's presentation; pointers are to static storage.
+int sk_mp3_iso_tables(sk_mp3_tables *out) {
+    if (!out) return SK_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    for (int t = 0; t < 32; ++t) {
+        out->big_values[t].xlen = sk_mp3_iso::select[t].xlen;
+        out->big_values[t].linbits = sk_mp3_iso::linbits[t];
+        out->big_values[t].hlen = sk_mp3_iso::select[t].hlen;
+        out->big_values[t].hcod = sk_mp3_iso::select[t].hcod;
+    }
+    std::memcpy(out->count1_hlen, sk_mp3_iso::count1_hlen, sizeof out->count1_hlen);
+    std::memcpy(out->count1_hcod, sk_mp3_iso::count1_hcod, sizeof out->count1_hcod);
+    std::memcpy(out->slen, sk_mp3_iso::slen, sizeof out->slen);
+    std::memcpy(out->lsf_partitions, sk_mp3_iso::lsf_partitions, sizeof out->lsf_partitions);
+    std::memcpy(out->long_offsets, sk_mp3_iso::long_offsets, sizeof out->long_offsets);
+    std::memcpy(out->short_offsets, sk_mp3_iso::short_offsets, sizeof out->short_offsets);
+    std::memset(out->rates_present, 1, sizeof out->rates_present);
+    std::memcpy(out->pretab, sk_mp3_iso::pretab, sizeof out->pretab);
+    for (int i = 0; i < 512; ++i) out->window[i] = (float)sk_mp3_iso::window_q16[i] * (1.0f / 65536.0f);  // exact: |q16| < 2^17
+    return SK_OK;
+}
+
+int sk_mp3_codebook_create_iso(sk_mp3_codebook **out) {
+    sk_mp3_tables t;
+    const int rc = sk_mp3_iso_tables(&t);
+    return rc == SK_OK ? sk_mp3_codebook_create(&t, out) : rc;
+}
+
 int sk_mp3_decode_main_data(const sk_mp3_codebook *cb, const sk_mp3_frame_info *h, const sk_mp3_side_info *side, const uint8_t *main, size_t main_len,
                             sk_mp3_granule_data out[2][2]) {
     if (!cb || !h || !side || !out || (main_len && !main)) return SK_ERR_INVALID_ARG;
@@ -326,6 +360,7 @@ int sk_mp3_decode_main_data(const sk_mp3_codebook *cb, const sk_mp3_frame_info *
 struct sk_mp3_decoder {
     sk_engine *engine = nullptr;
     const sk_mp3_codebook *cb = nullptr;
+    sk_mp3_codebook *own_cb = nullptr;  // the standard's tables, when the caller passed none
     std::vector<uint8_t> buffer, reservoir;
     uint32_t sample_rate = 0;  // of the first frame (Option::get_or_insert, lib.rs:203-204)
     uint8_t channels = 0;
@@ -468,8 +503,18 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
 extern "C" {
 
 int sk_mp3_decoder_create(sk_engine *e, const sk_mp3_codebook *cb, sk_mp3_decoder **out) {
-    if (!e || !cb || !out) return SK_ERR_INVALID_ARG;
+    if (!e || !out) return SK_ERR_INVALID_ARG;
     *out = nullptr;
+    sk_mp3_codebook *own = nullptr;
+    if (!cb) {  // Mp3Decoder::new() takes no tables: the decoder it wraps has the standard's built in
+        const int rc = sk_mp3_codebook_create_iso(&own);
+        if (rc != SK_OK) return rc;
+        cb = own;
+    }
+    struct Guard {
+        sk_mp3_codebook *p;
+        ~Guard() { delete p; }
+    } guard{own};
     static const uint32_t rates[9] = {44100, 48000, 32000, 22050, 24000, 16000, 11025, 12000, 8000};
     for (int row = 0; row < 9; ++row)
         if (cb->t.rates_present[row]) {
@@ -482,6 +527,8 @@ int sk_mp3_decoder_create(sk_engine *e, const sk_mp3_codebook *cb, sk_mp3_decode
     if (!d) return SK_ERR_OOM;
     d->engine = e;
     d->cb = cb;
+    d->own_cb = own;
+    guard.p = nullptr;
     d->buffer.reserve(16 * 1024);  // lib.rs:160
     *out = d;
     return SK_OK;
@@ -490,6 +537,7 @@ int sk_mp3_decoder_create(sk_engine *e, const sk_mp3_codebook *cb, sk_mp3_decode
 void sk_mp3_decoder_destroy(sk_mp3_decoder *d) {
     if (!d) return;
     if (d->stream_open) (void)sk_stream_close(d->engine, d->stream);
+    delete d->own_cb;
     delete d;
 }
 

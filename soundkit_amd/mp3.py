@@ -1,9 +1,8 @@
-"""Host-side mirror of soundkit-mp3's decoder (soundkit-mp3/src/lib.rs:147-374) as far as this tree builds it: frame sync,
-header, side information and the bit reservoir (csrc/mp3_bitstream.cpp, host); requantisation, joint stereo and the
-short-block reorder (csrc/mp3_requant.hip) and the hybrid synthesis filterbank (csrc/mp3_hybrid.hip) on the GPU; the
-reference's `f32_to_i16` tail.  Between the two halves sits the Huffman stage of `nanomp3::Decoder::decode`, which needs
-ISO/IEC 11172-3 Table B.7 -- data this tree does not hold (include/soundkit_amd.h).  The synthesis window D and the
-scale-factor band tables are supplied by the caller."""
+"""Host-side mirror of soundkit-mp3's decoder (soundkit-mp3/src/lib.rs:147-374): frame sync, header, side information,
+the bit reservoir, scale factors and the Huffman stage on the host (csrc/mp3_bitstream.cpp, csrc/mp3_decoder.cpp);
+requantisation, joint stereo and the short-block reorder (csrc/mp3_requant.hip) and the hybrid synthesis filterbank
+(csrc/mp3_hybrid.hip) on the GPU; the reference's `f32_to_i16` tail.  The standard's data tables (ISO/IEC 11172-3 B.3 /
+B.6 / B.7 / B.8, 13818-3 2.4.3.2) are csrc/mp3_iso_tables.h; `Mp3Decoder()` uses them unless given another Codebook."""
 import ctypes as C
 
 import numpy as np
@@ -136,12 +135,24 @@ def requantize(granules, quant, engine=None):
 
 # ---- parts 2 + 3 over caller-supplied tables, and the decoder handle -----------------------------------------------------------
 
-class Codebook:
-    """sk_mp3_codebook: host-side decoding structures built from an Mp3Tables (Table B.7 and friends, from the caller)"""
+def iso_tables():
+    """the standard's tables as the library holds them (sk_mp3_iso_tables) -> Mp3Tables"""
+    from ._lib import Mp3Tables
+    t = Mp3Tables()
+    check(lib.sk_mp3_iso_tables(C.byref(t)), "sk_mp3_iso_tables")
+    return t
 
-    def __init__(self, tables):
+
+class Codebook:
+    """sk_mp3_codebook: host-side decoding structures built from an Mp3Tables; tables=None: the standard's (Table B.7 and
+    friends, csrc/mp3_iso_tables.h)"""
+
+    def __init__(self, tables=None):
         self._h = C.c_void_p()
-        check(lib.sk_mp3_codebook_create(C.byref(tables), C.byref(self._h)), "sk_mp3_codebook_create")
+        if tables is None:
+            check(lib.sk_mp3_codebook_create_iso(C.byref(self._h)), "sk_mp3_codebook_create_iso")
+        else:
+            check(lib.sk_mp3_codebook_create(C.byref(tables), C.byref(self._h)), "sk_mp3_codebook_create")
 
     def close(self):
         if self._h:
@@ -167,11 +178,12 @@ class Mp3Decoder:
     """soundkit-mp3's Mp3Decoder (soundkit-mp3/src/lib.rs:147-374): new / sample_rate / channels / buffer_len / reset /
     decode_i16 / decode_i32 / decode_f32, bytes in at any chunking, interleaved samples out; errors raise SoundkitError"""
 
-    def __init__(self, codebook, engine=None):
+    def __init__(self, codebook=None, engine=None):
         self._engine = engine or default_engine()
-        self._codebook = codebook
+        self._codebook = codebook  # None: Mp3Decoder::new() -- the standard's tables
         self._h = C.c_void_p()
-        check(lib.sk_mp3_decoder_create(self._engine._h, codebook._h, C.byref(self._h)), "sk_mp3_decoder_create", self._engine._h)
+        check(lib.sk_mp3_decoder_create(self._engine._h, codebook._h if codebook is not None else None, C.byref(self._h)),
+              "sk_mp3_decoder_create", self._engine._h)
 
     def close(self):
         if self._h:
