@@ -368,6 +368,15 @@ def self_launch(n):
     return 0
 
 
+def print_line_and_leave_if_stalled(out, stalled):
+    """the result line always comes out; a run in which any leg stalled then leaves with code 3 -- at once, without tearing the
+    engine down (a device that stopped answering would hold the teardown too; the record is on stderr)"""
+    print(json.dumps(out))
+    if stalled:
+        sys.stdout.flush()
+        os._exit(3)  # a stall is never rc 0, whichever leg of the line it was in
+
+
 def dry_run(args, world, rank):
     """SK_BENCH_DRY_RUN=1: the launch / rendezvous / reduction skeleton of the bench on gloo without a GPU (the CPU test
     of `--gpus N`): every rank joins, the timed region is reduced with max, rank 0 prints who it saw."""
@@ -383,8 +392,11 @@ def dry_run(args, world, rank):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(ranks), "steps": args.steps, "warmup": args.warmup,
-                          "elapsed_max_s": elapsed}))
+        out = {"dry_run": True, "n_gpus": world, "ranks_seen": int(ranks), "steps": args.steps, "warmup": args.warmup, "elapsed_max_s": elapsed}
+        stalled = os.environ.get("SK_BENCH_DRY_STALL") == "1"  # the test of the exit code: as if the end_to_end extra had stalled
+        if stalled:
+            out["end_to_end"] = {"error": "stalled"}
+        print_line_and_leave_if_stalled(out, stalled)
 
 
 def main():
@@ -886,10 +898,7 @@ def main():
             out["cpu_reference_published"] = {"value": 31278.3, "unit": "frames/s", "cores": 1, "kind": "reference-published",
                                               "sample": "soundkit-aac-lc README.md:105, soundkit-lc-reuse: whole AAC-LC decode (entropy + "
                                                         "synthesis), hardware unstated; not measured here"}
-        print(json.dumps(out))
-        if stalled:  # the device may not answer: leave without tearing the engine down (the line is out, the record on stderr)
-            sys.stdout.flush()
-            os._exit(0)
+        print_line_and_leave_if_stalled(out, stalled)
     if world > 1:
         dist.destroy_process_group()
     eng.close()

@@ -48,7 +48,8 @@ typedef enum sk_status {
     SK_ERR_BAD_STREAM = -5,  /* stream id not open */
     SK_ERR_UNSUPPORTED = -6, /* e.g. resample ratio other than 48k->16k on the MFMA path */
     SK_ERR_CAPACITY = -7,    /* max_streams exhausted */
-    SK_ERR_TIMEOUT = -8      /* the device did not finish a tick within the engine's wait bound (sk_engine_set_wait_bound) */
+    SK_ERR_TIMEOUT = -8,     /* the device did not finish a tick within the engine's wait bound (sk_engine_set_wait_bound) */
+    SK_ERR_INTERNAL = -9     /* a C++ exception other than std::bad_alloc (that one: SK_ERR_OOM) was caught at the ABI; sk_last_exception() */
 } sk_status;
 
 /* per-frame status words written by the AAC entry points */
@@ -96,6 +97,19 @@ int sk_engine_set_wait_bound(sk_engine *, double seconds);
 int sk_engine_set_resampler_exact(sk_engine *, int exact);
 int sk_engine_debug_fail_after(sk_engine *, int n_hip_calls);
 const char *sk_strerror(int status);
+/* Exception barrier: no C++ exception leaves the library -- every entry point catches what is thrown below it and returns
+ * SK_ERR_OOM (std::bad_alloc) or SK_ERR_INTERNAL; worker threads of the scheduler turn an exception into the error of the
+ * stream they were serving (soundkit-decoder/src/lib.rs:3131-3134: an error ends that stream only).  Text of the last
+ * exception caught on the calling thread ("" if none): */
+const char *sk_last_exception(void);
+/* Test hook: the (n+1)-th entry into the library from now throws (kind 0 std::bad_alloc, 1 std::length_error, 2 a type that
+ * is no std::exception) as if an allocation inside had failed; n < 0 switches it off.  Returns the previous countdown. */
+int sk_debug_throw_after(int n, int kind);
+/* Test hook for the scheduler's own threads: the (n+1)-th passage of point `where` throws std::bad_alloc -- 0: inside the
+ * per-stream guard of an entropy thread (that stream ends with SK_ERR_OOM, the others go on); 1 entropy thread, 2 submission
+ * thread, 3 delivery thread outside any per-stream guard (the lane stops: every open stream ends with the error, later
+ * spawns return it, the process lives). */
+int sk_debug_throw_in_thread(int n, int where);
 const char *sk_version(void);
 
 /* AacLcDecoder::new (decoder.rs:56-78): allocates the per-channel DspChannel state

@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "soundkit_amd.h")
 SK_OK = 0
 AAC_UNIT_SIDE_BYTES = 1600  # SK_AAC_UNIT_SIDE_BYTES
 ERR_NAMES = {0: "SK_OK", -1: "SK_ERR_INVALID_ARG", -2: "SK_ERR_NO_DEVICE", -3: "SK_ERR_HIP", -4: "SK_ERR_OOM",
-             -5: "SK_ERR_BAD_STREAM", -6: "SK_ERR_UNSUPPORTED", -7: "SK_ERR_CAPACITY",
+             -5: "SK_ERR_BAD_STREAM", -6: "SK_ERR_UNSUPPORTED", -7: "SK_ERR_CAPACITY", -8: "SK_ERR_TIMEOUT", -9: "SK_ERR_INTERNAL",
              -101: "UnexpectedEof", -102: "InvalidAudioObjectType", -103: "UnsupportedAudioObjectType",
              -104: "UnsupportedSamplingFrequencyIndex", -105: "UnsupportedChannelConfig", -106: "UnsupportedFeature",
              -107: "InvalidConfig", -108: "InvalidBitstream",
@@ -276,6 +276,9 @@ _sig = {
     "sk_aac_plan_run_tail_s16_dev": (_i, [_vp, _vp, _vp, _sz, _u32, _u32, _vp, _sz, C.POINTER(_u32)]),
     "sk_aac_expand_q_decode": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "sk_engine_where": (C.c_char_p, [_vp]),
+    "sk_last_exception": (C.c_char_p, []),
+    "sk_debug_throw_after": (_i, [_i, _i]),
+    "sk_debug_throw_in_thread": (_i, [_i, _i]),
     "sk_engine_set_wait_bound": (_i, [_vp, C.c_double]),
     "sk_engine_set_resampler_exact": (_i, [_vp, _i]),
     "sk_engine_debug_fail_after": (_i, [_vp, _i]),
@@ -310,4 +313,6 @@ def check(status, what, engine_handle=None):
         detail = ""
         if engine_handle is not None and status in (-3, -4, -8):
             detail = lib.sk_engine_last_hip_error(engine_handle).decode()
+        if status in (-4, -9) and not detail:
+            detail = lib.sk_last_exception().decode()
         raise SoundkitError(status, what, detail)

@@ -15,6 +15,7 @@
 // esc_count 0 is rejected (decoder.rs:396-399), PNS uses the LCG of spectral.rs:2447-2450 seeded once
 // per decoder.
 #include "../../include/soundkit_amd.h"
+#include "sk_abi.h"
 
 #include <cmath>
 #include <cstring>
@@ -1047,7 +1048,8 @@ struct sk_aac_decoder {
 
 extern "C" {
 
-int sk_aac_decoder_create(const uint8_t *asc, size_t asc_len, sk_aac_decoder **out) {
+int sk_aac_decoder_create(const uint8_t *asc, size_t asc_len, sk_aac_decoder **out) try {
+    sk::abi_enter();
     if (!asc || !out) return SK_ERR_INVALID_ARG;
     *out = nullptr;
     sk_aac_decoder *dec = new (std::nothrow) sk_aac_decoder();
@@ -1061,28 +1063,48 @@ int sk_aac_decoder_create(const uint8_t *asc, size_t asc_len, sk_aac_decoder **o
     }
     *out = dec;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_aac_decoder_create");
 }
 
-void sk_aac_decoder_destroy(sk_aac_decoder *dec) { delete dec; }
+void sk_aac_decoder_destroy(sk_aac_decoder *dec) try {
+    sk::abi_enter();
+    delete dec;
+} catch (...) {
+    (void)sk::abi_caught("sk_aac_decoder_destroy");
+}
 
-int sk_aac_decoder_info(const sk_aac_decoder *dec, uint32_t *sample_rate, uint8_t *channels) {
+int sk_aac_decoder_info(const sk_aac_decoder *dec, uint32_t *sample_rate, uint8_t *channels) try {
+    sk::abi_enter();
     if (!dec) return SK_ERR_INVALID_ARG;
     if (sample_rate) *sample_rate = dec->d.sample_rate;
     if (channels) *channels = (uint8_t)dec->d.channels;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_aac_decoder_info");
 }
 
-int sk_aac_decoder_tool_usage(const sk_aac_decoder *dec, uint32_t out[8]) {
+int sk_aac_decoder_tool_usage(const sk_aac_decoder *dec, uint32_t out[8]) try {
+    sk::abi_enter();
     if (!dec || !out) return SK_ERR_INVALID_ARG;
     const Decoder &d = dec->d;
     const uint32_t v[8] = {d.n_frames, d.n_short, d.n_transition, d.n_tns, d.n_pns_bands, d.n_is_bands, d.n_ms_bands, d.n_pulse};
     std::memcpy(out, v, sizeof(v));
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_aac_decoder_tool_usage");
 }
 
-const char *sk_aac_decoder_last_error(const sk_aac_decoder *dec) { return dec ? dec->d.last_error.c_str() : ""; }
+const char *sk_aac_decoder_last_error(const sk_aac_decoder *dec) try {
+    sk::abi_enter();
+    return dec ? dec->d.last_error.c_str() : "";
+} catch (...) {
+    (void)sk::abi_caught("sk_aac_decoder_last_error");
+    return sk::abi_message();
+}
 
-int sk_aac_decoder_parse(sk_aac_decoder *dec, const uint8_t *au, size_t len, float *coeffs, sk_aac_frame_desc *desc) {
+int sk_aac_decoder_parse(sk_aac_decoder *dec, const uint8_t *au, size_t len, float *coeffs, sk_aac_frame_desc *desc) try {
+    sk::abi_enter();
     if (!dec || (!au && len) || !coeffs || !desc) return SK_ERR_INVALID_ARG;
     try {
         parse_access_unit(dec->d, au, len, coeffs, desc);
@@ -1091,12 +1113,15 @@ int sk_aac_decoder_parse(sk_aac_decoder *dec, const uint8_t *au, size_t len, flo
         return e.code;
     }
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_aac_decoder_parse");
 }
 
 // The Huffman half alone: quantised values as i16 + the side record the device needs to dequantise,
 // fill noise, run the stereo tools and TNS (aac_entropy_core.h WireUnit).  The core's parser is used for it -- the same
 // source the device runs -- so what the device rebuilds is what this call saw.
-int sk_aac_decoder_parse_q(sk_aac_decoder *dec, const uint8_t *au, size_t len, int16_t *quant, void *side, sk_aac_frame_desc *desc) {
+int sk_aac_decoder_parse_q(sk_aac_decoder *dec, const uint8_t *au, size_t len, int16_t *quant, void *side, sk_aac_frame_desc *desc) try {
+    sk::abi_enter();
     if (!dec || (!au && len) || !quant || !side || !desc || len > 8192) return SK_ERR_INVALID_ARG;
     static_assert(sizeof(sk_ec::WireUnit) == SK_AAC_UNIT_SIDE_BYTES, "sk_aac_unit_side size");
     static const sk_ec::Tables view = [] {
@@ -1146,11 +1171,14 @@ int sk_aac_decoder_parse_q(sk_aac_decoder *dec, const uint8_t *au, size_t len, i
         desc->window_shape[c] = c < dec->d.channels ? shape[c] : 0;
     }
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_aac_decoder_parse_q");
 }
 
 // parse_adts_access_unit, soundkit-decoder/src/lib.rs:1007-1027 (+ the 13-bit frame length for framing a file)
 int sk_adts_parse(const uint8_t *data, size_t len, size_t *frame_len, size_t *payload_off, size_t *payload_len,
-                  uint8_t asc[2]) {
+                  uint8_t asc[2]) try {
+    sk::abi_enter();
     if (!data || len < 7 || data[0] != 0xff || (data[1] & 0xf6) != 0xf0) return SK_AAC_ERR_INVALID_BITSTREAM;
     const unsigned aot = ((data[2] >> 6) & 3) + 1;
     const unsigned sr = (data[2] >> 2) & 0x0f;
@@ -1167,6 +1195,8 @@ int sk_adts_parse(const uint8_t *data, size_t len, size_t *frame_len, size_t *pa
     if (payload_off) *payload_off = header;
     if (payload_len) *payload_len = flen - header;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_adts_parse");
 }
 
 }  // extern "C"

@@ -7,6 +7,7 @@
 // Here the frames a call finds are parsed on the host (csrc/aac_frontend.cpp) and synthesised in one batched engine
 // call (sk_aac_synthesize_s16: IMDCT + window + overlap-add + float_sample_to_i16 on the GPU).
 #include "../../include/soundkit_amd.h"
+#include "sk_abi.h"
 
 #include <cstring>
 #include <new>
@@ -37,33 +38,49 @@ struct sk_adts_decoder {
 
 extern "C" {
 
-int sk_adts_decoder_create(sk_engine *e, sk_adts_decoder **out) {
+int sk_adts_decoder_create(sk_engine *e, sk_adts_decoder **out) try {
+    sk::abi_enter();
     if (!e || !out) return SK_ERR_INVALID_ARG;
     sk_adts_decoder *d = new (std::nothrow) sk_adts_decoder();
     if (!d) return SK_ERR_OOM;
     d->engine = e;
     *out = d;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_adts_decoder_create");
 }
 
-void sk_adts_decoder_destroy(sk_adts_decoder *d) {
+void sk_adts_decoder_destroy(sk_adts_decoder *d) try {
+    sk::abi_enter();
     if (!d) return;
     if (d->stream != 0xffffffffu) (void)sk_stream_close(d->engine, d->stream);
     if (d->front) sk_aac_decoder_destroy(d->front);
     delete d;
+} catch (...) {
+    (void)sk::abi_caught("sk_adts_decoder_destroy");
 }
 
-int sk_adts_decoder_info(const sk_adts_decoder *d, uint32_t *sample_rate, uint8_t *channels) {
+int sk_adts_decoder_info(const sk_adts_decoder *d, uint32_t *sample_rate, uint8_t *channels) try {
+    sk::abi_enter();
     if (!d) return SK_ERR_INVALID_ARG;
     if (sample_rate) *sample_rate = d->sample_rate;
     if (channels) *channels = d->channels;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_adts_decoder_info");
 }
 
-const char *sk_adts_decoder_last_error(const sk_adts_decoder *d) { return d ? d->last_error.c_str() : ""; }
+const char *sk_adts_decoder_last_error(const sk_adts_decoder *d) try {
+    sk::abi_enter();
+    return d ? d->last_error.c_str() : "";
+} catch (...) {
+    (void)sk::abi_caught("sk_adts_decoder_last_error");
+    return sk::abi_message();
+}
 
 int sk_adts_decoder_decode_i16(sk_adts_decoder *d, const uint8_t *input, size_t len, int16_t *output, size_t out_cap,
-                               size_t *written) {
+                               size_t *written) try {
+    sk::abi_enter();
     if (!d || !written || (len && !input) || (out_cap && !output)) return SK_ERR_INVALID_ARG;
     *written = 0;
     auto fail = [&](int rc, const std::string &msg) {
@@ -147,15 +164,20 @@ int sk_adts_decoder_decode_i16(sk_adts_decoder *d, const uint8_t *input, size_t 
     d->channels = d->fe_channels;
     *written = n_floats;  // one i16 per spectral coefficient: channels * 1024 per frame
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_adts_decoder_decode_i16");
 }
 
-int sk_adts_decoder_decode_f32(sk_adts_decoder *d, const uint8_t *input, size_t len, float *output, size_t out_cap, size_t *written) {
+int sk_adts_decoder_decode_f32(sk_adts_decoder *d, const uint8_t *input, size_t len, float *output, size_t out_cap, size_t *written) try {
+    sk::abi_enter();
     if (!d || !written || (out_cap && !output)) return SK_ERR_INVALID_ARG;
     std::vector<int16_t> tmp(out_cap);  // lib.rs:255-265: decode to i16, then / 32768
     const int rc = sk_adts_decoder_decode_i16(d, input, len, tmp.data(), out_cap, written);
     if (rc != SK_OK) return rc;
     for (size_t i = 0; i < *written; ++i) output[i] = (float)tmp[i] / 32768.0f;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_adts_decoder_decode_f32");
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 // buffers, and turns batches of frames into per-(stream, channel) wave tasks.
 // There is no CPU compute path here: without a GPU sk_engine_create fails.
 #include "../../include/soundkit_amd.h"
+#include "sk_abi.h"
 
 #include <hip/hip_runtime.h>
 
@@ -458,15 +459,22 @@ bool stream_ok(const sk_engine *e, uint32_t id) { return id < e->streams.size() 
 
 extern "C" {
 
-const char *sk_version(void) { return "soundkit_amd 0.1.0 (gfx950)"; }
+const char *sk_version(void) try {
+    sk::abi_enter();
+    return "soundkit_amd 0.1.0 (gfx950)";
+} catch (...) {
+    (void)sk::abi_caught("sk_version");
+    return sk::abi_message();
+}
 
-const char *sk_strerror(int status) {
+const char *sk_strerror(int status) try {
+    sk::abi_enter();
     switch (status) {
     case SK_OK: return "ok";
     case SK_ERR_INVALID_ARG: return "invalid argument";
     case SK_ERR_NO_DEVICE: return "no usable HIP device";
     case SK_ERR_HIP: return "HIP runtime error";
-    case SK_ERR_OOM: return "out of device memory";
+    case SK_ERR_OOM: return "out of memory (device or host)";
     case SK_ERR_BAD_STREAM: return "stream is not open";
     case SK_ERR_UNSUPPORTED: return "unsupported configuration";
     case SK_ERR_CAPACITY: return "capacity exhausted (streams, handles or caller buffer)";
@@ -479,6 +487,7 @@ const char *sk_strerror(int status) {
     case SK_AAC_ERR_UNSUPPORTED_SF_INDEX: return "unsupported AAC sampling frequency index";
     case SK_AAC_ERR_UNSUPPORTED_CHANNEL_CONFIG: return "unsupported AAC channel configuration";
     case SK_ERR_TIMEOUT: return "the device did not finish in time";
+    case SK_ERR_INTERNAL: return "internal error (a C++ exception was caught at the ABI)";
     case SK_MP3_NEED_MORE: return "more MP3 input needed";
     case SK_MP3_NO_SYNC: return "not an MPEG audio frame header";
     case SK_MP3_UNSUPPORTED: return "unsupported MPEG audio layer or feature";
@@ -488,9 +497,13 @@ const char *sk_strerror(int status) {
     case SK_AAC_ERR_INVALID_BITSTREAM: return "invalid AAC bitstream";
     default: return "unknown status";
     }
+} catch (...) {
+    (void)sk::abi_caught("sk_strerror");
+    return sk::abi_message();
 }
 
-int sk_engine_create(int device, uint32_t max_streams, sk_engine **out) {
+int sk_engine_create(int device, uint32_t max_streams, sk_engine **out) try {
+    sk::abi_enter();
     if (!out || max_streams == 0) return SK_ERR_INVALID_ARG;
     *out = nullptr;
     int count = 0;
@@ -527,9 +540,12 @@ int sk_engine_create(int device, uint32_t max_streams, sk_engine **out) {
     }
     *out = e;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_engine_create");
 }
 
-void sk_engine_destroy(sk_engine *e) {
+void sk_engine_destroy(sk_engine *e) try {
+    sk::abi_enter();
     if (!e) return;
     {
         DeviceGuard guard(e);
@@ -559,41 +575,84 @@ void sk_engine_destroy(sk_engine *e) {
         if (e->stream) (void)hipStreamDestroy(e->stream);
     }
     delete e;
+} catch (...) {
+    (void)sk::abi_caught("sk_engine_destroy");
 }
 
-int sk_engine_device(const sk_engine *e) { return e ? e->device : -1; }
-uint32_t sk_engine_max_streams(const sk_engine *e) { return e ? e->max_streams : 0; }
-void *sk_engine_hip_stream(sk_engine *e) { return e ? (void *)e->stream : nullptr; }
-const char *sk_engine_last_hip_error(const sk_engine *e) { return e ? e->last_hip_error.c_str() : ""; }
+int sk_engine_device(const sk_engine *e) try {
+    sk::abi_enter();
+    return e ? e->device : -1;
+} catch (...) {
+    return sk::abi_caught("sk_engine_device");
+}
+uint32_t sk_engine_max_streams(const sk_engine *e) try {
+    sk::abi_enter();
+    return e ? e->max_streams : 0;
+} catch (...) {
+    (void)sk::abi_caught("sk_engine_max_streams");
+    return 0;
+}
+void *sk_engine_hip_stream(sk_engine *e) try {
+    sk::abi_enter();
+    return e ? (void *)e->stream : nullptr;
+} catch (...) {
+    (void)sk::abi_caught("sk_engine_hip_stream");
+    return nullptr;
+}
+const char *sk_engine_last_hip_error(const sk_engine *e) try {
+    sk::abi_enter();
+    return e ? e->last_hip_error.c_str() : "";
+} catch (...) {
+    (void)sk::abi_caught("sk_engine_last_hip_error");
+    return sk::abi_message();
+}
 
-const char *sk_engine_where(const sk_engine *e) { return e ? e->where.load() : ""; }
+const char *sk_engine_where(const sk_engine *e) try {
+    sk::abi_enter();
+    return e ? e->where.load() : "";
+} catch (...) {
+    (void)sk::abi_caught("sk_engine_where");
+    return sk::abi_message();
+}
 
-int sk_engine_debug_fail_after(sk_engine *e, int n_hip_calls) {
+int sk_engine_debug_fail_after(sk_engine *e, int n_hip_calls) try {
+    sk::abi_enter();
     if (!e || n_hip_calls < 0) return SK_ERR_INVALID_ARG;
     e->fail_after.store(n_hip_calls);
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_engine_debug_fail_after");
 }
 
-int sk_engine_set_resampler_exact(sk_engine *e, int exact) {
+int sk_engine_set_resampler_exact(sk_engine *e, int exact) try {
+    sk::abi_enter();
     if (!e) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     e->sinc_exact = exact != 0;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_engine_set_resampler_exact");
 }
 
-int sk_engine_set_wait_bound(sk_engine *e, double seconds) {
+int sk_engine_set_wait_bound(sk_engine *e, double seconds) try {
+    sk::abi_enter();
     if (!e || !(seconds > 0.0)) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     e->sync_timeout_s = seconds;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_engine_set_wait_bound");
 }
 
-int sk_engine_synchronize(sk_engine *e) {
+int sk_engine_synchronize(sk_engine *e) try {
+    sk::abi_enter();
     if (!e) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e);
     SK_HIP(hipStreamSynchronize(e->stream), "stream synchronize");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_engine_synchronize");
 }
 
 // ---- streams --------------------------------------------------------------------------------
@@ -606,7 +665,8 @@ static int reset_stream_state(sk_engine *e, uint32_t id) {
     return SK_OK;
 }
 
-int sk_stream_open(sk_engine *e, uint32_t sample_rate, uint8_t channels, uint32_t *stream_out) {
+int sk_stream_open(sk_engine *e, uint32_t sample_rate, uint8_t channels, uint32_t *stream_out) try {
+    sk::abi_enter();
     if (!e || !stream_out || channels < 1 || channels > SK_MAX_CHANNELS || sample_rate == 0) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     if (e->free_ids.empty()) return SK_ERR_CAPACITY;
@@ -621,18 +681,24 @@ int sk_stream_open(sk_engine *e, uint32_t sample_rate, uint8_t channels, uint32_
     s.channels = channels;
     *stream_out = id;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_stream_open");
 }
 
-int sk_stream_close(sk_engine *e, uint32_t id) {
+int sk_stream_close(sk_engine *e, uint32_t id) try {
+    sk::abi_enter();
     if (!e) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
     e->streams[id] = StreamInfo();
     e->free_ids.push_back(id);
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_stream_close");
 }
 
-int sk_stream_reset(sk_engine *e, uint32_t id) {
+int sk_stream_reset(sk_engine *e, uint32_t id) try {
+    sk::abi_enter();
     if (!e) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
@@ -644,9 +710,12 @@ int sk_stream_reset(sk_engine *e, uint32_t id) {
     if (s.rs_open && e->d_rs)
         SK_HIP(hipMemsetAsync(e->d_rs + (size_t)id * 2 * kRsRow, 0, 2 * kRsRow * sizeof(float), e->stream), "reset rs");
     return reset_stream_state(e, id);
+} catch (...) {
+    return sk::abi_caught("sk_stream_reset");
 }
 
-int sk_stream_get_state(sk_engine *e, uint32_t id, float *delay_out, uint8_t *prev_shape_out) {
+int sk_stream_get_state(sk_engine *e, uint32_t id, float *delay_out, uint8_t *prev_shape_out) try {
+    sk::abi_enter();
     if (!e || !delay_out || !prev_shape_out) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
@@ -658,9 +727,12 @@ int sk_stream_get_state(sk_engine *e, uint32_t id, float *delay_out, uint8_t *pr
            "get shape");
     SK_HIP(hipStreamSynchronize(e->stream), "get state sync");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_stream_get_state");
 }
 
-int sk_stream_set_state(sk_engine *e, uint32_t id, const float *delay, const uint8_t *prev_shape) {
+int sk_stream_set_state(sk_engine *e, uint32_t id, const float *delay, const uint8_t *prev_shape) try {
+    sk::abi_enter();
     if (!e || !delay || !prev_shape) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
@@ -674,11 +746,14 @@ int sk_stream_set_state(sk_engine *e, uint32_t id, const float *delay, const uin
            "set shape");
     SK_HIP(hipStreamSynchronize(e->stream), "set state sync");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_stream_set_state");
 }
 
 // ---- AAC synthesis ----------------------------------------------------------------------------
 
-void sk_aac_plan_destroy(sk_aac_plan *p) {
+void sk_aac_plan_destroy(sk_aac_plan *p) try {
+    sk::abi_enter();
     if (!p) return;
     if (p->eng) {
         DeviceGuard guard(p->eng->device);
@@ -691,10 +766,24 @@ void sk_aac_plan_destroy(sk_aac_plan *p) {
         if (p->d_spair_tasks) (void)hipFree(p->d_spair_tasks);
     }
     delete p;
+} catch (...) {
+    (void)sk::abi_caught("sk_aac_plan_destroy");
 }
 
-uint64_t sk_aac_plan_elements(const sk_aac_plan *p) { return p ? p->elements : 0; }
-uint32_t sk_aac_plan_frames_ok(const sk_aac_plan *p) { return p ? p->n_frames_ok : 0; }
+uint64_t sk_aac_plan_elements(const sk_aac_plan *p) try {
+    sk::abi_enter();
+    return p ? p->elements : 0;
+} catch (...) {
+    (void)sk::abi_caught("sk_aac_plan_elements");
+    return 0;
+}
+uint32_t sk_aac_plan_frames_ok(const sk_aac_plan *p) try {
+    sk::abi_enter();
+    return p ? p->n_frames_ok : 0;
+} catch (...) {
+    (void)sk::abi_caught("sk_aac_plan_frames_ok");
+    return 0;
+}
 
 }  // extern "C"
 
@@ -858,7 +947,8 @@ int build_plan_host(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, in
 
 extern "C" {
 
-int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, int32_t *status, sk_aac_plan **out) {
+int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n, int32_t *status, sk_aac_plan **out) try {
+    sk::abi_enter();
     if (!e || !out || (n && !descs)) return SK_ERR_INVALID_ARG;
     *out = nullptr;
     std::lock_guard<std::mutex> lock(e->mu);
@@ -895,6 +985,8 @@ int sk_aac_plan_create(sk_engine *e, const sk_aac_frame_desc *descs, uint32_t n,
     }
     *out = p;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_aac_plan_create");
 }
 
 static int run_plan(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, float *d_pcm, int16_t *d_pcm16 = nullptr) {
@@ -923,22 +1015,28 @@ static int run_plan(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, f
     return SK_OK;
 }
 
-int sk_aac_plan_run_f32_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, float *d_pcm) {
+int sk_aac_plan_run_f32_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, float *d_pcm) try {
+    sk::abi_enter();
     if (!e || !p || p->eng != e) return SK_ERR_INVALID_ARG;
     if (p->n_tasks == 0) return SK_OK;
     if (!d_coeffs || !d_pcm) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e);
     return run_plan(e, p, d_coeffs, d_pcm);
+} catch (...) {
+    return sk::abi_caught("sk_aac_plan_run_f32_dev");
 }
 
-int sk_aac_plan_run_s16_planar_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, int16_t *d_pcm16) {
+int sk_aac_plan_run_s16_planar_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, int16_t *d_pcm16) try {
+    sk::abi_enter();
     if (!e || !p || p->eng != e) return SK_ERR_INVALID_ARG;
     if (p->n_tasks == 0) return SK_OK;
     if (!d_coeffs || !d_pcm16 || ((uintptr_t)d_pcm16 & 7)) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e);
     return run_plan(e, p, d_coeffs, nullptr, d_pcm16);
+} catch (...) {
+    return sk::abi_caught("sk_aac_plan_run_s16_planar_dev");
 }
 
 // The decode tail as one launch (k_aac_tail): sk_aac_plan_run_s16_planar_dev followed by the one-shot
@@ -947,7 +1045,8 @@ int sk_aac_plan_run_s16_planar_dev(sk_engine *e, const sk_aac_plan *p, const flo
 // length: build_plan_host), every stream with the same channel count and the same number of frames, each stream's frames
 // `frames_per_stream` consecutive entries from its frame 0; anything else: SK_ERR_UNSUPPORTED, use the two calls.
 int sk_aac_plan_run_tail_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, size_t stream_stride, uint32_t channels,
-                                 uint32_t frames_per_stream, int16_t *d_out, size_t out_stride, uint32_t *out_frames) {
+                                 uint32_t frames_per_stream, int16_t *d_out, size_t out_stride, uint32_t *out_frames) try {
+    sk::abi_enter();
     if (!e || !p || p->eng != e || channels < 1 || channels > SK_MAX_CHANNELS) return SK_ERR_INVALID_ARG;
     const uint64_t samples = (uint64_t)frames_per_stream * SK_AAC_FRAME_LEN;
     if (samples > 0xfffffffcull) return SK_ERR_INVALID_ARG;
@@ -977,9 +1076,12 @@ int sk_aac_plan_run_tail_s16_dev(sk_engine *e, const sk_aac_plan *p, const float
     ta.stream_stride = stream_stride;
     SK_HIP(sk::launch_aac_tail(ta, e->stream), "launch decode tail (fused synthesis + fir)");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_aac_plan_run_tail_s16_dev");
 }
 
-int sk_aac_plan_run_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, int16_t *d_pcm) {
+int sk_aac_plan_run_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, int16_t *d_pcm) try {
+    sk::abi_enter();
     if (!e || !p || p->eng != e) return SK_ERR_INVALID_ARG;
     if (p->n_tasks == 0) return SK_OK;
     if (!d_coeffs || !d_pcm) return SK_ERR_INVALID_ARG;
@@ -991,6 +1093,8 @@ int sk_aac_plan_run_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_c
     SK_HIP(sk::launch_frames_to_s16((const float *)e->aux_buf.p, d_pcm, p->d_spans, p->n_frames_ok, e->stream),
            "launch s16 interleave");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_aac_plan_run_s16_dev");
 }
 
 static int synthesize_host(sk_engine *e, const sk_aac_frame_desc *descs, const float *coeffs, void *pcm_out, uint32_t n,
@@ -1040,24 +1144,34 @@ static int synthesize_host(sk_engine *e, const sk_aac_frame_desc *descs, const f
 }
 
 int sk_aac_synthesize_f32(sk_engine *e, const sk_aac_frame_desc *descs, const float *coeffs, float *pcm_out, uint32_t n,
-                          int32_t *status) {
+                          int32_t *status) try {
+    sk::abi_enter();
     return synthesize_host(e, descs, coeffs, pcm_out, n, status, false);
+} catch (...) {
+    return sk::abi_caught("sk_aac_synthesize_f32");
 }
 
 int sk_aac_synthesize_s16(sk_engine *e, const sk_aac_frame_desc *descs, const float *coeffs, int16_t *pcm_out,
-                          uint32_t n, int32_t *status) {
+                          uint32_t n, int32_t *status) try {
+    sk::abi_enter();
     return synthesize_host(e, descs, coeffs, pcm_out, n, status, true);
+} catch (...) {
+    return sk::abi_caught("sk_aac_synthesize_s16");
 }
 
-int sk_aac_dequantize_dev(sk_engine *e, const int16_t *d_quant, const int16_t *d_sf, float *d_out, size_t n) {
+int sk_aac_dequantize_dev(sk_engine *e, const int16_t *d_quant, const int16_t *d_sf, float *d_out, size_t n) try {
+    sk::abi_enter();
     if (!e || (n && (!d_quant || !d_sf || !d_out))) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e);
     SK_HIP(sk::launch_dequantize(d_quant, d_sf, d_out, n, e->d_pow43, e->d_sftab, e->stream), "launch dequantize");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_aac_dequantize_dev");
 }
 
-int sk_aac_dequantize(sk_engine *e, const int16_t *quant, const int16_t *sf, float *out, size_t n) {
+int sk_aac_dequantize(sk_engine *e, const int16_t *quant, const int16_t *sf, float *out, size_t n) try {
+    sk::abi_enter();
     if (!e || (n && (!quant || !sf || !out))) return SK_ERR_INVALID_ARG;
     if (n == 0) return SK_OK;
     std::lock_guard<std::mutex> lock(e->mu);
@@ -1071,6 +1185,8 @@ int sk_aac_dequantize(sk_engine *e, const int16_t *quant, const int16_t *sf, flo
     SK_HIP(hipMemcpyAsync(out, e->out_buf.p, n * 4, hipMemcpyDeviceToHost, e->stream), "D2H dequant");
     SK_HIP(hipStreamSynchronize(e->stream), "dequant sync");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_aac_dequantize");
 }
 
 // ---- PCM conversion ----------------------------------------------------------------------------
@@ -1078,31 +1194,50 @@ int sk_aac_dequantize(sk_engine *e, const int16_t *quant, const int16_t *sf, flo
 static const int8_t kOpIn[SK_PCM_OP_COUNT] = {2, 2, 2, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 2, 2, 4, 4, 4, 2, 4, 4, 4, 4};
 static const int8_t kOpOut[SK_PCM_OP_COUNT] = {4, 2, 2, 4, 2, 2, 4, 4, 4, 4, 4, 4, 2, 2, 2, 2, 4, 4, 2, 2, 4, 2, 2, 2, 4, 4, 2, 2, 4};
 
-int sk_pcm_op_in_bytes(int op) { return (op < 0 || op >= SK_PCM_OP_COUNT) ? -1 : kOpIn[op]; }
-int sk_pcm_op_out_bytes(int op) { return (op < 0 || op >= SK_PCM_OP_COUNT) ? -1 : kOpOut[op]; }
+int sk_pcm_op_in_bytes(int op) try {
+    sk::abi_enter();
+    return (op < 0 || op >= SK_PCM_OP_COUNT) ? -1 : kOpIn[op];
+} catch (...) {
+    return sk::abi_caught("sk_pcm_op_in_bytes");
+}
+int sk_pcm_op_out_bytes(int op) try {
+    sk::abi_enter();
+    return (op < 0 || op >= SK_PCM_OP_COUNT) ? -1 : kOpOut[op];
+} catch (...) {
+    return sk::abi_caught("sk_pcm_op_out_bytes");
+}
 
-int sk_pcm_fmt_bytes(int fmt) {
+int sk_pcm_fmt_bytes(int fmt) try {
+    sk::abi_enter();
     switch (fmt) {
     case SK_FMT_S16LE: case SK_FMT_S16BE: return 2;
     case SK_FMT_S24LE: case SK_FMT_S24BE: return 3;
     case SK_FMT_S32LE: case SK_FMT_S32BE: case SK_FMT_F32LE: case SK_FMT_F32BE: return 4;
     default: return -1;
     }
+} catch (...) {
+    return sk::abi_caught("sk_pcm_fmt_bytes");
 }
 
-int sk_pcm_convert_dev(sk_engine *e, int op, const void *d_in, void *d_out, size_t n) {
+int sk_pcm_convert_dev(sk_engine *e, int op, const void *d_in, void *d_out, size_t n) try {
+    sk::abi_enter();
     if (!e || op < 0 || op >= SK_PCM_OP_COUNT || (n && (!d_in || !d_out))) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e);
     SK_HIP(sk::launch_pcm_convert(op, d_in, d_out, n, e->stream), "launch pcm convert");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_pcm_convert_dev");
 }
 
-int sk_pcm_convert(sk_engine *e, int op, const void *in, void *out, size_t n) {
+int sk_pcm_convert(sk_engine *e, int op, const void *in, void *out, size_t n) try {
+    sk::abi_enter();
     if (op < 0 || op >= SK_PCM_OP_COUNT) return SK_ERR_INVALID_ARG;
     return host_roundtrip(e, in, n * kOpIn[op], out, n * kOpOut[op], [&](void *di, void *dout) {
         return sk::launch_pcm_convert(op, di, dout, n, e->stream);
     });
+} catch (...) {
+    return sk::abi_caught("sk_pcm_convert");
 }
 
 #define SK_DEV_ENTRY(call)                              \
@@ -1113,60 +1248,90 @@ int sk_pcm_convert(sk_engine *e, int op, const void *in, void *out, size_t n) {
         return SK_OK;                                   \
     } while (0)
 
-int sk_pcm_interleave_i16_dev(sk_engine *e, const int16_t *d_planar, size_t frames, uint32_t ch, uint8_t *d_out) {
+int sk_pcm_interleave_i16_dev(sk_engine *e, const int16_t *d_planar, size_t frames, uint32_t ch, uint8_t *d_out) try {
+    sk::abi_enter();
     if (!e || ch == 0 || (frames && (!d_planar || !d_out))) return SK_ERR_INVALID_ARG;
     SK_DEV_ENTRY(sk::launch_interleave(d_planar, d_out, frames, ch, 2, e->stream));
+} catch (...) {
+    return sk::abi_caught("sk_pcm_interleave_i16_dev");
 }
-int sk_pcm_deinterleave_i16_dev(sk_engine *e, const uint8_t *d_in, size_t frames, uint32_t ch, int16_t *d_planar) {
+int sk_pcm_deinterleave_i16_dev(sk_engine *e, const uint8_t *d_in, size_t frames, uint32_t ch, int16_t *d_planar) try {
+    sk::abi_enter();
     if (!e || ch == 0 || (frames && (!d_in || !d_planar))) return SK_ERR_INVALID_ARG;
     SK_DEV_ENTRY(sk::launch_deinterleave(d_in, d_planar, frames, ch, 2, e->stream));
+} catch (...) {
+    return sk::abi_caught("sk_pcm_deinterleave_i16_dev");
 }
-int sk_pcm_deinterleave_s24_dev(sk_engine *e, const uint8_t *d_in, size_t frames, uint32_t ch, int32_t *d_planar) {
+int sk_pcm_deinterleave_s24_dev(sk_engine *e, const uint8_t *d_in, size_t frames, uint32_t ch, int32_t *d_planar) try {
+    sk::abi_enter();
     if (!e || ch == 0 || (frames && (!d_in || !d_planar))) return SK_ERR_INVALID_ARG;
     SK_DEV_ENTRY(sk::launch_deinterleave_s24(d_in, d_planar, frames, ch, e->stream));
+} catch (...) {
+    return sk::abi_caught("sk_pcm_deinterleave_s24_dev");
 }
-int sk_pcm_deinterleave_f32_dev(sk_engine *e, const uint8_t *d_in, size_t frames, uint32_t ch, float *d_planar) {
+int sk_pcm_deinterleave_f32_dev(sk_engine *e, const uint8_t *d_in, size_t frames, uint32_t ch, float *d_planar) try {
+    sk::abi_enter();
     if (!e || ch == 0 || (frames && (!d_in || !d_planar))) return SK_ERR_INVALID_ARG;
     SK_DEV_ENTRY(sk::launch_deinterleave(d_in, d_planar, frames, ch, 4, e->stream));
+} catch (...) {
+    return sk::abi_caught("sk_pcm_deinterleave_f32_dev");
 }
-int sk_pcm_interleave_f32_dev(sk_engine *e, const float *d_planar, size_t frames, uint32_t ch, uint8_t *d_out) {
+int sk_pcm_interleave_f32_dev(sk_engine *e, const float *d_planar, size_t frames, uint32_t ch, uint8_t *d_out) try {
+    sk::abi_enter();
     if (!e || ch == 0 || (frames && (!d_planar || !d_out))) return SK_ERR_INVALID_ARG;
     SK_DEV_ENTRY(sk::launch_interleave(d_planar, d_out, frames, ch, 4, e->stream));
+} catch (...) {
+    return sk::abi_caught("sk_pcm_interleave_f32_dev");
 }
 
-int sk_pcm_interleave_i16(sk_engine *e, const int16_t *planar, size_t frames, uint32_t ch, uint8_t *out) {
+int sk_pcm_interleave_i16(sk_engine *e, const int16_t *planar, size_t frames, uint32_t ch, uint8_t *out) try {
+    sk::abi_enter();
     if (ch == 0) return SK_ERR_INVALID_ARG;
     const size_t bytes = frames * ch * 2;
     return host_roundtrip(e, planar, bytes, out, bytes, [&](void *di, void *dout) {
         return sk::launch_interleave(di, dout, frames, ch, 2, e->stream);
     });
+} catch (...) {
+    return sk::abi_caught("sk_pcm_interleave_i16");
 }
-int sk_pcm_deinterleave_i16(sk_engine *e, const uint8_t *in, size_t frames, uint32_t ch, int16_t *planar) {
+int sk_pcm_deinterleave_i16(sk_engine *e, const uint8_t *in, size_t frames, uint32_t ch, int16_t *planar) try {
+    sk::abi_enter();
     if (ch == 0) return SK_ERR_INVALID_ARG;
     const size_t bytes = frames * ch * 2;
     return host_roundtrip(e, in, bytes, planar, bytes, [&](void *di, void *dout) {
         return sk::launch_deinterleave(di, dout, frames, ch, 2, e->stream);
     });
+} catch (...) {
+    return sk::abi_caught("sk_pcm_deinterleave_i16");
 }
-int sk_pcm_deinterleave_s24(sk_engine *e, const uint8_t *in, size_t frames, uint32_t ch, int32_t *planar) {
+int sk_pcm_deinterleave_s24(sk_engine *e, const uint8_t *in, size_t frames, uint32_t ch, int32_t *planar) try {
+    sk::abi_enter();
     if (ch == 0) return SK_ERR_INVALID_ARG;
     return host_roundtrip(e, in, frames * ch * 3, planar, frames * ch * 4, [&](void *di, void *dout) {
         return sk::launch_deinterleave_s24((const uint8_t *)di, (int32_t *)dout, frames, ch, e->stream);
     });
+} catch (...) {
+    return sk::abi_caught("sk_pcm_deinterleave_s24");
 }
-int sk_pcm_deinterleave_f32(sk_engine *e, const uint8_t *in, size_t frames, uint32_t ch, float *planar) {
+int sk_pcm_deinterleave_f32(sk_engine *e, const uint8_t *in, size_t frames, uint32_t ch, float *planar) try {
+    sk::abi_enter();
     if (ch == 0) return SK_ERR_INVALID_ARG;
     const size_t bytes = frames * ch * 4;
     return host_roundtrip(e, in, bytes, planar, bytes, [&](void *di, void *dout) {
         return sk::launch_deinterleave(di, dout, frames, ch, 4, e->stream);
     });
+} catch (...) {
+    return sk::abi_caught("sk_pcm_deinterleave_f32");
 }
-int sk_pcm_interleave_f32(sk_engine *e, const float *planar, size_t frames, uint32_t ch, uint8_t *out) {
+int sk_pcm_interleave_f32(sk_engine *e, const float *planar, size_t frames, uint32_t ch, uint8_t *out) try {
+    sk::abi_enter();
     if (ch == 0) return SK_ERR_INVALID_ARG;
     const size_t bytes = frames * ch * 4;
     return host_roundtrip(e, planar, bytes, out, bytes, [&](void *di, void *dout) {
         return sk::launch_interleave(di, dout, frames, ch, 4, e->stream);
     });
+} catch (...) {
+    return sk::abi_caught("sk_pcm_interleave_f32");
 }
 
 static bool to_f32_args_ok(int variant, int fmt) {
@@ -1178,70 +1343,104 @@ static bool from_f32_fmt_ok(int fmt) {
 }
 
 int sk_pcm_bytes_to_f32_planar_dev(sk_engine *e, int variant, int fmt, const uint8_t *d_in, size_t frames, uint32_t ch,
-                                   float *d_planar) {
+                                   float *d_planar) try {
+    sk::abi_enter();
     if (!e || ch == 0 || !to_f32_args_ok(variant, fmt) || (frames && (!d_in || !d_planar))) return SK_ERR_INVALID_ARG;
     SK_DEV_ENTRY(sk::launch_bytes_to_f32_planar(variant, fmt, d_in, frames, ch, d_planar, e->stream));
+} catch (...) {
+    return sk::abi_caught("sk_pcm_bytes_to_f32_planar_dev");
 }
 int sk_pcm_bytes_to_f32_planar(sk_engine *e, int variant, int fmt, const uint8_t *in, size_t frames, uint32_t ch,
-                               float *planar) {
+                               float *planar) try {
+    sk::abi_enter();
     if (ch == 0 || !to_f32_args_ok(variant, fmt)) return SK_ERR_INVALID_ARG;
     return host_roundtrip(e, in, frames * ch * sk_pcm_fmt_bytes(fmt), planar, frames * ch * 4, [&](void *di, void *dout) {
         return sk::launch_bytes_to_f32_planar(variant, fmt, (const uint8_t *)di, frames, ch, (float *)dout, e->stream);
     });
+} catch (...) {
+    return sk::abi_caught("sk_pcm_bytes_to_f32_planar");
 }
 int sk_pcm_f32_planar_to_bytes_dev(sk_engine *e, int fmt, const float *d_planar, size_t frames, uint32_t ch,
-                                   uint8_t *d_out) {
+                                   uint8_t *d_out) try {
+    sk::abi_enter();
     if (!e || ch == 0 || !from_f32_fmt_ok(fmt) || (frames && (!d_planar || !d_out))) return SK_ERR_INVALID_ARG;
     SK_DEV_ENTRY(sk::launch_f32_planar_to_bytes(fmt, d_planar, frames, ch, d_out, e->stream));
+} catch (...) {
+    return sk::abi_caught("sk_pcm_f32_planar_to_bytes_dev");
 }
-int sk_pcm_f32_planar_to_bytes(sk_engine *e, int fmt, const float *planar, size_t frames, uint32_t ch, uint8_t *out) {
+int sk_pcm_f32_planar_to_bytes(sk_engine *e, int fmt, const float *planar, size_t frames, uint32_t ch, uint8_t *out) try {
+    sk::abi_enter();
     if (ch == 0 || !from_f32_fmt_ok(fmt)) return SK_ERR_INVALID_ARG;
     return host_roundtrip(e, planar, frames * ch * 4, out, frames * ch * sk_pcm_fmt_bytes(fmt), [&](void *di, void *dout) {
         return sk::launch_f32_planar_to_bytes(fmt, (const float *)di, frames, ch, (uint8_t *)dout, e->stream);
     });
+} catch (...) {
+    return sk::abi_caught("sk_pcm_f32_planar_to_bytes");
 }
 int sk_pcm_f32_planar_to_bytes_batch_dev(sk_engine *e, int fmt, const float *d_planar, size_t batch, size_t plane_stride,
-                                         size_t frames, uint32_t ch, uint8_t *d_out) {
+                                         size_t frames, uint32_t ch, uint8_t *d_out) try {
+    sk::abi_enter();
     if (!e || ch == 0 || !from_f32_fmt_ok(fmt) || plane_stride < frames || batch > 65535 ||
         (frames && batch && (!d_planar || !d_out)))
         return SK_ERR_INVALID_ARG;
     SK_DEV_ENTRY(sk::launch_f32_planar_to_bytes_batch(fmt, d_planar, batch, plane_stride, frames, ch, d_out, e->stream));
+} catch (...) {
+    return sk::abi_caught("sk_pcm_f32_planar_to_bytes_batch_dev");
 }
-int sk_pcm_downmix_mono_dev(sk_engine *e, const float *d_planar, size_t frames, uint32_t ch, float *d_mono) {
+int sk_pcm_downmix_mono_dev(sk_engine *e, const float *d_planar, size_t frames, uint32_t ch, float *d_mono) try {
+    sk::abi_enter();
     if (!e || ch == 0 || (frames && (!d_planar || !d_mono))) return SK_ERR_INVALID_ARG;
     SK_DEV_ENTRY(sk::launch_downmix_mono(d_planar, frames, ch, d_mono, e->stream));
+} catch (...) {
+    return sk::abi_caught("sk_pcm_downmix_mono_dev");
 }
-int sk_pcm_downmix_mono(sk_engine *e, const float *planar, size_t frames, uint32_t ch, float *mono) {
+int sk_pcm_downmix_mono(sk_engine *e, const float *planar, size_t frames, uint32_t ch, float *mono) try {
+    sk::abi_enter();
     if (ch == 0) return SK_ERR_INVALID_ARG;
     return host_roundtrip(e, planar, frames * ch * 4, mono, frames * 4, [&](void *di, void *dout) {
         return sk::launch_downmix_mono((const float *)di, frames, ch, (float *)dout, e->stream);
     });
+} catch (...) {
+    return sk::abi_caught("sk_pcm_downmix_mono");
 }
 static bool exact_fmt_ok(int fmt) { return fmt >= SK_FMT_S24LE && fmt <= SK_FMT_S32BE; }
-int sk_pcm_exact_to_i16_dev(sk_engine *e, int fmt, const uint8_t *d_in, size_t samples, uint8_t *d_out) {
+int sk_pcm_exact_to_i16_dev(sk_engine *e, int fmt, const uint8_t *d_in, size_t samples, uint8_t *d_out) try {
+    sk::abi_enter();
     if (!e || !exact_fmt_ok(fmt) || (samples && (!d_in || !d_out))) return SK_ERR_INVALID_ARG;
     SK_DEV_ENTRY(sk::launch_exact_to_i16(fmt, d_in, samples, d_out, e->stream));
+} catch (...) {
+    return sk::abi_caught("sk_pcm_exact_to_i16_dev");
 }
-int sk_pcm_exact_to_i16(sk_engine *e, int fmt, const uint8_t *in, size_t samples, uint8_t *out) {
+int sk_pcm_exact_to_i16(sk_engine *e, int fmt, const uint8_t *in, size_t samples, uint8_t *out) try {
+    sk::abi_enter();
     if (!exact_fmt_ok(fmt)) return SK_ERR_INVALID_ARG;
     return host_roundtrip(e, in, samples * sk_pcm_fmt_bytes(fmt), out, samples * 2, [&](void *di, void *dout) {
         return sk::launch_exact_to_i16(fmt, (const uint8_t *)di, samples, (uint8_t *)dout, e->stream);
     });
+} catch (...) {
+    return sk::abi_caught("sk_pcm_exact_to_i16");
 }
 
 // ---- 48 kHz -> 16 kHz FIR ----------------------------------------------------------------------
 
-uint32_t sk_downsample_48k_16k_out_frames(uint32_t frames) {
+uint32_t sk_downsample_48k_16k_out_frames(uint32_t frames) try {
+    sk::abi_enter();
     // rubato SincFixedIn: idx starts at -128, advances by 3 before each output, loop runs while
     // idx < frames - 257 - 3
     if (frames <= 132) return 0;
     return (frames - 132 + 2) / 3;
+} catch (...) {
+    (void)sk::abi_caught("sk_downsample_48k_16k_out_frames");
+    return 0;
 }
 
-int sk_downsample_48k_16k_taps(sk_engine *e, float *taps256) {
+int sk_downsample_48k_16k_taps(sk_engine *e, float *taps256) try {
+    sk::abi_enter();
     if (!e || !taps256) return SK_ERR_INVALID_ARG;
     std::memcpy(taps256, e->h_taps.data(), 256 * sizeof(float));
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_downsample_48k_16k_taps");
 }
 
 static sk::FirArgs fir_base(sk_engine *e) {
@@ -1254,7 +1453,8 @@ static sk::FirArgs fir_base(sk_engine *e) {
 }
 
 int sk_downsample_48k_16k_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uint32_t rows, uint32_t frames,
-                                  float *d_out, size_t out_stride, uint32_t *out_frames) {
+                                  float *d_out, size_t out_stride, uint32_t *out_frames) try {
+    sk::abi_enter();
     if (!e) return SK_ERR_INVALID_ARG;
     const uint32_t n_out = sk_downsample_48k_16k_out_frames(frames);
     if (out_frames) *out_frames = n_out;
@@ -1274,11 +1474,14 @@ int sk_downsample_48k_16k_f32_dev(sk_engine *e, const float *d_in, size_t in_str
     a.out_count = n_out;
     SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch fir");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_downsample_48k_16k_f32_dev");
 }
 
 int sk_downsample_48k_16k_frames_dev(sk_engine *e, const float *d_pcm, size_t stream_stride, size_t frame_stride,
                                      uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream, float *d_out,
-                                     size_t out_stride, uint32_t *out_frames) {
+                                     size_t out_stride, uint32_t *out_frames) try {
+    sk::abi_enter();
     if (!e || channels < 1 || channels > SK_MAX_CHANNELS) return SK_ERR_INVALID_ARG;
     const uint64_t samples = (uint64_t)frames_per_stream * SK_AAC_FRAME_LEN;
     if (samples > 0xfffffffcull) return SK_ERR_INVALID_ARG;
@@ -1305,11 +1508,14 @@ int sk_downsample_48k_16k_frames_dev(sk_engine *e, const float *d_pcm, size_t st
     a.out_count = n_out;
     SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch fir (frame-packed input)");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_downsample_48k_16k_frames_dev");
 }
 
 int sk_downsample_48k_16k_frames_s16_dev(sk_engine *e, const float *d_pcm, size_t stream_stride, size_t frame_stride,
                                          uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream, int16_t *d_out,
-                                         size_t out_stride, uint32_t *out_frames) {
+                                         size_t out_stride, uint32_t *out_frames) try {
+    sk::abi_enter();
     if (!e || channels < 1 || channels > SK_MAX_CHANNELS) return SK_ERR_INVALID_ARG;
     const uint64_t samples = (uint64_t)frames_per_stream * SK_AAC_FRAME_LEN;
     if (samples > 0xfffffffcull) return SK_ERR_INVALID_ARG;
@@ -1339,6 +1545,8 @@ int sk_downsample_48k_16k_frames_s16_dev(sk_engine *e, const float *d_pcm, size_
     a.out_count = n_out;
     SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch fir (frame-packed input, s16 output)");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_downsample_48k_16k_frames_s16_dev");
 }
 
 static int fir_from_s16(sk_engine *e, const int16_t *d_pcm16, size_t stream_stride, size_t frame_stride, uint32_t channels,
@@ -1347,16 +1555,22 @@ static int fir_from_s16(sk_engine *e, const int16_t *d_pcm16, size_t stream_stri
 
 int sk_downsample_48k_16k_frames_s16_to_s16_dev(sk_engine *e, const int16_t *d_pcm16, size_t stream_stride, size_t frame_stride,
                                                 uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream, int16_t *d_out,
-                                                size_t out_stride, uint32_t *out_frames) {
+                                                size_t out_stride, uint32_t *out_frames) try {
+    sk::abi_enter();
     return fir_from_s16(e, d_pcm16, stream_stride, frame_stride, channels, n_streams, frames_per_stream, d_out, nullptr, out_stride,
                         out_frames);
+} catch (...) {
+    return sk::abi_caught("sk_downsample_48k_16k_frames_s16_to_s16_dev");
 }
 
 int sk_downsample_48k_16k_frames_s16_to_f32_dev(sk_engine *e, const int16_t *d_pcm16, size_t stream_stride, size_t frame_stride,
                                                 uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream, float *d_out,
-                                                size_t out_stride, uint32_t *out_frames) {
+                                                size_t out_stride, uint32_t *out_frames) try {
+    sk::abi_enter();
     return fir_from_s16(e, d_pcm16, stream_stride, frame_stride, channels, n_streams, frames_per_stream, nullptr, d_out, out_stride,
                         out_frames);
+} catch (...) {
+    return sk::abi_caught("sk_downsample_48k_16k_frames_s16_to_f32_dev");
 }
 
 static int fir_from_s16(sk_engine *e, const int16_t *d_pcm16, size_t stream_stride, size_t frame_stride, uint32_t channels,
@@ -1395,7 +1609,8 @@ static int fir_from_s16(sk_engine *e, const int16_t *d_pcm16, size_t stream_stri
 }
 
 int sk_downsample_48k_16k_f32(sk_engine *e, const float *in, uint32_t rows, uint32_t frames, float *out,
-                              uint32_t *out_frames) {
+                              uint32_t *out_frames) try {
+    sk::abi_enter();
     if (!e) return SK_ERR_INVALID_ARG;
     const uint32_t n_out = sk_downsample_48k_16k_out_frames(frames);
     if (out_frames) *out_frames = n_out;
@@ -1419,6 +1634,8 @@ int sk_downsample_48k_16k_f32(sk_engine *e, const float *in, uint32_t rows, uint
                             hipMemcpyDeviceToHost, e->stream), "D2H fir output");
     SK_HIP(hipStreamSynchronize(e->stream), "fir sync");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_downsample_48k_16k_f32");
 }
 
 }  // extern "C" (helpers below are C++)
@@ -1496,16 +1713,21 @@ static const IndexSet &streaming_set(RatioTable &tab, uint64_t n) {
 
 extern "C" {
 
-uint32_t sk_downsample_out_frames(uint32_t frames, uint32_t in_hz, uint32_t out_hz) {
+uint32_t sk_downsample_out_frames(uint32_t frames, uint32_t in_hz, uint32_t out_hz) try {
+    sk::abi_enter();
     if (!in_hz || !out_hz) return 0;
     std::vector<double> idx;
     double nl = 0.0;
     chunk_indices((double)out_hz / (double)in_hz, -128.0, frames, idx, &nl);
     return (uint32_t)idx.size();
+} catch (...) {
+    (void)sk::abi_caught("sk_downsample_out_frames");
+    return 0;
 }
 
 int sk_downsample_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uint32_t rows, uint32_t frames,
-                          uint32_t in_hz, uint32_t out_hz, float *d_out, size_t out_stride, uint32_t *out_frames) {
+                          uint32_t in_hz, uint32_t out_hz, float *d_out, size_t out_stride, uint32_t *out_frames) try {
+    sk::abi_enter();
     if (!e) return SK_ERR_INVALID_ARG;
     if (!common_rate(in_hz) || !common_rate(out_hz)) return SK_ERR_UNSUPPORTED;
     if (in_hz == 48000 && out_hz == 16000)
@@ -1544,7 +1766,12 @@ int sk_downsample_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uin
     a.exact = e->sinc_exact;
     if (!a.exact) {
         const size_t want = sk::sinc_mfma_scratch_bytes(1, n_out, a.step);
-        if (want && e->sinc_scratch.reserve(want) == hipSuccess) a.scratch = e->sinc_scratch.p, a.scratch_bytes = e->sinc_scratch.cap;
+        // want == 0: a ratio the matrix-core form does not take (decided by the ratio alone).  A failed allocation is an
+        // error, never a silent change of arithmetic: the same row must get the same bits alone or in any batch.
+        if (want) {
+            SK_HIP(e->sinc_scratch.reserve(want), "alloc resampler tap fragments");
+            a.scratch = e->sinc_scratch.p, a.scratch_bytes = e->sinc_scratch.cap;
+        }
     }
     const uint32_t rows_per_launch = 65535u * sk::sinc_rows_per_block();  // grid.y limit
     for (uint32_t r0 = 0; r0 < rows; r0 += rows_per_launch) {
@@ -1556,10 +1783,13 @@ int sk_downsample_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uin
     }
     SK_HIP(hipStreamSynchronize(e->stream), "resample sync");  // the index set lives in host memory until the copy is done
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_downsample_f32_dev");
 }
 
 int sk_downsample_f32(sk_engine *e, const float *in, uint32_t rows, uint32_t frames, uint32_t in_hz, uint32_t out_hz,
-                      float *out, uint32_t out_cap, uint32_t *out_frames) {
+                      float *out, uint32_t out_cap, uint32_t *out_frames) try {
+    sk::abi_enter();
     if (!e) return SK_ERR_INVALID_ARG;
     if (!common_rate(in_hz) || !common_rate(out_hz)) return SK_ERR_UNSUPPORTED;
     const uint32_t n_out = sk_downsample_out_frames(frames, in_hz, out_hz);
@@ -1584,6 +1814,8 @@ int sk_downsample_f32(sk_engine *e, const float *in, uint32_t rows, uint32_t fra
                             hipMemcpyDeviceToHost, e->stream), "D2H resample output");
     SK_HIP(hipStreamSynchronize(e->stream), "resample sync");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_downsample_f32");
 }
 
 // ---- MPEG Layer III hybrid synthesis (mp3_hybrid.hip) -------------------------------------------------------------------
@@ -1729,7 +1961,8 @@ int mp3_synthesize(sk_engine *e, const sk_mp3_granule_desc *descs, const float *
 
 }  // namespace
 
-int sk_mp3_set_synthesis_window(sk_engine *e, const float *d512) {
+int sk_mp3_set_synthesis_window(sk_engine *e, const float *d512) try {
+    sk::abi_enter();
     if (!e || !d512) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e);
@@ -1738,21 +1971,32 @@ int sk_mp3_set_synthesis_window(sk_engine *e, const float *d512) {
     SK_HIP(hipMemcpy(e->d_mp3_tables + kMp3Imdct + kMp3Matrix, d512, kMp3Window * sizeof(float), hipMemcpyHostToDevice), "upload mp3 window");
     e->mp3_window_set = true;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_set_synthesis_window");
 }
 
 int sk_mp3_hybrid_synthesize_f32(sk_engine *e, const sk_mp3_granule_desc *descs, const float *xr, float *pcm_out, uint32_t n,
-                                 int32_t *status) {
+                                 int32_t *status) try {
+    sk::abi_enter();
     return mp3_synthesize(e, descs, xr, pcm_out, n, status, false, false);
+} catch (...) {
+    return sk::abi_caught("sk_mp3_hybrid_synthesize_f32");
 }
 
 int sk_mp3_hybrid_synthesize_s16(sk_engine *e, const sk_mp3_granule_desc *descs, const float *xr, int16_t *pcm_out, uint32_t n,
-                                 int32_t *status) {
+                                 int32_t *status) try {
+    sk::abi_enter();
     return mp3_synthesize(e, descs, xr, pcm_out, n, status, true, false);
+} catch (...) {
+    return sk::abi_caught("sk_mp3_hybrid_synthesize_s16");
 }
 
 int sk_mp3_hybrid_synthesize_f32_dev(sk_engine *e, const sk_mp3_granule_desc *descs, const float *d_xr, float *d_pcm, uint32_t n,
-                                     int32_t *status) {
+                                     int32_t *status) try {
+    sk::abi_enter();
     return mp3_synthesize(e, descs, d_xr, d_pcm, n, status, false, true);
+} catch (...) {
+    return sk::abi_caught("sk_mp3_hybrid_synthesize_f32_dev");
 }
 
 // ---- Layer III requantisation / stereo / reorder (mp3_requant.hip) -----------------------------------------------------------
@@ -1788,7 +2032,8 @@ int ensure_mp3_requant(sk_engine *e) {
 }  // namespace
 
 int sk_mp3_set_band_tables(sk_engine *e, uint32_t sample_rate, const uint16_t *long_offsets, const uint16_t *short_offsets,
-                           const uint8_t *pretab) {
+                           const uint8_t *pretab) try {
+    sk::abi_enter();
     if (!e || !long_offsets || !short_offsets || !pretab) return SK_ERR_INVALID_ARG;
     const int slot = mp3_rate_slot(sample_rate);
     if (slot < 0) return SK_ERR_UNSUPPORTED;
@@ -1839,6 +2084,8 @@ int sk_mp3_set_band_tables(sk_engine *e, uint32_t sample_rate, const uint16_t *l
            "upload mp3 line map");
     e->mp3_bands_set[slot] = true;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_set_band_tables");
 }
 
 namespace {
@@ -1936,7 +2183,8 @@ int mp3_decode_granules(sk_engine *e, const sk_mp3_requant_granule *granules, co
 
 }  // namespace
 
-int sk_mp3_requantize(sk_engine *e, const sk_mp3_requant_granule *granules, const int16_t *is, float *xr, uint32_t n, int32_t *status) {
+int sk_mp3_requantize(sk_engine *e, const sk_mp3_requant_granule *granules, const int16_t *is, float *xr, uint32_t n, int32_t *status) try {
+    sk::abi_enter();
     if (!e || (n && (!granules || !is || !xr))) return SK_ERR_INVALID_ARG;
     if (n == 0) return SK_OK;
     for (uint32_t i = 0; i < n; ++i)
@@ -1949,19 +2197,28 @@ int sk_mp3_requantize(sk_engine *e, const sk_mp3_requant_granule *granules, cons
     SK_HIP(hipMemcpyAsync(xr, e->out_buf.p, lines * sizeof(float), hipMemcpyDeviceToHost, e->stream), "D2H mp3 lines");
     SK_HIP(hipStreamSynchronize(e->stream), "mp3 requantisation sync");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_requantize");
 }
 
 int sk_mp3_decode_granules_f32(sk_engine *e, const sk_mp3_requant_granule *granules, const sk_mp3_granule_desc *descs, const int16_t *is,
-                               float *pcm_out, uint32_t n, int32_t *status) {
+                               float *pcm_out, uint32_t n, int32_t *status) try {
+    sk::abi_enter();
     return mp3_decode_granules(e, granules, descs, is, pcm_out, n, status, false);
+} catch (...) {
+    return sk::abi_caught("sk_mp3_decode_granules_f32");
 }
 
 int sk_mp3_decode_granules_s16(sk_engine *e, const sk_mp3_requant_granule *granules, const sk_mp3_granule_desc *descs, const int16_t *is,
-                               int16_t *pcm_out, uint32_t n, int32_t *status) {
+                               int16_t *pcm_out, uint32_t n, int32_t *status) try {
+    sk::abi_enter();
     return mp3_decode_granules(e, granules, descs, is, pcm_out, n, status, true);
+} catch (...) {
+    return sk::abi_caught("sk_mp3_decode_granules_s16");
 }
 
-int sk_resampler_open(sk_engine *e, uint32_t id, uint32_t in_hz, uint32_t out_hz) {
+int sk_resampler_open(sk_engine *e, uint32_t id, uint32_t in_hz, uint32_t out_hz) try {
+    sk::abi_enter();
     if (!e) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
@@ -1985,14 +2242,19 @@ int sk_resampler_open(sk_engine *e, uint32_t id, uint32_t in_hz, uint32_t out_hz
     s.rs_last_index = -128.0;
     SK_HIP(hipMemsetAsync(e->d_rs + (size_t)id * 2 * kRsRow, 0, 2 * kRsRow * sizeof(float), e->stream), "clear rs rows");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_resampler_open");
 }
 
-int sk_resampler_close(sk_engine *e, uint32_t id) {
+int sk_resampler_close(sk_engine *e, uint32_t id) try {
+    sk::abi_enter();
     if (!e) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
     e->streams[id].rs_open = false;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_resampler_close");
 }
 
 }  // extern "C"
@@ -2053,7 +2315,7 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
         groups[Key{s.rs_table, 0, fir ? s.rs_last_index : 0.0}].push_back(ci);
     }
     std::vector<double> idx, starts;
-    std::vector<uint32_t> row_map, out_off, row_set, set_count, counts;
+    std::vector<uint32_t> row_map, out_off, row_set, set_count, counts, g_map, g_off, g_set;
     std::vector<double> new_lasts;
     std::vector<sk::RowCopy> slides;
     for (auto &g : groups) {
@@ -2160,7 +2422,7 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
                     std::vector<uint32_t> order(row_map.size());
                     for (uint32_t r = 0; r < order.size(); ++r) order[r] = r;
                     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return row_set[x] < row_set[y]; });
-                    std::vector<uint32_t> g_map, g_off, g_set;
+                    g_map.clear(), g_off.clear(), g_set.clear();  // function-level: they outlive the asynchronous uploads below
                     for (size_t k = 0; k < order.size(); ++k) {
                         if (k > 0 && row_set[order[k]] != row_set[order[k - 1]])
                             while (g_map.size() % per_block) {
@@ -2203,7 +2465,10 @@ int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector
                 a.exact = e->sinc_exact;
                 if (!a.exact) {
                     const size_t want = sk::sinc_mfma_scratch_bytes(a.n_sets, max_count, a.step);
-                    if (want && e->sinc_scratch.reserve(want) == hipSuccess) a.scratch = e->sinc_scratch.p, a.scratch_bytes = e->sinc_scratch.cap;
+                    if (want) {  // a failed allocation is an error, not another arithmetic (see sk_downsample_f32_dev)
+                        SK_HIP(e->sinc_scratch.reserve(want), "alloc resampler tap fragments");
+                        a.scratch = e->sinc_scratch.p, a.scratch_bytes = e->sinc_scratch.cap;
+                    }
                 }
                 const uint32_t rows_per_launch = 65535u * sk::sinc_rows_per_block();  // grid.y limit; a multiple of the block's rows
                 for (uint32_t r0 = 0; r0 < a.rows; r0 += rows_per_launch) {
@@ -2257,7 +2522,8 @@ int rs_collect(sk_engine *e, const uint32_t *streams, uint32_t n_streams, std::v
 extern "C" {
 
 int sk_resampler_process_f32(sk_engine *e, const uint32_t *streams, uint32_t n_streams, const float *in, uint32_t frames,
-                             float *out, uint32_t out_cap, uint32_t *out_frames) {
+                             float *out, uint32_t out_cap, uint32_t *out_frames) try {
+    sk::abi_enter();
     if (!e || (n_streams && (!streams || !out_frames)) || (frames && n_streams && !in)) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e);
@@ -2316,10 +2582,13 @@ int sk_resampler_process_f32(sk_engine *e, const uint32_t *streams, uint32_t n_s
                                 hipMemcpyDeviceToHost, e->stream), "D2H resampler output");
     SK_HIP(hipStreamSynchronize(e->stream), "resampler sync");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_resampler_process_f32");
 }
 
 int sk_resampler_flush_f32(sk_engine *e, const uint32_t *streams, uint32_t n_streams, float *out, uint32_t out_cap,
-                           uint32_t *out_frames) {
+                           uint32_t *out_frames) try {
+    sk::abi_enter();
     if (!e || (n_streams && (!streams || !out_frames || !out))) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e);
@@ -2368,6 +2637,8 @@ int sk_resampler_flush_f32(sk_engine *e, const uint32_t *streams, uint32_t n_str
                                 hipMemcpyDeviceToHost, e->stream), "D2H flush output");
     SK_HIP(hipStreamSynchronize(e->stream), "flush sync");
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_resampler_flush_f32");
 }
 
 }  // extern "C"
@@ -2392,7 +2663,8 @@ struct TickCall {           // one sk_tick_stream
 
 extern "C" {
 
-size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n_streams, uint32_t *max_outputs) {
+size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n_streams, uint32_t *max_outputs) try {
+    sk::abi_enter();
     size_t bytes = 0;
     uint64_t outs = 0;
     for (uint32_t i = 0; i < n_streams; ++i) {
@@ -2410,6 +2682,9 @@ size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n_streams, uint32_t 
     }
     if (max_outputs) *max_outputs = (uint32_t)std::min<uint64_t>(outs, 0xffffffffu);
     return bytes;
+} catch (...) {
+    (void)sk::abi_caught("sk_tick_out_bound");
+    return 0;
 }
 
 }  // extern "C"
@@ -3028,22 +3303,29 @@ extern "C" {
 
 int sk_tick_run(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs,
                 const float *coeffs, uint32_t n_frames, uint8_t *out, size_t out_cap, sk_tick_output *outs,
-                uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) {
+                uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) try {
+    sk::abi_enter();
     return tick_impl(e, ts, n_streams, descs, coeffs, nullptr, nullptr, 0, n_frames, out, out_cap, outs, outs_cap, n_outs, out_bytes);
+} catch (...) {
+    return sk::abi_caught("sk_tick_run");
 }
 
 int sk_tick_run_q(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const void *sides,
                   const int16_t *quant, uint32_t n_units, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap,
-                  uint32_t *n_outs, size_t *out_bytes) {
+                  uint32_t *n_outs, size_t *out_bytes) try {
+    sk::abi_enter();
     if (n_units && (!sides || !quant || !descs)) return SK_ERR_INVALID_ARG;
     static const uint8_t none[8] = {0};
     return tick_impl(e, ts, n_streams, descs, nullptr, nullptr, nullptr, 0, n_units, out, out_cap, outs, outs_cap, n_outs, out_bytes, nullptr,
                      sides ? (const uint8_t *)sides : none, quant);
+} catch (...) {
+    return sk::abi_caught("sk_tick_run_q");
 }
 
 int sk_aac_entropy_decode(sk_engine *e, const uint32_t *streams, const uint32_t *units_per_stream, uint32_t n_streams,
                           const sk_au_item *units, uint32_t n_units, const uint8_t *au_bytes, size_t au_bytes_len, float *coeffs_out,
-                          sk_aac_frame_desc *descs_out, int32_t *status_out) {
+                          sk_aac_frame_desc *descs_out, int32_t *status_out) try {
+    sk::abi_enter();
     if (!e || (n_streams && (!streams || !units_per_stream)) || (n_units && (!units || !coeffs_out || !descs_out || !status_out)))
         return SK_ERR_INVALID_ARG;
     if (n_units == 0) return SK_OK;
@@ -3053,11 +3335,14 @@ int sk_aac_entropy_decode(sk_engine *e, const uint32_t *streams, const uint32_t 
     uint32_t n_outs = 0;
     return tick_impl(e, ts.data(), n_streams, nullptr, nullptr, units, au_bytes, au_bytes_len, n_units, nullptr, 0, nullptr, 0, &n_outs,
                      nullptr, &probe);
+} catch (...) {
+    return sk::abi_caught("sk_aac_entropy_decode");
 }
 
 int sk_aac_expand_q_decode(sk_engine *e, const uint32_t *streams, const uint32_t *units_per_stream, uint32_t n_streams,
                            const sk_aac_frame_desc *descs, const void *sides, const int16_t *quant, uint32_t n_units, float *coeffs_out,
-                           sk_aac_frame_desc *descs_out, int32_t *status_out) {
+                           sk_aac_frame_desc *descs_out, int32_t *status_out) try {
+    sk::abi_enter();
     if (!e || (n_streams && (!streams || !units_per_stream)) ||
         (n_units && (!descs || !sides || !quant || !coeffs_out || !descs_out || !status_out)))
         return SK_ERR_INVALID_ARG;
@@ -3068,15 +3353,31 @@ int sk_aac_expand_q_decode(sk_engine *e, const uint32_t *streams, const uint32_t
     uint32_t n_outs = 0;
     return tick_impl(e, ts.data(), n_streams, descs, nullptr, nullptr, nullptr, 0, n_units, nullptr, 0, nullptr, 0, &n_outs, nullptr, &probe,
                      (const uint8_t *)sides, quant);
+} catch (...) {
+    return sk::abi_caught("sk_aac_expand_q_decode");
 }
 
 int sk_tick_run_au(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_au_item *units, uint32_t n_units,
                    const uint8_t *au_bytes, size_t au_bytes_len, uint8_t *out, size_t out_cap, sk_tick_output *outs,
-                   uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) {
+                   uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) try {
+    sk::abi_enter();
     if (n_units && !units) return SK_ERR_INVALID_ARG;
     static const sk_au_item none{};
     return tick_impl(e, ts, n_streams, nullptr, nullptr, units ? units : &none, au_bytes, au_bytes_len, n_units, out, out_cap, outs,
                      outs_cap, n_outs, out_bytes);
+} catch (...) {
+    return sk::abi_caught("sk_tick_run_au");
+}
+
+}  // extern "C"
+
+extern "C" {
+
+const char *sk_last_exception(void) { return sk::abi_message(); }
+
+int sk_debug_throw_after(int n, int kind) {
+    sk::g_abi_throw_kind.store(kind < 0 || kind > 2 ? 0 : kind, std::memory_order_relaxed);
+    return sk::g_abi_throw_after.exchange(n < 0 ? -1 : n, std::memory_order_relaxed);
 }
 
 }  // extern "C"

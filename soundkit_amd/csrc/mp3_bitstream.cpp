@@ -7,6 +7,7 @@
 // the reference's two MP3 fixtures, whose frames must chain exactly and whose side information must add up
 // (tests/test_mp3_bitstream.py).
 #include "../../include/soundkit_amd.h"
+#include "sk_abi.h"
 
 #include <cstring>
 
@@ -37,7 +38,8 @@ struct BitReader {
 
 extern "C" {
 
-int sk_mp3_parse_header(const uint8_t *d, size_t len, sk_mp3_frame_info *out) {
+int sk_mp3_parse_header(const uint8_t *d, size_t len, sk_mp3_frame_info *out) try {
+    sk::abi_enter();
     if (!d || !out) return SK_ERR_INVALID_ARG;
     if (len < 4) return SK_MP3_NEED_MORE;
     if (d[0] != 0xff || (d[1] & 0xe0) != 0xe0) return SK_MP3_NO_SYNC;
@@ -65,9 +67,12 @@ int sk_mp3_parse_header(const uint8_t *d, size_t len, sk_mp3_frame_info *out) {
     out->side_info_bytes = v == 0 ? (out->channels == 1 ? 17 : 32) : (out->channels == 1 ? 9 : 17);
     if (out->frame_bytes < 4u + (out->has_crc ? 2u : 0u) + out->side_info_bytes) return SK_MP3_NO_SYNC;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_parse_header");
 }
 
-int sk_mp3_parse_side_info(const uint8_t *frame, size_t len, const sk_mp3_frame_info *h, sk_mp3_side_info *out) {
+int sk_mp3_parse_side_info(const uint8_t *frame, size_t len, const sk_mp3_frame_info *h, sk_mp3_side_info *out) try {
+    sk::abi_enter();
     if (!frame || !h || !out) return SK_ERR_INVALID_ARG;
     const size_t at = 4u + (h->has_crc ? 2u : 0u);
     if (len < at + h->side_info_bytes) return SK_MP3_NEED_MORE;
@@ -114,12 +119,15 @@ int sk_mp3_parse_side_info(const uint8_t *frame, size_t len, const sk_mp3_frame_
             if (s.big_values > 288) return SK_MP3_INVALID;  // 2 x big_values lines must fit the 576 of a granule
         }
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_parse_side_info");
 }
 
 // Frames of a byte stream: an ID3v2 tag in front is stepped over (its length is in the tag), bytes that are no header are
 // skipped one at a time, and a candidate header counts as a frame only if the next frame's header follows it where its
 // length says (or the data ends there) -- the usual guard against sync words inside audio data.
-int sk_mp3_scan(const uint8_t *d, size_t len, sk_mp3_frame_info *frames, uint32_t cap, uint32_t *n_frames, size_t *consumed) {
+int sk_mp3_scan(const uint8_t *d, size_t len, sk_mp3_frame_info *frames, uint32_t cap, uint32_t *n_frames, size_t *consumed) try {
+    sk::abi_enter();
     if (!d || !n_frames || (cap && !frames)) return SK_ERR_INVALID_ARG;
     *n_frames = 0;
     size_t pos = 0;
@@ -150,6 +158,8 @@ int sk_mp3_scan(const uint8_t *d, size_t len, sk_mp3_frame_info *frames, uint32_
     }
     if (consumed) *consumed = pos;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_scan");
 }
 
 // The main data of frame k starts main_data_begin bytes BEFORE its own main-data area, in what earlier frames left unused
@@ -157,7 +167,8 @@ int sk_mp3_scan(const uint8_t *d, size_t len, sk_mp3_frame_info *frames, uint32_
 // bytes of the frames before it, oldest first (at least main_data_begin of them, else SK_MP3_NEED_MORE: a stream joined in
 // the middle).  Returns the number of bytes written to out.
 int sk_mp3_main_data(const uint8_t *frame, size_t frame_len, const sk_mp3_frame_info *h, const sk_mp3_side_info *side, const uint8_t *prev,
-                     size_t prev_len, uint8_t *out, size_t out_cap, size_t *out_len) {
+                     size_t prev_len, uint8_t *out, size_t out_cap, size_t *out_len) try {
+    sk::abi_enter();
     if (!frame || !h || !side || !out || !out_len || (prev_len && !prev)) return SK_ERR_INVALID_ARG;
     const size_t head = 4u + (h->has_crc ? 2u : 0u) + h->side_info_bytes;
     if (frame_len < h->frame_bytes || h->frame_bytes < head) return SK_MP3_NEED_MORE;
@@ -173,6 +184,8 @@ int sk_mp3_main_data(const uint8_t *frame, size_t frame_len, const sk_mp3_frame_
         for (int c = 0; c < side->channels; ++c) bits += side->gr[g][c].part2_3_length;
     if (bits > 8 * (back + own)) return SK_MP3_INVALID;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_main_data");
 }
 
 }  // extern "C"

@@ -8,6 +8,7 @@
 // binary decoding tries here.  Host code throughout; the arithmetic behind it (requantisation, stereo, reorder, hybrid
 // synthesis) runs on the GPU, one launch each per decode call (mp3_requant.hip, mp3_hybrid.hip).
 #include "../../include/soundkit_amd.h"
+#include "sk_abi.h"
 #include "mp3_iso_tables.h"
 
 #include <cmath>
@@ -253,7 +254,8 @@ int huffman(const sk_mp3_codebook &cb, const sk_mp3_frame_info &h, const sk_mp3_
 
 extern "C" {
 
-int sk_mp3_codebook_create(const sk_mp3_tables *t, sk_mp3_codebook **out) {
+int sk_mp3_codebook_create(const sk_mp3_tables *t, sk_mp3_codebook **out) try {
+    sk::abi_enter();
     if (!t || !out) return SK_ERR_INVALID_ARG;
     *out = nullptr;
     std::unique_ptr<sk_mp3_codebook> cb(new (std::nothrow) sk_mp3_codebook);
@@ -291,12 +293,20 @@ int sk_mp3_codebook_create(const sk_mp3_tables *t, sk_mp3_codebook **out) {
     }
     *out = cb.release();
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_codebook_create");
 }
 
-void sk_mp3_codebook_destroy(sk_mp3_codebook *cb) { delete cb; }
+void sk_mp3_codebook_destroy(sk_mp3_codebook *cb) try {
+    sk::abi_enter();
+    delete cb;
+} catch (...) {
+    (void)sk::abi_caught("sk_mp3_codebook_destroy");
+}
 
 // The standard's own tables (csrc/mp3_iso_tables.h) in the caller's presentation; pointers are to static storage.
-int sk_mp3_iso_tables(sk_mp3_tables *out) {
+int sk_mp3_iso_tables(sk_mp3_tables *out) try {
+    sk::abi_enter();
     if (!out) return SK_ERR_INVALID_ARG;
     std::memset(out, 0, sizeof *out);
     for (int t = 0; t < 32; ++t) {
@@ -315,16 +325,22 @@ int sk_mp3_iso_tables(sk_mp3_tables *out) {
     std::memcpy(out->pretab, sk_mp3_iso::pretab, sizeof out->pretab);
     for (int i = 0; i < 512; ++i) out->window[i] = (float)sk_mp3_iso::window_q16[i] * (1.0f / 65536.0f);  // exact: |q16| < 2^17
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_iso_tables");
 }
 
-int sk_mp3_codebook_create_iso(sk_mp3_codebook **out) {
+int sk_mp3_codebook_create_iso(sk_mp3_codebook **out) try {
+    sk::abi_enter();
     sk_mp3_tables t;
     const int rc = sk_mp3_iso_tables(&t);
     return rc == SK_OK ? sk_mp3_codebook_create(&t, out) : rc;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_codebook_create_iso");
 }
 
 int sk_mp3_decode_main_data(const sk_mp3_codebook *cb, const sk_mp3_frame_info *h, const sk_mp3_side_info *side, const uint8_t *main, size_t main_len,
-                            sk_mp3_granule_data out[2][2]) {
+                            sk_mp3_granule_data out[2][2]) try {
+    sk::abi_enter();
     if (!cb || !h || !side || !out || (main_len && !main)) return SK_ERR_INVALID_ARG;
     if (side->granules < 1 || side->granules > 2 || side->channels < 1 || side->channels > 2) return SK_ERR_INVALID_ARG;
     std::memset(out, 0, sizeof(sk_mp3_granule_data) * 4);
@@ -351,6 +367,8 @@ int sk_mp3_decode_main_data(const sk_mp3_codebook *cb, const sk_mp3_frame_info *
             start = end;
         }
     return worst;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_decode_main_data");
 }
 
 }  // extern "C"
@@ -375,6 +393,12 @@ struct sk_mp3_decoder {
     std::vector<int16_t> is;
     std::vector<float> pcm;
     std::vector<int32_t> status;
+    std::vector<uint8_t> staged_reservoir, main;
+    struct Queued {
+        uint32_t first_granule, granules;
+        size_t first_sample, samples;
+    };
+    std::vector<Queued> queued;
 };
 
 namespace {
@@ -405,8 +429,20 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
     uint32_t n_found = 0;
     size_t scanned = 0;
     int rc = sk_mp3_scan(d->buffer.data(), d->buffer.size(), d->found.data(), (uint32_t)d->found.size(), &n_found, &scanned);
-    if (rc != SK_OK) return rc;
+    if (rc != SK_OK) {
+        d->buffer.resize(d->buffer.size() - len);  // a failed call leaves the decoder as it was
+        return rc;
+    }
     if (n_found > d->found.size()) n_found = (uint32_t)d->found.size();
+
+    // Everything the call changes is staged here and committed after the device work succeeded: a failed call can be
+    // repeated (the same frames are parsed again against the same reservoir).
+    d->staged_reservoir = d->reservoir;
+    std::vector<uint8_t> &reservoir = d->staged_reservoir;
+    uint32_t sample_rate = d->sample_rate;
+    uint8_t channels = d->channels;
+    uint64_t frames = d->frames;
+    d->queued.clear();
 
     d->granules.clear(), d->descs.clear(), d->is.clear();
     size_t samples = 0, consumed = 0;
@@ -419,11 +455,11 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
         sk_mp3_side_info side;
         const size_t head = 4u + (h.has_crc ? 2u : 0u) + h.side_info_bytes;
         bool decodable = sk_mp3_parse_side_info(frame, h.frame_bytes, &h, &side) == SK_OK;
-        std::vector<uint8_t> main(d->reservoir.size() + h.frame_bytes);
+        d->main.resize(reservoir.size() + h.frame_bytes);
         size_t main_len = 0;
-        if (decodable) decodable = sk_mp3_main_data(frame, h.frame_bytes, &h, &side, d->reservoir.data(), d->reservoir.size(), main.data(), main.size(), &main_len) == SK_OK;
+        if (decodable) decodable = sk_mp3_main_data(frame, h.frame_bytes, &h, &side, reservoir.data(), reservoir.size(), d->main.data(), d->main.size(), &main_len) == SK_OK;
         sk_mp3_granule_data data[2][2];
-        if (decodable) decodable = sk_mp3_decode_main_data(d->cb, &h, &side, main.data(), main_len, data) == SK_OK;
+        if (decodable) decodable = sk_mp3_decode_main_data(d->cb, &h, &side, d->main.data(), main_len, data) == SK_OK;
         const bool joint = h.mode == 1;
         if (decodable && h.version != 1 && joint && (h.mode_ext & 1)) decodable = false;  // 13818-3 intensity stereo: not built
         if (decodable) {
@@ -432,15 +468,20 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
                 break;
             }
             if (!d->stream_open || d->stream_channels != h.channels) {  // the carried synthesis state belongs to a channel count
+                if (!d->granules.empty()) break;  // granules queued for the old stream go first; this frame waits for the next call
                 if (d->stream_open) (void)sk_stream_close(d->engine, d->stream);
                 d->stream_open = false;
                 rc = sk_stream_open(d->engine, h.sample_rate, h.channels, &d->stream);
-                if (rc != SK_OK) return rc;
+                if (rc != SK_OK) {
+                    d->buffer.resize(d->buffer.size() - len);
+                    return rc;
+                }
                 d->stream_open = true;
                 d->stream_channels = h.channels;
             }
-            if (!d->sample_rate) d->sample_rate = h.sample_rate;
-            if (!d->channels) d->channels = h.channels;
+            if (!sample_rate) sample_rate = h.sample_rate;
+            if (!channels) channels = h.channels;
+            d->queued.push_back({(uint32_t)d->granules.size(), h.granules, samples, frame_samples});
             for (int gr = 0; gr < h.granules; ++gr) {
                 sk_mp3_requant_granule g;
                 std::memset(&g, 0, sizeof g);
@@ -469,15 +510,15 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
                 d->descs.push_back(desc);
             }
             samples += frame_samples;
-            d->frames += 1;
+            frames += 1;
         }
         // whatever became of the frame, its own main data is what later frames reach back into
-        if (h.frame_bytes > head) d->reservoir.insert(d->reservoir.end(), frame + head, frame + h.frame_bytes);
-        if (d->reservoir.size() > kReservoirKept) d->reservoir.erase(d->reservoir.begin(), d->reservoir.end() - kReservoirKept);
+        if (h.frame_bytes > head) reservoir.insert(reservoir.end(), frame + head, frame + h.frame_bytes);
+        if (reservoir.size() > kReservoirKept) reservoir.erase(reservoir.begin(), reservoir.end() - kReservoirKept);
         consumed = h.offset + h.frame_bytes;
         if (decodable && out_cap - samples < SK_MP3_MAX_SAMPLES_PER_FRAME) stopped = true;  // lib.rs:300-302
+        if (k + 1 == n_found) consumed = scanned;  // every frame taken: garbage in front of an incomplete frame goes too
     }
-    if (!stopped && result == SK_OK) consumed = scanned;  // garbage in front of an incomplete frame goes too
 
     const uint32_t n = (uint32_t)d->granules.size();
     if (n) {
@@ -491,8 +532,30 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
             rc = sk_mp3_decode_granules_f32(d->engine, d->granules.data(), d->descs.data(), d->is.data(), d->pcm.data(), n, d->status.data());
             for (size_t i = 0; rc == SK_OK && i < samples; ++i) ((int32_t *)out)[i] = mp3_f32_to_i32(d->pcm[i]);
         }
-        if (rc != SK_OK) return rc;
+        if (rc != SK_OK) {
+            d->buffer.resize(d->buffer.size() - len);
+            return rc;
+        }
+        // a frame one of whose granules a GPU stage rejected is consumed without output, like the frames the host stages
+        // reject: its samples are taken out of what the call returns
+        const size_t width = kind == Out::I16 ? 2 : 4;
+        size_t kept = 0;
+        for (const auto &q : d->queued) {
+            bool ok = true;
+            for (uint32_t g = 0; g < q.granules; ++g) ok = ok && d->status[q.first_granule + g] == 0;
+            if (!ok) {
+                frames -= 1;
+                continue;
+            }
+            if (kept != q.first_sample) std::memmove((uint8_t *)out + kept * width, (uint8_t *)out + q.first_sample * width, q.samples * width);
+            kept += q.samples;
+        }
+        samples = kept;
+    } else if (n_found == 0) {
+        consumed = scanned;
     }
+    d->reservoir.swap(d->staged_reservoir);
+    d->sample_rate = sample_rate, d->channels = channels, d->frames = frames;
     d->buffer.erase(d->buffer.begin(), d->buffer.begin() + (ptrdiff_t)consumed);
     *written = samples;
     return result;
@@ -502,7 +565,8 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
 
 extern "C" {
 
-int sk_mp3_decoder_create(sk_engine *e, const sk_mp3_codebook *cb, sk_mp3_decoder **out) {
+int sk_mp3_decoder_create(sk_engine *e, const sk_mp3_codebook *cb, sk_mp3_decoder **out) try {
+    sk::abi_enter();
     if (!e || !out) return SK_ERR_INVALID_ARG;
     *out = nullptr;
     sk_mp3_codebook *own = nullptr;
@@ -532,41 +596,61 @@ int sk_mp3_decoder_create(sk_engine *e, const sk_mp3_codebook *cb, sk_mp3_decode
     d->buffer.reserve(16 * 1024);  // lib.rs:160
     *out = d;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_decoder_create");
 }
 
-void sk_mp3_decoder_destroy(sk_mp3_decoder *d) {
+void sk_mp3_decoder_destroy(sk_mp3_decoder *d) try {
+    sk::abi_enter();
     if (!d) return;
     if (d->stream_open) (void)sk_stream_close(d->engine, d->stream);
     delete d->own_cb;
     delete d;
+} catch (...) {
+    (void)sk::abi_caught("sk_mp3_decoder_destroy");
 }
 
-int sk_mp3_decoder_reset(sk_mp3_decoder *d) {
+int sk_mp3_decoder_reset(sk_mp3_decoder *d) try {
+    sk::abi_enter();
     if (!d) return SK_ERR_INVALID_ARG;
     if (d->stream_open) (void)sk_stream_close(d->engine, d->stream);
     d->stream_open = false;
     d->buffer.clear(), d->reservoir.clear();
     d->sample_rate = 0, d->channels = 0;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_decoder_reset");
 }
 
-int sk_mp3_decoder_info(const sk_mp3_decoder *d, uint32_t *sample_rate, uint8_t *channels, size_t *buffer_len, uint64_t *frames) {
+int sk_mp3_decoder_info(const sk_mp3_decoder *d, uint32_t *sample_rate, uint8_t *channels, size_t *buffer_len, uint64_t *frames) try {
+    sk::abi_enter();
     if (!d) return SK_ERR_INVALID_ARG;
     if (sample_rate) *sample_rate = d->sample_rate;
     if (channels) *channels = d->channels;
     if (buffer_len) *buffer_len = d->buffer.size();
     if (frames) *frames = d->frames;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_mp3_decoder_info");
 }
 
-int sk_mp3_decoder_decode_i16(sk_mp3_decoder *d, const uint8_t *input, size_t len, int16_t *out, size_t out_cap, size_t *written) {
+int sk_mp3_decoder_decode_i16(sk_mp3_decoder *d, const uint8_t *input, size_t len, int16_t *out, size_t out_cap, size_t *written) try {
+    sk::abi_enter();
     return decode(d, input, len, out, out_cap, written, Out::I16);
+} catch (...) {
+    return sk::abi_caught("sk_mp3_decoder_decode_i16");
 }
-int sk_mp3_decoder_decode_i32(sk_mp3_decoder *d, const uint8_t *input, size_t len, int32_t *out, size_t out_cap, size_t *written) {
+int sk_mp3_decoder_decode_i32(sk_mp3_decoder *d, const uint8_t *input, size_t len, int32_t *out, size_t out_cap, size_t *written) try {
+    sk::abi_enter();
     return decode(d, input, len, out, out_cap, written, Out::I32);
+} catch (...) {
+    return sk::abi_caught("sk_mp3_decoder_decode_i32");
 }
-int sk_mp3_decoder_decode_f32(sk_mp3_decoder *d, const uint8_t *input, size_t len, float *out, size_t out_cap, size_t *written) {
+int sk_mp3_decoder_decode_f32(sk_mp3_decoder *d, const uint8_t *input, size_t len, float *out, size_t out_cap, size_t *written) try {
+    sk::abi_enter();
     return decode(d, input, len, out, out_cap, written, Out::F32);
+} catch (...) {
+    return sk::abi_caught("sk_mp3_decoder_decode_f32");
 }
 
 }  // extern "C"

@@ -15,6 +15,7 @@
 // `max_stream_frames_per_tick` access units to a batch and is not scheduled again until that batch has been
 // delivered, so its frames reach the engine in order and its outputs never overtake each other.
 #include "../../include/soundkit_amd.h"
+#include "sk_abi.h"
 
 #include <hip/hip_runtime.h>
 
@@ -156,6 +157,7 @@ struct sk_lane {
     std::deque<int> free_batches, to_deliver;
     std::condition_variable deliver_cv;
     bool stop = false;
+    std::atomic<int> fatal{0};  // != 0: a thread of the lane died of an exception (lane_fatal); every stream got that error
 
     std::vector<std::thread> workers;
     std::thread submitter;
@@ -349,7 +351,14 @@ void parse_some(sk_lane *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_fr
     }
 }
 
-void worker_main(sk_lane *p) {
+// test hook (sk_debug_throw_in_thread): the n-th passage of point `where` throws std::bad_alloc
+std::atomic<int> g_thread_throw_after{-1}, g_thread_throw_where{-1};
+void thread_debug_point(int where) {
+    if (g_thread_throw_after.load(std::memory_order_relaxed) < 0 || g_thread_throw_where.load(std::memory_order_relaxed) != where) return;
+    if (g_thread_throw_after.fetch_sub(1) == 0) throw std::bad_alloc();
+}
+
+void worker_body(sk_lane *p) {
     const uint32_t per_stream = p->cfg.max_stream_frames_per_tick;
     const bool gpu_entropy = p->cfg.gpu_entropy == 1, quant = p->cfg.gpu_entropy == 2;
     std::vector<float> coeffs(gpu_entropy ? 0 : (size_t)per_stream * 2 * 1024);  // quant: the same storage holds i16 (half of it)
@@ -367,6 +376,7 @@ void worker_main(sk_lane *p) {
             handle = p->ready.front();
             p->ready.pop_front();
         }
+        thread_debug_point(1);
         PStream &s = *p->streams[handle];
         uint32_t room;
         {
@@ -383,7 +393,20 @@ void worker_main(sk_lane *p) {
         // room in the output queue bounds the access units of this pass: one AudioData per unit, or -- through the
         // streaming resampler -- one per completed chunk of 4096 source frames = 4 units (lib.rs:1970-2003)
         const uint32_t limit = std::min(per_stream, s.resample ? (room > per_stream / 4 ? per_stream : 4 * room) : room);
-        parse_some(p, s, limit, coeffs.data(), descs.data(), au_stage, au_items.data(), r);
+        try {
+            thread_debug_point(0);
+            parse_some(p, s, limit, coeffs.data(), descs.data(), au_stage, au_items.data(), r);
+        } catch (...) {
+            // whatever was thrown while this stream's input was parsed is this stream's error and nobody else's
+            // (soundkit-decoder/src/lib.rs:3131-3134); the frames of this pass are dropped with it
+            r = Parsed{};
+            r.failed = true;
+            r.fail_status = sk::abi_caught("entropy thread");
+            try {
+                r.fail_msg = std::string("Decoding failed: ") + sk_strerror(r.fail_status) + ": " + sk::abi_message();
+            } catch (...) {
+            }
+        }
         {
             std::lock_guard<std::mutex> lk(s.mu);  // read by mark_schedulable and the state dump
             s.more = (r.n_frames == limit || r.budget_stop) && !r.eof && !r.failed;
@@ -478,7 +501,7 @@ void push_error(PStream &s, int32_t status, const std::string &msg) {
     s.out.push_back(std::move(o));
 }
 
-void submit_main(sk_lane *p) {
+void submit_body(sk_lane *p) {
     std::vector<sk_tick_stream> ts;
     for (;;) {
         Batch *b;
@@ -508,6 +531,7 @@ void submit_main(sk_lane *p) {
             p->free_batches.pop_front();
         }
         p->room_cv.notify_all();  // room again
+        thread_debug_point(2);
 
         const Clock::time_point t0 = Clock::now();
         const uint32_t n_streams = (uint32_t)b->ts.size(), n_frames = (uint32_t)b->n_descs;
@@ -609,7 +633,7 @@ void watchdog_main(sk_lane *p, int secs);
 
 // Hands a finished tick's outputs to the streams' queues: outputs first (in order), then the end-of-stream /
 // error notes, then the stream is free to be parsed again.
-void deliver_main(sk_lane *p) {
+void deliver_body(sk_lane *p) {
     std::vector<uint32_t> wake;  // streams that can be parsed again: queued in one go, one wake-up
     std::vector<uint32_t> listed;  // handles that now have something to receive
     for (;;) {
@@ -627,6 +651,7 @@ void deliver_main(sk_lane *p) {
             b = &p->batches[index];
             slice = b->next_slice++;  // this thread serves the rows / entries congruent to `slice`
         }
+        thread_debug_point(3);
         const uint32_t n_slices = p->n_deliver;
         const Clock::time_point t_deliver = Clock::now();
         const uint32_t n_streams = (uint32_t)b->ts.size();
@@ -726,6 +751,68 @@ void deliver_main(sk_lane *p) {
         p->deliver_ns.fetch_add(ns_since(t_deliver));
     }
 }
+
+// A thread of the lane that dies of an exception outside the per-stream guard (an allocation while it held a batch, say)
+// cannot know which invariants it left broken, so the lane stops as a whole -- but it stops as an ERROR, not as
+// std::terminate: every open stream gets the status as its last output (the reference's "an error ends the stream",
+// soundkit-decoder/src/lib.rs:3131-3134, for all of the lane's streams at once), later calls on the lane return it, and the
+// process lives.  Never throws.
+void lane_fatal(sk_lane *p, int status) noexcept {
+    int expected = 0;
+    if (!p->fatal.compare_exchange_strong(expected, status)) return;  // once
+    char text[320];
+    std::snprintf(text, sizeof text, "Decoding failed: %s: %s", sk_strerror(status), sk::abi_message());
+    for (uint32_t h = 0; h < p->streams.size(); ++h) {
+        PStream &s = *p->streams[h];
+        bool list = false;
+        try {
+            std::lock_guard<std::mutex> lk(s.mu);
+            if (!s.open || s.cancelled) continue;
+            if (!s.finished) {
+                try {
+                    push_error(s, status, text);
+                } catch (...) {
+                }
+                s.finished = true;
+                p->n_errors.fetch_add(1);
+            }
+            // s.busy stays: a thread that has not noticed the stop yet may still hold the stream; a cancel of such a handle
+            // defers the release, and the lane's teardown (lane_destroy, after joining the threads) releases what is left
+            if (!s.out_listed) s.out_listed = list = true;
+            s.cv_out.notify_all();
+        } catch (...) {
+        }
+        if (list) {
+            try {
+                std::lock_guard<std::mutex> lk(p->oq->mu);
+                p->oq->ready.push_back(h * p->n_lanes + p->lane_index);
+            } catch (...) {
+            }
+            p->oq->cv.notify_all();
+        }
+    }
+    {
+        std::lock_guard<std::mutex> a(p->rq_mu);  // lane_destroy's order
+        std::lock_guard<std::mutex> b(p->batch_mu);
+        p->stop = true;
+    }
+    p->rq_cv.notify_all();
+    p->batch_cv.notify_all();
+    p->room_cv.notify_all();
+    p->deliver_cv.notify_all();
+}
+
+template <void (*Body)(sk_lane *)>
+void guarded_main(sk_lane *p, const char *what) noexcept {
+    try {
+        Body(p);
+    } catch (...) {
+        lane_fatal(p, sk::abi_caught(what));
+    }
+}
+void worker_main(sk_lane *p) { guarded_main<worker_body>(p, "entropy thread"); }
+void submit_main(sk_lane *p) { guarded_main<submit_body>(p, "submission thread"); }
+void deliver_main(sk_lane *p) { guarded_main<deliver_body>(p, "delivery thread"); }
 
 // CPUs this process may actually use: the affinity mask, cut down by a cgroup v2 / v1 CPU quota when there is one
 unsigned usable_cpus() {
@@ -959,6 +1046,7 @@ void lane_destroy(sk_lane *p) {
 
 int lane_spawn(sk_lane *p, const sk_decode_options *opt, uint32_t *handle) {
     if (!p || !handle) return SK_ERR_INVALID_ARG;
+    if (const int dead = p->fatal.load()) return dead;
     sk_decode_options o{};
     if (opt) o = *opt;
     // apply_output_options' argument checks (lib.rs:3360-3376), made when the pipeline is created
@@ -995,6 +1083,7 @@ int lane_send(sk_lane *p, uint32_t handle, const uint8_t *data, size_t len) {
     PStream *s = stream_of(p, handle);
     if (!s || (len && !data)) return SK_ERR_INVALID_ARG;
     if (len > kMaxInputChunkBytes) return SK_PIPE_CHUNK_TOO_LARGE;  // lib.rs:2796-2798
+    if (p->fatal.load()) return SK_PIPE_CLOSED;  // the lane's threads are gone: Disconnected
     std::lock_guard<std::mutex> lk(s->mu);
     if (!s->open || s->cancelled) return SK_PIPE_CLOSED;
     if (s->finished) return SK_PIPE_CLOSED;  // the worker has ended: TrySendError::Disconnected, lib.rs:2827-2833
@@ -1119,7 +1208,8 @@ inline sk_lane *lane_of(sk_pipeline *p, uint32_t handle, uint32_t *inner) {
 
 extern "C" {
 
-int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline **out) {
+int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline **out) try {
+    sk::abi_enter();
     if (!e || !out) return SK_ERR_INVALID_ARG;
     *out = nullptr;
     sk_pipeline_config c{};
@@ -1165,9 +1255,12 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
     }
     *out = p;
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_pipeline_create");
 }
 
-void sk_pipeline_destroy(sk_pipeline *p) {
+void sk_pipeline_destroy(sk_pipeline *p) try {
+    sk::abi_enter();
     if (!p) return;
     for (auto &q : p->oqs) {
         {
@@ -1184,9 +1277,12 @@ void sk_pipeline_destroy(sk_pipeline *p) {
     for (sk_lane *l : p->lanes) lane_destroy(l);
     for (sk_engine *e : p->owned_engines) sk_engine_destroy(e);
     delete p;
+} catch (...) {
+    (void)sk::abi_caught("sk_pipeline_destroy");
 }
 
-int sk_pipeline_spawn(sk_pipeline *p, const sk_decode_options *opt, uint32_t *handle) {
+int sk_pipeline_spawn(sk_pipeline *p, const sk_decode_options *opt, uint32_t *handle) try {
+    sk::abi_enter();
     if (!p || !handle || p->lanes.empty()) return SK_ERR_INVALID_ARG;
     const uint32_t n = (uint32_t)p->lanes.size();
     const uint32_t first = p->next_lane.fetch_add(1) % n;
@@ -1202,35 +1298,55 @@ int sk_pipeline_spawn(sk_pipeline *p, const sk_decode_options *opt, uint32_t *ha
         if (rc != SK_ERR_CAPACITY) return rc;
     }
     return rc;
+} catch (...) {
+    return sk::abi_caught("sk_pipeline_spawn");
 }
 
-int sk_pipeline_send(sk_pipeline *p, uint32_t handle, const uint8_t *data, size_t len) {
+int sk_pipeline_send(sk_pipeline *p, uint32_t handle, const uint8_t *data, size_t len) try {
+    sk::abi_enter();
     uint32_t inner;
     sk_lane *l = lane_of(p, handle, &inner);
     return l ? lane_send(l, inner, data, len) : SK_ERR_INVALID_ARG;
+} catch (...) {
+    return sk::abi_caught("sk_pipeline_send");
 }
 
-int sk_pipeline_finish(sk_pipeline *p, uint32_t handle) { return sk_pipeline_send(p, handle, nullptr, 0); }  // lib.rs:2838-2840
+int sk_pipeline_finish(sk_pipeline *p, uint32_t handle) try {
+    sk::abi_enter();
+    return sk_pipeline_send(p, handle, nullptr, 0);
+} catch (...) {
+    return sk::abi_caught("sk_pipeline_finish");
+}  // lib.rs:2838-2840
 
-int sk_pipeline_try_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info) {
+int sk_pipeline_try_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info) try {
+    sk::abi_enter();
     uint32_t inner;
     sk_lane *l = lane_of(p, handle, &inner);
     return l ? lane_try_recv(l, inner, data, cap, info) : SK_ERR_INVALID_ARG;
+} catch (...) {
+    return sk::abi_caught("sk_pipeline_try_recv");
 }
 
-int sk_pipeline_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info, uint32_t timeout_ms) {
+int sk_pipeline_recv(sk_pipeline *p, uint32_t handle, uint8_t *data, size_t cap, sk_audio_info *info, uint32_t timeout_ms) try {
+    sk::abi_enter();
     uint32_t inner;
     sk_lane *l = lane_of(p, handle, &inner);
     return l ? lane_recv(l, inner, data, cap, info, timeout_ms) : SK_ERR_INVALID_ARG;
+} catch (...) {
+    return sk::abi_caught("sk_pipeline_recv");
 }
 
-int sk_pipeline_cancel(sk_pipeline *p, uint32_t handle) {
+int sk_pipeline_cancel(sk_pipeline *p, uint32_t handle) try {
+    sk::abi_enter();
     uint32_t inner;
     sk_lane *l = lane_of(p, handle, &inner);
     return l ? lane_cancel(l, inner) : SK_ERR_INVALID_ARG;
+} catch (...) {
+    return sk::abi_caught("sk_pipeline_cancel");
 }
 
-int sk_pipeline_wait_outputs(sk_pipeline *p, uint32_t *handles, uint32_t cap, uint32_t timeout_ms) {
+int sk_pipeline_wait_outputs(sk_pipeline *p, uint32_t *handles, uint32_t cap, uint32_t timeout_ms) try {
+    sk::abi_enter();
     if (!p || !handles || !cap || p->oqs.empty()) return SK_ERR_INVALID_ARG;
     const uint32_t n_q = (uint32_t)p->oqs.size();
     thread_local uint32_t waiter_id = 0xffffffffu;
@@ -1269,24 +1385,35 @@ int sk_pipeline_wait_outputs(sk_pipeline *p, uint32_t *handles, uint32_t cap, ui
         s->out_listed = false;
     }
     return (int)n;
+} catch (...) {
+    return sk::abi_caught("sk_pipeline_wait_outputs");
 }
 
-size_t sk_pipeline_debug_dump(sk_pipeline *p, char *buf, size_t cap) {
+size_t sk_pipeline_debug_dump(sk_pipeline *p, char *buf, size_t cap) try {
+    sk::abi_enter();
     if (!p || !buf || !cap) return 0;
     size_t at = 0;
     buf[0] = 0;
     for (sk_lane *l : p->lanes)
         if (at + 1 < cap) at += lane_dump(l, buf + at, cap - at);
     return at;
+} catch (...) {
+    (void)sk::abi_caught("sk_pipeline_debug_dump");
+    return 0;
 }
 
-size_t sk_pipeline_queued_input_bytes(sk_pipeline *p, uint32_t handle) {  // lib.rs:2863-2866
+size_t sk_pipeline_queued_input_bytes(sk_pipeline *p, uint32_t handle) try {
+    sk::abi_enter();  // lib.rs:2863-2866
     uint32_t inner;
     sk_lane *l = lane_of(p, handle, &inner);
     return l ? lane_queued_input_bytes(l, inner) : 0;
+} catch (...) {
+    (void)sk::abi_caught("sk_pipeline_queued_input_bytes");
+    return 0;
 }
 
-int sk_pipeline_get_stats(sk_pipeline *p, sk_pipeline_stats *out) {
+int sk_pipeline_get_stats(sk_pipeline *p, sk_pipeline_stats *out) try {
+    sk::abi_enter();
     if (!p || !out) return SK_ERR_INVALID_ARG;
     std::memset(out, 0, sizeof(*out));
     for (sk_lane *l : p->lanes) {
@@ -1304,6 +1431,13 @@ int sk_pipeline_get_stats(sk_pipeline *p, sk_pipeline_stats *out) {
     }
     out->lanes = (uint32_t)p->lanes.size();
     return SK_OK;
+} catch (...) {
+    return sk::abi_caught("sk_pipeline_get_stats");
+}
+
+int sk_debug_throw_in_thread(int n, int where) {
+    g_thread_throw_where.store(where, std::memory_order_relaxed);
+    return g_thread_throw_after.exchange(n < 0 ? -1 : n, std::memory_order_relaxed);
 }
 
 }  // extern "C"

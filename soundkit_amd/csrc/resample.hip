@@ -607,22 +607,32 @@ static uint32_t sinc_mfma_tiles_per_block(double step) {
     return tiles;
 }
 
-// The fragments are built and used in passes of at most kPassTiles tiles (64 K outputs) per index set, so the scratch does not
-// grow with the length of the rows and the form never depends on it.
+// The fragments are built and used in passes of at most kPassTiles tiles (64 K outputs) per index set -- fewer when many index
+// sets share the launch, so that the scratch stays within kScratchBudget -- so the scratch grows neither with the length of
+// the rows nor without bound with the number of sets, and the FORM never depends on either: it is chosen by the ratio alone.
 constexpr uint32_t kPassTiles = 4096;
+constexpr size_t kScratchBudget = (size_t)8 << 30;
+
+static bool sinc_mfma_takes(double step) {
+    const uint32_t windows = sinc_mfma_windows(step);
+    return windows <= (uint32_t)kMaxWindows && 32.0 * windows + 8.0 <= (double)kMfmaSpan;
+}
+static uint32_t sinc_mfma_pass_tiles(uint32_t n_sets, uint32_t out_count, double step) {
+    const size_t per_tile = (size_t)sinc_mfma_windows(step) * 3 * 1024 + sizeof(TileMeta);
+    const size_t all = std::min<size_t>((out_count + 15) / 16, kPassTiles);
+    const size_t fit = kScratchBudget / (per_tile * (size_t)n_sets);
+    return (uint32_t)std::max<size_t>(1, std::min(all, fit));
+}
 
 size_t sinc_mfma_scratch_bytes(uint32_t n_sets, uint32_t out_count, double step) {
-    if (n_sets == 0 || out_count == 0) return 0;
-    const uint32_t windows = sinc_mfma_windows(step);
-    if (windows > (uint32_t)kMaxWindows || 32.0 * windows + 8.0 > (double)kMfmaSpan) return 0;
-    const size_t tiles = std::min<size_t>((out_count + 15) / 16, kPassTiles);
-    const size_t bytes = (size_t)n_sets * tiles * ((size_t)windows * 3 * 1024 + sizeof(TileMeta)) + 256;
-    return bytes > ((size_t)64 << 30) ? 0 : bytes;
+    if (n_sets == 0 || out_count == 0 || !sinc_mfma_takes(step)) return 0;
+    const size_t per_tile = (size_t)sinc_mfma_windows(step) * 3 * 1024 + sizeof(TileMeta);
+    return (size_t)n_sets * sinc_mfma_pass_tiles(n_sets, out_count, step) * per_tile + 512;
 }
 
 static hipError_t launch_sinc_mfma(const SincArgs &a, hipStream_t s) {
     const uint32_t windows = sinc_mfma_windows(a.step), all_tiles = (a.out_count + 15) / 16, tpb = sinc_mfma_tiles_per_block(a.step);
-    const uint32_t pass_tiles = std::min(all_tiles, kPassTiles);
+    const uint32_t pass_tiles = sinc_mfma_pass_tiles(a.n_sets, a.out_count, a.step);
     const size_t frag_bytes = (size_t)a.n_sets * pass_tiles * windows * 3 * 1024;
     u32x4 *frags = reinterpret_cast<u32x4 *>(a.scratch);
     TileMeta *meta = reinterpret_cast<TileMeta *>(reinterpret_cast<unsigned char *>(a.scratch) + ((frag_bytes + 255) & ~(size_t)255));
@@ -651,9 +661,11 @@ hipError_t launch_sinc_resample(const SincArgs &a, hipStream_t s) {
     // The matrix-core form whenever the caller lent scratch for it -- for ONE row as for thousands: a row's samples must not
     // depend on how many other rows shared its launch (tests/test_scheduler_gpu.py compares a stream in a batch of many with
     // the same stream alone, bit for bit), and the two forms differ in the last bits.
-    if (!a.exact && a.scratch && a.n_sets) {
-        const size_t need = sinc_mfma_scratch_bytes(a.n_sets, a.out_count, a.step);
-        if (need && need <= a.scratch_bytes) return launch_sinc_mfma(a, s);
+    if (!a.exact && a.n_sets && sinc_mfma_takes(a.step)) {
+        // a caller that asked for this form and did not bring its scratch is wrong; computing another arithmetic instead would
+        // hide it (and give the row other bits than it gets elsewhere)
+        if (!a.scratch || sinc_mfma_scratch_bytes(a.n_sets, a.out_count, a.step) > a.scratch_bytes) return hipErrorInvalidValue;
+        return launch_sinc_mfma(a, s);
     }
     const uint32_t row_blocks = (a.rows + kRows - 1) / kRows;
     if (row_blocks > 65535) return hipErrorInvalidValue;

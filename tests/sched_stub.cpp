@@ -553,6 +553,65 @@ static int scenario_tick_failure(sk_engine *e) {
     return 0;
 }
 
+// An exception in one of the scheduler's own threads (an allocation that fails, say) must never reach std::terminate:
+// inside the per-stream guard of an entropy thread it is THAT stream's error (the others finish untouched); anywhere else
+// it stops the lane as an error -- every open stream ends with the status, later spawns return it -- and the process lives.
+static int scenario_thread_exceptions(sk_engine *e) {
+    for (int where = 0; where < 4; ++where) {
+        sk_pipeline_config cfg{};
+        cfg.entropy_threads = 3;
+        cfg.max_streams = 8;
+        cfg.max_frames_per_tick = 16;
+        cfg.max_stream_frames_per_tick = 4;
+        cfg.tick_wait_us = 50;
+        cfg.lanes = 1;
+        cfg.gpu_entropy = g_front_end;
+        sk_pipeline *p = nullptr;
+        CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
+        const uint32_t n = 8;
+        std::vector<uint32_t> handles(n);
+        for (auto &h : handles) CHECK(sk_pipeline_spawn(p, nullptr, &h) == SK_OK);
+        sk_debug_throw_in_thread(where == 0 ? 5 : 9, where);
+        std::thread feeder([&] {
+            for (int loop = 0; loop < 2; ++loop)
+                for (uint32_t i = 0; i < n; ++i) {
+                    int rc;
+                    while ((rc = sk_pipeline_send(p, handles[i], clip.data(), clip.size())) == SK_PIPE_INPUT_FULL)
+                        std::this_thread::sleep_for(std::chrono::microseconds(100));
+                    if (rc != SK_OK && rc != SK_PIPE_CLOSED) std::abort();
+                }
+            for (uint32_t i = 0; i < n; ++i) {
+                int rc;
+                while ((rc = sk_pipeline_finish(p, handles[i])) == SK_PIPE_INPUT_FULL) std::this_thread::sleep_for(std::chrono::microseconds(100));
+            }
+        });
+        std::vector<std::vector<Got>> got(n);
+        std::vector<int> errors(n, 0);
+        CHECK(drain_all(p, handles, got, errors) == 0);
+        feeder.join();
+        sk_debug_throw_in_thread(-1, 0);
+        uint32_t failed = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            CHECK(errors[i] <= 1);
+            failed += (uint32_t)errors[i];
+            if (!errors[i]) CHECK(got[i].size() == 48 * 2);
+            for (size_t k = 0; k < got[i].size(); ++k) CHECK(got[i][k].unit == k);  // in order and complete up to the error
+        }
+        uint32_t h2 = 0;
+        if (where == 0) {
+            CHECK(failed == 1);  // one stream paid; the lane is alive
+            CHECK(sk_pipeline_spawn(p, nullptr, &h2) == SK_ERR_CAPACITY);
+        } else {
+            CHECK(failed >= 1);  // every stream that was still open
+            CHECK(sk_pipeline_spawn(p, nullptr, &h2) == SK_ERR_OOM);
+        }
+        for (uint32_t h : handles) CHECK(sk_pipeline_cancel(p, h) == SK_OK);
+        sk_pipeline_destroy(p);
+        for (uint32_t i = 0; i < e->open.size(); ++i) e->open[i] = 0;  // a dead lane cannot hand its engine streams back one by one
+    }
+    return 0;
+}
+
 static int scenario_cancel_churn(sk_engine *e);
 static int scenario_cancel_churn(sk_engine *e) {
     sk_pipeline_config cfg{};
@@ -696,6 +755,7 @@ int main(int argc, char **argv) {
     if (int rc = scenario_tick_failure(&e)) return rc;
     g_front_end = 0;
     g_lanes = 1;
+    if (int rc = scenario_thread_exceptions(&e)) return rc;
     if (int rc = scenario_max_length_frames(&e)) return rc;
     g_lanes = 2;
     if (int rc = scenario_max_length_frames(&e)) return rc;

@@ -34,6 +34,14 @@ def test_under_an_external_launcher_it_is_one_rank():
     assert r.returncode == 0 and json.loads(r.stdout.strip())["n_gpus"] == 1
 
 
+def test_a_stalled_extra_still_prints_the_line_and_exits_non_zero():
+    """the default line's end_to_end extra stalling must not look like rc 0 to the driver (bench.py: print_line_and_leave_if_stalled)"""
+    r = run(["--gpus", "1"], WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", SK_BENCH_DRY_STALL="1")
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    out = json.loads(r.stdout.strip())
+    assert out["n_gpus"] == 1 and "stalled" in out["end_to_end"]["error"]
+
+
 def test_refuses_a_world_that_is_not_what_was_asked_for():
     r = run(["--gpus", "4"], WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr and not r.stdout.strip()

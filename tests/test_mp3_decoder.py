@@ -253,5 +253,6 @@ def test_mutated_streams_under_sanitizers(tmp_path):
         files.append(path)
     out = subprocess.run([exe, "1500"] + files, capture_output=True, text=True, cwd=here)
     assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
-    calls, samples, errors, granules, gpu_calls = [int(x) for x in re.findall(r"\d+", out.stdout)]
+    calls, samples, errors, granules, gpu_calls, failed, retried, rejected, splices = [int(x) for x in re.findall(r"\d+", out.stdout)]
     assert calls > 50000 and samples > 10 ** 7 and granules > 30000 and errors > 0, out.stdout
+    assert failed > 100 and retried > 100 and rejected > 100 and splices > 100, out.stdout
