@@ -194,14 +194,71 @@ def cpu_baseline_pcm(target_s=10.0):
             "sample": "sko_pcm_convert FLOAT_TO_I16_ROUND, %d samples (16 Mi looped) in %.1f s" % (done, dt)}
 
 
-CPU_BASELINES = {"pcm": cpu_baseline_pcm, "fir": cpu_baseline_fir, "aac_synth": cpu_baseline_synth, "pipeline": cpu_baseline_pipeline}
+E2E_CLIP = "aac-stereo-48k.adts"
+
+
+def cpu_chain_decode(clip_bytes, loops, out_rate=16000, mono=True):
+    """The whole decode of one ADTS stream on the CPU, in the worker's order (soundkit-decoder lib.rs:1793-1813, 3324-3456; the
+    loop to mirror: aac-wasm-bench/src/lib.rs:1589-1611): ADTS framing + the product's HOST front-end (csrc/aac_frontend.cpp:
+    Huffman, stereo tools, TNS, PNS -- plain C++, no GPU) -> oracle synthesis -> float_sample_to_i16 -> / 32768 -> oracle
+    streaming resampler -> mono downmix -> s16.  -> (s16 mono samples, access units decoded).  cpu_baseline leg only."""
+    from oracle import oracle as O
+    from soundkit_amd import aac_lc
+    frames = aac_lc.split_adts(clip_bytes)
+    fe = aac_lc.AacLcFrontEnd(frames[0][0])
+    chans = [O.Channel() for _ in range(fe.channels)]
+    rs = O.StreamingResampler(fe.sample_rate, out_rate, fe.channels) if fe.sample_rate != out_rate else None
+    out, units = [], 0
+
+    def tail(planar):
+        if planar.shape[1]:
+            out.append(O.planar_f32_to_s16_interleaved(O.downmix_mono(planar)[None] if mono and planar.shape[0] > 1 else planar))
+    for _ in range(loops):
+        parsed = [fe.parse(au) for _, au in frames]
+        coeffs = np.stack([c for c, _, _ in parsed])
+        pcm, _ = O.synthesize_stream(coeffs, [sq for _, sq, _ in parsed], [sh for _, _, sh in parsed], chans)
+        for f in range(pcm.shape[0]):  # one AudioData per access unit enters the resampler, as in the worker
+            q = O.planar_f32_to_s16_interleaved(pcm[f]).reshape(1024, fe.channels).T.astype(np.float32) / np.float32(32768.0)
+            tail(rs.process(q) if rs else q)
+        units += len(frames)
+    if rs:
+        tail(rs.flush())
+    fe.close()
+    return (np.concatenate([o.reshape(-1) for o in out]) if out else np.zeros(0, np.int16)), units
+
+
+def cpu_baseline_decode(target_s=12.0):
+    """Whole-decode CPU baseline ('port'), single thread: cpu_chain_decode on the end_to_end clip, looped for ~target_s."""
+    clip = open(os.path.join(ROOT, "tests", "golden", "aac", E2E_CLIP), "rb").read()
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < target_s:
+        _, units = cpu_chain_decode(clip, 4)
+        done += units
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "host front-end (product C++: ADTS framing, Huffman, stereo tools, TNS) + oracle synthesis + s16 + oracle streaming "
+                      "48 -> 16 kHz resampler + mono + s16 per access unit, %d access units (%s looped) in %.1f s" % (done, E2E_CLIP, dt)}
+
+
+def pcm_stats_s16(lg, samples):
+    """PcmStats::from_pcm (aac-wasm-bench/src/lib.rs:66-101) of s16 samples as f32 = s / 32768, by the load generator's C helper"""
+    import ctypes as C
+    samples = np.ascontiguousarray(samples, np.int16)
+    rms, peak, fnv = C.c_double(0), C.c_double(0), C.c_uint64(0)
+    lg.sk_loadgen_pcm_stats.restype = None
+    lg.sk_loadgen_pcm_stats.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    lg.sk_loadgen_pcm_stats(samples.ctypes.data, samples.size, C.byref(rms), C.byref(peak), C.byref(fnv))
+    return {"sample_count": int(samples.size), "rms": rms.value, "peak_abs": peak.value, "fnv1a": "0x%016x" % fnv.value}
+
+
+CPU_BASELINES = {"decode": cpu_baseline_decode, "pcm": cpu_baseline_pcm, "fir": cpu_baseline_fir, "aac_synth": cpu_baseline_synth, "pipeline": cpu_baseline_pipeline}
 
 
 class EndToEndStalled(RuntimeError):
     """the load generator's progress deadline fired; its record is on stderr"""
 
 
-def end_to_end(args, eng, torch, dist, world, rank, device, emit=True):
+def end_to_end(args, eng, torch, dist, world, rank, device, emit=True, cpu_baseline=None):
     """SURVEY 8d config 5, scaled: `--streams` ADTS AAC-LC streams (the 48 access units of the reference's 48 kHz
     stereo TS sample, looped) through the batch scheduler: host entropy decode -> GPU ticks -> 16 kHz mono s16 out.
     One step = one pass of the clip through every stream.  Everything is inside the timed region: framing, Huffman,
@@ -224,6 +281,19 @@ def end_to_end(args, eng, torch, dist, world, rank, device, emit=True):
     lg.sk_loadgen_run.restype = C.c_int
     lg.sk_loadgen_run.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                   C.c_uint32, C.c_void_p]
+
+    class Check(C.Structure):  # sk_load_check; hash = NULL: capture only (no per-stream hashing in the timed region)
+        _fields_ = [("hash", C.c_void_p), ("outputs", C.c_void_p), ("bytes", C.c_void_p), ("errors", C.c_void_p), ("capture", C.c_void_p),
+                    ("n_capture", C.c_uint32), ("capture_buf", C.c_void_p), ("capture_cap", C.c_size_t), ("capture_len", C.c_void_p)]
+    lg.sk_loadgen_run_checked.restype = C.c_int
+    lg.sk_loadgen_run_checked.argtypes = lg.sk_loadgen_run.argtypes + [C.c_void_p]
+    # stream 0 of the first generator is kept whole: the line carries the PcmStats of what was decoded
+    # (aac-wasm-bench/src/lib.rs:66-101, 513-550: the reference's harness prints them beside every rate)
+    out_ch = args.out_channels or src_ch
+    cap_bytes = int(units * (args.steps + args.warmup + 1) * 1024 * 2 * out_ch * ((args.out_rate or src_rate) / src_rate + 0.01)) + (1 << 16)
+    cap_index = np.zeros(1, np.uint32)
+    cap_buf, cap_len = np.zeros(cap_bytes, np.uint8), np.zeros(1, np.uint64)
+    chk = Check(None, None, None, None, cap_index.ctypes.data, 1, cap_buf.ctypes.data, cap_bytes, cap_len.ctypes.data)
     cores = len(os.sched_getaffinity(0))
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -254,8 +324,8 @@ def end_to_end(args, eng, torch, dist, world, rank, device, emit=True):
         rcs = [0] * n_gen
 
         def one(i):
-            rcs[i] = lg.sk_loadgen_run(scheds[i % n_sched]._h, clip, len(clip), units, args.streams // n_gen, loops, C.byref(opt),
-                                       max(2, feeders // n_gen), 0, C.byref(results[i]))
+            rcs[i] = lg.sk_loadgen_run_checked(scheds[i % n_sched]._h, clip, len(clip), units, args.streams // n_gen, loops, C.byref(opt),
+                                               max(2, feeders // n_gen), 0, C.byref(results[i]), C.byref(chk) if i == 0 else None)
         ths = [threading.Thread(target=one, args=(i,)) for i in range(n_gen)]
         for t in ths:
             t.start()
@@ -334,6 +404,22 @@ def end_to_end(args, eng, torch, dist, world, rank, device, emit=True):
         "roofline": None,
         "note": "host-bound: the entropy threads limit this number; the device-resident rooflines are the default workload's",
     }
+    # what was decoded: PcmStats of stream 0 (16-bit samples as f32), and the same stream decoded by the CPU chain
+    captured = np.frombuffer(cap_buf[:int(cap_len[0])].tobytes(), "<i2")
+    out["pcm_stats"] = dict(pcm_stats_s16(lg, captured), stream=0, sample_rate=args.out_rate or src_rate, channels=out_ch,
+                            access_units=units * args.steps)
+    if args.clip == E2E_CLIP and (args.out_rate or src_rate) == 16000 and out_ch == 1 and not args.no_cpu_baseline:
+        want, _ = cpu_chain_decode(clip, args.steps)  # cpu_baseline leg: the checker's decode of the same stream
+        cpu = pcm_stats_s16(lg, want)
+        same_len = want.size == captured.size
+        d = np.abs(want.astype(np.int32) - captured.astype(np.int32)) if same_len else None
+        out["pcm_stats"]["cpu_chain"] = dict(cpu, max_abs_diff_lsb=int(d.max()) if same_len and d.size else None,
+                                             differing_fraction=float((d > 0).mean()) if same_len and d.size else None,
+                                             same_sample_count=bool(same_len),
+                                             note="host front-end + oracle tail on the same bytes; the FIR sums its products in another "
+                                                  "order than the CPU chain: +-1 LSB on < 1 % of the samples, so the checksums differ")
+    if cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline
     if emit:
         print(json.dumps(out))
     return out
@@ -459,9 +545,13 @@ def main():
         return dry_run(args, world, rank)
 
     # child processes are started before anything here initialises the GPU
-    all_cores = None
+    all_cores = whole_decode = None
     if not args.no_cpu_baseline and args.workload in CPU_BASELINES and world == 1 and not args.cpu_baseline_single_core_only:
         all_cores = cpu_baseline_all_cores(args.workload)
+    if not args.no_cpu_baseline and args.workload in ("pipeline", "end_to_end") and world == 1 and rank == 0:
+        # the whole decode on the host's cores, beside the end_to_end figure (north_star: "the reference ... CPU path timed on the
+        # node's own host cores in the same run")
+        whole_decode = cpu_baseline_all_cores("decode", 6.0)
 
     import torch
     import torch.distributed as dist
@@ -479,7 +569,7 @@ def main():
     ext = torch.cuda.ExternalStream(eng.hip_stream, device=device)
 
     if args.workload == "end_to_end":
-        end_to_end(args, eng, torch, dist, world, rank, device)
+        end_to_end(args, eng, torch, dist, world, rank, device, cpu_baseline=whole_decode)
         if world > 1:
             dist.destroy_process_group()
         eng.close()
@@ -884,7 +974,7 @@ def main():
               out["end_to_end"] = {"value": e2e["value"], "unit": "frames/s", "x_realtime": e2e["x_realtime"], "front_end": e2e["config"]["front_end"],
                                  "host_cores": e2e["config"]["host_cores"], "streams": args.streams, "access_units": args.streams * 48 * a2.steps,
                                  "seconds": e2e["ms_per_step"] * a2.steps / 1000.0, "scheduler": e2e["scheduler"],
-                                 "workload": e2e["config"]["workload"],
+                                 "workload": e2e["config"]["workload"], "pcm_stats": e2e.get("pcm_stats"),
                                  "note": "everything in the timed region: ADTS framing on host threads, Huffman decode / stereo tools / TNS, "
                                          "synthesis, streaming 48 -> 16 kHz resampler, mono downmix, s16 pack on the GPU, D2H, delivery; "
                                          "host-fed (the 16-core share frames and delivers), not a kernel figure"}
@@ -895,6 +985,9 @@ def main():
             # reference's own published single-thread rate (whole AAC-LC decode, hardware unstated)
             out["cpu_baseline"] = all_cores or single
             out["cpu_baseline_single_core"] = single
+            if whole_decode:
+                out["cpu_baseline_whole_decode"] = dict(whole_decode, note="the counterpart of end_to_end.value: everything from ADTS bytes to "
+                                                        "16 kHz mono s16 on the host's cores; cpu_baseline above is the decode TAIL only")
             out["cpu_reference_published"] = {"value": 31278.3, "unit": "frames/s", "cores": 1, "kind": "reference-published",
                                               "sample": "soundkit-aac-lc README.md:105, soundkit-lc-reuse: whole AAC-LC decode (entropy + "
                                                         "synthesis), hardware unstated; not measured here"}

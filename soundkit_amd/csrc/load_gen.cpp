@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -83,6 +84,7 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
     if (chk) {
         for (uint32_t i = 0; i < n_streams; ++i) {
             index_of[handles[i]] = i;
+            if (!chk->hash) continue;  // capture only (the bench's PcmStats of one stream): no per-stream bookkeeping
             chk->hash[i] = 0xcbf29ce484222325ull;
             chk->outputs[i] = 0;
             chk->bytes[i] = 0;
@@ -169,7 +171,8 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
                     // with per-stream checks a stream is drained by one consumer at a time: receive-then-hash must not
                     // interleave with another thread's, or the order-sensitive hash would see outputs out of order
                     std::unique_lock<std::mutex> drain_lock;
-                    if (chk && h <= max_handle) drain_lock = std::unique_lock<std::mutex>(locks[index_of[h]]);
+                    const bool checked = chk && h <= max_handle && (chk->hash || capture_slot[index_of[h]] >= 0);
+                    if (checked) drain_lock = std::unique_lock<std::mutex>(locks[index_of[h]]);
                     for (;;) {
                         const int rc = sk_pipeline_try_recv(p, h, buf.data(), buf.size(), &info);
                         if (rc == 1) {
@@ -181,22 +184,24 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
                                 f += info.frames;
                                 b += info.bytes;
                             }
-                            if (chk) {
+                            if (checked) {
                                 const uint32_t i = index_of[h];
                                 if (info.is_error) {
-                                    ++chk->errors[i];
+                                    if (chk->hash) ++chk->errors[i];
                                     continue;
                                 }
-                                uint64_t hsh = chk->hash[i];
-                                auto mix = [&](const uint8_t *d, size_t n) {
-                                    for (size_t q = 0; q < n; ++q) hsh = (hsh ^ d[q]) * 0x100000001b3ull;
-                                };
-                                const uint32_t head[4] = {info.frames, info.channel_count, info.bits_per_sample, info.sampling_rate};
-                                mix(reinterpret_cast<const uint8_t *>(head), sizeof head);
-                                mix(buf.data(), info.bytes);
-                                chk->hash[i] = hsh;
-                                ++chk->outputs[i];
-                                chk->bytes[i] += info.bytes;
+                                if (chk->hash) {
+                                    uint64_t hsh = chk->hash[i];
+                                    auto mix = [&](const uint8_t *d, size_t n) {
+                                        for (size_t q = 0; q < n; ++q) hsh = (hsh ^ d[q]) * 0x100000001b3ull;
+                                    };
+                                    const uint32_t head[4] = {info.frames, info.channel_count, info.bits_per_sample, info.sampling_rate};
+                                    mix(reinterpret_cast<const uint8_t *>(head), sizeof head);
+                                    mix(buf.data(), info.bytes);
+                                    chk->hash[i] = hsh;
+                                    ++chk->outputs[i];
+                                    chk->bytes[i] += info.bytes;
+                                }
                                 const int32_t slot = capture_slot[i];
                                 if (slot >= 0 && chk->capture_len[slot] + info.bytes <= chk->capture_cap) {
                                     std::memcpy(chk->capture_buf + (size_t)slot * chk->capture_cap + chk->capture_len[slot], buf.data(), info.bytes);
@@ -260,6 +265,26 @@ int sk_loadgen_run_checked(sk_pipeline *p, const uint8_t *clip, size_t clip_len,
     res->errors = errors.load();
     res->input_full = input_full.load();
     return stalled ? SK_ERR_TIMEOUT : SK_OK;
+}
+
+// PcmStats::from_pcm (aac-wasm-bench/src/lib.rs:66-101) of 16-bit samples taken as f32 = s / 32768 (audio_bytes::i16le_to_f32):
+// sample count, RMS, peak and FNV-1a over the f32 bit patterns -- what the reference's harness prints beside every rate
+void sk_loadgen_pcm_stats(const int16_t *pcm, size_t n, double *rms, double *peak_abs, uint64_t *checksum) {
+    double sum = 0.0, peak = 0.0;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; ++i) {
+        const float f = (float)pcm[i] / 32768.0f;
+        const double d = (double)f;
+        sum += d * d;
+        peak = std::max(peak, std::fabs(d));
+        uint32_t bits;
+        std::memcpy(&bits, &f, 4);
+        h ^= (uint64_t)bits;
+        h *= 0x100000001b3ull;
+    }
+    if (rms) *rms = n ? std::sqrt(sum / (double)n) : 0.0;
+    if (peak_abs) *peak_abs = peak;
+    if (checksum) *checksum = h;
 }
 
 }  // extern "C"
