@@ -267,13 +267,23 @@ def end_to_end(args, eng, torch, dist, world, rank, device, emit=True, cpu_basel
     from soundkit_amd import pipeline, sharding
     from soundkit_amd._lib import DecodeOptionsC
     from soundkit_amd import aac_lc
-    clip = open(os.path.join(ROOT, "tests", "golden", "aac", args.clip), "rb").read()
-    adts = aac_lc.split_adts(clip)
-    units = len(adts)
-    clip = clip[:sum(len(au) + 7 for _, au in adts)]  # whole frames only: the clip is looped
-    src = aac_lc.AacLcFrontEnd(adts[0][0])
-    src_rate, src_ch = src.sample_rate, src.channels
-    src.close()
+    is_mp3 = args.clip.endswith(".mp3")
+    unit_frames = 576 if is_mp3 else 1024  # PCM frames per unit: an MP3 granule / an AAC access unit
+    if is_mp3:  # an MPEG Layer III stream: the scheduler picks the decoder from the first bytes; a unit = one granule
+        from soundkit_amd import mp3 as mp3_mod
+        clip = open(os.path.join(ROOT, "tests", "golden", "mp3", args.clip), "rb").read()
+        found, used = mp3_mod.scan(clip)
+        clip = clip[found[0].offset:used]  # without the ID3 tag: the clip is looped
+        units = sum(f.granules for f in found)
+        src_rate, src_ch = found[0].sample_rate, found[0].channels
+    else:
+        clip = open(os.path.join(ROOT, "tests", "golden", "aac", args.clip), "rb").read()
+        adts = aac_lc.split_adts(clip)
+        units = len(adts)
+        clip = clip[:sum(len(au) + 7 for _, au in adts)]  # whole frames only: the clip is looped
+        src = aac_lc.AacLcFrontEnd(adts[0][0])
+        src_rate, src_ch = src.sample_rate, src.channels
+        src.close()
     lg = C.CDLL(os.path.join(ROOT, "soundkit_amd", "libsk_loadgen.so"))
 
     class Result(C.Structure):
@@ -290,7 +300,7 @@ def end_to_end(args, eng, torch, dist, world, rank, device, emit=True, cpu_basel
     # stream 0 of the first generator is kept whole: the line carries the PcmStats of what was decoded
     # (aac-wasm-bench/src/lib.rs:66-101, 513-550: the reference's harness prints them beside every rate)
     out_ch = args.out_channels or src_ch
-    cap_bytes = int(units * (args.steps + args.warmup + 1) * 1024 * 2 * out_ch * ((args.out_rate or src_rate) / src_rate + 0.01)) + (1 << 16)
+    cap_bytes = int(units * (args.steps + args.warmup + 1) * unit_frames * 2 * out_ch * ((args.out_rate or src_rate) / src_rate + 0.01)) + (1 << 16)
     cap_index = np.zeros(1, np.uint32)
     cap_buf, cap_len = np.zeros(cap_bytes, np.uint8), np.zeros(1, np.uint64)
     chk = Check(None, None, None, None, cap_index.ctypes.data, 1, cap_buf.ctypes.data, cap_bytes, cap_len.ctypes.data)
@@ -378,16 +388,20 @@ def end_to_end(args, eng, torch, dist, world, rank, device, emit=True, cpu_basel
     st = {k: after[k] - before[k] for k in ("ticks", "frames", "outputs", "parse_ns", "tick_ns", "idle_ns", "deliver_ns")}
     value = world * res.access_units / elapsed
     out = {
-        "metric": "AAC-LC 1024-sample frames/s (whole node) + xrealtime, end to end through the batch scheduler",
-        "value": value, "unit": "frames/s", "x_realtime": value / (src_rate / 1024.0), "n_gpus": world, "steps": args.steps,
+        "metric": ("MP3 576-sample granules/s (whole node) + xrealtime, end to end through the batch scheduler" if is_mp3 else
+                   "AAC-LC 1024-sample frames/s (whole node) + xrealtime, end to end through the batch scheduler"),
+        "value": value, "unit": "granules/s" if is_mp3 else "frames/s", "x_realtime": value / (src_rate / float(unit_frames)), "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "reference fixture %s (%d access units), looped" % (args.clip, units),
-        "config": {"workload": "end_to_end: %d ADTS AAC-LC streams x %d access units, %d Hz %d ch -> %s Hz %s s16, host entropy "
-                               "decode on %d threads + GPU ticks" % (args.streams, units * args.steps, src_rate, src_ch,
+        "config": {"workload": "end_to_end: %d %s streams x %d %s, %d Hz %d ch -> %s Hz %s s16, host entropy "
+                               "decode on %d threads + GPU ticks" % (args.streams, "MPEG Layer III" if is_mp3 else "ADTS AAC-LC", units * args.steps,
+                                                                     "granules" if is_mp3 else "access units", src_rate, src_ch,
                                                                      args.out_rate or src_rate,
                                                                      "mono" if args.out_channels == 1 else "source-channel", threads),
                    "streams_per_gpu": args.streams, "entropy_threads": threads, "feeder_threads": feeders, "host_cores": cores,
-                   "front_end": ["host threads (f32 spectra over PCIe)", "gpu (k_aac_entropy_parse/link/finish, one access unit per lane)",
+                   "front_end": ("host threads: MP3 framing, reservoir, scale factors, Huffman codes; i16 lines + granule records over PCIe; "
+                                 "k_mp3_requant + k_mp3_hybrid on the device") if is_mp3 else
+                                ["host threads (f32 spectra over PCIe)", "gpu (k_aac_entropy_parse/link/finish, one access unit per lane)",
                                  "host Huffman decode, i16 + side records over PCIe, k_aac_expand_q/link/finish on the device"][front_mode],
                    "schedulers": n_sched, "lanes": int(after.get("lanes", n_sched)),
                    "host_cores_busy": ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / elapsed,

@@ -552,7 +552,11 @@ typedef struct sk_tick_stream {
     uint8_t out_channels; /* DecodeOptions::output_channels resolved (source channels when None) */
     uint8_t resample;     /* 1: route through the stream's resampler (sk_resampler_open) */
     uint8_t flush;        /* 1: end of stream: flush the resampler after these frames */
+    uint8_t codec;        /* SK_TICK_AAC (0) | SK_TICK_MP3: an MP3 stream's units are GRANULES (576 PCM frames each), taken in order
+                           * from sk_tick_input's mp3_* arrays; only sk_tick_run_mixed accepts them */
+    uint8_t reserved[3];
 } sk_tick_stream;
+enum { SK_TICK_AAC = 0, SK_TICK_MP3 = 1 };
 
 typedef struct sk_tick_output {
     uint32_t stream_index; /* index into the tick's stream table */
@@ -571,6 +575,31 @@ size_t sk_tick_out_bound(const sk_tick_stream *streams, uint32_t n_streams, uint
 int sk_tick_run(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, const sk_aac_frame_desc *descs,
                 const float *coeffs, uint32_t n_frames, uint8_t *out_bytes, size_t out_cap, sk_tick_output *outputs,
                 uint32_t outputs_cap, uint32_t *n_outputs, size_t *out_bytes_used);
+
+/* One tick over streams of both codecs -- the worker's per-format dispatch (FormatDecoder::process,
+ * soundkit-decoder/src/lib.rs:2222-2241) for a whole batch: the AAC streams' units in ONE of the three forms above (spectra,
+ * access units, or quantised values: leave the others NULL), the MP3 streams' granules as sk_mp3_decode_granules_* takes them
+ * (Huffman stage done on the host: sk_mp3_decode_main_data), listed stream by stream in the order of `streams`.  An MP3
+ * granule becomes what Mp3Decoder hands the worker -- i16 through f32_to_i16 (soundkit-mp3/src/lib.rs:376-385) -- and then
+ * takes the same apply_output_options path as an AAC unit (fast path, or / 32768 -> StreamingResampler -> downmix -> bytes).
+ * Outputs: one AudioData per AAC access unit / MP3 granule without resampling, one per 4096-frame chunk with it.
+ * The engine must hold the MP3 tables (sk_mp3_set_band_tables / sk_mp3_set_synthesis_window, or any sk_mp3_decoder_create). */
+typedef struct sk_tick_input {
+    const sk_aac_frame_desc *descs;          /* host front-end: descs + coeffs; quantised hand-over: descs + q_sides + q_quant */
+    const float *coeffs;
+    const struct sk_au_item *units;          /* GPU front-end: units + au_bytes */
+    const uint8_t *au_bytes;
+    size_t au_bytes_len;
+    const void *q_sides;
+    const int16_t *q_quant;
+    uint32_t n_aac_units;
+    uint32_t n_mp3_granules;
+    const sk_mp3_requant_granule *mp3_granules;
+    const sk_mp3_granule_desc *mp3_descs;
+    const int16_t *mp3_is;                   /* [granule][channel][576], granules packed back to back */
+} sk_tick_input;
+int sk_tick_run_mixed(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, const sk_tick_input *in, uint8_t *out_bytes,
+                      size_t out_cap, sk_tick_output *outputs, uint32_t outputs_cap, uint32_t *n_outputs, size_t *out_bytes_used);
 
 /* The same tick with the entropy front-end on the GPU too (SURVEY 8f ranks 1 + 4): instead of spectra, the raw access
  * units (ADTS headers stripped) of every stream.  units[k] addresses unit k in au_bytes; units are listed stream by

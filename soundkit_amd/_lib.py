@@ -90,7 +90,14 @@ class Mp3GranuleData(C.Structure):
 class TickStream(C.Structure):
     """sk_tick_stream"""
     _fields_ = [("stream", C.c_uint32), ("n_frames", C.c_uint32), ("out_bits", C.c_uint8), ("out_channels", C.c_uint8),
-                ("resample", C.c_uint8), ("flush", C.c_uint8)]
+                ("resample", C.c_uint8), ("flush", C.c_uint8), ("codec", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+
+
+class TickInput(C.Structure):
+    """sk_tick_input"""
+    _fields_ = [("descs", C.c_void_p), ("coeffs", C.c_void_p), ("units", C.c_void_p), ("au_bytes", C.c_void_p), ("au_bytes_len", C.c_size_t),
+                ("q_sides", C.c_void_p), ("q_quant", C.c_void_p), ("n_aac_units", C.c_uint32), ("n_mp3_granules", C.c_uint32),
+                ("mp3_granules", C.c_void_p), ("mp3_descs", C.c_void_p), ("mp3_is", C.c_void_p)]
 
 
 class TickOutput(C.Structure):
@@ -285,6 +292,7 @@ _sig = {
     "sk_pipeline_debug_dump": (_sz, [_vp, _vp, _sz]),
     "sk_tick_out_bound": (_sz, [_vp, _u32, C.POINTER(_u32)]),
     "sk_tick_run": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
+    "sk_tick_run_mixed": (_i, [_vp, _vp, _u32, _vp, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
 }
 for _name in ("sk_pcm_interleave_i16", "sk_pcm_deinterleave_i16", "sk_pcm_deinterleave_s24", "sk_pcm_deinterleave_f32",
               "sk_pcm_interleave_f32"):

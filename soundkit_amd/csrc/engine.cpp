@@ -230,7 +230,7 @@ struct sk_engine {
     DevBuf sinc_scratch;      // tap fragments of the matrix-core resampler (resample.hip), sized per launch
     bool sinc_exact = false;  // sk_engine_set_resampler_exact: the scalar form that keeps rubato's order of operations
     // sk_tick_run: synthesis output, resampler output, packed bytes, small-array arena (+ pinned host mirror)
-    DevBuf tick_pcm, tick_res, tick_out, tick_arena, tick_au, tick_side, tick_q;
+    DevBuf tick_pcm, tick_res, tick_out, tick_arena, tick_au, tick_side, tick_q, tick_mp3_in, tick_mp3_xr;
     // entropy decode on the device (sk_tick_run_au): per-stream PNS generator state and the front-end's tables
     uint32_t *d_pns = nullptr;
     void *d_ec_blob = nullptr;
@@ -2657,6 +2657,15 @@ struct TickCall {           // one sk_tick_stream
     int32_t bad_status = 0; // status of that rejected frame
     int rs_call = -1;       // index into the RsCall vector when the stream resamples
     std::vector<std::pair<uint32_t, uint32_t>> chunks;  // (column, frames) of each resampled AudioData
+    bool mp3 = false;       // SK_TICK_MP3: `first` indexes the tick's granules, a unit is a granule
+    uint32_t ulen = 1024;   // PCM frames per unit: 1024 (AAC access unit) or 576 (MP3 granule); a unit's channel rows are 1024 floats apart
+};
+
+struct TickMp3 {  // the MP3 part of sk_tick_input
+    const sk_mp3_requant_granule *granules = nullptr;
+    const sk_mp3_granule_desc *descs = nullptr;
+    const int16_t *is = nullptr;
+    uint32_t n = 0;
 };
 
 }  // namespace
@@ -2794,10 +2803,108 @@ struct EntropyProbe {  // sk_aac_entropy_decode: stop after the front-end and ha
     int32_t *status;
 };
 
+// The MP3 granules of a tick (e->mu held, device selected): requantisation + joint stereo + reorder, then the hybrid synthesis,
+// queued on e->stream with no synchronisation.  Channel row r of the granules (their channels in array order) lands at
+// pcm_rows + r * 1024 (576 samples), each sample as f32_to_i16(x) / 32768 -- Mp3Decoder's i16 AudioData as the f32
+// audio_data_to_f32_channels makes of it.  status[g]: 0, or why granule g cannot be decoded (its stream ends there).
+int tick_mp3_queue(sk_engine *e, const TickMp3 &mp3, float *pcm_rows, AuxArena &aux, std::vector<int32_t> &status) {
+    int rc = ensure_mp3(e);
+    if (rc == SK_OK) rc = ensure_mp3_requant(e);
+    if (rc != SK_OK) return rc;
+    if (!e->mp3_window_set) return SK_ERR_UNSUPPORTED;  // no Table B.3 on this engine: sk_mp3_decoder_create / sk_mp3_set_synthesis_window first
+    const uint32_t n = mp3.n;
+    status.assign(n, 0);
+    std::vector<sk::Mp3RequantRecord> records(n);
+    std::vector<uint32_t> touched;
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const sk_mp3_requant_granule &g = mp3.granules[i];
+        const sk_mp3_granule_desc &d = mp3.descs[i];
+        sk::Mp3RequantRecord &r = records[i];
+        std::memset(&r, 0, sizeof r);
+        r.off = (uint32_t)off;
+        r.channels = g.channels;
+        off += g.channels;
+        const int slot = mp3_rate_slot(g.sample_rate);
+        const bool joint = g.channels == 2 && (g.ms_stereo || g.intensity_stereo);
+        int32_t st = SK_OK;
+        if (slot < 0 || !e->mp3_bands_set[slot]) st = SK_MP3_UNSUPPORTED;
+        for (uint32_t c = 0; c < g.channels && st == SK_OK; ++c) {
+            const sk_mp3_requant_channel &ch = g.ch[c];
+            if (ch.block_type > 3 || ch.mixed_block_flag > 1 || ch.scalefac_scale > 1 || ch.preflag > 1 || (ch.mixed_block_flag && ch.block_type != 2) ||
+                d.block_type[c] != ch.block_type || d.mixed_block_flag[c] != ch.mixed_block_flag)
+                st = SK_MP3_INVALID;
+            else if (ch.mixed_block_flag && e->mp3_bands[slot][37] == 0xffff) st = SK_MP3_UNSUPPORTED;
+        }
+        if (st == SK_OK && joint) {
+            if ((g.ch[0].block_type == 2) != (g.ch[1].block_type == 2) || g.ch[0].mixed_block_flag != g.ch[1].mixed_block_flag) st = SK_MP3_INVALID;
+            else if (g.intensity_stereo && (g.lsf || g.ch[0].mixed_block_flag)) st = SK_MP3_UNSUPPORTED;  // as sk_mp3_requantize
+        }
+        status[i] = st;
+        r.slot = st == SK_OK ? (uint8_t)slot : 0xff;
+        r.flags = joint ? (uint8_t)((g.ms_stereo ? 1 : 0) | (g.intensity_stereo ? 2 : 0)) : 0;
+        r.ch[0] = g.ch[0];
+        if (g.channels == 2) r.ch[1] = g.ch[1];
+        if (st == SK_OK)
+            for (uint32_t c = 0; c < d.channels; ++c)
+                if (e->state_count[d.stream * 2 + c]++ == 0) touched.push_back(d.stream * 2 + c);
+    }
+    std::vector<sk::SynthTask> tasks(touched.size());
+    uint32_t n_entries = 0;
+    for (size_t t = 0; t < touched.size(); ++t) {
+        tasks[t] = sk::SynthTask{touched[t], n_entries, 0, 0};
+        n_entries += e->state_count[touched[t]];
+        e->state_task[touched[t]] = (uint32_t)t;
+    }
+    std::vector<sk::SynthEntry> entries(n_entries);
+    for (uint32_t i = 0; i < n; ++i) {
+        const sk_mp3_granule_desc &d = mp3.descs[i];
+        if (status[i] != SK_OK) continue;
+        for (uint32_t c = 0; c < d.channels; ++c) {
+            sk::SynthTask &t = tasks[e->state_task[d.stream * 2 + c]];
+            entries[t.begin + t.count++] = sk::SynthEntry{records[i].off + c, (uint32_t)d.block_type[c] | ((uint32_t)d.mixed_block_flag[c] << 2) |
+                                                                                   ((uint32_t)(d.channels - 1) << 3) | (c << 4)};
+        }
+    }
+    for (uint32_t state : touched) e->state_count[state] = 0;
+    const size_t lines = (size_t)off * 576;
+    SK_HIP(e->tick_mp3_in.reserve(lines * sizeof(int16_t) + 16), "alloc tick mp3 quantised lines");
+    SK_HIP(e->tick_mp3_xr.reserve(lines * sizeof(float) + 16), "alloc tick mp3 lines");
+    SK_HIP(hipMemcpyAsync(e->tick_mp3_in.p, mp3.is, lines * sizeof(int16_t), hipMemcpyHostToDevice, e->stream), "H2D tick mp3 quantised lines");
+    sk::Mp3RequantArgs q{};
+    SK_HIP(aux.put(records, e->stream, &q.records), "upload tick mp3 granule records");
+    q.is = (const int16_t *)e->tick_mp3_in.p;
+    q.xr = (float *)e->tick_mp3_xr.p;
+    q.n = n;
+    q.pow43 = (const float *)e->d_mp3_rq;
+    q.root4 = q.pow43 + sk::kMp3Pow43;
+    q.is_k = q.root4 + 4;
+    q.bands = (const uint16_t *)(e->d_mp3_rq + kRqBandsAt);
+    q.pretab = e->d_mp3_rq + kRqPretabAt;
+    q.line_map = (const uint32_t *)(e->d_mp3_rq + kRqMapAt);
+    SK_HIP(sk::launch_mp3_requant(q, e->stream), "launch tick mp3 requantisation");
+    if (tasks.empty()) return SK_OK;
+    sk::Mp3Args a{};
+    a.xr = (const float *)e->tick_mp3_xr.p;
+    a.pcm = pcm_rows;
+    a.planar_stride = 1024;
+    a.state = e->d_mp3_state;
+    SK_HIP(aux.put(tasks, e->stream, &a.tasks), "upload tick mp3 tasks");
+    SK_HIP(aux.put(entries, e->stream, &a.entries), "upload tick mp3 entries");
+    a.n_tasks = (uint32_t)tasks.size();
+    a.imdct = e->d_mp3_tables;
+    a.matrix = a.imdct + kMp3Imdct;
+    a.window = a.matrix + kMp3Matrix;
+    a.cs_ca = a.window + kMp3Window;
+    SK_HIP(sk::launch_mp3_hybrid(a, e->stream), "launch tick mp3 hybrid synthesis");
+    return SK_OK;
+}
+
+
 int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
               const sk_au_item *units, const uint8_t *au_bytes, size_t au_len, uint32_t n_frames, uint8_t *out, size_t out_cap,
               sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes, const EntropyProbe *probe,
-              const uint8_t *q_sides, const int16_t *q_quant) {
+              const uint8_t *q_sides, const int16_t *q_quant, const TickMp3 &mp3) {
     const bool au_mode = units != nullptr;
     const bool q_mode = q_sides != nullptr;  // quantised hand-over: descs from the host, spectra rebuilt on the device
     std::vector<sk_aac_frame_desc> au_descs;
@@ -2805,19 +2912,21 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     if (!au_mode && !q_mode && n_frames && (!descs || !coeffs)) return SK_ERR_INVALID_ARG;
     if (q_mode && n_frames && (!descs || !q_quant)) return SK_ERR_INVALID_ARG;
     if (au_mode && n_frames && !au_bytes) return SK_ERR_INVALID_ARG;
+    if (mp3.n && (!mp3.granules || !mp3.descs || !mp3.is)) return SK_ERR_INVALID_ARG;
     *n_outs = 0;
     if (out_bytes) *out_bytes = 0;
-    if (n_streams == 0) return n_frames == 0 ? SK_OK : SK_ERR_INVALID_ARG;
+    if (n_streams == 0) return n_frames == 0 && mp3.n == 0 ? SK_OK : SK_ERR_INVALID_ARG;
     DeviceGuard guard(e);
     if (au_mode) {  // the descs are implied: every unit of a stream carries that stream's channel count
         uint64_t total = 0;
-        for (uint32_t i = 0; i < n_streams; ++i) total += ts[i].n_frames;
+        for (uint32_t i = 0; i < n_streams; ++i) total += ts[i].codec == SK_TICK_MP3 ? 0 : ts[i].n_frames;
         if (total != n_frames) return SK_ERR_INVALID_ARG;
         if (au_len > 0xffffffffull) return SK_ERR_INVALID_ARG;  // unit offsets and the bit reader count in 32 bits
         au_descs.resize(n_frames);
         uint32_t k = 0;
         for (uint32_t i = 0; i < n_streams; ++i) {
             if (!stream_ok(e, ts[i].stream)) return SK_ERR_BAD_STREAM;
+            if (ts[i].codec == SK_TICK_MP3) continue;
             for (uint32_t f = 0; f < ts[i].n_frames; ++f, ++k) {
                 au_descs[k] = sk_aac_frame_desc{};
                 au_descs[k].stream = ts[i].stream;
@@ -2844,7 +2953,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     std::vector<TickCall> tc(n_streams);
     {
         std::vector<uint8_t> seen(e->streams.size(), 0);
-        uint64_t total = 0;
+        uint64_t total = 0, total_mp3 = 0;
         for (uint32_t i = 0; i < n_streams; ++i) {
             const sk_tick_stream &t = ts[i];
             if (!stream_ok(e, t.stream)) return SK_ERR_BAD_STREAM;
@@ -2852,6 +2961,20 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             if (t.out_bits != 16 && t.out_bits != 24 && t.out_bits != 32) return SK_ERR_INVALID_ARG;
             if (t.out_channels == 0) return SK_ERR_INVALID_ARG;
             if (t.resample && !e->streams[t.stream].rs_open) return SK_ERR_BAD_STREAM;
+            if (t.codec == SK_TICK_MP3) {  // its units are the next n_frames granules
+                if (total_mp3 + t.n_frames > mp3.n) return SK_ERR_INVALID_ARG;
+                tc[i].ch = e->streams[t.stream].channels;
+                for (uint32_t f = 0; f < t.n_frames; ++f) {
+                    const uint32_t g = (uint32_t)total_mp3 + f;
+                    if (mp3.descs[g].stream != t.stream || mp3.descs[g].channels != tc[i].ch || mp3.granules[g].channels != tc[i].ch) return SK_ERR_INVALID_ARG;
+                }
+                tc[i].first = (uint32_t)total_mp3;
+                tc[i].mp3 = true;
+                tc[i].ulen = 576;
+                total_mp3 += t.n_frames;
+                continue;
+            }
+            if (t.codec != SK_TICK_AAC) return SK_ERR_INVALID_ARG;
             if (total + t.n_frames > n_frames) return SK_ERR_INVALID_ARG;
             for (uint32_t f = 0; f < t.n_frames; ++f)
                 if (descs[total + f].stream != t.stream) return SK_ERR_INVALID_ARG;
@@ -2859,7 +2982,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             tc[i].first = (uint32_t)total;
             total += t.n_frames;
         }
-        if (total != n_frames) return SK_ERR_INVALID_ARG;
+        if (total != n_frames || total_mp3 != mp3.n) return SK_ERR_INVALID_ARG;
     }
 
     // ---- synthesis of the whole batch ----
@@ -2870,8 +2993,16 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     if (rc != SK_OK) return rc;
     std::vector<uint64_t> off1024(n_frames + 1, 0);
     for (uint32_t i = 0; i < n_frames; ++i) off1024[i + 1] = off1024[i] + descs[i].channels;
+    // the MP3 granules' channel rows follow the AAC units' in the PCM staging buffer (rows of 1024 floats, 576 of them used)
+    std::vector<uint64_t> mp3_row(mp3.n + 1, 0);
+    mp3_row[0] = hp.off1024;
+    for (uint32_t g = 0; g < mp3.n; ++g) mp3_row[g + 1] = mp3_row[g] + mp3.granules[g].channels;
+    const uint64_t total_rows = mp3_row[mp3.n];
+    if (total_rows * 1024 > 0xffffffffull) return SK_ERR_INVALID_ARG;
+    auto unit_row = [&](uint32_t i, uint32_t f) { return tc[i].mp3 ? mp3_row[tc[i].first + f] : off1024[tc[i].first + f]; };
     for (uint32_t i = 0; i < n_streams; ++i) {
         tc[i].good = ts[i].n_frames;
+        if (tc[i].mp3) continue;  // decided when the granules are queued (tick_mp3 below)
         for (uint32_t f = 0; f < ts[i].n_frames; ++f)
             if (status[tc[i].first + f] != 0) {
                 tc[i].good = f;
@@ -2881,9 +3012,9 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     }
     lap(0);
     const size_t elems = (size_t)hp.off1024 * 1024;
-    const size_t arena_bytes = ((size_t)16 << 20) + (size_t)n_frames * 512 + (size_t)n_streams * 1024;
+    const size_t arena_bytes = ((size_t)16 << 20) + (size_t)n_frames * 512 + (size_t)n_streams * 1024 + (size_t)mp3.n * 512;
     SK_HIP(e->in_buf.reserve(elems * 4 + 16), "alloc tick coeffs");
-    SK_HIP(e->tick_pcm.reserve(elems * 4 + 16), "alloc tick pcm");
+    SK_HIP(e->tick_pcm.reserve((size_t)total_rows * 1024 * 4 + 16), "alloc tick pcm");
     SK_HIP(e->tick_arena.reserve(arena_bytes), "alloc tick arena");
     if (e->h_arena_cap < e->tick_arena.cap) {
         if (e->h_arena) (void)hipHostFree(e->h_arena);
@@ -2894,6 +3025,20 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     }
     AuxArena aux{(uint8_t *)e->tick_arena.p, e->tick_arena.cap, 0, e->h_arena};
     float *d_pcm = (float *)e->tick_pcm.p;
+    if (mp3.n) {  // queued in front of the AAC work: nothing below waits for it separately
+        std::vector<int32_t> mp3_status;
+        rc = tick_mp3_queue(e, mp3, d_pcm + (size_t)hp.off1024 * 1024, aux, mp3_status);
+        if (rc != SK_OK) return rc;
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            if (!tc[i].mp3) continue;
+            for (uint32_t f = 0; f < ts[i].n_frames; ++f)
+                if (mp3_status[tc[i].first + f] != 0) {
+                    tc[i].good = f;
+                    tc[i].bad_status = mp3_status[tc[i].first + f];
+                    break;
+                }
+        }
+    }
     if (!hp.tasks.empty()) {
         sk::SynthArgs a{};
         a.coeffs = (const float *)e->in_buf.p;
@@ -2923,7 +3068,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             std::vector<sk::EntropyUnit> eu(n_frames);
             std::vector<sk::EntropyTask> et;
             for (uint32_t i = 0; i < n_streams; ++i) {
-                if (ts[i].n_frames == 0) continue;
+                if (ts[i].n_frames == 0 || tc[i].mp3) continue;
                 const StreamInfo &si = e->streams[ts[i].stream];
                 et.push_back(sk::EntropyTask{ts[i].stream, tc[i].first, ts[i].n_frames, sf_index_of(si.sample_rate), si.channels});
                 for (uint32_t f = 0; f < ts[i].n_frames; ++f) {
@@ -3036,6 +3181,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             e->where.store("tick: resampler rounds, pack");
             t_au[1] = std::chrono::duration<double, std::milli>(TClock::now() - q0).count();
             for (uint32_t i = 0; i < n_streams; ++i) {
+                if (tc[i].mp3) continue;
                 tc[i].good = ts[i].n_frames;
                 tc[i].bad_status = 0;
                 for (uint32_t f = 0; f < ts[i].n_frames; ++f)
@@ -3065,7 +3211,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
         tc[i].rs_call = (int)calls.size();
         calls.push_back(c);
         call_stream.push_back(i);
-        const uint64_t max_chunks = ((uint64_t)s.rs_fill + (uint64_t)tc[i].good * 1024) / kRsChunk + 1;
+        const uint64_t max_chunks = ((uint64_t)s.rs_fill + (uint64_t)tc[i].good * tc[i].ulen) / kRsChunk + 1;
         const uint64_t per_chunk = (uint64_t)std::ceil((double)kRsChunk * (double)s.rs_out_hz / (double)s.rs_in_hz) + 2;
         if (max_chunks * per_chunk > 0x7fffffffull) return SK_ERR_INVALID_ARG;
         res_cap = std::max<uint32_t>(res_cap, (uint32_t)(max_chunks * per_chunk));
@@ -3086,14 +3232,14 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 RsCall &c = calls[ci];
                 const TickCall &t = tc[call_stream[ci]];
                 StreamInfo &s = e->streams[c.id];
-                const uint32_t total_in = t.good * 1024;
+                const uint32_t total_in = t.good * t.ulen;
                 uint32_t take = std::min(total_in - c.consumed, kRsChunk - s.rs_fill);
-                while (take) {  // pieces never straddle a frame of the packed synthesis output
-                    const uint32_t frame = c.consumed / 1024, within = c.consumed % 1024;
-                    const uint32_t n = std::min(take, 1024 - within);
-                    for (uint32_t ch = 0; ch < c.channels; ++ch)
-                        jobs.push_back(sk::RowCopy{(off1024[t.first + frame] + ch) * 1024 + within,
-                                                   ((uint64_t)c.id * 2 + ch) * kRsRow + kRsHist + s.rs_fill, n, 1});
+                while (take) {  // pieces never straddle a unit of the packed synthesis output
+                    const uint32_t frame = c.consumed / t.ulen, within = c.consumed % t.ulen;
+                    const uint32_t n = std::min(take, t.ulen - within);
+                    for (uint32_t ch = 0; ch < c.channels; ++ch)  // MP3 rows hold q / 32768 already: a plain copy
+                        jobs.push_back(sk::RowCopy{(unit_row(call_stream[ci], frame) + ch) * 1024 + within,
+                                                   ((uint64_t)c.id * 2 + ch) * kRsRow + kRsHist + s.rs_fill, n, t.mp3 ? 0u : 1u});
                     s.rs_fill += n;
                     c.consumed += n;
                     take -= n;
@@ -3191,14 +3337,15 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 const StreamInfo &s = e->streams[t.stream];
                 (void)s;
                 const bool direct = t.out_bits == 16 && t.out_channels == ch;
+                const uint32_t ulen = tc[i].ulen;
+                const uint8_t mode = tc[i].mp3 ? (uint8_t)sk::kPackFromQ : (uint8_t)(direct ? sk::kPackDirect : sk::kPackViaS16);
                 for (uint32_t f = 0; f < tc[i].good; ++f) {
-                    sk_tick_output *o = emit(i, 1024, ch_out, t.out_bits, 0);
+                    sk_tick_output *o = emit(i, ulen, ch_out, t.out_bits, 0);
                     if (!o) return SK_ERR_INVALID_ARG;
                     if (pass) {
-                        const float *src = d_pcm + off1024[tc[i].first + f] * 1024;
-                        packs.push_back(sk::PackJob{src, src + 1024, d_out + o->byte_offset, 1024, (uint8_t)ch, (uint8_t)ch_out,
-                                                    t.out_bits, (uint8_t)(direct ? sk::kPackDirect : sk::kPackViaS16)});
-                        max_pack_frames = std::max<uint32_t>(max_pack_frames, 1024);
+                        const float *src = d_pcm + unit_row(i, f) * 1024;
+                        packs.push_back(sk::PackJob{src, src + 1024, d_out + o->byte_offset, ulen, (uint8_t)ch, (uint8_t)ch_out, t.out_bits, mode});
+                        max_pack_frames = std::max<uint32_t>(max_pack_frames, ulen);
                     }
                 }
             } else {
@@ -3265,7 +3412,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
 int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_aac_frame_desc *descs, const float *coeffs,
               const sk_au_item *units, const uint8_t *au_bytes, size_t au_len, uint32_t n_frames, uint8_t *out, size_t out_cap,
               sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes, const EntropyProbe *probe = nullptr,
-              const uint8_t *q_sides = nullptr, const int16_t *q_quant = nullptr) {
+              const uint8_t *q_sides = nullptr, const int16_t *q_quant = nullptr, const TickMp3 &mp3 = TickMp3{}) {
     if (!e) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
     TickWhere where(e);
@@ -3281,7 +3428,7 @@ int tick_impl(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             saved.push_back(Saved{ts[i].stream, s.rs_fill, s.rs_chunks, s.rs_last_index});
         }
     const int rc = tick_body(e, ts, n_streams, descs, coeffs, units, au_bytes, au_len, n_frames, out, out_cap, outs, outs_cap, n_outs,
-                             out_bytes, probe, q_sides, q_quant);
+                             out_bytes, probe, q_sides, q_quant, mp3);
     if (rc != SK_OK) {
         for (const Saved &v : saved) {
             StreamInfo &s = e->streams[v.id];
@@ -3320,6 +3467,23 @@ int sk_tick_run_q(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, co
                      sides ? (const uint8_t *)sides : none, quant);
 } catch (...) {
     return sk::abi_caught("sk_tick_run_q");
+}
+
+int sk_tick_run_mixed(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_tick_input *in, uint8_t *out, size_t out_cap,
+                      sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *out_bytes) try {
+    sk::abi_enter();
+    if (!in) return SK_ERR_INVALID_ARG;
+    const int forms = (in->coeffs ? 1 : 0) + (in->units ? 1 : 0) + (in->q_sides ? 1 : 0);
+    if (forms > 1 || (in->n_aac_units && forms == 0)) return SK_ERR_INVALID_ARG;  // the AAC units in ONE form
+    if (in->q_sides && in->n_aac_units && (!in->q_quant || !in->descs)) return SK_ERR_INVALID_ARG;
+    TickMp3 mp3;
+    mp3.granules = in->mp3_granules, mp3.descs = in->mp3_descs, mp3.is = in->mp3_is, mp3.n = in->n_mp3_granules;
+    for (uint32_t g = 0; g < mp3.n && mp3.granules; ++g)
+        if (mp3.granules[g].channels < 1 || mp3.granules[g].channels > 2) return SK_ERR_INVALID_ARG;
+    return tick_impl(e, ts, n_streams, in->descs, in->coeffs, in->units, in->au_bytes, in->au_bytes_len, in->n_aac_units, out, out_cap, outs, outs_cap,
+                     n_outs, out_bytes, nullptr, (const uint8_t *)in->q_sides, in->q_quant, mp3);
+} catch (...) {
+    return sk::abi_caught("sk_tick_run_mixed");
 }
 
 int sk_aac_entropy_decode(sk_engine *e, const uint32_t *streams, const uint32_t *units_per_stream, uint32_t n_streams,

@@ -18,7 +18,7 @@ const uint16_t kBitrateV1L3[16] = {0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160,
 const uint16_t kBitrateV2L3[16] = {0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, 0};
 const uint32_t kSampleRate[3][3] = {{44100, 48000, 32000}, {22050, 24000, 16000}, {11025, 12000, 8000}};  // MPEG-1, -2, -2.5
 
-struct BitReader {
+struct Mp3HeaderBits {
     const uint8_t *p;
     size_t len;
     size_t pos = 0;  // in bits
@@ -77,7 +77,7 @@ int sk_mp3_parse_side_info(const uint8_t *frame, size_t len, const sk_mp3_frame_
     const size_t at = 4u + (h->has_crc ? 2u : 0u);
     if (len < at + h->side_info_bytes) return SK_MP3_NEED_MORE;
     std::memset(out, 0, sizeof *out);
-    BitReader b{frame + at, h->side_info_bytes};
+    Mp3HeaderBits b{frame + at, h->side_info_bytes};
     const bool v1 = h->version == 1;
     const int ch = h->channels;
     out->granules = h->granules;

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(kWaves * 64, 3) void k_mp3_hybrid(Mp3Args a) {
                 // granule `off / channels`-th block of 576 x channels interleaved samples: element (32 ss + sb) * channels + ch
                 const size_t at = (off - ch) * 576 + (size_t)(32 * ss + sb) * channels + ch;
                 if (OUT16) a.pcm16[at] = mp3_to_i16(sum);
+                else if (a.planar_stride) a.pcm[off * a.planar_stride + (size_t)(32 * ss + sb)] = (float)mp3_to_i16(sum) * (1.0f / 32768.0f);
                 else a.pcm[at] = sum;
             }
             wave_sync();

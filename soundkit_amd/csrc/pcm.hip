@@ -415,6 +415,15 @@ __global__ __launch_bounds__(256) void k_pack_jobs(const PackJob *jobs, uint32_t
         float x[2];
         x[0] = job.src0[f];
         x[1] = job.ch_in > 1 ? job.src1[f] : 0.0f;
+        if (job.mode == kPackFromQ && job.bits == 16 && job.ch_out == job.ch_in) {  // the fast path on rows that hold q / 32768
+            if (job.ch_in > 1) {
+                const uint32_t lo = (uint32_t)(int)(x[0] * 32768.0f) & 0xffff, hi = (uint32_t)(int)(x[1] * 32768.0f) & 0xffff;
+                reinterpret_cast<uint32_t *>(job.dst)[f] = lo | (hi << 16);
+            } else {
+                reinterpret_cast<uint16_t *>(job.dst)[f] = (uint16_t)(int)(x[0] * 32768.0f);
+            }
+            continue;
+        }
         if (job.mode == kPackDirect) {
             if (job.ch_in > 1) {
                 const uint32_t lo = (uint32_t)float_sample_to_i16(x[0]) & 0xffff, hi = (uint32_t)float_sample_to_i16(x[1]) & 0xffff;

@@ -69,7 +69,11 @@ struct PStream {
     uint32_t rate = 0, engine_stream = kNoStream;
     uint8_t channels = 0;
     bool resample = false;
+    // which decoder the stream's first bytes select (detect_and_init_decoder, soundkit-decoder/src/lib.rs:3041-3053): 0 not known yet
+    uint8_t codec = 0;
+    std::vector<uint8_t> mp3_reservoir;  // main data of the frames seen so far (main_data_begin reaches back into it)
 };
+constexpr uint8_t kCodecAac = 1, kCodecMp3 = 2;
 
 struct BatchEntry {  // bookkeeping beside one sk_tick_stream
     uint32_t handle = 0;
@@ -94,6 +98,11 @@ struct Batch {
     std::vector<sk_au_item> units;  // sized once, indexed like descs
     std::vector<sk_tick_stream> ts;
     std::vector<BatchEntry> entries;
+    // MP3 streams' granules (their units), in the order of their streams in ts; sized by ensure_mp3 at the first MP3 stream
+    std::vector<sk_mp3_requant_granule> mp3_gr;
+    std::vector<sk_mp3_granule_desc> mp3_desc;
+    int16_t *mp3_is = nullptr;  // pinned: [granule][channel][576], 2 x 576 per granule reserved
+    size_t n_mp3 = 0, mp3_rows = 0;
     uint32_t writers = 0;  // claims whose memcpy is still running
     // the tick's results, handed from the submission thread to the delivery thread
     uint8_t *out_pinned = nullptr;
@@ -109,6 +118,8 @@ struct Batch {
         n_floats = 0;
         n_descs = 0;
         au_used = 0;
+        n_mp3 = 0;
+        mp3_rows = 0;
         ts.clear();
         entries.clear();
         row_of.clear();
@@ -158,6 +169,10 @@ struct sk_lane {
     std::condition_variable deliver_cv;
     bool stop = false;
     std::atomic<int> fatal{0};  // != 0: a thread of the lane died of an exception (lane_fatal); every stream got that error
+    // MP3: the standard's tables, made (and installed on the engine) when the first MP3 stream shows up
+    std::mutex mp3_mu;
+    sk_mp3_codebook *mp3_cb = nullptr;
+    std::atomic<bool> mp3_ready{false};
 
     std::vector<std::thread> workers;
     std::thread submitter;
@@ -211,6 +226,8 @@ void release_device_side(sk_lane *p, PStream &s) {
         s.pending.clear();
         s.pending.shrink_to_fit();
         s.pending_pos = 0;
+        s.mp3_reservoir.clear();
+        s.mp3_reservoir.shrink_to_fit();
     }
     if (engine_stream != kNoStream) (void)sk_stream_close(p->engine, engine_stream);  // also drops its resampler
     if (fe) sk_aac_decoder_destroy(fe);
@@ -226,7 +243,173 @@ struct Parsed {  // what one worker pass produced for one stream
     std::string fail_msg;
     std::vector<uint8_t> raw;  // quantised hand-over: the pass's access units, kept for the error text (BatchEntry::raw)
     std::vector<uint32_t> raw_len;
+    // an MP3 stream's pass: n_frames counts GRANULES (the tick's units for such a stream)
+    bool mp3 = false;
+    std::vector<sk_mp3_requant_granule> mp3_gr;
+    std::vector<sk_mp3_granule_desc> mp3_desc;
+    std::vector<int16_t> mp3_is;
 };
+
+// 1 = a chunk was appended to s.pending, 0 = nothing queued right now, -1 = the end-of-stream marker was taken (s.saw_eof set)
+int pull_input(PStream &s) {
+    std::vector<uint8_t> chunk;
+    bool got = false;
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        if (!s.in.empty()) {
+            chunk = std::move(s.in.front());
+            s.in.pop_front();
+            got = true;
+        }
+    }
+    if (!got) return 0;
+    if (chunk.empty()) {
+        s.saw_eof = true;
+        return -1;
+    }
+    s.queued_bytes.fetch_sub(chunk.size());
+    if (s.pending_pos > 0 && s.pending_pos >= s.pending.size() / 2) {  // compact
+        s.pending.erase(s.pending.begin(), s.pending.begin() + (ptrdiff_t)s.pending_pos);
+        s.pending_pos = 0;
+    }
+    s.pending.insert(s.pending.end(), chunk.begin(), chunk.end());
+    return 1;
+}
+
+// The tables an MP3 stream needs: the code book for the host's Huffman stage, band tables and synthesis window on the engine;
+// the batches get their granule arrays.  Once per lane, at the first MP3 stream.
+int ensure_mp3(sk_lane *p);
+
+// What the stream's first bytes are (detect_audio at lib.rs:3042 looks at magic numbers; on this path two formats exist):
+// an ID3v2 tag or an MPEG audio sync with a layer field -> MP3; an ADTS sync (layer bits 00) -> AAC.  0 = not enough bytes yet.
+uint8_t sniff_codec(const uint8_t *d, size_t n) {
+    if (n >= 3 && d[0] == 'I' && d[1] == 'D' && d[2] == '3') return kCodecMp3;
+    for (size_t i = 0; i + 1 < n; ++i)
+        if (d[i] == 0xff && (d[i + 1] & 0xe0) == 0xe0) return ((d[i + 1] >> 1) & 3) == 0 ? kCodecAac : kCodecMp3;
+    return n >= 8192 ? kCodecAac : 0;  // no sync in 8 KiB: let the ADTS path resynchronise (it ends the stream at EOF)
+}
+
+// An MP3 stream's pass (nanomp3 inside Mp3Decoder::decode_i16, soundkit-mp3/src/lib.rs:279-305, up to its Huffman stage): frame
+// sync, header, side information, bit reservoir, scale factors and Huffman codes on this thread; what is left -- requantisation,
+// stereo, reorder, hybrid synthesis -- are the granules handed to the tick.  A frame that cannot be decoded (the reservoir
+// does not reach back far enough, damaged Huffman data, a feature not built) is consumed without output, as sk_mp3_decoder_*
+// does.  At most `limit` granules per pass.
+void parse_some_mp3(sk_lane *p, PStream &s, uint32_t limit, Parsed &r) {
+    r.mp3 = true;
+    auto fail = [&](int32_t st, const std::string &msg) {
+        r.failed = true;
+        r.fail_status = st;
+        r.fail_msg = msg;
+    };
+    int rc = ensure_mp3(p);
+    if (rc != SK_OK) {
+        fail(rc, std::string("Decoding failed: MP3 tables: ") + sk_strerror(rc));
+        return;
+    }
+    std::vector<sk_mp3_frame_info> found(64);
+    std::vector<uint8_t> main;
+    constexpr size_t kReservoirKept = 2048;
+    while (r.n_frames < limit && !r.failed) {
+        const size_t avail = s.pending.size() - s.pending_pos;
+        uint32_t n_found = 0;
+        size_t scanned = 0;
+        if (avail >= 4) {
+            rc = sk_mp3_scan(s.pending.data() + s.pending_pos, avail, found.data(), (uint32_t)found.size(), &n_found, &scanned);
+            if (rc != SK_OK) {
+                fail(rc, std::string("Decoding failed: ") + sk_strerror(rc));
+                break;
+            }
+            if (n_found > found.size()) n_found = (uint32_t)found.size();
+        }
+        if (n_found == 0) {
+            s.pending_pos += scanned;  // garbage in front of an incomplete frame goes
+            if (s.saw_eof) {
+                r.eof = true;
+                break;
+            }
+            const int got = pull_input(s);
+            if (got == 0) break;  // needs more input
+            continue;
+        }
+        size_t consumed = 0;
+        for (uint32_t k = 0; k < n_found && !r.failed; ++k) {
+            const sk_mp3_frame_info &h = found[k];
+            if (r.n_frames + h.granules > limit) {
+                r.budget_stop = true;
+                break;
+            }
+            const uint8_t *frame = s.pending.data() + s.pending_pos + h.offset;
+            const size_t head = 4u + (h.has_crc ? 2u : 0u) + h.side_info_bytes;
+            sk_mp3_side_info side;
+            bool ok = sk_mp3_parse_side_info(frame, h.frame_bytes, &h, &side) == SK_OK;
+            size_t main_len = 0;
+            main.resize(s.mp3_reservoir.size() + h.frame_bytes);
+            if (ok) ok = sk_mp3_main_data(frame, h.frame_bytes, &h, &side, s.mp3_reservoir.data(), s.mp3_reservoir.size(), main.data(), main.size(), &main_len) == SK_OK;
+            sk_mp3_granule_data data[2][2];
+            if (ok) ok = sk_mp3_decode_main_data(p->mp3_cb, &h, &side, main.data(), main_len, data) == SK_OK;
+            const bool joint = h.mode == 1;
+            if (ok && h.version != 1 && joint && (h.mode_ext & 1)) ok = false;  // 13818-3 intensity stereo: not built
+            if (ok) {
+                if (s.engine_stream == kNoStream) {  // the first frame that decodes fixes rate and channels (lib.rs:203-204)
+                    s.rate = h.sample_rate;
+                    s.channels = h.channels;
+                    rc = sk_stream_open(p->engine, s.rate, s.channels, &s.engine_stream);
+                    if (rc != SK_OK) {
+                        fail(rc, std::string("Decoding failed: engine stream: ") + sk_strerror(rc));
+                        break;
+                    }
+                    const uint32_t target = s.opt.output_sample_rate ? s.opt.output_sample_rate : s.rate;
+                    s.resample = target != s.rate;
+                    if (s.resample) {
+                        rc = sk_resampler_open(p->engine, s.engine_stream, s.rate, target);
+                        if (rc != SK_OK) {
+                            fail(rc, "Decoding failed: Failed to create resampler: unsupported rate pair");
+                            break;
+                        }
+                    }
+                } else if (h.channels != s.channels || h.sample_rate != s.rate) {
+                    fail(SK_MP3_UNSUPPORTED, "Decoding failed: MP3 sample rate or channel count changed mid-stream");
+                    break;
+                }
+                for (int gr = 0; gr < h.granules; ++gr) {
+                    sk_mp3_requant_granule g;
+                    std::memset(&g, 0, sizeof g);
+                    g.sample_rate = h.sample_rate;
+                    g.channels = h.channels;
+                    g.ms_stereo = joint && (h.mode_ext & 2);
+                    g.intensity_stereo = joint && (h.mode_ext & 1);
+                    g.lsf = h.version != 1;
+                    sk_mp3_granule_desc d;
+                    std::memset(&d, 0, sizeof d);
+                    d.stream = s.engine_stream;
+                    d.channels = h.channels;
+                    for (int ch = 0; ch < h.channels; ++ch) {
+                        const sk_mp3_granule_side &gs = side.gr[gr][ch];
+                        const sk_mp3_granule_data &src = data[gr][ch];
+                        sk_mp3_requant_channel &c = g.ch[ch];
+                        c.global_gain = gs.global_gain, c.scalefac_scale = gs.scalefac_scale, c.preflag = src.preflag;
+                        c.block_type = gs.block_type, c.mixed_block_flag = gs.mixed_block_flag;
+                        std::memcpy(c.subblock_gain, gs.subblock_gain, 3);
+                        std::memcpy(c.scalefac_l, src.scalefac_l, 22);
+                        std::memcpy(c.scalefac_s, src.scalefac_s, 39);
+                        d.block_type[ch] = gs.block_type, d.mixed_block_flag[ch] = gs.mixed_block_flag;
+                        r.mp3_is.insert(r.mp3_is.end(), src.is, src.is + 576);
+                    }
+                    r.mp3_gr.push_back(g);
+                    r.mp3_desc.push_back(d);
+                    r.n_frames += 1;
+                }
+            }
+            // whatever became of the frame, its own main data is what later frames reach back into
+            if (h.frame_bytes > head) s.mp3_reservoir.insert(s.mp3_reservoir.end(), frame + head, frame + h.frame_bytes);
+            if (s.mp3_reservoir.size() > kReservoirKept) s.mp3_reservoir.erase(s.mp3_reservoir.begin(), s.mp3_reservoir.end() - (ptrdiff_t)kReservoirKept);
+            consumed = h.offset + h.frame_bytes;
+            if (k + 1 == n_found && n_found < found.size()) consumed = scanned;
+        }
+        s.pending_pos += consumed;
+        if (r.budget_stop) break;
+    }
+}
 
 // Pulls ADTS frames out of the stream's byte queue and runs the front-end on them, at most `limit` frames.
 void parse_some(sk_lane *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_frame_desc *descs, std::vector<uint8_t> &au_stage,
@@ -238,6 +421,19 @@ void parse_some(sk_lane *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_fr
         r.fail_status = st;
         r.fail_msg = msg;
     };
+    while (s.codec == 0) {  // the worker's detect_and_init_decoder: the stream's first bytes choose the decoder
+        s.codec = sniff_codec(s.pending.data() + s.pending_pos, s.pending.size() - s.pending_pos);
+        if (s.codec) break;
+        if (s.saw_eof) {
+            s.codec = kCodecAac;  // too short to tell: the ADTS path ends it
+            break;
+        }
+        if (pull_input(s) == 0) return;  // needs more input
+    }
+    if (s.codec == kCodecMp3) {
+        parse_some_mp3(p, s, limit, r);
+        return;
+    }
     while (r.n_frames < limit && !r.failed) {
         // make sure a whole frame is in `pending`
         size_t avail = s.pending.size() - s.pending_pos;
@@ -259,27 +455,7 @@ void parse_some(sk_lane *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_fr
                 r.eof = true;
                 break;
             }
-            std::vector<uint8_t> chunk;
-            bool got = false;
-            {
-                std::lock_guard<std::mutex> lk(s.mu);
-                if (!s.in.empty()) {
-                    chunk = std::move(s.in.front());
-                    s.in.pop_front();
-                    got = true;
-                }
-            }
-            if (!got) break;  // needs more input
-            if (chunk.empty()) {
-                s.saw_eof = true;
-                continue;
-            }
-            s.queued_bytes.fetch_sub(chunk.size());
-            if (s.pending_pos > 0 && s.pending_pos >= s.pending.size() / 2) {  // compact
-                s.pending.erase(s.pending.begin(), s.pending.begin() + (ptrdiff_t)s.pending_pos);
-                s.pending_pos = 0;
-            }
-            s.pending.insert(s.pending.end(), chunk.begin(), chunk.end());
+            if (pull_input(s) == 0) break;  // needs more input
             continue;
         }
         const uint8_t *frame = s.pending.data() + s.pending_pos;
@@ -349,6 +525,40 @@ void parse_some(sk_lane *p, PStream &s, uint32_t limit, float *coeffs, sk_aac_fr
         r.n_frames += 1;
         r.n_floats += (size_t)s.channels * 1024;
     }
+}
+
+int ensure_mp3(sk_lane *p) {
+    if (p->mp3_ready.load(std::memory_order_acquire)) return SK_OK;
+    std::lock_guard<std::mutex> lk(p->mp3_mu);
+    if (p->mp3_ready.load(std::memory_order_relaxed)) return SK_OK;
+    sk_mp3_tables t;
+    int rc = sk_mp3_iso_tables(&t);
+    if (rc != SK_OK) return rc;
+    static const uint32_t rates[9] = {44100, 48000, 32000, 22050, 24000, 16000, 11025, 12000, 8000};
+    for (int row = 0; row < 9 && rc == SK_OK; ++row) rc = sk_mp3_set_band_tables(p->engine, rates[row], t.long_offsets[row], t.short_offsets[row], t.pretab);
+    if (rc == SK_OK) rc = sk_mp3_set_synthesis_window(p->engine, t.window);
+    if (rc != SK_OK) return rc;
+    if (!p->mp3_cb) {
+        rc = sk_mp3_codebook_create(&t, &p->mp3_cb);
+        if (rc != SK_OK) return rc;
+    }
+    {
+        // the batches' granule arrays: workers copy into disjoint ranges without the lock, so they are sized once, here, while
+        // no MP3 claim can exist yet (an MP3 pass reaches the batches only behind this function)
+        std::lock_guard<std::mutex> bl(p->batch_mu);
+        for (Batch &b : p->batches) {
+            if (b.mp3_is) continue;
+            const size_t cap = p->cfg.max_frames_per_tick;
+            if (hipHostMalloc((void **)&b.mp3_is, cap * 2 * 576 * sizeof(int16_t) + 64, hipHostMallocPortable) != hipSuccess) {
+                b.mp3_is = nullptr;
+                return SK_ERR_OOM;
+            }
+            b.mp3_gr.resize(cap);
+            b.mp3_desc.resize(cap);
+        }
+    }
+    p->mp3_ready.store(true, std::memory_order_release);
+    return SK_OK;
 }
 
 // test hook (sk_debug_throw_in_thread): the n-th passage of point `where` throws std::bad_alloc
@@ -431,13 +641,13 @@ void worker_body(sk_lane *p) {
         }
         // claim room in the batch being filled
         Batch *b;
-        size_t desc_at, float_at, au_at;
+        size_t desc_at, float_at, au_at, mp3_at = 0, mp3_row_at = 0;
         {
             std::unique_lock<std::mutex> lk(p->batch_mu);
             p->workers_waiting_room.fetch_add(1);
             p->room_cv.wait(lk, [&] {
                 const Batch &f = p->batches[p->filling];
-                return p->stop || (f.n_descs + r.n_frames <= p->cfg.max_frames_per_tick &&
+                return p->stop || (f.n_descs + f.n_mp3 + r.n_frames <= p->cfg.max_frames_per_tick &&
                                    (gpu_entropy ? f.au_used + r.n_au_bytes <= f.au_cap : f.n_floats + r.n_floats <= f.coeff_cap) &&
                                    (!quant || f.au_used + r.n_au_bytes <= f.au_cap));
             });
@@ -447,10 +657,18 @@ void worker_body(sk_lane *p) {
             desc_at = b->n_descs;
             float_at = b->n_floats;
             au_at = b->au_used;
-            b->n_descs += r.n_frames;
+            mp3_at = b->n_mp3;
+            mp3_row_at = b->mp3_rows;
+            if (r.mp3) {
+                b->n_mp3 += r.n_frames;
+                b->mp3_rows += r.mp3_is.size() / 576;
+            } else {
+                b->n_descs += r.n_frames;
+            }
             b->n_floats += r.n_floats;
             b->au_used += r.n_au_bytes;
             sk_tick_stream t{};
+            t.codec = r.mp3 ? SK_TICK_MP3 : SK_TICK_AAC;
             t.stream = s.engine_stream == kNoStream ? 0 : s.engine_stream;
             t.n_frames = r.n_frames;
             t.out_bits = s.opt.output_bits_per_sample ? s.opt.output_bits_per_sample : 16;
@@ -473,7 +691,11 @@ void worker_body(sk_lane *p) {
             b->entries.push_back(std::move(be));
             b->writers += 1;
         }
-        if (r.n_frames && gpu_entropy) {
+        if (r.n_frames && r.mp3) {
+            std::memcpy(b->mp3_gr.data() + mp3_at, r.mp3_gr.data(), r.n_frames * sizeof(sk_mp3_requant_granule));
+            std::memcpy(b->mp3_desc.data() + mp3_at, r.mp3_desc.data(), r.n_frames * sizeof(sk_mp3_granule_desc));
+            std::memcpy(b->mp3_is + mp3_row_at * 576, r.mp3_is.data(), r.mp3_is.size() * sizeof(int16_t));
+        } else if (r.n_frames && gpu_entropy) {
             std::memcpy(b->au_bytes + au_at, au_stage.data(), r.n_au_bytes);
             for (uint32_t k = 0; k < r.n_frames; ++k)
                 b->units[desc_at + k] = sk_au_item{(uint32_t)(au_at + au_items[k].byte_offset), au_items[k].byte_len};
@@ -562,7 +784,18 @@ void submit_body(sk_lane *p) {
                     b->rc = SK_ERR_OOM;
             }
             if (b->recs.size() < max_out) b->recs.resize(max_out);
-            if (b->rc == SK_OK && p->cfg.gpu_entropy == 2)
+            if (b->rc == SK_OK && b->n_mp3) {  // streams of both codecs in this tick: the AAC units in the lane's form, the MP3 granules beside them
+                sk_tick_input in{};
+                in.n_aac_units = n_frames;
+                if (p->cfg.gpu_entropy == 2) in.descs = b->descs.data(), in.q_sides = b->au_bytes, in.q_quant = reinterpret_cast<const int16_t *>(b->coeffs);
+                else if (p->cfg.gpu_entropy) in.units = b->units.data(), in.au_bytes = b->au_bytes, in.au_bytes_len = b->au_used + 8;
+                else in.descs = b->descs.data(), in.coeffs = b->coeffs;
+                if (n_frames == 0) in.descs = nullptr, in.coeffs = nullptr, in.units = nullptr, in.q_sides = nullptr;
+                in.n_mp3_granules = (uint32_t)b->n_mp3;
+                in.mp3_granules = b->mp3_gr.data(), in.mp3_descs = b->mp3_desc.data(), in.mp3_is = b->mp3_is;
+                b->rc = sk_tick_run_mixed(p->engine, ts.data(), (uint32_t)ts.size(), &in, b->out_pinned, b->out_pinned_cap, b->recs.data(), max_out,
+                                          &b->n_out, &used);
+            } else if (b->rc == SK_OK && p->cfg.gpu_entropy == 2)
                 b->rc = sk_tick_run_q(p->engine, ts.data(), (uint32_t)ts.size(), b->descs.data(), b->au_bytes,
                                       reinterpret_cast<const int16_t *>(b->coeffs), n_frames, b->out_pinned, b->out_pinned_cap, b->recs.data(),
                                       max_out, &b->n_out, &used);
@@ -576,7 +809,7 @@ void submit_body(sk_lane *p) {
         p->submit_where = 4;
         p->tick_ns.fetch_add(ns_since(t0));
         p->n_ticks.fetch_add(1);
-        p->n_frames.fetch_add(n_frames);
+        p->n_frames.fetch_add(n_frames + (uint32_t)b->n_mp3);
         b->rec_begin.assign(b->row_of.size() + 1, b->n_out);
         {
             uint32_t k = 0;
@@ -1040,7 +1273,9 @@ void lane_destroy(sk_lane *p) {
         if (b.coeffs) (void)hipHostFree(b.coeffs);
         if (b.au_bytes) (void)hipHostFree(b.au_bytes);
         if (b.out_pinned) (void)hipHostFree(b.out_pinned);
+        if (b.mp3_is) (void)hipHostFree(b.mp3_is);
     }
+    if (p->mp3_cb) sk_mp3_codebook_destroy(p->mp3_cb);
     delete p;
 }
 
@@ -1075,6 +1310,8 @@ int lane_spawn(sk_lane *p, const sk_decode_options *opt, uint32_t *handle) {
     s.rate = 0;
     s.channels = 0;
     s.resample = false;
+    s.codec = 0;
+    s.mp3_reservoir.clear();
     *handle = h;
     return SK_OK;
 }

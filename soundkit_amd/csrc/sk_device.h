@@ -279,6 +279,9 @@ struct Mp3Args {
     const float *xr;       // [granule-channels][576] requantised, stereo-processed, reordered frequency lines
     float *pcm;            // interleaved f32 out ...
     int16_t *pcm16;        // ... or s16 (f32_to_i16, soundkit-mp3 lib.rs:376-385); one of the two
+    uint32_t planar_stride;  // != 0 (the scheduler's tick, with pcm): channel row `off` goes to pcm + off * planar_stride, 576 samples,
+                             // each as f32_to_i16(sample) / 32768 -- the i16 AudioData Mp3Decoder hands the worker, as the f32 that
+                             // audio_data_to_f32_channels makes of it (soundkit-decoder lib.rs:3563-3617); exact in f32
     float *state;          // [states][kMp3StateFloats]
     const SynthTask *tasks;      // state = stream * 2 + channel
     const SynthEntry *entries;   // off1024 = index of the channel's 576 lines; win = block_type | mixed << 2 | (channels - 1) << 3 | channel << 4
@@ -366,6 +369,7 @@ enum PackMode : uint8_t {
     kPackPlain = 0,   // src is already the f32 the reference holds (resampler output)
     kPackViaS16 = 1,  // src is synthesis output: q = float_sample_to_i16(x); the f32 is q / 32768
     kPackDirect = 2,  // fast path (lib.rs:3339-3345): the bytes are q itself, s16le
+    kPackFromQ = 3,   // src is q / 32768 already (MP3 rows of a tick): the fast path's bytes are (int)(x * 32768), exact
 };
 struct PackJob {
     const float *src0, *src1;  // channel rows (src1 unused when ch_in == 1)

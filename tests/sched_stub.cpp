@@ -5,6 +5,8 @@
 // checked without a GPU.  (Test infrastructure: the product library never contains this file.)
 #include "../soundkit_amd/csrc/pipeline.cpp"
 #include "../soundkit_amd/csrc/aac_frontend.cpp"
+#include "../soundkit_amd/csrc/mp3_bitstream.cpp"  // MP3 streams: the real framing, reservoir and Huffman stage (the standard's tables)
+#include "../soundkit_amd/csrc/mp3_decoder.cpp"
 #include "../soundkit_amd/csrc/load_gen.cpp"  // the bench's load generator: its feeder / consumer loops run under the sanitizers too
 
 #include <atomic>
@@ -96,9 +98,9 @@ struct Emit {
         cursor += 64;
         return SK_OK;
     }
-    int unit(const sk_tick_stream &t, uint32_t row, uint32_t sum) {
+    int unit(const sk_tick_stream &t, uint32_t row, uint32_t sum, uint32_t frames = 1024) {
         int rc = SK_OK;
-        if (!t.resample) rc = put(t, row, 1024, sum);
+        if (!t.resample) rc = put(t, row, frames, sum);
         else if (++e->rs_fill[t.stream] == 4) {
             e->rs_fill[t.stream] = 0;
             rc = put(t, row, 4096, sum);
@@ -120,6 +122,52 @@ struct Emit {
     std::map<uint32_t, int> seen;                                                        \
     Emit em{e, out, out_cap, outs, outs_cap}
 
+// what pipeline.cpp / mp3_decoder.cpp call for MP3 on the engine
+int sk_mp3_set_band_tables(sk_engine *, uint32_t, const uint16_t *, const uint16_t *, const uint8_t *) { return SK_OK; }
+int sk_mp3_set_synthesis_window(sk_engine *, const float *) { return SK_OK; }
+int sk_mp3_decode_granules_f32(sk_engine *, const sk_mp3_requant_granule *, const sk_mp3_granule_desc *, const int16_t *, float *, uint32_t, int32_t *) {
+    return SK_ERR_UNSUPPORTED;  // the decoder handle is not what the scheduler drives
+}
+int sk_mp3_decode_granules_s16(sk_engine *, const sk_mp3_requant_granule *, const sk_mp3_granule_desc *, const int16_t *, int16_t *, uint32_t, int32_t *) {
+    return SK_ERR_UNSUPPORTED;
+}
+// the mixed tick's stand-in: AAC units counted (their bytes are checked by the single-codec stand-ins), MP3 granules checked the
+// way engine.cpp checks them and summed; one "AudioData" of 576 frames per granule
+int sk_tick_run_mixed(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_tick_input *in, uint8_t *out, size_t out_cap,
+                      sk_tick_output *outs, uint32_t outs_cap, uint32_t *n_outs, size_t *used) {
+    STUB_TICK_PROLOGUE();
+    uint32_t f = 0, g = 0;
+    size_t row = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (seen[ts[i].stream]++) return SK_ERR_INVALID_ARG;
+        if (ts[i].stream >= e->open.size() || !e->open[ts[i].stream]) return SK_ERR_BAD_STREAM;
+        const uint32_t ch = e->channels[ts[i].stream];
+        for (uint32_t j = 0; j < ts[i].n_frames; ++j) {
+            if (ts[i].codec == SK_TICK_MP3) {
+                if (g >= in->n_mp3_granules || in->mp3_descs[g].stream != ts[i].stream || in->mp3_descs[g].channels != ch || in->mp3_granules[g].channels != ch)
+                    return SK_ERR_INVALID_ARG;
+                uint32_t sum = 0;
+                for (uint32_t c = 0; c < ch * 576; ++c) {
+                    const int v = in->mp3_is[row * 576 + c];
+                    if (v > 8206 || v < -8206) return SK_ERR_INVALID_ARG;
+                    sum = sum * 31u + (uint16_t)v;
+                }
+                row += ch;
+                ++g;
+                if (int rc = em.unit(ts[i], i, sum, 576)) return rc;
+            } else {
+                if (f >= in->n_aac_units) return SK_ERR_INVALID_ARG;
+                ++f;
+                if (int rc = em.unit(ts[i], i, 0)) return rc;
+            }
+        }
+        if (int rc = em.end_of_row(ts[i], i)) return rc;
+    }
+    if (f != in->n_aac_units || g != in->n_mp3_granules) return SK_ERR_INVALID_ARG;
+    *n_outs = em.k;
+    if (used) *used = em.cursor;
+    return SK_OK;
+}
 // the device front-end's stand-in: checks the unit table the way engine.cpp does
 int sk_tick_run_au(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const sk_au_item *units, uint32_t n_units,
                    const uint8_t *au, size_t au_len, uint8_t *out, size_t out_cap, sk_tick_output *outs, uint32_t outs_cap,
@@ -612,6 +660,97 @@ static int scenario_thread_exceptions(sk_engine *e) {
     return 0;
 }
 
+// Streams of both codecs behind one scheduler (the worker's per-format dispatch, soundkit-decoder/src/lib.rs:2222-2241, 3041-3053):
+// the first bytes choose the decoder; AAC streams give one unit of 1024 frames per access unit, MP3 streams one of 576 per
+// granule, each stream's units in order and complete, whatever the chunking; a damaged MP3 stream ends or loses frames alone.
+static std::vector<uint8_t> mp3_clip;
+static int scenario_mixed_codecs(sk_engine *e) {
+    sk_pipeline_config cfg{};
+    cfg.entropy_threads = 3;
+    cfg.max_streams = 12;
+    cfg.max_frames_per_tick = 40;
+    cfg.max_stream_frames_per_tick = 5;
+    cfg.tick_wait_us = 50;
+    cfg.lanes = g_lanes;
+    cfg.gpu_entropy = g_front_end;
+    sk_pipeline *p = nullptr;
+    CHECK(sk_pipeline_create(e, &cfg, &p) == SK_OK);
+    const uint32_t n = 12, loops = 2;
+    std::vector<uint32_t> handles(n);
+    for (auto &h : handles) CHECK(sk_pipeline_spawn(p, nullptr, &h) == SK_OK);
+    std::thread feeder([&] {
+        for (uint32_t i = 0; i < n; ++i) {
+            const std::vector<uint8_t> &src = (i & 1) ? mp3_clip : clip;
+            for (uint32_t loop = 0; loop < loops; ++loop) {
+                size_t at = 0;
+                while (at < src.size()) {
+                    const size_t len = std::min<size_t>(src.size() - at, 1 + rnd() % 3000);
+                    int rc;
+                    while ((rc = sk_pipeline_send(p, handles[i], src.data() + at, len)) == SK_PIPE_INPUT_FULL)
+                        std::this_thread::sleep_for(std::chrono::microseconds(100));
+                    if (rc != SK_OK) std::abort();
+                    at += len;
+                }
+            }
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            int rc;
+            while ((rc = sk_pipeline_finish(p, handles[i])) == SK_PIPE_INPUT_FULL) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+    });
+    std::vector<std::vector<Got>> got(n);
+    std::vector<uint32_t> frames_seen(n, 0);
+    std::vector<int> errors(n, 0);
+    {
+        std::vector<uint8_t> buf(1 << 16);
+        std::vector<char> ended(n, 0);
+        size_t live = n;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (live) {
+            CHECK(std::chrono::steady_clock::now() - t0 < std::chrono::seconds(120));
+            for (uint32_t i = 0; i < n; ++i) {
+                if (ended[i]) continue;
+                sk_audio_info info;
+                const int rc = sk_pipeline_try_recv(p, handles[i], buf.data(), buf.size(), &info);
+                if (rc == 1) {
+                    if (info.is_error) errors[i] += 1;
+                    else {
+                        uint32_t w[4];
+                        std::memcpy(w, buf.data(), 16);
+                        CHECK(w[3] == 0xabcd1234u);
+                        CHECK(info.frames == ((i & 1) ? 576u : 1024u));
+                        CHECK(info.sampling_rate == ((i & 1) ? 16000u : 48000u) && info.channel_count == 2);
+                        got[i].push_back(Got{w[0], w[1], w[2]});
+                    }
+                } else if (rc == SK_PIPE_CLOSED) {
+                    ended[i] = 1;
+                    --live;
+                }
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    feeder.join();
+    for (uint32_t i = 0; i < n; ++i) {
+        CHECK(errors[i] == 0);
+        // the MP3 file twice in a row: the second pass's first frame reaches into a reservoir that holds the first pass's tail,
+        // which is what a decoder makes of a concatenation -- every frame still decodes (82 granules per pass)
+        CHECK(got[i].size() == ((i & 1) ? 82u * loops : 48u * loops));
+        for (size_t k = 0; k < got[i].size(); ++k) CHECK(got[i][k].unit == k);
+        if (i >= 2 && (i & 1)) {  // every MP3 stream got the same bytes: the same sums in the same order (the stand-in does not sum AAC units of a mixed tick)
+            CHECK(got[i].size() == got[i - 2].size());
+            for (size_t k = 0; k < got[i].size(); ++k) {
+                if (got[i][k].sum != got[i - 2][k].sum) std::fprintf(stderr, "stream %u unit %zu: sum %08x, stream %u has %08x\n", i, k, got[i][k].sum, i - 2, got[i - 2][k].sum);
+                CHECK(got[i][k].sum == got[i - 2][k].sum);
+            }
+        }
+    }
+    for (uint32_t h : handles) CHECK(sk_pipeline_cancel(p, h) == SK_OK);
+    sk_pipeline_destroy(p);
+    for (uint8_t o : e->open) CHECK(o == 0);
+    return 0;
+}
+
 static int scenario_cancel_churn(sk_engine *e);
 static int scenario_cancel_churn(sk_engine *e) {
     sk_pipeline_config cfg{};
@@ -753,6 +892,22 @@ int main(int argc, char **argv) {
     }
     g_lanes = 2;
     if (int rc = scenario_tick_failure(&e)) return rc;
+    {   // the reference's stereo MP3 fixture beside the AAC one
+        std::string path = argv[1];
+        const size_t at = path.rfind("/aac/");
+        if (at == std::string::npos) return 66;
+        path = path.substr(0, at) + "/mp3/stereo16k_A_Tusk_encoded.mp3";
+        FILE *m = std::fopen(path.c_str(), "rb");
+        if (!m) return 67;
+        mp3_clip.resize(1 << 20);
+        mp3_clip.resize(std::fread(mp3_clip.data(), 1, mp3_clip.size(), m));
+        std::fclose(m);
+    }
+    for (uint32_t fe = 0; fe < 3; ++fe) {
+        g_front_end = fe;
+        g_lanes = fe == 1 ? 2 : 1;
+        if (int rc = scenario_mixed_codecs(&e)) return rc;
+    }
     g_front_end = 0;
     g_lanes = 1;
     if (int rc = scenario_thread_exceptions(&e)) return rc;
