@@ -1182,7 +1182,21 @@ __global__ __launch_bounds__(256) void k_reset_streams(float *delay, uint8_t *sh
     if (threadIdx.x == 2) pns[id] = 0x1f2e3d4cu;
 }
 
+// base[ids[b] * span .. + span) = 0 for every listed id (span a multiple of 4 floats, rows 16-byte aligned): the resampler rows and
+// the Layer III state of the streams opened in a row, one launch instead of one fill per stream
+__global__ __launch_bounds__(256) void k_zero_spans(float *base, const uint32_t *ids, uint32_t span) {
+    f4 *d = reinterpret_cast<f4 *>(base + (size_t)ids[blockIdx.x] * span);
+    for (uint32_t i = threadIdx.x; i < span / 4; i += 256) d[i] = (f4){0.f, 0.f, 0.f, 0.f};
+}
+
 }  // namespace
+
+hipError_t launch_zero_spans(float *base, const uint32_t *ids, uint32_t n, uint32_t span_floats, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (span_floats % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_zero_spans, dim3(n), dim3(256), 0, s, base, ids, span_floats);
+    return hipGetLastError();
+}
 
 hipError_t launch_reset_streams(float *delay, uint8_t *shape, uint32_t *pns, const uint32_t *ids, uint32_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;

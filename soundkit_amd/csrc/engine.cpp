@@ -247,6 +247,8 @@ struct sk_engine {
     // streams opened (or reset) since the last launch: their device state is cleared by ONE launch in front of the next call
     // that touches the device (sk_stream_open used to cost a launch each: 4096 of them in front of a batch)
     std::vector<uint32_t> pending_reset;
+    std::vector<uint32_t> pending_rs_reset;  // streams whose resampler rows are to be cleared (sk_resampler_open / sk_stream_reset)
+    uint32_t *d_rs_reset_ids = nullptr;
     uint32_t *d_reset_ids = nullptr;
     // diagnostics: where the current tick stands (read by sk_pipeline_debug_dump without the engine's lock), the bound on
     // its waits for the device, and a failure-injection countdown for the error-path tests (sk_engine_debug_fail_after)
@@ -295,16 +297,24 @@ struct DeviceGuard {
 };
 
 void flush_stream_resets(sk_engine *e) {
+    hipError_t he = hipSuccess;
+    if (!e->pending_rs_reset.empty() && e->d_rs) {  // the resampler rows of the streams opened since the last call: one launch
+        const uint32_t n = (uint32_t)e->pending_rs_reset.size();
+        if (!e->d_rs_reset_ids) he = hipMalloc((void **)&e->d_rs_reset_ids, (size_t)e->max_streams * sizeof(uint32_t));
+        if (he == hipSuccess) he = hipMemcpyAsync(e->d_rs_reset_ids, e->pending_rs_reset.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
+        if (he == hipSuccess) he = sk::launch_zero_spans(e->d_rs, e->d_rs_reset_ids, n, 2 * kRsRow, e->stream);
+        if (he != hipSuccess) (void)e->hip_fail(he, "reset resampler rows");
+    }
+    e->pending_rs_reset.clear();
     if (e->pending_reset.empty()) return;
     const uint32_t n = (uint32_t)e->pending_reset.size();
-    hipError_t he = hipSuccess;
+    he = hipSuccess;
     if (!e->d_reset_ids) he = hipMalloc((void **)&e->d_reset_ids, (size_t)e->max_streams * sizeof(uint32_t));
     // pageable source: the copy is staged before the call returns, the list can be reused at once
     if (he == hipSuccess) he = hipMemcpyAsync(e->d_reset_ids, e->pending_reset.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
     if (he == hipSuccess) he = sk::launch_reset_streams(e->d_delay, e->d_prev_shape, e->d_pns, e->d_reset_ids, n, e->stream);
-    if (he == hipSuccess && e->d_mp3_state)
-        for (uint32_t id : e->pending_reset)  // the Layer III overlap and polyphase FIFO of both channels
-            (void)hipMemsetAsync(e->d_mp3_state + (size_t)id * 2 * sk::kMp3StateFloats, 0, 2 * sk::kMp3StateFloats * sizeof(float), e->stream);
+    if (he == hipSuccess && e->d_mp3_state)  // the Layer III overlap and polyphase FIFO of both channels
+        he = sk::launch_zero_spans(e->d_mp3_state, e->d_reset_ids, n, 2 * sk::kMp3StateFloats, e->stream);
     if (he != hipSuccess) (void)e->hip_fail(he, "reset stream state");  // the launch that follows reports it
     e->pending_reset.clear();
 }
@@ -551,6 +561,7 @@ void sk_engine_destroy(sk_engine *e) try {
         DeviceGuard guard(e);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         if (e->d_reset_ids) (void)hipFree(e->d_reset_ids);
+        if (e->d_rs_reset_ids) (void)hipFree(e->d_rs_reset_ids);
         e->sinc_scratch.release();
         for (void *p : {(void *)e->d_mp3_rq, (void *)e->d_mp3_tables, (void *)e->d_mp3_state, (void *)e->d_pns, e->d_ec_blob, (void *)e->d_delay, (void *)e->d_prev_shape, (void *)e->d_rs, (void *)e->d_tables,
                         (void *)e->d_pow43, (void *)e->d_sftab, (void *)e->d_taps, (void *)e->d_afrag16, (void *)e->d_afrag_f16,
@@ -707,8 +718,7 @@ int sk_stream_reset(sk_engine *e, uint32_t id) try {
     s.rs_fill = 0;
     s.rs_chunks = 0;
     s.rs_last_index = -128.0;
-    if (s.rs_open && e->d_rs)
-        SK_HIP(hipMemsetAsync(e->d_rs + (size_t)id * 2 * kRsRow, 0, 2 * kRsRow * sizeof(float), e->stream), "reset rs");
+    if (s.rs_open && e->d_rs) e->pending_rs_reset.push_back(id);  // cleared with the next call's first launch (flush_stream_resets)
     return reset_stream_state(e, id);
 } catch (...) {
     return sk::abi_caught("sk_stream_reset");
@@ -2223,7 +2233,9 @@ int sk_resampler_open(sk_engine *e, uint32_t id, uint32_t in_hz, uint32_t out_hz
     std::lock_guard<std::mutex> lock(e->mu);
     if (!stream_ok(e, id)) return SK_ERR_BAD_STREAM;
     if (!common_rate(in_hz) || !common_rate(out_hz)) return SK_ERR_UNSUPPORTED;  // as downsample_audio rejects them
-    DeviceGuard guard(e);
+    // the plain guard: opening a resampler queues nothing per stream -- a scheduler opens thousands in a row, and their rows
+    // (like their synthesis state) are cleared by ONE launch in front of the next call that touches the device
+    DeviceGuard guard(e->device);
     if (!e->d_rs) {
         const size_t bytes = (size_t)e->max_streams * 2 * kRsRow * sizeof(float);
         SK_HIP(hipMalloc((void **)&e->d_rs, bytes), "alloc resampler history");
@@ -2240,7 +2252,8 @@ int sk_resampler_open(sk_engine *e, uint32_t id, uint32_t in_hz, uint32_t out_hz
     s.rs_fill = 0;
     s.rs_chunks = 0;
     s.rs_last_index = -128.0;
-    SK_HIP(hipMemsetAsync(e->d_rs + (size_t)id * 2 * kRsRow, 0, 2 * kRsRow * sizeof(float), e->stream), "clear rs rows");
+    e->pending_rs_reset.push_back(id);
+    if (e->pending_rs_reset.size() >= e->max_streams) flush_stream_resets(e);
     return SK_OK;
 } catch (...) {
     return sk::abi_caught("sk_resampler_open");

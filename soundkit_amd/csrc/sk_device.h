@@ -68,6 +68,7 @@ hipError_t launch_aac_tail(const TailArgs &ta, hipStream_t s);
 // wave-uniform eight-short arm; without: the caller vouches that no entry is EightShort
 hipError_t launch_aac_synth_pairs(const SynthArgs &a, bool with_short, hipStream_t s);
 hipError_t launch_reset_streams(float *delay, uint8_t *shape, uint32_t *pns, const uint32_t *ids, uint32_t n, hipStream_t s);
+hipError_t launch_zero_spans(float *base, const uint32_t *ids, uint32_t n, uint32_t span_floats, hipStream_t s);
 hipError_t launch_frames_to_s16(const float *planar, int16_t *out, const FrameSpan *frames, uint32_t n, hipStream_t s);
 hipError_t launch_dequantize(const int16_t *q, const int16_t *sf, float *out, size_t n, const float *pow43,
                              const float *sftab, hipStream_t s);
