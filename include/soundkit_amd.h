@@ -256,7 +256,7 @@ int sk_mp3_hybrid_synthesize_f32_dev(sk_engine *, const sk_mp3_granule_desc *des
 enum sk_mp3_status {
     SK_MP3_NEED_MORE = -301,   /* not enough bytes for the header / side information / frame / reservoir */
     SK_MP3_NO_SYNC = -302,     /* not a frame header */
-    SK_MP3_UNSUPPORTED = -303, /* Layer I / II, free format; LSF intensity stereo in sk_mp3_requantize */
+    SK_MP3_UNSUPPORTED = -303, /* Layer I / II, free format; intensity stereo in mixed blocks */
     SK_MP3_INVALID = -304      /* a field combination the syntax forbids */
 };
 typedef struct sk_mp3_frame_info { /* nanomp3::FrameInfo (lib.rs:188-215 reads sample_rate, channels, bitrate) + framing */
@@ -299,7 +299,11 @@ typedef struct sk_mp3_requant_channel {
 } sk_mp3_requant_channel;
 typedef struct sk_mp3_requant_granule {
     uint32_t sample_rate;
-    uint8_t channels, ms_stereo, intensity_stereo, lsf; /* mode_ext bits of a joint-stereo frame; lsf: MPEG-2 / 2.5 */
+    uint8_t channels, ms_stereo, intensity_stereo, lsf; /* mode_ext bits of a joint-stereo frame; lsf: MPEG-2 / 2.5.  intensity_stereo: bit 0
+                                                         * = on; bit 1 (lsf only) = intensity_scale, the low bit of the right channel's
+                                                         * scalefac_compress (13818-3 2.4.3.2: i0 = 2^-1/2 instead of 2^-1/4).  In an lsf
+                                                         * intensity granule bit 7 of a RIGHT-channel scale factor marks its position as
+                                                         * "not intensity coded" (the largest value its field holds); the factor is bits 0-6 */
     sk_mp3_requant_channel ch[2];
 } sk_mp3_requant_granule;
 int sk_mp3_set_band_tables(sk_engine *, uint32_t sample_rate, const uint16_t long_offsets[23], const uint16_t short_offsets[14],
@@ -350,7 +354,8 @@ typedef struct sk_mp3_granule_data {
     uint8_t scalefac_l[22];
     uint8_t scalefac_s[13][3];
     uint8_t preflag;     /* MPEG-1: the side information's; LSF: implied by scalefac_compress */
-    uint8_t intensity_scale; /* LSF intensity channel: scalefac_compress & 1 (not used: such granules are rejected later) */
+    uint8_t intensity_scale; /* LSF intensity channel: scalefac_compress & 1 (-> sk_mp3_requant_granule::intensity_stereo bit 1); its
+                              * scale factors carry bit 7 where the position is the field's largest value ("not intensity coded") */
     uint16_t part2_bits; /* what the scale factors took of part2_3_length */
     uint16_t nonzero_lines; /* lines up to and including the last decoded pair / quadruple */
     uint16_t part3_bits; /* what the accepted pairs / quadruples took; a well-formed granule: part2_bits + part3_bits == part2_3_length */

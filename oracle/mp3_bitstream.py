@@ -186,9 +186,9 @@ def requantize_granule(g, quant, long_offsets, short_offsets, pretab):
             where[c][i] = (band, w, dest)
             q = int(quant[c][i])
             if w < 0:
-                exponent = (ch["global_gain"] - 210) / 4.0 - mult * (ch["scalefac_l"][band] + (int(pretab[band]) if ch["preflag"] else 0))
+                exponent = (ch["global_gain"] - 210) / 4.0 - mult * ((ch["scalefac_l"][band] & 0x7F) + (int(pretab[band]) if ch["preflag"] else 0))
             else:
-                exponent = (ch["global_gain"] - 210 - 8 * ch["subblock_gain"][w]) / 4.0 - mult * ch["scalefac_s"][band][w]
+                exponent = (ch["global_gain"] - 210 - 8 * ch["subblock_gain"][w]) / 4.0 - mult * (ch["scalefac_s"][band][w] & 0x7F)
             vals[c][i] = math.copysign(abs(q) ** (4.0 / 3.0) * 2.0 ** exponent, q) if q else 0.0
     if channels == 2 and (ms_stereo or intensity_stereo):
         top = {}
@@ -202,7 +202,16 @@ def requantize_granule(g, quant, long_offsets, short_offsets, pretab):
             done = False
             if intensity_stereo and band > top.get(w, -1):
                 pos = right["scalefac_l"][min(band, 20)] if w < 0 else right["scalefac_s"][min(band, 11)][w]
-                if pos < 7:
+                if g.get("lsf"):
+                    # ISO/IEC 13818-3 2.4.3.2: is_pos 0: both channels take the line; odd: left scaled by i0^((is_pos + 1) / 2),
+                    # even: right by i0^(is_pos / 2); i0 = 2^-1/4, or 2^-1/2 when intensity_scale (intensity_stereo bit 1) is set
+                    if not pos & 0x80:
+                        steps = ((pos + 1) >> 1) << (1 if intensity_stereo & 2 else 0)
+                        f = 2.0 ** (-steps / 4.0)
+                        x = vals[0][i]
+                        vals[0][i], vals[1][i] = (x * f, x) if pos & 1 else (x, x * f)
+                        done = True
+                elif pos < 7:
                     if pos == 6:
                         kl = 1.0
                     else:
@@ -305,7 +314,10 @@ def scale_factors(tables, h, side, gr, ch, bits, first_granule):
     column = (2 if s["mixed_block_flag"] else 1) if short else 0
     values = []
     for part, count in enumerate(tables["lsf_partitions"][row][column]):
-        values += [bits.take(lens[part]) for _ in range(count)]
+        for _ in range(count):
+            v = bits.take(lens[part])
+            # 13818-3 2.4.3.2: in the intensity channel the largest value of a field means "not intensity coded" (bit 7 here)
+            values.append(v | 0x80 if row >= 3 and lens[part] > 0 and v == (1 << lens[part]) - 1 else v)
     if column == 0:
         sl[:len(values)] = values
     else:
@@ -433,8 +445,6 @@ class Decoder:
         if main is None:
             return None
         joint = h["mode"] == 1
-        if h["version"] != 1 and joint and (h["mode_ext"] & 1):
-            return None
         grs = decode_main_data(self.tables, h, side, main)
         if any(g is None for row in grs for g in row):
             return None
@@ -443,8 +453,14 @@ class Decoder:
         long_offsets, short_offsets = self.tables["bands"][h["sample_rate"]]
         out = []
         for gr in range(h["granules"]):
-            g = {"channels": h["channels"], "ms_stereo": int(joint and bool(h["mode_ext"] & 2)),
-                 "intensity_stereo": int(joint and bool(h["mode_ext"] & 1)), "ch": []}
+            lsf = h["version"] != 1
+            intensity = int(joint and bool(h["mode_ext"] & 1))
+            if intensity and lsf and h["channels"] == 2 and side["gr"][gr][1]["scalefac_compress"] & 1:
+                intensity |= 2  # intensity_scale
+            if intensity and any(side["gr"][gr][c]["mixed_block_flag"] for c in range(h["channels"])):
+                return None  # intensity stereo in mixed blocks: not built (the product rejects the granule too)
+            g = {"channels": h["channels"], "ms_stereo": int(joint and bool(h["mode_ext"] & 2)), "intensity_stereo": intensity, "lsf": int(lsf),
+                 "ch": []}
             for ch in range(h["channels"]):
                 s, d = side["gr"][gr][ch], grs[gr][ch]
                 g["ch"].append({"global_gain": s["global_gain"], "scalefac_scale": s["scalefac_scale"], "preflag": d["preflag"],

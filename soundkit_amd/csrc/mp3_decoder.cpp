@@ -166,7 +166,9 @@ int scale_factors_lsf(const sk_mp3_codebook &cb, const sk_mp3_frame_info &h, con
     const int long_bands = column == 0 ? 22 : (column == 2 ? 6 : 0);
     for (int part = 0; part < 4; ++part)
         for (int k = 0; k < parts[part]; ++k, ++index) {
-            const uint8_t v = (uint8_t)b.get(slen[part]);
+            uint8_t v = (uint8_t)b.get(slen[part]);
+            // 13818-3 2.4.3.2: in the intensity channel the largest value a field can hold says "this band is not intensity coded"
+            if (intensity_channel && slen[part] > 0 && v == (1u << slen[part]) - 1u) v |= 0x80;
             if (index < long_bands) {
                 if (index < 22) g.scalefac_l[index] = v;
             } else {
@@ -461,7 +463,6 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
         sk_mp3_granule_data data[2][2];
         if (decodable) decodable = sk_mp3_decode_main_data(d->cb, &h, &side, d->main.data(), main_len, data) == SK_OK;
         const bool joint = h.mode == 1;
-        if (decodable && h.version != 1 && joint && (h.mode_ext & 1)) decodable = false;  // 13818-3 intensity stereo: not built
         if (decodable) {
             if (samples + frame_samples > out_cap) {  // write_frame_*: "Output buffer too small for decoded frame"
                 result = SK_ERR_CAPACITY;
@@ -490,6 +491,7 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
                 g.ms_stereo = joint && (h.mode_ext & 2);
                 g.intensity_stereo = joint && (h.mode_ext & 1);
                 g.lsf = h.version != 1;
+                if (g.lsf && g.intensity_stereo && h.channels == 2 && data[gr][1].intensity_scale) g.intensity_stereo |= 2;
                 sk_mp3_granule_desc desc;
                 std::memset(&desc, 0, sizeof desc);
                 desc.stream = d->stream;

@@ -7,6 +7,8 @@
 //   2.4.3.4.9.3  MPEG-1 intensity: in the bands above the last one where the right channel holds anything (per window for
 //                short blocks) the right channel's scale factor is a position is_pos; L = xr k, R = xr (1 - k),
 //                k = t / (1 + t), t = tan(is_pos pi / 12); is_pos 7 = "not intensity coded"
+//   13818-3 2.4.3.2  MPEG-2 / 2.5 intensity: the same bands, ratios 1 : i0^n or i0^n : 1 (i0 = 2^-1/4 or 2^-1/2 by intensity_scale);
+//                the position that means "not intensity coded" is the largest value its field holds -- the host marks it (bit 7)
 //   2.4.3.4.8    short blocks: band-by-band [window][line] -> [line][window]
 // The scale-factor band offsets (Table B.8) and the pre-emphasis table are caller-supplied (sk_mp3_set_band_tables): this
 // tree does not hold them.  oracle/mp3_requant.py is the f64 checker; parity of the MP3 row is unpinned.
@@ -89,8 +91,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
         const sk_mp3_requant_channel &ch = g.ch[c];
         const int mult = ch.scalefac_scale ? 4 : 2;
         int q = (int)ch.global_gain - 210;
-        if (lane < 22) q -= mult * ((int)ch.scalefac_l[lane] + (ch.preflag ? (int)a.pretab[g.slot * 24 + lane] : 0));
-        else if (lane < 61) q -= 8 * (int)ch.subblock_gain[(lane - 22) % 3] + mult * (int)ch.scalefac_s[(lane - 22) / 3][(lane - 22) % 3];
+        // (bit 7 of a scale factor marks an LSF intensity position as "not intensity coded", below; the factor is the low bits)
+        if (lane < 22) q -= mult * ((int)(ch.scalefac_l[lane] & 0x7f) + (ch.preflag ? (int)a.pretab[g.slot * 24 + lane] : 0));
+        else if (lane < 61) q -= 8 * (int)ch.subblock_gain[(lane - 22) % 3] + mult * (int)(ch.scalefac_s[(lane - 22) / 3][(lane - 22) % 3] & 0x7f);
         qtab[wave][c][lane] = (int16_t)q;
     }
     wave_sync();
@@ -123,7 +126,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
     }
 
     if (channels == 2 && (g.flags & 3)) {
-        const bool ms = g.flags & 1, intensity = g.flags & 2;
+        const bool ms = g.flags & 1, intensity = g.flags & 2, lsf = g.flags & 4;
+        const int lsf_shift = (g.flags >> 3) & 1;  // 13818-3: intensity_scale, the low bit of the right channel's scalefac_compress
         if (intensity) {
             top[0] = wave_max(top[0]);
             if (is_short) {
@@ -141,7 +145,19 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
                 if (at.band > bound) {
                     // the last band has no scale factor of its own: it takes the position of the one below
                     const int pos = at.win < 0 ? right.scalefac_l[min(at.band, 20)] : right.scalefac_s[min(at.band, 11)][at.win];
-                    if (pos < 7) {
+                    if (lsf) {
+                        // ISO/IEC 13818-3 2.4.3.2: is_pos = 0: both channels get the line; odd: the left one is scaled by
+                        // i0^((is_pos + 1) / 2), even: the right one by i0^(is_pos / 2), i0 = 2^-1/4 or 2^-1/2 (intensity_scale).
+                        // A position equal to the largest value its field can hold means "not intensity coded" (host: bit 7).
+                        if (!(pos & 0x80)) {
+                            const int steps = ((pos + 1) >> 1) << lsf_shift;  // in units of 2^-1/4
+                            const float f = ldexpf(a.root4[(4 - (steps & 3)) & 3], -((steps + 3) >> 2));  // 2^(-steps / 4): one table rounding
+                            const float x = v[0][k];
+                            v[0][k] = (pos & 1) ? x * f : x;
+                            v[1][k] = (pos & 1) ? x : x * f;
+                            done = true;
+                        }
+                    } else if (pos < 7) {
                         const float kl = a.is_k[pos];
                         const float x = v[0][k];
                         v[0][k] = x * kl;

@@ -348,7 +348,6 @@ void parse_some_mp3(sk_lane *p, PStream &s, uint32_t limit, Parsed &r) {
             sk_mp3_granule_data data[2][2];
             if (ok) ok = sk_mp3_decode_main_data(p->mp3_cb, &h, &side, main.data(), main_len, data) == SK_OK;
             const bool joint = h.mode == 1;
-            if (ok && h.version != 1 && joint && (h.mode_ext & 1)) ok = false;  // 13818-3 intensity stereo: not built
             if (ok) {
                 if (s.engine_stream == kNoStream) {  // the first frame that decodes fixes rate and channels (lib.rs:203-204)
                     s.rate = h.sample_rate;
@@ -379,6 +378,7 @@ void parse_some_mp3(sk_lane *p, PStream &s, uint32_t limit, Parsed &r) {
                     g.ms_stereo = joint && (h.mode_ext & 2);
                     g.intensity_stereo = joint && (h.mode_ext & 1);
                     g.lsf = h.version != 1;
+                    if (g.lsf && g.intensity_stereo && h.channels == 2 && data[gr][1].intensity_scale) g.intensity_stereo |= 2;
                     sk_mp3_granule_desc d;
                     std::memset(&d, 0, sizeof d);
                     d.stream = s.engine_stream;

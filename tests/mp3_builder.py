@@ -116,7 +116,7 @@ def put_pair(w, table, x, y):
             w.put(1 if v < 0 else 0, 1)
 
 
-def random_granule(rng, tables, h, gr, first_granule, budget_bits, shape=None, allow_mixed=True):
+def random_granule(rng, tables, h, gr, first_granule, budget_bits, shape=None, allow_mixed=True, intensity_channel=False):
     """-> (side dict, scalefac_l, scalefac_s, is[576], BitWriter) within budget_bits (and 4095); shape = (window_switching,
     block_type, mixed_block_flag) to copy (the second channel of a joint-stereo pair)"""
     long_o, short_o = tables["bands"][h["sample_rate"]]
@@ -161,6 +161,35 @@ def random_granule(rng, tables, h, gr, first_granule, budget_bits, shape=None, a
                         else:
                             sl[band] = int(rng.integers(0, 1 << n))
                             w.put(sl[band], n)
+        elif intensity_channel:
+            # 13818-3 2.4.3.2, the right channel of an intensity-stereo frame: scalefac_compress >> 1 selects three (four) field
+            # widths and a row 3..5 of the partition table; its low bit is intensity_scale.  Fields at their largest value
+            # ("not intensity coded") come up by themselves: widths are small
+            kind = 3 + int(rng.integers(0, 3))
+            if kind == 3:
+                lens = [int(rng.integers(0, 5)), int(rng.integers(0, 6)), int(rng.integers(0, 6)), 0]
+                sfc = lens[0] * 36 + lens[1] * 6 + lens[2]
+            elif kind == 4:
+                lens = [int(rng.integers(0, 4)), int(rng.integers(0, 4)), int(rng.integers(0, 4)), 0]
+                sfc = 180 + ((lens[0] << 4) | (lens[1] << 2) | lens[2])
+            else:
+                lens = [int(rng.integers(0, 4)), int(rng.integers(0, 3)), 0, 0]
+                sfc = 244 + lens[0] * 3 + lens[1]
+            assert sfc < 256
+            s["scalefac_compress"] = (sfc << 1) | int(rng.integers(0, 2))
+            column = (2 if mixed else 1) if short else 0
+            values = []
+            for part, count in enumerate(LSF_PARTITIONS[kind][column]):
+                for _ in range(count):
+                    v = int(rng.integers(0, 1 << lens[part]))
+                    w.put(v, lens[part])
+                    values.append(v | 0x80 if lens[part] > 0 and v == (1 << lens[part]) - 1 else v)  # as the decoders mark it
+            if column == 0:
+                sl[:len(values)] = values
+            else:
+                for k, v in enumerate(values):
+                    band, win = divmod(k, 3)
+                    ss[band][win] = v
         else:
             kind = int(rng.integers(0, 3))
             if kind == 0:
@@ -274,7 +303,7 @@ def pack_side_info(h, side):
 def build_stream(tables, seed, version=1, rate=44100, channels=2, mode=None, n_frames=12, crc=False, bitrate_indices=(5, 9, 12),
                  joint_modes=(0, 2)):
     """-> (bytes, [per frame: dict(header, side, granules=[gr][ch] dict(is, scalefac_l, scalefac_s, preflag))])
-    mode: 0 stereo, 1 joint stereo (mode_ext from joint_modes: bit 1 = mid/side; MPEG-1 only: bit 0 = intensity), 2 dual, 3 mono"""
+    mode: 0 stereo, 1 joint stereo (mode_ext from joint_modes: bit 1 = mid/side, bit 0 = intensity), 2 dual, 3 mono"""
     rng = np.random.default_rng(seed)
     if mode is None:
         mode = 3 if channels == 1 else 1
@@ -303,7 +332,8 @@ def build_stream(tables, seed, version=1, rate=44100, channels=2, mode=None, n_f
             for ch in range(channels):
                 share = (budget - len(w_all)) // (n_units - unit)
                 s, sl, ss, values, w = random_granule(rng, tables, h, gr, first[ch] if gr == 1 else None, int(share * rng.uniform(0.3, 1.0)),
-                                                      shape if mode == 1 else None, allow_mixed=not (mode == 1 and mode_ext & 1))
+                                                      shape if mode == 1 else None, allow_mixed=not (mode == 1 and mode_ext & 1),
+                                                      intensity_channel=version != 1 and mode == 1 and bool(mode_ext & 1) and ch == 1)
                 shape = (s["window_switching"], s["block_type"], s["mixed_block_flag"])  # a joint pair is cut up the same way
                 if gr == 1:
                     side["scfsi"][ch] = s["scfsi"]
@@ -312,7 +342,9 @@ def build_stream(tables, seed, version=1, rate=44100, channels=2, mode=None, n_f
                 if gr == 1 and first[ch] is None:
                     assert not any(s["scfsi"])
                 row_side.append(s)
-                row.append({"is": values, "scalefac_l": sl, "scalefac_s": ss, "preflag": s["preflag"] if version == 1 else int(s["scalefac_compress"] >= 500)})
+                lsf_is = version != 1 and mode == 1 and bool(mode_ext & 1) and ch == 1
+                row.append({"is": values, "scalefac_l": sl, "scalefac_s": ss,
+                            "preflag": s["preflag"] if version == 1 else int(not lsf_is and s["scalefac_compress"] >= 500)})
                 w_all.bits.extend(w.bits)
                 unit += 1
             side["gr"].append(row_side)

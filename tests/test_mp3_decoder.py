@@ -26,7 +26,10 @@ STREAMS = [dict(version=1, rate=44100, channels=2, mode=1, joint_modes=(0, 2)), 
            dict(version=1, rate=32000, channels=2, mode=0, crc=True), dict(version=1, rate=44100, channels=2, mode=1, joint_modes=(1, 3)),
            dict(version=2, rate=22050, channels=2, mode=1, joint_modes=(0, 2), bitrate_indices=(8, 10, 13)),
            dict(version=2, rate=16000, channels=1, bitrate_indices=(6, 9, 12)), dict(version=25, rate=11025, channels=2, mode=2, bitrate_indices=(8, 11)),
-           dict(version=25, rate=8000, channels=1, bitrate_indices=(7, 8), crc=True)]
+           dict(version=25, rate=8000, channels=1, bitrate_indices=(7, 8), crc=True),
+           # 13818-3 intensity stereo: the right channel's scale factors in the 9-bit intensity form, largest values marked (bit 7)
+           dict(version=2, rate=24000, channels=2, mode=1, joint_modes=(1, 3), bitrate_indices=(8, 10, 13)),
+           dict(version=25, rate=12000, channels=2, mode=1, joint_modes=(1, 2, 3), bitrate_indices=(6, 8))]
 
 
 @pytest.mark.parametrize("k", range(len(STREAMS)))

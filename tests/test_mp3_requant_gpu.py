@@ -1,4 +1,4 @@
-"""csrc/mp3_requant.hip (Layer III requantisation, mid/side and MPEG-1 intensity stereo, short-block reorder on gfx950,
+"""csrc/mp3_requant.hip (Layer III requantisation, mid/side, MPEG-1 and 13818-3 intensity stereo, short-block reorder on gfx950,
 behind sk_mp3_requantize) against oracle/mp3_bitstream.py requantize_granule (ISO/IEC 11172-3 2.4.3.4.7-9 in f64).
 Tolerance: 1e-6 relative per line (north_star's float tolerance; for a joint-stereo pair relative to the larger of the
 two channels at that line, since mid/side is a sum and a difference).  The scale-factor band tables are synthetic
@@ -138,6 +138,37 @@ def test_mid_side_and_intensity_stereo(engine, block_type):
     assert np.array_equal(xr[0], plain[0])
 
 
+@pytest.mark.parametrize("block_type", [0, 2, 3])
+def test_lsf_intensity_stereo(engine, block_type):
+    """ISO/IEC 13818-3 2.4.3.2: positions up to 31 in the right channel's scale factors, ratios 1 : i0^n / i0^n : 1 with i0 = 2^-1/4 or
+    2^-1/2 (intensity_stereo bit 1), bit 7 = "not intensity coded" (the field's largest value, marked by the host), with and
+    without mid/side in the bands below the bound"""
+    rng = np.random.default_rng(70 + block_type)
+    long_o, short_o, pretab = tables(4)
+    assert mp3.set_band_tables(24000, long_o, short_o, pretab, engine) == SK_OK
+    granules, quant = [], []
+    for k in range(96):
+        ms, scale = k & 1, (k >> 1) & 1
+        left, right = random_channel(rng, block_type, 0), random_channel(rng, block_type, 0)
+        left["preflag"] = right["preflag"] = 0
+        mark = lambda v: int(v) | (0x80 if rng.random() < 0.2 else 0)
+        right["scalefac_l"] = [mark(v) for v in rng.integers(0, 32, 21)] + [0]
+        right["scalefac_s"] = [[mark(v) for v in rng.integers(0, 32, 3)] for _ in range(12)] + [[0, 0, 0]]
+        granules.append({"sample_rate": 24000, "channels": 2, "ms_stereo": ms, "intensity_stereo": 1 | (scale << 1), "lsf": 1, "ch": [left, right]})
+        quant.append(random_quant(rng))
+        quant.append(random_quant(rng, [0, int(rng.integers(0, 577)), int(rng.integers(0, 300)), 576][k % 4]))
+    quant = np.stack(quant)
+    xr, status = mp3.requantize(granules, quant, engine)
+    check(granules, quant, xr, status, long_o, short_o, pretab)
+    # position 0 everywhere, right channel empty: both channels carry the left channel's lines
+    g = granules[0]
+    g["ch"][1]["scalefac_l"], g["ch"][1]["scalefac_s"] = [0] * 22, [[0, 0, 0]] * 13
+    g["ms_stereo"] = 0
+    q = np.stack([random_quant(rng), np.zeros(576, np.int16)])
+    xr, status = mp3.requantize([g], q, engine)
+    assert not status.any() and np.array_equal(xr[0], xr[1]) and xr[0].any()
+
+
 def test_rejected_granules_are_silent_and_do_not_disturb_the_others():
     import soundkit_amd
     engine = soundkit_amd.Engine(0, 4)  # its own: which rates have band tables is engine state
@@ -165,7 +196,8 @@ def rejected_granules(engine):
     cases = [(good, SK_OK), (granule(8000), UNSUPPORTED),                                   # no table for that rate
              (granule(22050, bt=(2, 0), ms_stereo=1), INVALID),                             # a pair cut up differently
              (granule(22050, bt=(2, 0)), SK_OK),                                            # ... which is fine without joint stereo
-             (granule(22050, intensity_stereo=1, lsf=1), UNSUPPORTED),                      # 13818-3 intensity
+             (granule(22050, intensity_stereo=1, lsf=1), SK_OK),                            # 13818-3 intensity, i0 = 2^-1/4
+             (granule(22050, intensity_stereo=3, lsf=1, ms_stereo=1), SK_OK),               # ... i0 = 2^-1/2, mid/side below the bound
              (granule(22050, bt=(2, 2), mixed=(1, 1), intensity_stereo=1), UNSUPPORTED),
              (granule(24000, bt=(2, 2), mixed=(1, 1)), UNSUPPORTED),                        # tables without a boundary at line 36
              (granule(22050, bt=(1, 1), mixed=(1, 1)), INVALID), (good, SK_OK)]
