@@ -311,7 +311,7 @@ def end_to_end(args, eng, torch, dist, world, rank, device, emit=True, cpu_basel
             cores = min(cores, int(int(quota) / int(period)))
     except (OSError, ValueError):
         pass
-    share = max(4, min(cores // world, 16))  # the pool gives a one-GPU job 16 cores
+    share = max(4, min(cores, 16))  # the pool gives a one-GPU job 16 cores; with several ranks `cores` is already this rank's share
     threads = args.entropy_threads or max(1, share - 3 - args.feeders)
     feeders = args.feeders
     import threading
@@ -468,6 +468,63 @@ def self_launch(n):
     return 0
 
 
+def gpu_numa_node(local_rank):
+    """NUMA node of GPU `local_rank` from sysfs (the amdgpu render nodes in PCI order), or -1: no GPU call is made"""
+    try:
+        cards = []
+        base = "/sys/class/drm"
+        for name in sorted(os.listdir(base)):
+            if name.startswith("renderD"):
+                dev = os.path.realpath(os.path.join(base, name, "device"))
+                vendor = open(os.path.join(dev, "vendor")).read().strip()
+                if vendor == "0x1002":
+                    cards.append(dev)
+        cards.sort()
+        if local_rank < len(cards):
+            return int(open(os.path.join(cards[local_rank], "numa_node")).read().strip())
+    except (OSError, ValueError):
+        pass
+    return -1
+
+
+def cpu_node(cpu):
+    try:
+        for name in os.listdir("/sys/devices/system/cpu/cpu%d" % cpu):
+            if name.startswith("node") and name[4:].isdigit():
+                return int(name[4:])
+    except OSError:
+        pass
+    return 0
+
+
+def rank_cpu_budget(world, rank, gpu_nodes=None, cpus=None):
+    """The host cores of rank `rank` of `world`: the process's affinity set cut into `world` disjoint shares of equal size
+    (+-1), each rank's share on its GPU's NUMA node where the node has enough cores left -- so that N ranks on one host do
+    not fight over the same cores (every rank runs entropy threads, a submission thread, delivery threads and a load
+    generator) and a rank's pinned buffers and threads sit beside its GPU.  Pure function of its arguments (tested on CPU)."""
+    if cpus is None:
+        cpus = sorted(os.sched_getaffinity(0))[:usable_cores()]  # a cgroup CPU quota below the affinity count bounds the whole job
+    cpus = sorted(cpus)
+    if world <= 1:
+        return cpus
+    gpu_nodes = list(gpu_nodes) if gpu_nodes is not None else [gpu_numa_node(r) for r in range(world)]
+    by_node = {}
+    for c in cpus:
+        by_node.setdefault(cpu_node(c), []).append(c)
+    want = [len(cpus) // world + (1 if r < len(cpus) % world else 0) for r in range(world)]
+    shares = [[] for _ in range(world)]
+    order = sorted(range(world), key=lambda r: (gpu_nodes[r], r))
+    for r in order:  # first the cores of the rank's own node ...
+        pool = by_node.get(gpu_nodes[r], [])
+        while pool and len(shares[r]) < want[r]:
+            shares[r].append(pool.pop(0))
+    left = sorted(c for pool in by_node.values() for c in pool)
+    for r in order:  # ... then whatever is left, in order
+        while left and len(shares[r]) < want[r]:
+            shares[r].append(left.pop(0))
+    return sorted(shares[rank])
+
+
 def print_line_and_leave_if_stalled(out, stalled):
     """the result line always comes out; a run in which any leg stalled then leaves with code 3 -- at once, without tearing the
     engine down (a device that stopped answering would hold the teardown too; the record is on stderr)"""
@@ -488,11 +545,17 @@ def dry_run(args, world, rank):
         dist.barrier()
     elapsed = sharding.reduce_elapsed(0.001 * (rank + 1))
     ranks = sharding.sum_units(1)
+    mine = rank_cpu_budget(world, rank)
+    gathered = [mine]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        out = {"dry_run": True, "n_gpus": world, "ranks_seen": int(ranks), "steps": args.steps, "warmup": args.warmup, "elapsed_max_s": elapsed}
+        out = {"dry_run": True, "n_gpus": world, "ranks_seen": int(ranks), "steps": args.steps, "warmup": args.warmup, "elapsed_max_s": elapsed,
+               "cpu_budget": gathered}
         stalled = os.environ.get("SK_BENCH_DRY_STALL") == "1"  # the test of the exit code: as if the end_to_end extra had stalled
         if stalled:
             out["end_to_end"] = {"error": "stalled"}
@@ -557,6 +620,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if os.environ.get("SK_BENCH_DRY_RUN") == "1":
         return dry_run(args, world, rank)
+    if world > 1:  # each rank on its own share of the host's cores, beside its GPU (before any thread exists)
+        try:
+            os.sched_setaffinity(0, rank_cpu_budget(world, local_rank))
+        except OSError:
+            pass
 
     # child processes are started before anything here initialises the GPU
     all_cores = whole_decode = None

@@ -26,6 +26,32 @@ def test_gpus_2_without_a_launcher_starts_two_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 4 and out["warmup"] == 1
     assert abs(out["elapsed_max_s"] - 0.002) < 1e-9   # max over ranks, not rank 0's own 0.001
+    # every rank has its own share of the host's cores: disjoint, inside the affinity set, equal to within one core
+    a, b = out["cpu_budget"]
+    assert a and b and not set(a) & set(b) and set(a) | set(b) <= set(os.sched_getaffinity(0))
+    assert abs(len(a) - len(b)) <= 1
+
+
+def test_rank_core_budgets_follow_the_gpus_numa_nodes():
+    sys.path.insert(0, ROOT)
+    import bench
+    cpus = list(range(64))
+    node_of = lambda c: c // 32
+    real = bench.cpu_node
+    bench.cpu_node = node_of
+    try:
+        shares = [bench.rank_cpu_budget(8, r, gpu_nodes=[0, 0, 0, 0, 1, 1, 1, 1], cpus=cpus) for r in range(8)]
+        assert all(len(s) == 8 for s in shares) and sorted(c for s in shares for c in s) == cpus
+        assert all(node_of(c) == (0 if r < 4 else 1) for r, s in enumerate(shares) for c in s)
+        # a lopsided host (six GPUs on node 0): the ranks still get equal, disjoint shares; node 0's ranks spill onto node 1
+        shares = [bench.rank_cpu_budget(8, r, gpu_nodes=[0, 0, 0, 0, 0, 0, 1, 1], cpus=cpus) for r in range(8)]
+        assert all(len(s) == 8 for s in shares) and sorted(c for s in shares for c in s) == cpus
+        assert all(node_of(c) == 1 for s in shares[6:] for c in s)
+        # unknown topology, 7 cores for 2 ranks
+        shares = [bench.rank_cpu_budget(2, r, gpu_nodes=[-1, -1], cpus=list(range(7))) for r in range(2)]
+        assert sorted(len(s) for s in shares) == [3, 4] and not set(shares[0]) & set(shares[1])
+    finally:
+        bench.cpu_node = real
 
 
 def test_under_an_external_launcher_it_is_one_rank():
