@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc.json")  # rocprofv3 --pmc passes of this same workload (tools/profile_bench.sh)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc.json")  # rocprofv3 --pmc passes of this same workload (tools/profile_bench.sh)
 PMC_KERNEL = {"aac_synth_s16out": "k_aac_synth", "aac_synth": "k_aac_synth_f32out", "fir_pipeline_s16in": "k_fir_48k_16k"}
 
 
