@@ -10,8 +10,8 @@
 //   13818-3 2.4.3.2  MPEG-2 / 2.5 intensity: the same bands, ratios 1 : i0^n or i0^n : 1 (i0 = 2^-1/4 or 2^-1/2 by intensity_scale);
 //                the position that means "not intensity coded" is the largest value its field holds -- the host marks it (bit 7)
 //   2.4.3.4.8    short blocks: band-by-band [window][line] -> [line][window]
-// The scale-factor band offsets (Table B.8) and the pre-emphasis table are caller-supplied (sk_mp3_set_band_tables): this
-// tree does not hold them.  oracle/mp3_requant.py is the f64 checker; parity of the MP3 row is unpinned.
+// The scale-factor band offsets (Table B.8) and the pre-emphasis table are set per engine and rate (sk_mp3_set_band_tables;
+// sk_mp3_decoder_create installs the standard's, csrc/mp3_iso_tables.h).  oracle/mp3_bitstream.py (requantize_granule) is the f64 checker; what pins the MP3 row: DESIGN.md section 2.
 //
 // One wavefront per granule, four per block.  A lane takes the lines lane + 64 k (k < 9) of both channels in bitstream
 // order: band, window and destination from the engine's line map, requantised into registers; the highest
