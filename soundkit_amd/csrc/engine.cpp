@@ -34,7 +34,17 @@ constexpr float kPiF = 3.14159274101257324219f;  // f32 PI, as the reference use
 constexpr double kPi = 3.14159265358979323846;
 constexpr uint32_t kRsChunk = 4096;  // RESAMPLE_CHUNK_SIZE, soundkit-decoder lib.rs:79
 constexpr uint32_t kRsHist = 512;    // 2 * sinc_len kept in front of each chunk (rubato SincFixedIn buffer)
-constexpr uint32_t kRsRow = kRsChunk + kRsHist;
+// A resampler row holds the history and up to five chunks of a channel: [kRsBase unused | history 512 | chunk 0 | ... | chunk 4],
+// six blocks of 4096 floats.  Read with a row pitch of ONE block, chunk k of a row is the VIRTUAL row 6 * row + k of a launch:
+// it starts at block k, its history (the 512 samples in front of chunk k) sits kRsBase into it, and every complete chunk of
+// every stream of a call goes into one launch per resampler phase with the same per-chunk launch parameters a chunk-by-chunk
+// run would use -- so a stream's samples do not depend on how its input was cut into calls (an output's place in its matrix
+// tile is fixed by its chunk), while a tick needs one round of launches instead of one per chunk.
+constexpr uint32_t kRsBlocks = 6;
+constexpr uint32_t kRsBase = kRsChunk - kRsHist;          // 3584: where the history starts in a row
+constexpr uint32_t kRsWindow = kRsHist + kRsChunk;        // what one chunk's launch may read behind its virtual row's kRsBase
+constexpr uint32_t kRsMaxFill = (kRsBlocks - 1) * kRsChunk;  // samples a row can hold behind its history
+constexpr uint32_t kRsRow = kRsBlocks * kRsChunk;
 
 struct DevBuf {
     void *p = nullptr;
@@ -208,7 +218,7 @@ struct sk_engine {
 
     float *d_delay = nullptr;
     uint8_t *d_prev_shape = nullptr;
-    float *d_rs = nullptr;  // [max_streams * 2][kRsRow], allocated on first sk_resampler_open
+    float *d_rs = nullptr;  // [max_streams * 2][kRsRow] (kRsBlocks blocks of 4096), allocated on first sk_resampler_open
     // MP3 hybrid synthesis (mp3_hybrid.hip): tables and per-(stream, channel) state, allocated on first use
     float *d_mp3_tables = nullptr, *d_mp3_state = nullptr;
     bool mp3_window_set = false;
@@ -2280,6 +2290,7 @@ struct RsCall {  // one stream's slot in a batched call
     uint32_t consumed = 0;  // input frames appended so far
     uint32_t produced = 0;  // output frames produced so far
     uint32_t trim = 0;      // flush only: frames to drop from the end of the last chunk's output
+    std::vector<std::pair<uint32_t, uint32_t>> outs;  // (column, frames) of every chunk processed so far, in order: the AudioData boundaries
 };
 
 // bump allocator over a device scratch buffer for the small per-round arrays
@@ -2303,213 +2314,257 @@ struct AuxArena {
     }
 };
 
-// Runs every stream of `ready` (all with a full chunk) through its resampler, grouped by resampler
-// state so that one launch covers a whole group.  Outputs go to d_out (row stride out_stride) at each
-// stream's `produced` column; history slides; state advances.
+// Runs every COMPLETE chunk of every stream of `ready` through its resampler: one launch per resampler state that chunks share
+// (the three phases of the 48 -> 16 k FIR; one launch for every other ratio, with a time-index set per row), the chunks as virtual
+// rows (kRsBlocks above).  Outputs go to d_out (row stride out_stride) behind each stream's `produced` column, chunk after chunk;
+// what is left of the row (history + incomplete chunk) slides to the front; state advances.
 int rs_process_ready(sk_engine *e, std::vector<RsCall> &calls, const std::vector<size_t> &ready, float *d_out,
                      size_t out_stride, uint32_t out_cap, AuxArena &aux) {
+    struct Item {  // one complete chunk of one stream
+        size_t ci;
+        uint32_t k, col, count, set_index;
+        double last, new_last;
+        uint64_t chunk_no;
+        int table;
+        bool fir;
+    };
     struct Key {
         int table;
-        uint64_t chunks;
         double last;
-        bool operator<(const Key &o) const {
-            if (table != o.table) return table < o.table;
-            if (chunks != o.chunks) return chunks < o.chunks;
-            return last < o.last;
-        }
+        bool operator<(const Key &o) const { return table != o.table ? table < o.table : last < o.last; }
     };
-    std::map<Key, std::vector<size_t>> groups;
-    for (size_t ci : ready) {
-        const StreamInfo &s = e->streams[calls[ci].id];
-        // the integer-step FIR only cares where the chunk's first output sits relative to the chunk (three phases);
-        // the generic kernel's f64 index sequence depends on the whole history
-        // the generic kernel takes a time-index set per row, so streams of any age share one launch
-        const bool fir = s.rs_in_hz == 48000 && s.rs_out_hz == 16000;
-        groups[Key{s.rs_table, 0, fir ? s.rs_last_index : 0.0}].push_back(ci);
-    }
+    struct Phase {  // what a 48 -> 16 k chunk that starts at a given time index produces
+        uint32_t count;
+        double new_last, idx0;
+    };
+    std::vector<Item> items;
+    std::map<Key, Phase> phases;
+    std::map<Key, std::vector<size_t>> groups;  // -> indices into items
     std::vector<double> idx, starts;
-    std::vector<uint32_t> row_map, out_off, row_set, set_count, counts, g_map, g_off, g_set;
-    std::vector<double> new_lasts;
-    std::vector<sk::RowCopy> slides;
+    for (size_t ci : ready) {
+        RsCall &c = calls[ci];
+        const StreamInfo &s = e->streams[c.id];
+        const RatioTable &tab = e->ratio_tables[(size_t)s.rs_table];
+        const bool fir = s.rs_in_hz == 48000 && s.rs_out_hz == 16000;
+        const uint32_t n_chunks = s.rs_fill / kRsChunk;
+        double last = s.rs_last_index;
+        uint32_t col = c.produced;
+        for (uint32_t k = 0; k < n_chunks; ++k) {
+            Item it{};
+            it.ci = ci, it.k = k, it.col = col, it.last = last, it.chunk_no = s.rs_chunks + k, it.table = s.rs_table, it.fir = fir;
+            if (fir) {  // the integer-step FIR only cares where the chunk's first output sits relative to the chunk (three phases)
+                const Key key{s.rs_table, last};
+                auto ph = phases.find(key);
+                if (ph == phases.end()) {
+                    double new_last = 0.0;
+                    chunk_indices(tab.ratio, last, kRsChunk, idx, &new_last);
+                    ph = phases.emplace(key, Phase{(uint32_t)idx.size(), new_last, idx.empty() ? 0.0 : idx[0]}).first;
+                }
+                it.count = ph->second.count;
+                it.new_last = ph->second.new_last;
+                groups[key].push_back(items.size());
+            } else {  // the generic kernel takes a time-index set per row: chunks of any age share one launch (sets filled in below)
+                groups[Key{s.rs_table, 0.0}].push_back(items.size());
+            }
+            if (!fir) {
+                // count and new_last come from the chunk's index set; the shared walk is extended here, pointers are taken later
+                RatioTable &mut_tab = e->ratio_tables[(size_t)s.rs_table];
+                const IndexSet &set = streaming_set(mut_tab, it.chunk_no);
+                if (set.last_in == last) {
+                    it.count = set.count, it.new_last = set.new_last;
+                } else {  // a stream whose state does not sit on the shared walk
+                    IndexSet own;
+                    make_index_set(tab.ratio, last, kRsChunk, own);
+                    it.count = own.count, it.new_last = own.new_last;
+                }
+            }
+            if ((uint64_t)col + it.count > out_cap) return SK_ERR_INVALID_ARG;
+            col += it.count;
+            last = it.new_last;
+            items.push_back(it);
+        }
+    }
+    std::vector<uint32_t> row_map, out_off, row_set, set_count, g_map, g_off, g_set;
     for (auto &g : groups) {
         RatioTable &tab = e->ratio_tables[(size_t)g.first.table];
         const bool fir = tab.in_hz == 48000 && tab.out_hz == 16000;
-        // outputs and next last_index of every call of the group
-        counts.assign(g.second.size(), 0);
-        new_lasts.assign(g.second.size(), 0.0);
         std::map<uint64_t, uint32_t> local_set;  // generic: chunk number -> set index in this launch
         std::vector<const IndexSet *> sets;
-        std::vector<IndexSet> odd_sets;          // streams whose state does not sit on the shared walk
+        std::vector<IndexSet> odd_sets;          // chunks whose state does not sit on the shared walk
         odd_sets.reserve(g.second.size());
         uint32_t max_count = 0;
-        if (fir) {
-            double new_last = 0.0;
-            chunk_indices(tab.ratio, g.first.last, kRsChunk, idx, &new_last);
-            for (size_t k = 0; k < g.second.size(); ++k) {
-                counts[k] = (uint32_t)idx.size();
-                new_lasts[k] = new_last;
-            }
-            max_count = (uint32_t)idx.size();
-        }
         if (!fir) {  // extend the shared walk first: the loop below keeps pointers into it
             uint64_t deepest = 0;
-            for (size_t ci : g.second) deepest = std::max(deepest, e->streams[calls[ci].id].rs_chunks);
+            for (size_t ii : g.second) deepest = std::max(deepest, items[ii].chunk_no);
             (void)streaming_set(tab, deepest);
         }
         row_map.clear();
         out_off.clear();
         row_set.clear();
-        for (size_t k = 0; k < g.second.size(); ++k) {
-            RsCall &c = calls[g.second[k]];
-            uint32_t set_index = 0;
+        for (size_t ii : g.second) {
+            Item &it = items[ii];
+            const RsCall &c = calls[it.ci];
             if (!fir) {
-                const StreamInfo &st = e->streams[c.id];
-                const IndexSet *set = &streaming_set(tab, st.rs_chunks);
-                if (set->last_in != st.rs_last_index) {
+                const IndexSet *set = &streaming_set(tab, it.chunk_no);
+                if (set->last_in != it.last) {
                     odd_sets.emplace_back();
-                    make_index_set(tab.ratio, st.rs_last_index, kRsChunk, odd_sets.back());
+                    make_index_set(tab.ratio, it.last, kRsChunk, odd_sets.back());
                     set = &odd_sets.back();
-                    set_index = (uint32_t)sets.size();
+                    it.set_index = (uint32_t)sets.size();
                     sets.push_back(set);
                 } else {
-                    auto it = local_set.find(st.rs_chunks);
-                    if (it == local_set.end()) {
-                        it = local_set.emplace(st.rs_chunks, (uint32_t)sets.size()).first;
+                    auto f = local_set.find(it.chunk_no);
+                    if (f == local_set.end()) {
+                        f = local_set.emplace(it.chunk_no, (uint32_t)sets.size()).first;
                         sets.push_back(set);
                     }
-                    set_index = it->second;
+                    it.set_index = f->second;
                 }
-                counts[k] = set->count;
-                new_lasts[k] = set->new_last;
-                max_count = std::max(max_count, set->count);
             }
-            if ((uint64_t)c.produced + counts[k] > out_cap) return SK_ERR_INVALID_ARG;
+            max_count = std::max(max_count, it.count);
             for (uint32_t ch = 0; ch < c.channels; ++ch) {
-                const uint64_t off = (uint64_t)(c.row0 + ch) * out_stride + c.produced;
+                const uint64_t off = (uint64_t)(c.row0 + ch) * out_stride + it.col;
                 if (off > 0xffffffffull) return SK_ERR_INVALID_ARG;
-                row_map.push_back(c.id * 2 + ch);
+                row_map.push_back((c.id * 2 + ch) * kRsBlocks + it.k);  // the chunk as a virtual row of one block's pitch
                 out_off.push_back((uint32_t)off);
-                row_set.push_back(set_index);
+                row_set.push_back(it.set_index);
             }
         }
-        if (max_count) {
-            const uint32_t *d_map = nullptr, *d_off = nullptr;
-            uint32_t n_launch_rows = (uint32_t)row_map.size();
-            if (fir) {
-                SK_HIP(aux.put(row_map, e->stream, &d_map), "upload row map");
-                SK_HIP(aux.put(out_off, e->stream, &d_off), "upload out offsets");
-                // integer time base: output m sits at index 3m - 125.  Any origin works as long as output
-                // out_first + j reads the row at chunk-relative index idx[0] + 3j (+ kRsHist of history in front)
-                // ... and the origin that makes the row's sample 0 fall on a multiple of four lets the kernel stage with
-                // 16-byte loads (a function of the stream's own phase only, so a stream's samples do not depend on
-                // which launch it shares)
-                const int64_t fixed = 125 + (int64_t)std::llround(idx[0]) + (int64_t)kRsHist;
-                uint32_t first = 1024;
-                while ((3 * (int64_t)first - fixed) & 3) ++first;
-                sk::FirArgs a = fir_base(e);
-                a.in = e->d_rs;
-                a.in_stride = kRsRow;
-                a.rows = (uint32_t)row_map.size();
-                a.in_frames = kRsRow;
-                a.in_origin = (int32_t)(3 * (int64_t)first - 125 - (int64_t)std::llround(idx[0]) - (int64_t)kRsHist);
-                a.out = d_out;
-                a.out_stride = 0;
-                a.row_map = d_map;
-                a.out_off = d_off;
-                a.out_first = first;
-                a.out_count = max_count;
-                SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch streaming fir");
-            } else {
-                uint32_t stride = 0;
-                for (const IndexSet *set : sets) stride = std::max<uint32_t>(stride, (uint32_t)set->starts.size());
-                starts.assign((size_t)stride * sets.size(), 0.0);
-                set_count.clear();
-                for (size_t i = 0; i < sets.size(); ++i) {
-                    std::copy(sets[i]->starts.begin(), sets[i]->starts.end(), starts.begin() + (ptrdiff_t)(i * stride));
-                    set_count.push_back(sets[i]->count);
+        if (!max_count) continue;
+        const uint32_t *d_map = nullptr, *d_off = nullptr;
+        uint32_t n_launch_rows = (uint32_t)row_map.size();
+        if (fir) {
+            SK_HIP(aux.put(row_map, e->stream, &d_map), "upload row map");
+            SK_HIP(aux.put(out_off, e->stream, &d_off), "upload out offsets");
+            // integer time base: output m sits at index 3m - 125.  Any origin works as long as output
+            // out_first + j reads the row at chunk-relative index idx[0] + 3j (+ kRsBase + kRsHist of pad and history in front)
+            // ... and the origin that makes the row's sample 0 fall on a multiple of four lets the kernel stage with
+            // 16-byte loads (a function of the chunk's own phase only, so a stream's samples do not depend on
+            // which launch it shares, nor on how many chunks of it the launch holds)
+            const double idx0 = phases.at(g.first).idx0;
+            const int64_t fixed = 125 + (int64_t)std::llround(idx0) + (int64_t)kRsHist;
+            uint32_t first = 1024;
+            while ((3 * (int64_t)first - fixed) & 3) ++first;
+            sk::FirArgs a = fir_base(e);
+            a.in = e->d_rs;
+            a.in_stride = kRsChunk;
+            a.rows = (uint32_t)row_map.size();
+            a.in_frames = kRsBase + kRsWindow;
+            a.in_origin = (int32_t)(3 * (int64_t)first - 125 - (int64_t)std::llround(idx0) - (int64_t)kRsHist - (int64_t)kRsBase);
+            a.out = d_out;
+            a.out_stride = 0;
+            a.row_map = d_map;
+            a.out_off = d_off;
+            a.out_first = first;
+            a.out_count = max_count;
+            SK_HIP(sk::launch_fir_48k_16k(a, e->stream), "launch streaming fir");
+        } else {
+            uint32_t stride = 0;
+            for (const IndexSet *set : sets) stride = std::max<uint32_t>(stride, (uint32_t)set->starts.size());
+            starts.assign((size_t)stride * sets.size(), 0.0);
+            set_count.clear();
+            for (size_t i = 0; i < sets.size(); ++i) {
+                std::copy(sets[i]->starts.begin(), sets[i]->starts.end(), starts.begin() + (ptrdiff_t)(i * stride));
+                set_count.push_back(sets[i]->count);
+            }
+            // the generic kernel's workgroups take 64 consecutive rows that share their index set: rows ordered by set,
+            // each set's rows padded to a multiple of that with rows that read and write nothing (row_map 0xffffffff)
+            {
+                const uint32_t per_block = sk::sinc_rows_per_block();
+                std::vector<uint32_t> order(row_map.size());
+                for (uint32_t r = 0; r < order.size(); ++r) order[r] = r;
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return row_set[x] < row_set[y]; });
+                g_map.clear(), g_off.clear(), g_set.clear();  // function-level: they outlive the asynchronous uploads below
+                for (size_t k = 0; k < order.size(); ++k) {
+                    if (k > 0 && row_set[order[k]] != row_set[order[k - 1]])
+                        while (g_map.size() % per_block) {
+                            g_map.push_back(0xffffffffu);
+                            g_off.push_back(0);
+                            g_set.push_back(g_set.back());
+                        }
+                    g_map.push_back(row_map[order[k]]);
+                    g_off.push_back(out_off[order[k]]);
+                    g_set.push_back(row_set[order[k]]);
                 }
-                // the generic kernel's workgroups take 64 consecutive rows that share their index set: rows ordered by set,
-                // each set's rows padded to a multiple of that with rows that read and write nothing (row_map 0xffffffff)
-                {
-                    const uint32_t per_block = sk::sinc_rows_per_block();
-                    std::vector<uint32_t> order(row_map.size());
-                    for (uint32_t r = 0; r < order.size(); ++r) order[r] = r;
-                    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return row_set[x] < row_set[y]; });
-                    g_map.clear(), g_off.clear(), g_set.clear();  // function-level: they outlive the asynchronous uploads below
-                    for (size_t k = 0; k < order.size(); ++k) {
-                        if (k > 0 && row_set[order[k]] != row_set[order[k - 1]])
-                            while (g_map.size() % per_block) {
-                                g_map.push_back(0xffffffffu);
-                                g_off.push_back(0);
-                                g_set.push_back(g_set.back());
-                            }
-                        g_map.push_back(row_map[order[k]]);
-                        g_off.push_back(out_off[order[k]]);
-                        g_set.push_back(row_set[order[k]]);
-                    }
-                    SK_HIP(aux.put(g_map, e->stream, &d_map), "upload row map (grouped by index set)");
-                    SK_HIP(aux.put(g_off, e->stream, &d_off), "upload out offsets (grouped by index set)");
-                    row_set.swap(g_set);  // uploaded below; row_map stays the list of real rows (the history slide uses it)
-                    n_launch_rows = (uint32_t)g_map.size();
-                }
-                const double *d_starts = nullptr;
-                const uint32_t *d_count = nullptr, *d_set = nullptr;
-                SK_HIP(aux.put(starts, e->stream, &d_starts), "upload time indices");
-                SK_HIP(aux.put(set_count, e->stream, &d_count), "upload output counts");
-                SK_HIP(aux.put(row_set, e->stream, &d_set), "upload row sets");
-                sk::SincArgs a{};
-                a.in = e->d_rs;
-                a.in_stride = kRsRow;
-                a.out = d_out;
-                a.out_stride = 0;
-                a.sincs = tab.d_sincs;
-                a.set_starts = d_starts;
-                a.set_count = d_count;
-                a.row_set = d_set;
-                a.starts_stride = stride;
-                a.step = 1.0 / tab.ratio;
-                a.row_map = d_map;
-                a.out_off = d_off;
-                a.rows = n_launch_rows;
-                a.in_frames = kRsRow;
-                a.out_count = max_count;
-                a.in_origin = -(int32_t)kRsHist;  // indices are relative to the chunk start; the row starts 512 earlier
-                a.n_sets = (uint32_t)sets.size();
-                a.exact = e->sinc_exact;
-                if (!a.exact) {
-                    const size_t want = sk::sinc_mfma_scratch_bytes(a.n_sets, max_count, a.step);
-                    if (want) {  // a failed allocation is an error, not another arithmetic (see sk_downsample_f32_dev)
-                        SK_HIP(e->sinc_scratch.reserve(want), "alloc resampler tap fragments");
-                        a.scratch = e->sinc_scratch.p, a.scratch_bytes = e->sinc_scratch.cap;
-                    }
-                }
-                const uint32_t rows_per_launch = 65535u * sk::sinc_rows_per_block();  // grid.y limit; a multiple of the block's rows
-                for (uint32_t r0 = 0; r0 < a.rows; r0 += rows_per_launch) {
-                    sk::SincArgs part = a;
-                    part.rows = std::min<uint32_t>(rows_per_launch, a.rows - r0);
-                    part.row_map = d_map + r0;
-                    part.out_off = d_off + r0;
-                    part.row_set = d_set + r0;
-                    SK_HIP(sk::launch_sinc_resample(part, e->stream), "launch sinc resample");
+                SK_HIP(aux.put(g_map, e->stream, &d_map), "upload row map (grouped by index set)");
+                SK_HIP(aux.put(g_off, e->stream, &d_off), "upload out offsets (grouped by index set)");
+                row_set.swap(g_set);
+                n_launch_rows = (uint32_t)g_map.size();
+            }
+            const double *d_starts = nullptr;
+            const uint32_t *d_count = nullptr, *d_set = nullptr;
+            SK_HIP(aux.put(starts, e->stream, &d_starts), "upload time indices");
+            SK_HIP(aux.put(set_count, e->stream, &d_count), "upload output counts");
+            SK_HIP(aux.put(row_set, e->stream, &d_set), "upload row sets");
+            sk::SincArgs a{};
+            a.in = e->d_rs;
+            a.in_stride = kRsChunk;
+            a.out = d_out;
+            a.out_stride = 0;
+            a.sincs = tab.d_sincs;
+            a.set_starts = d_starts;
+            a.set_count = d_count;
+            a.row_set = d_set;
+            a.starts_stride = stride;
+            a.step = 1.0 / tab.ratio;
+            a.row_map = d_map;
+            a.out_off = d_off;
+            a.rows = n_launch_rows;
+            a.in_frames = kRsBase + kRsWindow;
+            a.out_count = max_count;
+            a.in_origin = -(int32_t)(kRsHist + kRsBase);  // indices are relative to the chunk start; the virtual row starts kRsBase + 512 earlier
+            a.n_sets = (uint32_t)sets.size();
+            a.exact = e->sinc_exact;
+            if (!a.exact) {
+                const size_t want = sk::sinc_mfma_scratch_bytes(a.n_sets, max_count, a.step);
+                if (want) {  // a failed allocation is an error, not another arithmetic (see sk_downsample_f32_dev)
+                    SK_HIP(e->sinc_scratch.reserve(want), "alloc resampler tap fragments");
+                    a.scratch = e->sinc_scratch.p, a.scratch_bytes = e->sinc_scratch.cap;
                 }
             }
+            const uint32_t rows_per_launch = 65535u * sk::sinc_rows_per_block();  // grid.y limit; a multiple of the block's rows
+            for (uint32_t r0 = 0; r0 < a.rows; r0 += rows_per_launch) {
+                sk::SincArgs part = a;
+                part.rows = std::min<uint32_t>(rows_per_launch, a.rows - r0);
+                part.row_map = d_map + r0;
+                part.out_off = d_off + r0;
+                part.row_set = d_set + r0;
+                SK_HIP(sk::launch_sinc_resample(part, e->stream), "launch sinc resample");
+            }
         }
-        // slide: the last 512 samples of the chunk become the next chunk's history (rubato copy_within)
-        slides.clear();
-        for (uint32_t phys : row_map) slides.push_back(sk::RowCopy{(uint64_t)phys * kRsRow + kRsChunk, (uint64_t)phys * kRsRow, kRsHist, 0});
-        const sk::RowCopy *d_slides = nullptr;
-        SK_HIP(aux.put(slides, e->stream, &d_slides), "upload slide jobs");
-        for (size_t j0 = 0; j0 < slides.size(); j0 += 65535)
-            SK_HIP(sk::launch_row_copies(e->d_rs, e->d_rs, d_slides + j0, (uint32_t)std::min<size_t>(65535, slides.size() - j0),
-                                         e->stream), "slide resampler history");
-        for (size_t k = 0; k < g.second.size(); ++k) {
-            RsCall &c = calls[g.second[k]];
-            StreamInfo &s = e->streams[c.id];
-            s.rs_chunks += 1;
-            s.rs_last_index = new_lasts[k];
-            s.rs_fill = 0;
-            c.produced += counts[k];
+    }
+    // state, AudioData boundaries, and the slide: what is behind the processed chunks -- their last 512 samples (the next chunk's
+    // history, rubato's copy_within) and the incomplete chunk -- moves to the front of the row.  Source and destination overlap
+    // only when one chunk went and more than 3584 samples stay: such a row is moved in two launches, the second for the part whose
+    // destination the first one's source covered.
+    std::vector<sk::RowCopy> slides, tails;
+    for (const Item &it : items) {
+        RsCall &c = calls[it.ci];
+        c.outs.emplace_back(it.col, it.count);
+        c.produced = it.col + it.count;
+    }
+    for (size_t ci : ready) {
+        RsCall &c = calls[ci];
+        StreamInfo &s = e->streams[c.id];
+        const uint32_t n_chunks = s.rs_fill / kRsChunk;
+        if (!n_chunks) continue;
+        const uint32_t rest = s.rs_fill - n_chunks * kRsChunk, len = kRsHist + rest, gap = n_chunks * kRsChunk;
+        for (uint32_t ch = 0; ch < c.channels; ++ch) {
+            const uint64_t row = ((uint64_t)c.id * 2 + ch) * kRsRow + kRsBase;
+            slides.push_back(sk::RowCopy{row + gap, row, std::min(len, gap), 0});
+            if (len > gap) tails.push_back(sk::RowCopy{row + 2ull * gap, row + gap, len - gap, 0});
         }
+        s.rs_chunks += n_chunks;
+        s.rs_fill = rest;
+    }
+    for (const Item &it : items) e->streams[calls[it.ci].id].rs_last_index = it.new_last;  // items of a stream are in chunk order: the last one wins
+    for (std::vector<sk::RowCopy> *jobs : {&slides, &tails}) {
+        if (jobs->empty()) continue;
+        const sk::RowCopy *d_jobs = nullptr;
+        SK_HIP(aux.put(*jobs, e->stream, &d_jobs), "upload slide jobs");
+        for (size_t j0 = 0; j0 < jobs->size(); j0 += 65535)
+            SK_HIP(sk::launch_row_copies(e->d_rs, e->d_rs, d_jobs + j0, (uint32_t)std::min<size_t>(65535, jobs->size() - j0), e->stream),
+                   "slide resampler rows");
     }
     return SK_OK;
 }
@@ -2561,15 +2616,15 @@ int sk_resampler_process_f32(sk_engine *e, const uint32_t *streams, uint32_t n_s
         for (size_t ci = 0; ci < calls.size(); ++ci) {
             RsCall &c = calls[ci];
             StreamInfo &s = e->streams[c.id];
-            const uint32_t take = std::min(frames - c.consumed, kRsChunk - s.rs_fill);
+            const uint32_t take = std::min(frames - c.consumed, kRsMaxFill - s.rs_fill);  // up to five chunks per round
             if (take) {
                 for (uint32_t ch = 0; ch < c.channels; ++ch)
                     jobs.push_back(sk::RowCopy{(uint64_t)(c.row0 + ch) * frames + c.consumed,
-                                               ((uint64_t)c.id * 2 + ch) * kRsRow + kRsHist + s.rs_fill, take, 0});
+                                               ((uint64_t)c.id * 2 + ch) * kRsRow + kRsBase + kRsHist + s.rs_fill, take, 0});
                 s.rs_fill += take;
                 c.consumed += take;
             }
-            if (s.rs_fill == kRsChunk) ready.push_back(ci);
+            if (s.rs_fill >= kRsChunk) ready.push_back(ci);
         }
         if (jobs.empty() && ready.empty()) break;
         if (!jobs.empty()) {
@@ -2625,7 +2680,7 @@ int sk_resampler_flush_f32(sk_engine *e, const uint32_t *streams, uint32_t n_str
             c.trim = (uint32_t)std::llround(((double)padded * (double)s.rs_out_hz) / (double)s.rs_in_hz);
         for (uint32_t ch = 0; ch < c.channels && padded; ++ch)
             for (uint32_t o = 0; o < padded; o += 8192)
-                pads.push_back(sk::RowCopy{0, ((uint64_t)c.id * 2 + ch) * kRsRow + kRsHist + remaining + o,
+                pads.push_back(sk::RowCopy{0, ((uint64_t)c.id * 2 + ch) * kRsRow + kRsBase + kRsHist + remaining + o,
                                            std::min<uint32_t>(8192, padded - o), 0});
         s.rs_fill = kRsChunk;
         ready.push_back(ci);
@@ -3246,18 +3301,18 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 const TickCall &t = tc[call_stream[ci]];
                 StreamInfo &s = e->streams[c.id];
                 const uint32_t total_in = t.good * t.ulen;
-                uint32_t take = std::min(total_in - c.consumed, kRsChunk - s.rs_fill);
+                uint32_t take = std::min(total_in - c.consumed, kRsMaxFill - s.rs_fill);  // a tick's units of a stream: one round
                 while (take) {  // pieces never straddle a unit of the packed synthesis output
                     const uint32_t frame = c.consumed / t.ulen, within = c.consumed % t.ulen;
                     const uint32_t n = std::min(take, t.ulen - within);
                     for (uint32_t ch = 0; ch < c.channels; ++ch)  // MP3 rows hold q / 32768 already: a plain copy
                         jobs.push_back(sk::RowCopy{(unit_row(call_stream[ci], frame) + ch) * 1024 + within,
-                                                   ((uint64_t)c.id * 2 + ch) * kRsRow + kRsHist + s.rs_fill, n, t.mp3 ? 0u : 1u});
+                                                   ((uint64_t)c.id * 2 + ch) * kRsRow + kRsBase + kRsHist + s.rs_fill, n, t.mp3 ? 0u : 1u});
                     s.rs_fill += n;
                     c.consumed += n;
                     take -= n;
                 }
-                if (s.rs_fill == kRsChunk) ready.push_back(ci);
+                if (s.rs_fill >= kRsChunk) ready.push_back(ci);
             }
             if (jobs.empty() && ready.empty()) break;
             if (!jobs.empty()) {
@@ -3268,14 +3323,13 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                                                  e->stream), "tick append chunk");
             }
             if (!ready.empty()) {
-                before.clear();
-                for (size_t ci : ready) before.push_back(calls[ci].produced);
                 rc = rs_process_ready(e, calls, ready, d_res, res_stride, res_cap, aux);
                 if (rc != SK_OK) return rc;
-                for (size_t k = 0; k < ready.size(); ++k) {
-                    const RsCall &c = calls[ready[k]];
-                    if (c.produced > before[k])
-                        tc[call_stream[ready[k]]].chunks.emplace_back(before[k], c.produced - before[k]);
+                for (size_t ci : ready) {  // one AudioData per chunk (lib.rs:1979-2003), empty ones are not sent
+                    RsCall &c = calls[ci];
+                    for (const auto &o : c.outs)
+                        if (o.second) tc[call_stream[ci]].chunks.emplace_back(o.first, o.second);
+                    c.outs.clear();
                 }
             }
         }
@@ -3293,7 +3347,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 c.trim = (uint32_t)std::llround(((double)padded * (double)s.rs_out_hz) / (double)s.rs_in_hz);
             for (uint32_t ch = 0; ch < c.channels && padded; ++ch)
                 for (uint32_t o = 0; o < padded; o += 8192)
-                    pads.push_back(sk::RowCopy{0, ((uint64_t)c.id * 2 + ch) * kRsRow + kRsHist + remaining + o,
+                    pads.push_back(sk::RowCopy{0, ((uint64_t)c.id * 2 + ch) * kRsRow + kRsBase + kRsHist + remaining + o,
                                                std::min<uint32_t>(8192, padded - o), 0});
             s.rs_fill = kRsChunk;
             ready.push_back(ci);

@@ -184,6 +184,37 @@ def test_generic_ratio_streaming_matches_oracle(engine, oracle, in_hz, out_hz):
     assert got.shape[1] > 0 and rel_rms(got, want) < 1e-6 and np.abs(got - want).max() < 2e-6
 
 
+@pytest.mark.parametrize("in_hz,out_hz", [(48000, 16000), (44100, 16000), (16000, 48000)])
+def test_streaming_rows_of_several_chunks_and_overlapping_slides(engine, oracle, in_hz, out_hz):
+    """A call may bring up to five chunks of a stream at once (they run as virtual rows of one launch per phase), and what stays
+    behind them slides to the front of the row -- in two dependent launches when one chunk went and more than 3584 samples
+    stay (source and destination overlap).  Every size below hits one of those edges; the samples must not depend on it."""
+    rng = np.random.default_rng(in_hz + 7)
+    x = rng.uniform(-1, 1, (2, 120000)).astype(np.float32)
+    ours = decoder.StreamingResampler(in_hz, out_hz, 2, engine)
+    ref = oracle.StreamingResampler(in_hz, out_hz, 2)
+    whole = oracle.StreamingResampler(in_hz, out_hz, 2)
+    got, want, pos = [], [], 0
+    for size in [7700, 4000, 8190, 3, 20479, 20481, 4096 + 3585, 511, 24576, 1, 4095, 20480]:
+        blk = x[:, pos:pos + size]
+        pos += blk.shape[1]
+        a, b = ours.process(blk), ref.process(blk)
+        assert a.shape == b.shape, (size, a.shape, b.shape)
+        got.append(a), want.append(b)
+    a, b = ours.flush(), ref.flush()
+    assert a.shape == b.shape
+    got.append(a), want.append(b)
+    ours.close()
+    got, want = np.concatenate(got, 1), np.concatenate(want, 1)
+    assert rel_rms(got, want) < 1e-6 and np.abs(got - want).max() < 4e-6
+    # and bit for bit what one chunk at a time gives (the scheduler's promise: a stream's samples do not depend on its chunking)
+    one = decoder.StreamingResampler(in_hz, out_hz, 2, engine)
+    again = [one.process(x[:, p:min(p + 4096, pos)]) for p in range(0, pos, 4096)] + [one.flush()]
+    one.close()
+    assert np.array_equal(np.concatenate(again, 1), got)
+    del whole
+
+
 def test_streaming_batch_of_streams_one_call(engine, oracle):
     """Many streams per call (mono and stereo, two different ratios, unequal fill levels): every stream
     gets exactly what its own single-stream resampler would have produced."""
