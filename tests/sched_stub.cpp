@@ -678,9 +678,21 @@ static int scenario_mixed_codecs(sk_engine *e) {
     const uint32_t n = 12, loops = 2;
     std::vector<uint32_t> handles(n);
     for (auto &h : handles) CHECK(sk_pipeline_spawn(p, nullptr, &h) == SK_OK);
+    // streams 9 and 11: the MP3 file with bytes overwritten, cut out and inserted -- whatever the entropy thread makes of it (frames
+    // lost, the stream ended by an error), nothing may crash, stall or reach another stream (ASan / TSan runs of this harness)
+    std::vector<uint8_t> damaged[2] = {mp3_clip, mp3_clip};
+    for (int d = 0; d < 2; ++d) {
+        for (int hit = 0; hit < 40; ++hit) {
+            const size_t at = rnd() % damaged[d].size();
+            const uint32_t kind = rnd() % 3;
+            if (kind == 0) damaged[d][at] = (uint8_t)rnd();
+            else if (kind == 1) damaged[d].erase(damaged[d].begin() + (ptrdiff_t)at, damaged[d].begin() + (ptrdiff_t)std::min(damaged[d].size(), at + 1 + rnd() % 30));
+            else damaged[d].insert(damaged[d].begin() + (ptrdiff_t)at, (size_t)(1 + rnd() % 30), (uint8_t)rnd());
+        }
+    }
     std::thread feeder([&] {
         for (uint32_t i = 0; i < n; ++i) {
-            const std::vector<uint8_t> &src = (i & 1) ? mp3_clip : clip;
+            const std::vector<uint8_t> &src = i == 9 ? damaged[0] : (i == 11 ? damaged[1] : ((i & 1) ? mp3_clip : clip));
             for (uint32_t loop = 0; loop < loops; ++loop) {
                 size_t at = 0;
                 while (at < src.size()) {
@@ -688,6 +700,7 @@ static int scenario_mixed_codecs(sk_engine *e) {
                     int rc;
                     while ((rc = sk_pipeline_send(p, handles[i], src.data() + at, len)) == SK_PIPE_INPUT_FULL)
                         std::this_thread::sleep_for(std::chrono::microseconds(100));
+                    if (rc == SK_PIPE_CLOSED && (i == 9 || i == 11)) break;  // a damaged stream may have been ended by its error
                     if (rc != SK_OK) std::abort();
                     at += len;
                 }
@@ -732,12 +745,17 @@ static int scenario_mixed_codecs(sk_engine *e) {
     }
     feeder.join();
     for (uint32_t i = 0; i < n; ++i) {
+        if (i == 9 || i == 11) {  // damaged: at most one error, at most the undamaged count, what arrived is in order
+            CHECK(errors[i] <= 1 && got[i].size() <= 82u * loops);
+            for (size_t k = 0; k < got[i].size(); ++k) CHECK(got[i][k].unit == k);
+            continue;
+        }
         CHECK(errors[i] == 0);
         // the MP3 file twice in a row: the second pass's first frame reaches into a reservoir that holds the first pass's tail,
         // which is what a decoder makes of a concatenation -- every frame still decodes (82 granules per pass)
         CHECK(got[i].size() == ((i & 1) ? 82u * loops : 48u * loops));
         for (size_t k = 0; k < got[i].size(); ++k) CHECK(got[i][k].unit == k);
-        if (i >= 2 && (i & 1)) {  // every MP3 stream got the same bytes: the same sums in the same order (the stand-in does not sum AAC units of a mixed tick)
+        if (i >= 2 && (i & 1) && i != 11) {  // every MP3 stream got the same bytes: the same sums in the same order (the stand-in does not sum AAC units of a mixed tick)
             CHECK(got[i].size() == got[i - 2].size());
             for (size_t k = 0; k < got[i].size(); ++k) {
                 if (got[i][k].sum != got[i - 2][k].sum) std::fprintf(stderr, "stream %u unit %zu: sum %08x, stream %u has %08x\n", i, k, got[i][k].sum, i - 2, got[i - 2][k].sum);
