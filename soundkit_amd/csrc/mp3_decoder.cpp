@@ -20,7 +20,11 @@ struct sk_mp3_codebook {
     struct Trie {
         std::vector<int32_t> next;  // [node][bit]: > 0 child node, <= 0: -(symbol) - 1 ... 0 = empty
         uint8_t xlen = 0, linbits = 0;
+        // the next kLutBits bits of the stream -> (length << 16 | symbol + 1) of the code they start with, 0 if that code is longer
+        // (or the bits are no code): one look-up for the short codes, which are the frequent ones; the trie walk for the rest
+        std::vector<uint32_t> lut;
     };
+    static constexpr int kLutBits = 10;
     Trie big[32], count1[2];
     sk_mp3_tables t;  // hlen / hcod pointers inside are not kept (copied into the tries)
 };
@@ -57,7 +61,7 @@ bool trie_add(sk_mp3_codebook::Trie &t, uint32_t code, int len, int symbol) {
     return false;
 }
 
-struct Bits {
+struct Bits {  // bits past the end read as zero, and the position keeps counting (the callers compare it with the granule's end)
     const uint8_t *p;
     size_t len_bits;
     size_t pos = 0;
@@ -70,16 +74,59 @@ struct Bits {
         ++pos;
         return v;
     }
+    // the next n <= 24 bits without consuming them
+    uint32_t peek(int n) const {
+        const size_t byte = pos >> 3, total = (len_bits + 7) >> 3;
+        uint32_t w;
+        if (byte + 4 <= total) {
+            w = ((uint32_t)p[byte] << 24) | ((uint32_t)p[byte + 1] << 16) | ((uint32_t)p[byte + 2] << 8) | (uint32_t)p[byte + 3];
+        } else {
+            w = 0;
+            for (size_t i = 0; i < 4; ++i) w = (w << 8) | (byte + i < total ? (uint32_t)p[byte + i] : 0u);
+        }
+        return n ? (uint32_t)(w << (pos & 7)) >> (32 - n) : 0u;
+    }
     uint32_t get(int n) {
+        if (n == 0) return 0;
+        if (n <= 24 && pos + (size_t)n <= len_bits) {
+            const uint32_t v = peek(n);
+            pos += (size_t)n;
+            return v;
+        }
         uint32_t v = 0;
         for (int i = 0; i < n; ++i) v = (v << 1) | (uint32_t)bit();
         return v;
     }
 };
 
+void trie_build_lut(sk_mp3_codebook::Trie &t) {
+    constexpr int kBits = sk_mp3_codebook::kLutBits;
+    t.lut.assign((size_t)1 << kBits, 0u);
+    if (t.next.empty()) return;
+    for (uint32_t v = 0; v < (1u << kBits); ++v) {
+        int32_t node = 0;
+        for (int depth = 1; depth <= kBits; ++depth) {
+            const int32_t slot = t.next[(size_t)node * 2 + ((v >> (kBits - depth)) & 1u)];
+            if (slot < 0) {
+                t.lut[v] = ((uint32_t)depth << 16) | (uint32_t)(-slot);  // -slot = symbol + 1
+                break;
+            }
+            if (slot == kEmpty) break;
+            node = slot;
+        }
+    }
+}
+
 // -1: the bits are no code of this table
 int trie_read(const sk_mp3_codebook::Trie &t, Bits &b) {
     if (t.next.empty()) return -1;
+    if (b.pos + (size_t)sk_mp3_codebook::kLutBits <= b.len_bits) {
+        const uint32_t hit = t.lut[b.peek(sk_mp3_codebook::kLutBits)];
+        if (hit) {
+            b.pos += hit >> 16;
+            return (int)(hit & 0xffffu) - 1;
+        }
+    }
     int32_t node = 0;
     for (int depth = 0; depth < 33; ++depth) {
         const int32_t slot = t.next[(size_t)node * 2 + b.bit()];
@@ -272,10 +319,13 @@ int sk_mp3_codebook_create(const sk_mp3_tables *t, sk_mp3_codebook **out) try {
         dst.xlen = src.xlen, dst.linbits = src.linbits;
         for (int s = 0; s < src.xlen * src.xlen; ++s)
             if (!trie_add(dst, src.hcod[s], src.hlen[s], s)) return SK_MP3_INVALID;
+        trie_build_lut(dst);
     }
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 2; ++k) {
         for (int s = 0; s < 16; ++s)
             if (!trie_add(cb->count1[k], t->count1_hcod[k][s], t->count1_hlen[k][s], s)) return SK_MP3_INVALID;
+        trie_build_lut(cb->count1[k]);
+    }
     for (int i = 0; i < 16; ++i)
         if (t->slen[i][0] > 4 || t->slen[i][1] > 4) return SK_ERR_INVALID_ARG;  // a scale factor has at most 4 bits
     for (int row = 0; row < 6; ++row)
@@ -345,7 +395,8 @@ int sk_mp3_decode_main_data(const sk_mp3_codebook *cb, const sk_mp3_frame_info *
     sk::abi_enter();
     if (!cb || !h || !side || !out || (main_len && !main)) return SK_ERR_INVALID_ARG;
     if (side->granules < 1 || side->granules > 2 || side->channels < 1 || side->channels > 2) return SK_ERR_INVALID_ARG;
-    std::memset(out, 0, sizeof(sk_mp3_granule_data) * 4);
+    for (int gr = 0; gr < side->granules; ++gr)  // only the cells this frame has (one of four for an LSF mono frame)
+        for (int ch = 0; ch < side->channels; ++ch) std::memset(&out[gr][ch], 0, sizeof(sk_mp3_granule_data));
     size_t start = 0;
     int worst = SK_OK;
     for (int gr = 0; gr < side->granules; ++gr)
@@ -516,7 +567,7 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
         }
         // whatever became of the frame, its own main data is what later frames reach back into
         if (h.frame_bytes > head) reservoir.insert(reservoir.end(), frame + head, frame + h.frame_bytes);
-        if (reservoir.size() > kReservoirKept) reservoir.erase(reservoir.begin(), reservoir.end() - kReservoirKept);
+        if (reservoir.size() > 4 * kReservoirKept) reservoir.erase(reservoir.begin(), reservoir.end() - kReservoirKept);  // trimmed now and then, not per frame
         consumed = h.offset + h.frame_bytes;
         if (decodable && out_cap - samples < SK_MP3_MAX_SAMPLES_PER_FRAME) stopped = true;  // lib.rs:300-302
         if (k + 1 == n_found) consumed = scanned;  // every frame taken: garbage in front of an incomplete frame goes too

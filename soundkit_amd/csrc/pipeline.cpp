@@ -402,7 +402,7 @@ void parse_some_mp3(sk_lane *p, PStream &s, uint32_t limit, Parsed &r) {
             }
             // whatever became of the frame, its own main data is what later frames reach back into
             if (h.frame_bytes > head) s.mp3_reservoir.insert(s.mp3_reservoir.end(), frame + head, frame + h.frame_bytes);
-            if (s.mp3_reservoir.size() > kReservoirKept) s.mp3_reservoir.erase(s.mp3_reservoir.begin(), s.mp3_reservoir.end() - (ptrdiff_t)kReservoirKept);
+            if (s.mp3_reservoir.size() > 4 * kReservoirKept) s.mp3_reservoir.erase(s.mp3_reservoir.begin(), s.mp3_reservoir.end() - (ptrdiff_t)kReservoirKept);
             consumed = h.offset + h.frame_bytes;
             if (k + 1 == n_found && n_found < found.size()) consumed = scanned;
         }
