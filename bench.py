@@ -399,6 +399,7 @@ def end_to_end(args, eng, torch, dist, world, rank, device, emit=True, cpu_basel
                                                                      args.out_rate or src_rate,
                                                                      "mono" if args.out_channels == 1 else "source-channel", threads),
                    "streams_per_gpu": args.streams, "entropy_threads": threads, "feeder_threads": feeders, "host_cores": cores,
+                   "host_threads_on_numa_node": os.environ.get("SK_BENCH_PINNED_NODE"),
                    "front_end": ("host threads: MP3 framing, reservoir, scale factors, Huffman codes; i16 lines + granule records over PCIe; "
                                  "k_mp3_requant + k_mp3_hybrid on the device") if is_mp3 else
                                 ["host threads (f32 spectra over PCIe)", "gpu (k_aac_entropy_parse/link/finish, one access unit per lane)",
@@ -485,6 +486,28 @@ def gpu_numa_node(local_rank):
     except (OSError, ValueError):
         pass
     return -1
+
+
+def pin_to_gpu_node(torch, device_index):
+    """One rank on a two-socket host: keep this process's threads (entropy, submission, delivery, load generator) and the
+    pinned buffers they allocate on the GPU's own NUMA node.  The pool's cgroup bounds CPU TIME (16 cores' worth), not
+    placement: unpinned, the threads roam over both sockets and whole-decode runs of one build differ by 25 %.  Returns
+    the node, or None when the topology cannot be read (then nothing changes).  SK_BENCH_PIN=none switches it off."""
+    if os.environ.get("SK_BENCH_PIN") == "none":
+        return None
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        if node < 0:
+            return None
+        mine = [c for c in sorted(os.sched_getaffinity(0)) if cpu_node(c) == node]
+        if len(mine) < 4:
+            return None
+        os.sched_setaffinity(0, mine)
+        return node
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
 
 
 def cpu_node(cpu):
@@ -647,6 +670,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import soundkit_amd
+    pinned_node = pin_to_gpu_node(torch, local_rank) if world == 1 else None  # several ranks: rank_cpu_budget above already placed them
+    os.environ["SK_BENCH_PINNED_NODE"] = "none" if pinned_node is None else str(pinned_node)
     eng = soundkit_amd.Engine(local_rank, max(args.streams, 16))
     ext = torch.cuda.ExternalStream(eng.hip_stream, device=device)
 
