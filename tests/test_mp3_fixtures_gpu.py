@@ -115,3 +115,27 @@ def test_a_caller_supplied_codebook_of_the_same_tables_gives_the_same_bits(engin
         assert np.array_equal(decode_chunks(a, pieces(data, 4096)), decode_chunks(b, pieces(data, 4096)))
     finally:
         a.close(), b.close(), book.close()
+
+
+def test_a_mono_to_stereo_splice_never_mixes_the_two_in_one_launch(engine):
+    """Two streams back to back in one byte stream (channel count 1 -> 2): the decode call stops its launch in front of the first
+    stereo frame (granules queued for the mono engine stream must not be joined by ones for the stereo stream), the next call
+    goes on; nothing is lost, nothing comes out as silence, and every sample is what the two files give alone."""
+    mono, stereo = open(MONO, "rb").read(), open(STEREO, "rb").read()
+    alone = []
+    for data in (mono, stereo):
+        dec = mp3.Mp3Decoder(engine=engine)
+        try:
+            alone.append(decode_chunks(dec, [data], "i16", room=1 << 17))
+        finally:
+            dec.close()
+    for chunks in ([mono + stereo], pieces(mono + stereo, 5000), [mono[:9000], mono[9000:] + stereo[:700], stereo[700:]]):
+        dec = mp3.Mp3Decoder(engine=engine)
+        try:
+            got = decode_chunks(dec, chunks, "i16", room=1 << 17)
+            assert dec.frames_decoded() == 86 + 82
+            assert dec.sample_rate() == 16000 and dec.channels() == 1  # those of the first frame (soundkit-mp3/src/lib.rs:203-204)
+        finally:
+            dec.close()
+        assert got.size == alone[0].size + alone[1].size
+        assert np.array_equal(got[:alone[0].size], alone[0]) and np.array_equal(got[alone[0].size:], alone[1])
