@@ -256,7 +256,7 @@ int sk_mp3_hybrid_synthesize_f32_dev(sk_engine *, const sk_mp3_granule_desc *des
 enum sk_mp3_status {
     SK_MP3_NEED_MORE = -301,   /* not enough bytes for the header / side information / frame / reservoir */
     SK_MP3_NO_SYNC = -302,     /* not a frame header */
-    SK_MP3_UNSUPPORTED = -303, /* Layer I / II, free format; intensity stereo in mixed blocks */
+    SK_MP3_UNSUPPORTED = -303, /* Layer I / II; a free-format header whose frame length is not known (sk_mp3_scan_free measures it) */
     SK_MP3_INVALID = -304      /* a field combination the syntax forbids */
 };
 typedef struct sk_mp3_frame_info { /* nanomp3::FrameInfo (lib.rs:188-215 reads sample_rate, channels, bitrate) + framing */
@@ -283,6 +283,13 @@ int sk_mp3_parse_side_info(const uint8_t *frame, size_t len, const sk_mp3_frame_
 /* every frame of a byte stream (an ID3v2 tag in front is stepped over, garbage skipped, a header counts only if the next
  * frame's header follows it); *consumed = bytes up to the first incomplete frame */
 int sk_mp3_scan(const uint8_t *data, size_t len, sk_mp3_frame_info *frames, uint32_t cap, uint32_t *n_frames, size_t *consumed);
+/* The same with free-format streams (bit-rate index 0): the frame length is what lies between a header and the next two of the same
+ * stream, as minimp3's mp3d_find_frame measures it (nanomp3 is its port; soundkit-mp3/src/lib.rs:284).  *free_format_bytes carries
+ * that length (without the padding slot) from call to call, 0 at the start of a stream; sk_mp3_parse_header_free reads a header with
+ * it.  The decoder handles and the batch scheduler use these two. */
+int sk_mp3_scan_free(const uint8_t *data, size_t len, sk_mp3_frame_info *frames, uint32_t cap, uint32_t *n_frames, size_t *consumed,
+                     uint32_t *free_format_bytes);
+int sk_mp3_parse_header_free(const uint8_t *data, size_t len, uint32_t free_format_bytes, sk_mp3_frame_info *out);
 /* the bytes parts 2 + 3 of a frame are read from: main_data_begin bytes of the reservoir + the frame's own main data */
 int sk_mp3_main_data(const uint8_t *frame, size_t frame_len, const sk_mp3_frame_info *header, const sk_mp3_side_info *side,
                      const uint8_t *prev_main_data, size_t prev_len, uint8_t *out, size_t out_cap, size_t *out_len);

@@ -43,22 +43,31 @@ class Bits:
         return v
 
 
-def parse_header(b):
-    """4 bytes -> dict, or None if they are no Layer III frame header (free format counts as none)"""
+def parse_header(b, free_format_bytes=0):
+    """4 bytes -> dict, or None if they are no Layer III frame header.  A free-format header (bit-rate index 0) is one only when the
+    stream's frame length (without the padding slot) is given"""
     if len(b) < 4 or b[0] != 0xFF or (b[1] & 0xE0) != 0xE0:
         return None
     version_bits, layer_bits = (b[1] >> 3) & 3, (b[1] >> 1) & 3
     if version_bits == 1 or layer_bits != 1:
         return None
     bitrate_index, rate_index = b[2] >> 4, (b[2] >> 2) & 3
-    if bitrate_index in (0, 15) or rate_index == 3:
+    if bitrate_index == 15 or rate_index == 3 or (bitrate_index == 0 and not free_format_bytes):
         return None
     mpeg1 = version_bits == 3
-    kbps = (BITRATE_V1 if mpeg1 else BITRATE_V2)[bitrate_index]
     rate = SAMPLE_RATES[version_bits][rate_index]
     padding = (b[2] >> 1) & 1
+    if bitrate_index:
+        kbps = (BITRATE_V1 if mpeg1 else BITRATE_V2)[bitrate_index]
+        frame_bytes = (144 if mpeg1 else 72) * kbps * 1000 // rate + padding
+    else:
+        kbps = free_format_bytes * rate // ((144 if mpeg1 else 72) * 1000)
+        frame_bytes = free_format_bytes + padding
     mode = b[3] >> 6
     channels = 1 if mode == 3 else 2
+    side_info_bytes = (17 if channels == 1 else 32) if mpeg1 else (9 if channels == 1 else 17)
+    if frame_bytes < 4 + (0 if b[1] & 1 else 2) + side_info_bytes:
+        return None
     return {
         "version": 1 if mpeg1 else (2 if version_bits == 2 else 25),
         "has_crc": 0 if b[1] & 1 else 1,
@@ -70,8 +79,8 @@ def parse_header(b):
         "channels": channels,
         "granules": 2 if mpeg1 else 1,
         "samples_per_channel": 1152 if mpeg1 else 576,
-        "frame_bytes": (144 if mpeg1 else 72) * kbps * 1000 // rate + padding,
-        "side_info_bytes": (17 if channels == 1 else 32) if mpeg1 else (9 if channels == 1 else 17),
+        "frame_bytes": frame_bytes,
+        "side_info_bytes": side_info_bytes,
     }
 
 
@@ -116,16 +125,44 @@ def parse_side_info(frame, h):
     return out
 
 
-def scan(data):
-    """every frame of a byte string: [(offset, header)]"""
+def _same_stream(a, b):
+    """minimp3 hdr_compare: version, layer, sampling rate agree; both free format or neither"""
+    return b[0] == 0xFF and (a[1] ^ b[1]) & 0xFE == 0 and (a[2] ^ b[2]) & 0x0C == 0 and ((a[2] >> 4) == 0) == ((b[2] >> 4) == 0)
+
+
+def scan(data, free_format_bytes=None):
+    """every frame of a byte string: ([(offset, header)], bytes consumed).  With free_format_bytes (a one-element list: the state
+    carried between calls, [0] at the start of a stream) free-format frames are found too: their length is what lies between a header
+    and the next two of the same stream (minimp3 mp3d_find_frame; MAX_FREE_FORMAT_FRAME_SIZE 2304), measured once per stream."""
     pos = 0
     if len(data) >= 10 and data[:3] == b"ID3":
         pos = 10 + ((data[6] & 0x7F) << 21 | (data[7] & 0x7F) << 14 | (data[8] & 0x7F) << 7 | (data[9] & 0x7F))
         if data[5] & 0x10:
             pos += 10
     frames = []
+    ffb = free_format_bytes[0] if free_format_bytes else 0
     while pos + 4 <= len(data):
-        h = parse_header(data[pos:pos + 4])
+        here = data[pos:pos + 4]
+        h = parse_header(here, ffb)
+        if h is None and free_format_bytes is not None and not ffb and (here[2] >> 4) == 0 and parse_header(here, 4096) is not None:
+            wait = False
+            for k in range(4, 2304):
+                if pos + k + 4 > len(data):
+                    wait = True
+                    break
+                if not _same_stream(here, data[pos + k:pos + k + 4]):
+                    continue
+                fb = k - ((here[2] >> 1) & 1)
+                nxt_fb = fb + ((data[pos + k + 2] >> 1) & 1)
+                if pos + k + nxt_fb + 4 > len(data):
+                    wait = True
+                    break
+                if _same_stream(here, data[pos + k + nxt_fb:pos + k + nxt_fb + 4]):
+                    ffb = fb
+                    h = parse_header(here, ffb)
+                    break
+            if wait:
+                break
         if h is None:
             pos += 1
             continue
@@ -133,12 +170,16 @@ def scan(data):
         if nxt > len(data):
             break
         if nxt + 4 <= len(data):
-            follow = parse_header(data[nxt:nxt + 4])
+            follow = parse_header(data[nxt:nxt + 4], ffb)
             if follow is None or follow["version"] != h["version"] or follow["sample_rate"] != h["sample_rate"]:
+                if (here[2] >> 4) == 0:
+                    ffb = 0
                 pos += 1
                 continue
         frames.append((pos, h))
         pos = nxt
+    if free_format_bytes is not None:
+        free_format_bytes[0] = ffb
     return frames, pos
 
 
@@ -191,18 +232,44 @@ def requantize_granule(g, quant, long_offsets, short_offsets, pretab):
                 exponent = (ch["global_gain"] - 210 - 8 * ch["subblock_gain"][w]) / 4.0 - mult * (ch["scalefac_s"][band][w] & 0x7F)
             vals[c][i] = math.copysign(abs(q) ** (4.0 / 3.0) * 2.0 ** exponent, q) if q else 0.0
     if channels == 2 and (ms_stereo or intensity_stereo):
-        top = {}
+        # Which bands are intensity coded, as minimp3 decides it (nanomp3, the reference's decoder, is its port; minimp3.h
+        # L3_stereo_top_band, L3_intensity_stereo, L3_stereo_process): number the bands in the order of their scale factors --
+        # long bands, then short bands band by band and window by window (a mixed granule: its long bands, then its short bands;
+        # numbered from 64 here, only their order matters) -- and let bound[r % 3] be the highest number whose band holds a
+        # non-zero line of the right channel.  Long and
+        # mixed granules use max(bound) for all bands, short granules bound[window].  Band r is intensity coded iff
+        # r > bound and its position is legal.  The last band has no factor: it takes the position of the band below in its
+        # window if THAT one is above the bound, else 3 (MPEG-1) / 0 (13818-3) -- both channels alike.
+        lsf = bool(g.get("lsf"))
+        left_ch = g["ch"][0]
+        kind = (2 if left_ch["mixed_block_flag"] else 1) if left_ch["block_type"] == 2 else 0
+
+        def number(band, w):
+            band, w = int(band), int(w)
+            if w < 0:
+                return band
+            return (64 if kind == 2 else 0) + 3 * band + w
+        bound = [-1, -1, -1]
         for i in range(576):
             band, w, _ = where[1][i]
             if quant[1][i] != 0:
-                top[w] = max(top.get(w, -1), band)
+                r = number(band, w)
+                bound[r % 3] = max(bound[r % 3], r)
+        if kind != 1:
+            bound = [max(bound)] * 3
         right = g["ch"][1]
         for i in range(576):
             band, w, _ = where[0][i]
             done = False
-            if intensity_stereo and band > top.get(w, -1):
-                pos = right["scalefac_l"][min(band, 20)] if w < 0 else right["scalefac_s"][min(band, 11)][w]
-                if g.get("lsf"):
+            r = number(band, w)
+            if intensity_stereo and r > bound[r % 3]:
+                last = band >= (21 if w < 0 else 12)
+                below = r - (1 if w < 0 else 3)
+                if last and bound[r % 3] >= below:
+                    pos = 0 if lsf else 3
+                else:
+                    pos = right["scalefac_l"][min(band, 20)] if w < 0 else right["scalefac_s"][min(band, 11)][w]
+                if lsf:
                     # ISO/IEC 13818-3 2.4.3.2: is_pos 0: both channels take the line; odd: left scaled by i0^((is_pos + 1) / 2),
                     # even: right by i0^(is_pos / 2); i0 = 2^-1/4, or 2^-1/2 when intensity_scale (intensity_stereo bit 1) is set
                     if not pos & 0x80:
@@ -457,8 +524,6 @@ class Decoder:
             intensity = int(joint and bool(h["mode_ext"] & 1))
             if intensity and lsf and h["channels"] == 2 and side["gr"][gr][1]["scalefac_compress"] & 1:
                 intensity |= 2  # intensity_scale
-            if intensity and any(side["gr"][gr][c]["mixed_block_flag"] for c in range(h["channels"])):
-                return None  # intensity stereo in mixed blocks: not built (the product rejects the granule too)
             g = {"channels": h["channels"], "ms_stereo": int(joint and bool(h["mode_ext"] & 2)), "intensity_stereo": intensity, "lsf": int(lsf),
                  "ch": []}
             for ch in range(h["channels"]):

@@ -262,6 +262,8 @@ _sig = {
     "sk_mp3_parse_header": (_i, [_vp, _sz, _vp]),
     "sk_mp3_parse_side_info": (_i, [_vp, _sz, _vp, _vp]),
     "sk_mp3_scan": (_i, [_vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
+    "sk_mp3_scan_free": (_i, [_vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz), C.POINTER(_u32)]),
+    "sk_mp3_parse_header_free": (_i, [_vp, _sz, _u32, _vp]),
     "sk_mp3_main_data": (_i, [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "sk_mp3_decode_granules_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "sk_mp3_decode_granules_s16": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),

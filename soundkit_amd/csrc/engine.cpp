@@ -2139,8 +2139,6 @@ int mp3_requantize_locked(sk_engine *e, const sk_mp3_requant_granule *granules, 
         if (st == SK_OK && joint) {
             // the stereo step pairs line i of one channel with line i of the other: both must be cut up the same way
             if ((g.ch[0].block_type == 2) != (g.ch[1].block_type == 2) || g.ch[0].mixed_block_flag != g.ch[1].mixed_block_flag) st = SK_MP3_INVALID;
-            // intensity stereo in mixed blocks is not built (MPEG-1 and 13818-3 intensity in long and short blocks are)
-            else if (g.intensity_stereo && g.ch[0].mixed_block_flag) st = SK_MP3_UNSUPPORTED;  // intensity stereo in mixed blocks: not built
         }
         if (status) status[i] = st;
         r.slot = st == SK_OK ? (uint8_t)slot : 0xff;
@@ -2906,7 +2904,6 @@ int tick_mp3_queue(sk_engine *e, const TickMp3 &mp3, float *pcm_rows, AuxArena &
         }
         if (st == SK_OK && joint) {
             if ((g.ch[0].block_type == 2) != (g.ch[1].block_type == 2) || g.ch[0].mixed_block_flag != g.ch[1].mixed_block_flag) st = SK_MP3_INVALID;
-            else if (g.intensity_stereo && g.ch[0].mixed_block_flag) st = SK_MP3_UNSUPPORTED;  // intensity stereo in mixed blocks: not built  // as sk_mp3_requantize
         }
         status[i] = st;
         r.slot = st == SK_OK ? (uint8_t)slot : 0xff;

@@ -34,12 +34,10 @@ struct Mp3HeaderBits {
     }
 };
 
-}  // namespace
 
-extern "C" {
-
-int sk_mp3_parse_header(const uint8_t *d, size_t len, sk_mp3_frame_info *out) try {
-    sk::abi_enter();
+// free_format_bytes: the length (without the padding slot) of the stream's free-format frames once sk_mp3_scan_free has found
+// it, 0 = not known: a free-format header (bit-rate index 0: the length is not in the header) is then SK_MP3_UNSUPPORTED
+int parse_header(const uint8_t *d, size_t len, uint32_t free_format_bytes, sk_mp3_frame_info *out) {
     if (!d || !out) return SK_ERR_INVALID_ARG;
     if (len < 4) return SK_MP3_NEED_MORE;
     if (d[0] != 0xff || (d[1] & 0xe0) != 0xe0) return SK_MP3_NO_SYNC;
@@ -49,12 +47,11 @@ int sk_mp3_parse_header(const uint8_t *d, size_t len, sk_mp3_frame_info *out) tr
     if (layer_bits != 1) return layer_bits == 0 ? SK_MP3_NO_SYNC : SK_MP3_UNSUPPORTED;  // Layers I / II are not this path
     const unsigned bitrate_index = d[2] >> 4, sr_index = (d[2] >> 2) & 3;
     if (bitrate_index == 15 || sr_index == 3) return SK_MP3_NO_SYNC;
-    if (bitrate_index == 0) return SK_MP3_UNSUPPORTED;  // free format: the frame length is not in the header
+    if (bitrate_index == 0 && free_format_bytes == 0) return SK_MP3_UNSUPPORTED;  // free format, length not known (yet)
     const int v = version_bits == 3 ? 0 : (version_bits == 2 ? 1 : 2);
     std::memset(out, 0, sizeof *out);
     out->version = version_bits == 3 ? 1 : (version_bits == 2 ? 2 : 25);
     out->has_crc = (d[1] & 1) ? 0 : 1;
-    out->bitrate_kbps = v == 0 ? kBitrateV1L3[bitrate_index] : kBitrateV2L3[bitrate_index];
     out->sample_rate = kSampleRate[v][sr_index];
     out->padding = (d[2] >> 1) & 1;
     out->mode = d[3] >> 6;  // 0 stereo, 1 joint stereo, 2 dual channel, 3 single channel
@@ -62,13 +59,105 @@ int sk_mp3_parse_header(const uint8_t *d, size_t len, sk_mp3_frame_info *out) tr
     out->channels = out->mode == 3 ? 1 : 2;
     out->granules = v == 0 ? 2 : 1;
     out->samples_per_channel = v == 0 ? 1152 : 576;
-    // Layer III: 144 * bitrate / fs bytes for MPEG-1, 72 * bitrate / fs for the lower sampling frequencies, plus the padding slot
-    out->frame_bytes = (uint32_t)((v == 0 ? 144u : 72u) * (uint32_t)out->bitrate_kbps * 1000u / out->sample_rate + out->padding);
+    if (bitrate_index == 0) {
+        // free format: every frame of the stream has the length the scan measured between two headers (plus its own padding slot);
+        // the bit rate follows from it
+        out->frame_bytes = free_format_bytes + out->padding;
+        out->bitrate_kbps = (uint16_t)((uint64_t)free_format_bytes * out->sample_rate / ((v == 0 ? 144u : 72u) * 1000u));
+    } else {
+        out->bitrate_kbps = v == 0 ? kBitrateV1L3[bitrate_index] : kBitrateV2L3[bitrate_index];
+        // Layer III: 144 * bitrate / fs bytes for MPEG-1, 72 * bitrate / fs for the lower sampling frequencies, plus the padding slot
+        out->frame_bytes = (uint32_t)((v == 0 ? 144u : 72u) * (uint32_t)out->bitrate_kbps * 1000u / out->sample_rate + out->padding);
+    }
     out->side_info_bytes = v == 0 ? (out->channels == 1 ? 17 : 32) : (out->channels == 1 ? 9 : 17);
     if (out->frame_bytes < 4u + (out->has_crc ? 2u : 0u) + out->side_info_bytes) return SK_MP3_NO_SYNC;
     return SK_OK;
+}
+
+bool is_free_format(const uint8_t *d) { return (d[2] >> 4) == 0; }
+// two headers of one stream (minimp3's hdr_compare): version, layer and sampling rate agree and both are free format or neither is
+bool same_stream(const uint8_t *a, const uint8_t *b) {
+    return b[0] == 0xff && ((a[1] ^ b[1]) & 0xfe) == 0 && ((a[2] ^ b[2]) & 0x0c) == 0 && is_free_format(a) == is_free_format(b);
+}
+constexpr size_t kMaxFreeFormatFrame = 2304;  // minimp3's MAX_FREE_FORMAT_FRAME_SIZE
+
+int scan(const uint8_t *d, size_t len, sk_mp3_frame_info *frames, uint32_t cap, uint32_t *n_frames, size_t *consumed, uint32_t *free_format_bytes) {
+    if (!d || !n_frames || (cap && !frames)) return SK_ERR_INVALID_ARG;
+    *n_frames = 0;
+    uint32_t ffb = free_format_bytes ? *free_format_bytes : 0;
+    size_t pos = 0;
+    if (len >= 10 && d[0] == 'I' && d[1] == 'D' && d[2] == '3' && !((d[6] | d[7] | d[8] | d[9]) & 0x80)) {
+        const size_t tag = 10u + (((size_t)d[6] << 21) | ((size_t)d[7] << 14) | ((size_t)d[8] << 7) | d[9]) + ((d[5] & 0x10) ? 10u : 0u);
+        if (tag <= len) pos = tag;
+    }
+    while (pos + 4 <= len) {
+        sk_mp3_frame_info h;
+        int rc = parse_header(d + pos, len - pos, ffb, &h);
+        if (rc == SK_MP3_UNSUPPORTED && free_format_bytes && is_free_format(d + pos) && parse_header(d + pos, len - pos, 4096, &h) == SK_OK) {
+            // A free-format header and no length yet: the frame ends where a header of the same stream stands, and the frame after it
+            // ends with such a header too (mp3d_find_frame).  Until both are in the buffer the answer waits for more input.
+            const uint8_t *here = d + pos;
+            bool found = false, wait = false;
+            for (size_t k = 4; k < kMaxFreeFormatFrame; ++k) {
+                if (pos + k + 4 > len) {
+                    wait = true;
+                    break;
+                }
+                if (!same_stream(here, here + k)) continue;
+                const size_t fb = k - ((here[2] >> 1) & 1), next_fb = fb + ((here[k + 2] >> 1) & 1);
+                if (pos + k + next_fb + 4 > len) {
+                    wait = true;
+                    break;
+                }
+                if (!same_stream(here, here + k + next_fb)) continue;
+                ffb = (uint32_t)fb;
+                found = true;
+                break;
+            }
+            if (wait) break;
+            if (found) rc = parse_header(d + pos, len - pos, ffb, &h);
+        }
+        if (rc != SK_OK) {
+            ++pos;
+            continue;
+        }
+        const size_t next = pos + h.frame_bytes;
+        if (next > len) break;  // an incomplete frame at the end: needs more input
+        if (next + 4 <= len) {
+            sk_mp3_frame_info follow;
+            const int frc = parse_header(d + next, len - next, ffb, &follow);
+            if (frc != SK_OK || follow.version != h.version || follow.sample_rate != h.sample_rate) {
+                if (is_free_format(d + pos)) ffb = 0;  // not the stream's length after all: measure again at the next candidate
+                ++pos;
+                continue;
+            }
+        }
+        h.offset = (uint32_t)pos;
+        if (*n_frames < cap) frames[*n_frames] = h;
+        *n_frames += 1;
+        pos = next;
+    }
+    if (consumed) *consumed = pos;
+    if (free_format_bytes) *free_format_bytes = ffb;
+    return SK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sk_mp3_parse_header(const uint8_t *d, size_t len, sk_mp3_frame_info *out) try {
+    sk::abi_enter();
+    return parse_header(d, len, 0, out);
 } catch (...) {
     return sk::abi_caught("sk_mp3_parse_header");
+}
+
+int sk_mp3_parse_header_free(const uint8_t *d, size_t len, uint32_t free_format_bytes, sk_mp3_frame_info *out) try {
+    sk::abi_enter();
+    return parse_header(d, len, free_format_bytes, out);
+} catch (...) {
+    return sk::abi_caught("sk_mp3_parse_header_free");
 }
 
 int sk_mp3_parse_side_info(const uint8_t *frame, size_t len, const sk_mp3_frame_info *h, sk_mp3_side_info *out) try {
@@ -128,38 +217,21 @@ int sk_mp3_parse_side_info(const uint8_t *frame, size_t len, const sk_mp3_frame_
 // length says (or the data ends there) -- the usual guard against sync words inside audio data.
 int sk_mp3_scan(const uint8_t *d, size_t len, sk_mp3_frame_info *frames, uint32_t cap, uint32_t *n_frames, size_t *consumed) try {
     sk::abi_enter();
-    if (!d || !n_frames || (cap && !frames)) return SK_ERR_INVALID_ARG;
-    *n_frames = 0;
-    size_t pos = 0;
-    if (len >= 10 && d[0] == 'I' && d[1] == 'D' && d[2] == '3' && !((d[6] | d[7] | d[8] | d[9]) & 0x80)) {
-        const size_t tag = 10u + (((size_t)d[6] << 21) | ((size_t)d[7] << 14) | ((size_t)d[8] << 7) | d[9]) + ((d[5] & 0x10) ? 10u : 0u);
-        if (tag <= len) pos = tag;
-    }
-    while (pos + 4 <= len) {
-        sk_mp3_frame_info h;
-        if (sk_mp3_parse_header(d + pos, len - pos, &h) != SK_OK) {
-            ++pos;
-            continue;
-        }
-        const size_t next = pos + h.frame_bytes;
-        if (next > len) break;  // an incomplete frame at the end: needs more input
-        if (next + 4 <= len) {
-            sk_mp3_frame_info follow;
-            const int rc = sk_mp3_parse_header(d + next, len - next, &follow);
-            if (rc != SK_OK || follow.version != h.version || follow.sample_rate != h.sample_rate) {
-                ++pos;
-                continue;
-            }
-        }
-        h.offset = (uint32_t)pos;
-        if (*n_frames < cap) frames[*n_frames] = h;
-        *n_frames += 1;
-        pos = next;
-    }
-    if (consumed) *consumed = pos;
-    return SK_OK;
+    return scan(d, len, frames, cap, n_frames, consumed, nullptr);
 } catch (...) {
     return sk::abi_caught("sk_mp3_scan");
+}
+
+// The same with free-format streams (bit-rate index 0: the frame length is measured between headers, as minimp3's mp3d_find_frame
+// does).  *free_format_bytes carries the measured length from call to call (0 at the start of a stream) -- the last frames of a
+// stream have no two headers behind them to measure it again.
+int sk_mp3_scan_free(const uint8_t *d, size_t len, sk_mp3_frame_info *frames, uint32_t cap, uint32_t *n_frames, size_t *consumed,
+                     uint32_t *free_format_bytes) try {
+    sk::abi_enter();
+    if (!free_format_bytes) return SK_ERR_INVALID_ARG;
+    return scan(d, len, frames, cap, n_frames, consumed, free_format_bytes);
+} catch (...) {
+    return sk::abi_caught("sk_mp3_scan_free");
 }
 
 // The main data of frame k starts main_data_begin bytes BEFORE its own main-data area, in what earlier frames left unused

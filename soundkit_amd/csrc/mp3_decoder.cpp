@@ -436,6 +436,7 @@ struct sk_mp3_decoder {
     uint32_t sample_rate = 0;  // of the first frame (Option::get_or_insert, lib.rs:203-204)
     uint8_t channels = 0;
     uint64_t frames = 0;
+    uint32_t free_format_bytes = 0;  // a free-format stream's frame length once measured (sk_mp3_scan_free)
     bool stream_open = false;
     uint32_t stream = 0;
     uint8_t stream_channels = 0;
@@ -481,7 +482,9 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
     d->found.resize(d->buffer.size() / 24 + 2);
     uint32_t n_found = 0;
     size_t scanned = 0;
-    int rc = sk_mp3_scan(d->buffer.data(), d->buffer.size(), d->found.data(), (uint32_t)d->found.size(), &n_found, &scanned);
+    uint32_t free_format_bytes = d->free_format_bytes;  // staged like the rest: the scan may measure it anew
+    uint32_t free_format_run = d->free_format_bytes;
+    int rc = sk_mp3_scan_free(d->buffer.data(), d->buffer.size(), d->found.data(), (uint32_t)d->found.size(), &n_found, &scanned, &free_format_bytes);
     if (rc != SK_OK) {
         d->buffer.resize(d->buffer.size() - len);  // a failed call leaves the decoder as it was
         return rc;
@@ -569,8 +572,10 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
         if (h.frame_bytes > head) reservoir.insert(reservoir.end(), frame + head, frame + h.frame_bytes);
         if (reservoir.size() > 4 * kReservoirKept) reservoir.erase(reservoir.begin(), reservoir.end() - kReservoirKept);  // trimmed now and then, not per frame
         consumed = h.offset + h.frame_bytes;
+        // the free-format length in force behind this frame: what the scan of the bytes that stay buffered has to start from
+        if ((frame[2] >> 4) == 0) free_format_run = h.frame_bytes - h.padding;
         if (decodable && out_cap - samples < SK_MP3_MAX_SAMPLES_PER_FRAME) stopped = true;  // lib.rs:300-302
-        if (k + 1 == n_found) consumed = scanned;  // every frame taken: garbage in front of an incomplete frame goes too
+        if (k + 1 == n_found) consumed = scanned, free_format_run = free_format_bytes;  // every frame taken: garbage in front of an incomplete frame goes too
     }
 
     const uint32_t n = (uint32_t)d->granules.size();
@@ -606,9 +611,11 @@ int decode(sk_mp3_decoder *d, const uint8_t *input, size_t len, void *out, size_
         samples = kept;
     } else if (n_found == 0) {
         consumed = scanned;
+        free_format_run = free_format_bytes;
     }
     d->reservoir.swap(d->staged_reservoir);
     d->sample_rate = sample_rate, d->channels = channels, d->frames = frames;
+    d->free_format_bytes = free_format_run;
     d->buffer.erase(d->buffer.begin(), d->buffer.begin() + (ptrdiff_t)consumed);
     *written = samples;
     return result;
@@ -669,7 +676,7 @@ int sk_mp3_decoder_reset(sk_mp3_decoder *d) try {
     if (d->stream_open) (void)sk_stream_close(d->engine, d->stream);
     d->stream_open = false;
     d->buffer.clear(), d->reservoir.clear();
-    d->sample_rate = 0, d->channels = 0;
+    d->sample_rate = 0, d->channels = 0, d->free_format_bytes = 0;
     return SK_OK;
 } catch (...) {
     return sk::abi_caught("sk_mp3_decoder_reset");

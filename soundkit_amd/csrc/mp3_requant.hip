@@ -6,7 +6,8 @@
 //   2.4.3.4.9    mid/side: L = (M + S) / sqrt 2, R = (M - S) / sqrt 2
 //   2.4.3.4.9.3  MPEG-1 intensity: in the bands above the last one where the right channel holds anything (per window for
 //                short blocks) the right channel's scale factor is a position is_pos; L = xr k, R = xr (1 - k),
-//                k = t / (1 + t), t = tan(is_pos pi / 12); is_pos 7 = "not intensity coded"
+//                k = t / (1 + t), t = tan(is_pos pi / 12); is_pos 7 = "not intensity coded".  Which bands those are in a mixed
+//                granule, and what the last band (it has no factor of its own) takes, follows minimp3 -- see the kernel
 //   13818-3 2.4.3.2  MPEG-2 / 2.5 intensity: the same bands, ratios 1 : i0^n or i0^n : 1 (i0 = 2^-1/4 or 2^-1/2 by intensity_scale);
 //                the position that means "not intensity coded" is the largest value its field holds -- the host marks it (bit 7)
 //   2.4.3.4.8    short blocks: band-by-band [window][line] -> [line][window]
@@ -99,10 +100,17 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
     wave_sync();
     const int16_t *is = reinterpret_cast<const int16_t *>(xs[wave]);
 
-    const bool is_short = g.ch[0].block_type == 2;  // both channels agree whenever the stereo step looks at it (host check)
+    // Stereo tools as minimp3 does them (nanomp3, the reference's decoder, is its port; L3_stereo_top_band / L3_intensity_stereo /
+    // L3_stereo_process): the bands of a granule are numbered in the order their scale factors come -- long bands, then short
+    // bands band by band, window by window -- r = band | 3 band + window for long and short granules; a mixed granule: its long
+    // bands, then 64 + 3 band + window (only the order matters there, whatever band tables the engine was given).
+    // bound[r % 3] = the highest r holding a non-zero line of the right channel; long AND mixed granules use the largest of the
+    // three for every band, short granules one per window.  Band r is intensity coded iff r > bound and its position is a legal one.
+    const int layout0 = g.ch[0].block_type == 2 ? (g.ch[0].mixed_block_flag ? 2 : 1) : 0;  // both channels agree whenever this is used (host check)
+    auto running = [&](const Line &at) { return at.win < 0 ? at.band : (layout0 == 2 ? 64 : 0) + 3 * at.band + at.win; };
     float v[2][9];
     Line where[2][9];
-    int top[3] = {-1, -1, -1};  // highest band of the right channel holding a non-zero line: long -> [0], short -> per window
+    int bound[3] = {-1, -1, -1};
     for (int c = 0; c < channels; ++c) {
         const sk_mp3_requant_channel &ch = g.ch[c];
         const int layout = ch.block_type == 2 ? (ch.mixed_block_flag ? 2 : 1) : 0;
@@ -119,8 +127,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
             const float x = ldexpf(m, q >> 2);              // the power of two is exact
             v[c][k] = q_in < 0 ? -x : x;
             if (c == 1 && q_in != 0) {
-                if (at.win < 0) top[0] = max(top[0], at.band);
-                else top[at.win] = max(top[at.win], at.band);
+                const int r = running(at), m = r % 3;
+                bound[0] = m == 0 ? max(bound[0], r) : bound[0];
+                bound[1] = m == 1 ? max(bound[1], r) : bound[1];
+                bound[2] = m == 2 ? max(bound[2], r) : bound[2];
             }
         }
     }
@@ -129,11 +139,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
         const bool ms = g.flags & 1, intensity = g.flags & 2, lsf = g.flags & 4;
         const int lsf_shift = (g.flags >> 3) & 1;  // 13818-3: intensity_scale, the low bit of the right channel's scalefac_compress
         if (intensity) {
-            top[0] = wave_max(top[0]);
-            if (is_short) {
-                top[1] = wave_max(top[1]);
-                top[2] = wave_max(top[2]);
-            }
+            for (int w = 0; w < 3; ++w) bound[w] = wave_max(bound[w]);
+            if (layout0 != 1) bound[0] = bound[1] = bound[2] = max(max(bound[0], bound[1]), bound[2]);
         }
         const sk_mp3_requant_channel &right = g.ch[1];
 #pragma unroll
@@ -141,10 +148,17 @@ __global__ __launch_bounds__(kWaves * 64) void k_mp3_requant(Mp3RequantArgs a) {
             const Line at = where[0][k];
             bool done = false;
             if (intensity) {
-                const int bound = at.win < 0 ? top[0] : top[at.win];
-                if (at.band > bound) {
-                    // the last band has no scale factor of its own: it takes the position of the one below
-                    const int pos = at.win < 0 ? right.scalefac_l[min(at.band, 20)] : right.scalefac_s[min(at.band, 11)][at.win];
+                const int r = running(at);
+                const int limit = r % 3 == 0 ? bound[0] : (r % 3 == 1 ? bound[1] : bound[2]);
+                if (r > limit) {
+                    // The last band (long 21, short 12) has no scale factor of its own: it takes the position of the band below in its
+                    // window -- if that one is intensity coded itself; otherwise (the bound reaches it: its factor is a scale factor,
+                    // not a position) the position that leaves both channels alike: 3 (MPEG-1), 0 (13818-3).
+                    const bool last = at.win < 0 ? at.band >= 21 : at.band >= 12;
+                    const int below = r - (at.win < 0 ? 1 : 3);
+                    int pos;
+                    if (last && limit >= below) pos = lsf ? 0 : 3;
+                    else pos = at.win < 0 ? right.scalefac_l[min(at.band, 20)] : right.scalefac_s[min(at.band, 11)][at.win];
                     if (lsf) {
                         // ISO/IEC 13818-3 2.4.3.2: is_pos = 0: both channels get the line; odd: the left one is scaled by
                         // i0^((is_pos + 1) / 2), even: the right one by i0^(is_pos / 2), i0 = 2^-1/4 or 2^-1/2 (intensity_scale).

@@ -72,6 +72,7 @@ struct PStream {
     // which decoder the stream's first bytes select (detect_and_init_decoder, soundkit-decoder/src/lib.rs:3041-3053): 0 not known yet
     uint8_t codec = 0;
     std::vector<uint8_t> mp3_reservoir;  // main data of the frames seen so far (main_data_begin reaches back into it)
+    uint32_t mp3_free_format = 0;        // a free-format stream's frame length once measured (sk_mp3_scan_free)
 };
 constexpr uint8_t kCodecAac = 1, kCodecMp3 = 2;
 
@@ -313,8 +314,12 @@ void parse_some_mp3(sk_lane *p, PStream &s, uint32_t limit, Parsed &r) {
         const size_t avail = s.pending.size() - s.pending_pos;
         uint32_t n_found = 0;
         size_t scanned = 0;
+        // the free-format length: s.mp3_free_format is the one in force at pending_pos (behind the last frame taken); the scan's own
+        // end state replaces it only when everything scanned is consumed
+        uint32_t free_format_scan = s.mp3_free_format;
         if (avail >= 4) {
-            rc = sk_mp3_scan(s.pending.data() + s.pending_pos, avail, found.data(), (uint32_t)found.size(), &n_found, &scanned);
+            free_format_scan = s.mp3_free_format;
+            rc = sk_mp3_scan_free(s.pending.data() + s.pending_pos, avail, found.data(), (uint32_t)found.size(), &n_found, &scanned, &free_format_scan);
             if (rc != SK_OK) {
                 fail(rc, std::string("Decoding failed: ") + sk_strerror(rc));
                 break;
@@ -323,6 +328,7 @@ void parse_some_mp3(sk_lane *p, PStream &s, uint32_t limit, Parsed &r) {
         }
         if (n_found == 0) {
             s.pending_pos += scanned;  // garbage in front of an incomplete frame goes
+            s.mp3_free_format = free_format_scan;
             if (s.saw_eof) {
                 r.eof = true;
                 break;
@@ -404,7 +410,8 @@ void parse_some_mp3(sk_lane *p, PStream &s, uint32_t limit, Parsed &r) {
             if (h.frame_bytes > head) s.mp3_reservoir.insert(s.mp3_reservoir.end(), frame + head, frame + h.frame_bytes);
             if (s.mp3_reservoir.size() > 4 * kReservoirKept) s.mp3_reservoir.erase(s.mp3_reservoir.begin(), s.mp3_reservoir.end() - (ptrdiff_t)kReservoirKept);
             consumed = h.offset + h.frame_bytes;
-            if (k + 1 == n_found && n_found < found.size()) consumed = scanned;
+            if ((frame[2] >> 4) == 0) s.mp3_free_format = h.frame_bytes - h.padding;
+            if (k + 1 == n_found && n_found < found.size()) consumed = scanned, s.mp3_free_format = free_format_scan;
         }
         s.pending_pos += consumed;
         if (r.budget_stop) break;
@@ -1312,6 +1319,7 @@ int lane_spawn(sk_lane *p, const sk_decode_options *opt, uint32_t *handle) {
     s.resample = false;
     s.codec = 0;
     s.mp3_reservoir.clear();
+    s.mp3_free_format = 0;
     *handle = h;
     return SK_OK;
 }

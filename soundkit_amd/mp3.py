@@ -80,6 +80,15 @@ def scan(data, cap=1 << 16):
     return [frames[i] for i in range(min(n.value, cap))], used.value
 
 
+def scan_free(data, free_format_bytes=0, cap=1 << 16):
+    """sk_mp3_scan_free -> ([Mp3FrameInfo], bytes consumed, free_format_bytes to hand to the next call)"""
+    frames = (Mp3FrameInfo * cap)()
+    n, used, ffb = C.c_uint32(0), C.c_size_t(0), C.c_uint32(free_format_bytes)
+    b = _bytes(data)
+    check(lib.sk_mp3_scan_free(_ptr(b), len(data), frames, cap, C.byref(n), C.byref(used), C.byref(ffb)), "sk_mp3_scan_free")
+    return [frames[i] for i in range(min(n.value, cap))], used.value, ffb.value
+
+
 def main_data(frame, info, side, reservoir):
     """(status, the bytes parts 2 + 3 of this frame are read from)"""
     out = np.zeros(len(reservoir) + len(frame) + 16, np.uint8)

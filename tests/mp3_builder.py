@@ -187,8 +187,10 @@ def random_granule(rng, tables, h, gr, first_granule, budget_bits, shape=None, a
             if column == 0:
                 sl[:len(values)] = values
             else:
-                for k, v in enumerate(values):
-                    band, win = divmod(k, 3)
+                n_long = 6 if column == 2 else 0  # a mixed granule: six long bands, then short band 3 on
+                sl[:n_long] = values[:n_long]
+                for k, v in enumerate(values[n_long:]):
+                    band, win = divmod(k + (9 if column == 2 else 0), 3)
                     ss[band][win] = v
         else:
             kind = int(rng.integers(0, 3))
@@ -301,9 +303,10 @@ def pack_side_info(h, side):
 
 
 def build_stream(tables, seed, version=1, rate=44100, channels=2, mode=None, n_frames=12, crc=False, bitrate_indices=(5, 9, 12),
-                 joint_modes=(0, 2)):
+                 joint_modes=(0, 2), free_format_bytes=0):
     """-> (bytes, [per frame: dict(header, side, granules=[gr][ch] dict(is, scalefac_l, scalefac_s, preflag))])
-    mode: 0 stereo, 1 joint stereo (mode_ext from joint_modes: bit 1 = mid/side, bit 0 = intensity), 2 dual, 3 mono"""
+    mode: 0 stereo, 1 joint stereo (mode_ext from joint_modes: bit 1 = mid/side, bit 0 = intensity), 2 dual, 3 mono
+    free_format_bytes: a free-format stream (bit-rate index 0) whose frames are that long, plus a padding slot in some"""
     rng = np.random.default_rng(seed)
     if mode is None:
         mode = 3 if channels == 1 else 1
@@ -313,8 +316,11 @@ def build_stream(tables, seed, version=1, rate=44100, channels=2, mode=None, n_f
     positions = []
     for k in range(n_frames):
         mode_ext = int(rng.choice(joint_modes)) if mode == 1 else 0
-        hb = header_bytes(version, rate, int(rng.choice(bitrate_indices)), channels, mode, mode_ext, crc)
-        h = ref.parse_header(hb)
+        if free_format_bytes:
+            hb = header_bytes(version, rate, 0, channels, mode, mode_ext, crc, padding=int(rng.integers(0, 2)))
+        else:
+            hb = header_bytes(version, rate, int(rng.choice(bitrate_indices)), channels, mode, mode_ext, crc)
+        h = ref.parse_header(hb, free_format_bytes)
         slot = h["frame_bytes"] - 4 - (2 if crc else 0) - h["side_info_bytes"]
         assert slot > 0
         start = max(prev_end, slot_start - maxback)
@@ -332,7 +338,7 @@ def build_stream(tables, seed, version=1, rate=44100, channels=2, mode=None, n_f
             for ch in range(channels):
                 share = (budget - len(w_all)) // (n_units - unit)
                 s, sl, ss, values, w = random_granule(rng, tables, h, gr, first[ch] if gr == 1 else None, int(share * rng.uniform(0.3, 1.0)),
-                                                      shape if mode == 1 else None, allow_mixed=not (mode == 1 and mode_ext & 1),
+                                                      shape if mode == 1 else None,
                                                       intensity_channel=version != 1 and mode == 1 and bool(mode_ext & 1) and ch == 1)
                 shape = (s["window_switching"], s["block_type"], s["mixed_block_flag"])  # a joint pair is cut up the same way
                 if gr == 1:

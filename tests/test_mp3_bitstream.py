@@ -217,6 +217,99 @@ def test_scan_skips_garbage_and_false_syncs_and_stops_at_a_partial_frame():
     assert len(capped) == 5
 
 
+def test_free_format_frames_are_measured_between_headers():
+    """bit-rate index 0 (minimp3 mp3d_find_frame, which nanomp3 ports): the frame length is what lies between a header and the next
+    two of the same stream; it is measured once and carried from call to call; frames with a padding slot are one byte longer; the
+    stateless sk_mp3_scan / sk_mp3_parse_header keep treating such a header as unsupported"""
+    import mp3_builder as B
+    tables = B.make_tables(3, rates=(48000, 22050))
+    for seed, kw in enumerate([dict(version=1, rate=48000, channels=2, mode=0, free_format_bytes=1000),
+                               dict(version=2, rate=22050, channels=1, free_format_bytes=417),
+                               dict(version=1, rate=48000, channels=2, mode=1, crc=True, free_format_bytes=2303)]):
+        data, built = B.build_stream(tables, 700 + seed, n_frames=9, **kw)
+        ffb = kw["free_format_bytes"]
+        paddings = {f["header"]["padding"] for f in built}
+        assert paddings == {0, 1} or seed, paddings  # (the first stream is known to mix both)
+        junk = b"\x01\xff\xfb\x04" + bytes(40)  # a free-format header with nothing behind it
+        stream = junk + data
+        frames, used, state = mp3.scan_free(stream)
+        want_state = [0]
+        want, want_used = ref.scan(stream, want_state)
+        assert state == want_state[0] == ffb and used == want_used == len(stream)
+        assert [f.offset for f in frames] == [o for o, _ in want] and len(frames) == len(built)
+        at = len(junk)
+        for f, (off, h), b in zip(frames, want, built):
+            assert f.offset == at and f.frame_bytes == ffb + b["header"]["padding"] == h["frame_bytes"]
+            for k in HEADER_FIELDS:
+                assert getattr(f, k) == h[k], k
+            rc, info = mp3.parse_header(stream[at:at + 4])
+            assert rc == UNSUPPORTED  # without the measured length
+            at += f.frame_bytes
+        assert frames[0].bitrate_kbps == ffb * kw["rate"] // ((144 if kw["version"] == 1 else 72) * 1000)
+        assert mp3.scan(stream)[0] == []
+        # streaming: nothing is decided until two more headers are in the buffer; afterwards every complete frame is found at once,
+        # and the state lets the stream's last frames through
+        first, second = built[0]["header"]["frame_bytes"], built[1]["header"]["frame_bytes"]
+        got, used, state = mp3.scan_free(data[:first + second + 3])
+        assert got == [] and used == 0 and state == 0
+        got, used, state = mp3.scan_free(data[:first + second + 4])
+        assert [f.offset for f in got] == [0, first] and used == first + second and state == ffb
+        tail = data[sum(b["header"]["frame_bytes"] for b in built[:-1]):]
+        got, used, _ = mp3.scan_free(tail, state)
+        assert len(got) == 1 and used == len(tail)
+        got, used, _ = mp3.scan_free(tail)  # the length unknown and no header behind the frame: it waits
+        assert got == [] and used == 0
+    # a changed length in mid-stream: the follow check fails at the seam, the length is measured again behind it
+    a, _ = B.build_stream(tables, 710, version=1, rate=48000, channels=2, mode=0, n_frames=5, free_format_bytes=600)
+    b, _ = B.build_stream(tables, 711, version=1, rate=48000, channels=2, mode=0, n_frames=5, free_format_bytes=900)
+    state = [0]
+    want, _ = ref.scan(a + b, state)
+    frames, _, got_state = mp3.scan_free(a + b)
+    assert [f.offset for f in frames] == [o for o, _ in want] and got_state == state[0] == 900
+    assert len(frames) >= 8  # at most the frames at the seam are lost
+
+
+def test_oracle_intensity_bands_in_mixed_granules_and_the_last_band():
+    """the checker's rule (minimp3 L3_intensity_stereo) on cases that can be read off: a mixed granule has ONE bound for its long and
+    its short part; the last band takes the position of the band below only if that one is intensity coded itself"""
+    long_o = [0, 4, 8, 12, 16, 20, 24, 30, 36] + list(range(60, 60 + 13 * 36, 36))[:13] + [576]
+    short_o = [0, 4, 8, 12] + list(range(30, 30 + 9 * 18, 18))[:9] + [192]
+    assert len(long_o) == 23 and len(short_o) == 14
+    flat = {"global_gain": 210, "scalefac_scale": 0, "preflag": 0, "block_type": 2, "mixed_block_flag": 1, "subblock_gain": [0, 0, 0],
+            "scalefac_l": [0] * 22, "scalefac_s": [[0, 0, 0] for _ in range(13)]}
+    right = dict(flat, scalefac_l=[6] * 22, scalefac_s=[[6, 6, 6] for _ in range(13)])  # position 6: everything to the left channel
+    g = {"channels": 2, "ms_stereo": 0, "intensity_stereo": 1, "ch": [dict(flat), right]}
+    q = np.zeros((2, 576), np.int64)
+    q[0, :] = 1
+    # the right channel's last line is in the long part: every band above it -- long and short -- is intensity coded
+    q[1, 9] = 1  # long band 2
+    xr = ref.requantize_granule(g, q, long_o, short_o, [0] * 22)
+    assert np.all(xr[1, 12:] == 0) and np.all(xr[0, 12:] == 1) and xr[1, 9] == 0.125 and np.all(xr[0, :12] == 1)  # (below the bound a 6 is a scale factor: 2^-3)
+    # a line in window 0 of short band 5: the long part and windows 1, 2 of band 5 stop being intensity coded... the long part and
+    # everything up to (band 5, window 0) in scale-factor order, that is: windows 1 and 2 of band 5 come later and stay coded
+    q[1, :] = 0
+    first = 3 * short_o[5]  # bitstream order inside a short band: window 0's lines, then window 1's, then window 2's
+    q[1, first] = 1
+    xr = ref.requantize_granule(g, q, long_o, short_o, [0] * 22)
+    width = short_o[6] - short_o[5]
+    lines_w0 = [3 * (short_o[5] + j) + 0 for j in range(width)]
+    lines_w1 = [3 * (short_o[5] + j) + 1 for j in range(width)]
+    assert xr[1, lines_w0[0]] == 0.125 and np.all(xr[1, lines_w1] == 0) and np.all(xr[0, lines_w1] == 1)
+    assert np.all(xr[1, 3 * short_o[6]:] == 0)
+    # long granule: the right channel ends in band 20 -> band 21 (no factor of its own) takes position 3: both channels half of the line
+    longs = dict(flat, block_type=0, mixed_block_flag=0)
+    g = {"channels": 2, "ms_stereo": 0, "intensity_stereo": 1, "ch": [dict(longs), dict(longs, scalefac_l=[6] * 22)]}
+    q[1, :] = 0
+    q[1, long_o[20]] = 1
+    xr = ref.requantize_granule(g, q, long_o, short_o, [0] * 22)
+    assert np.allclose(xr[0, long_o[21]:], 0.5) and np.allclose(xr[1, long_o[21]:], 0.5)
+    # ... ends in band 19 -> band 21 takes band 20's position (6: all left)
+    q[1, :] = 0
+    q[1, long_o[19]] = 1
+    xr = ref.requantize_granule(g, q, long_o, short_o, [0] * 22)
+    assert np.all(xr[0, long_o[20]:] == 1) and np.all(xr[1, long_o[20]:] == 0)
+
+
 def test_oracle_requantisation_known_values():
     """the checker of tests/test_mp3_requant_gpu.py on values that can be worked out by hand"""
     long_o = list(range(0, 22 * 26, 26))[:22] + [576]

@@ -248,7 +248,10 @@ def test_mutated_streams_under_sanitizers(tmp_path):
     short_o = [0, 4, 8, 12] + [12 + 15 * (i - 3) for i in range(4, 13)] + [192]
     fixed["bands"] = {r: (long_o, short_o) for r in B.RATES}
     for k, params in enumerate((dict(version=1, rate=44100, channels=2, mode=1, joint_modes=(0, 2)), dict(version=2, rate=16000, channels=1, bitrate_indices=(8, 12)),
-                                dict(version=25, rate=11025, channels=2, mode=0, bitrate_indices=(9, 11), crc=True))):
+                                dict(version=25, rate=11025, channels=2, mode=0, bitrate_indices=(9, 11), crc=True),
+                                # free format, and intensity stereo in every kind of granule (mixed ones too)
+                                dict(version=1, rate=48000, channels=2, mode=1, joint_modes=(0, 1, 2, 3), free_format_bytes=640),
+                                dict(version=2, rate=24000, channels=2, mode=1, joint_modes=(1, 3), free_format_bytes=300))):
         data, _ = B.build_stream(fixed, 900 + k, n_frames=24, **params)
         path = str(tmp_path / ("stream%d.mp3" % k))
         with open(path, "wb") as fh:

@@ -24,7 +24,7 @@ def codebook():
 
 
 def oracle_pcm(data, skip_reservoir_misses=True):
-    frames, _ = ref.scan(data)
+    frames, _ = ref.scan(data, [0])
     dec = ref.Decoder(TABLES)
     out = [dec.frame(data, off, h) for off, h in frames]
     return [o for o in out if o is not None], frames
@@ -56,7 +56,11 @@ STREAMS = [dict(version=1, rate=44100, channels=2, mode=1, joint_modes=(0, 2)), 
            dict(version=25, rate=11025, channels=1, bitrate_indices=(8, 11)),
            # 13818-3 intensity stereo (with and without mid/side, both intensity scales, "not intensity coded" positions)
            dict(version=2, rate=24000, channels=2, mode=1, joint_modes=(1, 3), bitrate_indices=(8, 10, 13)),
-           dict(version=25, rate=8000, channels=2, mode=1, joint_modes=(1, 2, 3), bitrate_indices=(6, 8))]
+           dict(version=25, rate=8000, channels=2, mode=1, joint_modes=(1, 2, 3), bitrate_indices=(6, 8)),
+           # free format (bit-rate index 0): the frame length is measured between headers; with and without padding slots, up to
+           # the largest frame the scan looks for
+           dict(version=1, rate=48000, channels=2, mode=1, joint_modes=(0, 1, 2, 3), free_format_bytes=1000),
+           dict(version=2, rate=22050, channels=1, free_format_bytes=417), dict(version=1, rate=44100, channels=2, mode=0, crc=True, free_format_bytes=2200)]
 
 
 @pytest.mark.parametrize("k", range(len(STREAMS)))

@@ -115,7 +115,7 @@ def test_mid_side_and_intensity_stereo(engine, block_type):
     granules, quant = [], []
     for k in range(120):
         ms, intensity = [(1, 0), (0, 1), (1, 1), (0, 0)][k % 4]
-        mixed = int(block_type == 2 and not intensity and k % 8 >= 4)
+        mixed = int(block_type == 2 and k % 8 >= 4)  # mixed granules with and without intensity stereo
         left, right = random_channel(rng, block_type, mixed), random_channel(rng, block_type, mixed)
         # intensity positions live in the right channel's scale factors: 0..6 are positions, 7 says "not intensity coded"
         right["scalefac_l"] = [int(v) for v in rng.integers(0, 8, 21)] + [0]
@@ -123,6 +123,11 @@ def test_mid_side_and_intensity_stereo(engine, block_type):
         granules.append({"sample_rate": 48000, "channels": 2, "ms_stereo": ms, "intensity_stereo": intensity, "ch": [left, right]})
         quant.append(random_quant(rng))
         zero_from = [576, 0, int(rng.integers(0, 577)), int(rng.integers(0, 577))][k % 4 if k % 16 else 1]
+        if k % 16 in (5, 6):
+            # the right channel ends with the band below the last one: the last band is intensity coded and takes the default position
+            # (the band below holds a scale factor, not a position), k % 16 == 6: ends one band lower -- the last takes that band's position
+            back = 1 if k % 16 == 5 else 2
+            zero_from = 3 * int(short_o[13 - back]) if block_type == 2 else int(long_o[22 - back])
         quant.append(random_quant(rng, zero_from))
     quant = np.stack(quant)
     xr, status = mp3.requantize(granules, quant, engine)
@@ -149,7 +154,8 @@ def test_lsf_intensity_stereo(engine, block_type):
     granules, quant = [], []
     for k in range(96):
         ms, scale = k & 1, (k >> 1) & 1
-        left, right = random_channel(rng, block_type, 0), random_channel(rng, block_type, 0)
+        mixed = int(block_type == 2 and k % 8 >= 4)
+        left, right = random_channel(rng, block_type, mixed), random_channel(rng, block_type, mixed)
         left["preflag"] = right["preflag"] = 0
         mark = lambda v: int(v) | (0x80 if rng.random() < 0.2 else 0)
         right["scalefac_l"] = [mark(v) for v in rng.integers(0, 32, 21)] + [0]
@@ -198,7 +204,7 @@ def rejected_granules(engine):
              (granule(22050, bt=(2, 0)), SK_OK),                                            # ... which is fine without joint stereo
              (granule(22050, intensity_stereo=1, lsf=1), SK_OK),                            # 13818-3 intensity, i0 = 2^-1/4
              (granule(22050, intensity_stereo=3, lsf=1, ms_stereo=1), SK_OK),               # ... i0 = 2^-1/2, mid/side below the bound
-             (granule(22050, bt=(2, 2), mixed=(1, 1), intensity_stereo=1), UNSUPPORTED),
+             (granule(22050, bt=(2, 2), mixed=(1, 1), intensity_stereo=1), SK_OK),          # intensity in a mixed granule
              (granule(24000, bt=(2, 2), mixed=(1, 1)), UNSUPPORTED),                        # tables without a boundary at line 36
              (granule(22050, bt=(1, 1), mixed=(1, 1)), INVALID), (good, SK_OK)]
     granules = [g for g, _ in cases]

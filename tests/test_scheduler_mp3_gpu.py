@@ -134,3 +134,55 @@ def test_a_damaged_mp3_stream_is_alone_with_its_damage(engine):
     assert np.array_equal(joined[0], want_mp3) and np.array_equal(joined[3], want_mp3) and np.array_equal(joined[2], want_aac)
     # the damaged stream: what the single decoder makes of the same bytes (frames it cannot decode are consumed without output)
     assert np.array_equal(joined[1], want_bad) and want_bad.size < want_mp3.size
+
+
+def test_free_format_and_mixed_block_intensity_streams_behind_the_scheduler(engine):
+    """Streams written by tests/mp3_builder.py with the standard's code books: free format (the frame length measured between headers,
+    carried per stream) and joint stereo with intensity coding in every kind of granule, mixed ones included.  Each stream out of the
+    scheduler equals its single decoder, and that equals the f64 chain (oracle/mp3_bitstream.py Decoder)."""
+    import mp3_builder as B
+    from oracle import mp3_bitstream, mp3_iso
+    tables = mp3_iso.tables()
+    specs = [dict(version=1, rate=44100, channels=2, mode=1, joint_modes=(0, 1, 2, 3), free_format_bytes=700),
+             dict(version=2, rate=24000, channels=2, mode=1, joint_modes=(1, 3), free_format_bytes=431),
+             dict(version=1, rate=48000, channels=2, mode=1, joint_modes=(1, 3), bitrate_indices=(9, 12)),
+             dict(version=1, rate=32000, channels=1, free_format_bytes=2000)]
+    datas = [B.build_stream(tables, 940 + k, n_frames=30, **spec)[0] for k, spec in enumerate(specs)]
+    mixed_is = 0
+    for data, spec in zip(datas, specs):
+        state = [0]
+        frames, used = mp3_bitstream.scan(data, state)
+        assert len(frames) == 30 and used == len(data) and state[0] == spec.get("free_format_bytes", 0)
+        for off, h in frames:
+            side = mp3_bitstream.parse_side_info(data[off:off + h["frame_bytes"]], h)
+            mixed_is += sum(1 for gr in side["gr"] if h["mode"] == 1 and h["mode_ext"] & 1 and gr[0]["mixed_block_flag"])
+    assert mixed_is > 3, "the streams hold intensity-coded mixed granules"
+    want = []
+    for data, spec in zip(datas, specs):
+        rate, channels, samples = single_decoder(engine, "mp3", data)
+        assert (rate, channels) == (spec["rate"], spec["channels"])
+        dec = mp3_bitstream.Decoder(tables)
+        frames, _ = mp3_bitstream.scan(data, [0])
+        pcm = np.concatenate([dec.frame(data, off, h) for off, h in frames]).reshape(-1)
+        assert samples.size == pcm.size
+        q = np.clip(np.sign(pcm) * np.floor(np.abs(pcm) * 32767.0 + 0.5), -32768, 32767)
+        d = np.abs(samples.astype(np.int64) - q.astype(np.int64))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01, (int(d.max()), float((d > 0).mean()))
+        assert np.abs(samples.astype(np.int32)).max() > 500
+        want.append(samples)
+    sched = pipeline.BatchScheduler(engine, entropy_threads=3, max_streams=8, max_stream_frames_per_tick=6)
+    try:
+        handles = [sched.spawn() for _ in datas]
+        feeder = threading.Thread(target=feed_all, args=(handles, datas, [700, 333, 4096, 1999]))
+        feeder.start()
+        got = drain(handles, 120)
+        feeder.join()
+        for h in handles:
+            h.cancel()
+    finally:
+        sched.close()
+    for outs, samples, spec in zip(got, want, specs):
+        assert outs and not any(isinstance(a, Exception) for a in outs)
+        assert all(a.sampling_rate == spec["rate"] and a.channel_count == spec["channels"] for a in outs)
+        mine = np.concatenate([np.frombuffer(a.data.tobytes(), "<i2") for a in outs])
+        assert np.array_equal(mine, samples)
