@@ -315,6 +315,12 @@ __global__ __launch_bounds__(kWaves * 64) void k_sinc_resample(SincArgs a, uint3
 #define SK_MFMA_SPAN 704
 #define SK_MFMA_BLOCKS 1
 #endif
+#ifndef SK_MFMA_PITCH_PAD
+#define SK_MFMA_PITCH_PAD 32
+#endif
+#ifndef SK_MFMA_PREFETCH_B
+#define SK_MFMA_PREFETCH_B 1
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -322,9 +328,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMfmaRows = SK_MFMA_ROWS;           // rows per workgroup: row groups of 16
 constexpr int kMfmaTiles = SK_MFMA_TILES;         // tiles (of 16 outputs) per workgroup at most: one per wave
 constexpr int kMfmaSpan = SK_MFMA_SPAN;           // samples staged per row
-constexpr int kMfmaPitch = 2 * (128 * ((kMfmaSpan + 127) / 128)) + 16;  // bytes per row of a plane: whole 128-sample groups + 16 = 1552 = 16 * 97, an odd multiple of 16 (conflict-free b128 reads)
+// bytes per row of a plane: whole 128-sample groups + 32 = 1568 = 16 * 98.  The B operand is one ds_read_b128 per plane, lane 16 q + j on
+// row j at slot q + const; a wave's read is served in four groups of sixteen lanes that are not its quarters ({0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31} and the same 32 lanes up: fir_bf16.hip, MI355X_MICROARCH.md), so the rows' slots  j * pitch + [4 <= j < 12]  must
+// differ modulo 16: a pitch of 2 or 6 modulo 8 slots.  (97 slots, "an odd multiple", put 40 % of the LDS cycles into bank conflicts:
+// profiles/r03_resample_pmc.json.)
+constexpr int kMfmaPitch = 2 * (128 * ((kMfmaSpan + 127) / 128)) + SK_MFMA_PITCH_PAD;
 constexpr int kMfmaPlane = kMfmaRows * kMfmaPitch;
-static_assert((kMfmaPitch / 16) % 2 == 1 && kMfmaRows % 16 == 0 && kMfmaRows % kMfmaTiles == 0, "row pitch: an odd multiple of 16 bytes");
+static_assert(kMfmaPitch % 16 == 0 && kMfmaRows % 16 == 0 && kMfmaRows % kMfmaTiles == 0, "row pitch: whole 16-byte slots");
 constexpr int kMaxWindows = 12;                  // windows of a tile held in registers: steps up to ~6.9 (96 -> 16 kHz: 6); beyond: the scalar form
 
 struct TileMeta {
@@ -532,33 +543,62 @@ __global__ __launch_bounds__(kMfmaTiles * 64, SK_MFMA_BLOCKS) void k_sinc_mfma(S
             for (int s = 0; s < kMaxWindows; ++s) asm volatile("" : "+v"(h[s][0]), "+v"(h[s][1]), "+v"(h[s][2]));
             constexpr int kGroups = kMfmaRows / 16;
             f32x4 acc[kGroups];
+            // where the results go, asked for in front of the matrix instructions (two dependent trips to memory otherwise, after them)
+            float *dst_of[kGroups];
+#pragma unroll
+            for (int rg = 0; rg < kGroups; ++rg) {
+                const uint32_t row = rb * kMfmaRows + (uint32_t)(rg * 16 + j);
+                const bool there = row < a.rows && !(a.row_map && a.row_map[row] == 0xffffffffu);  // (0xffffffff: a padding row of the host's grouping)
+                dst_of[rg] = there ? a.out + (size_t)row * a.out_stride + (a.out_off ? a.out_off[row] : 0) : nullptr;
+            }
 #pragma unroll
             for (int rg = 0; rg < kGroups; ++rg) acc[rg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            struct BSet {
+                u32x4 x[3];
+            };
+            auto read_b = [&](int s, int rg) __attribute__((always_inline)) {
+                BSet b;
+                const unsigned char *bp = planes + (rg * 16 + j) * kMfmaPitch + 2 * (off + 32 * s + 8 * q);
 #pragma unroll
-            for (int s = 0; s < kMaxWindows; ++s) {
-                if (s >= windows) continue;  // (wave-uniform; no break: the loop must unroll for h[s] to stay in registers)
+                for (int k = 0; k < 3; ++k) b.x[k] = *reinterpret_cast<const u32x4 *>(bp + k * kMfmaPlane);
+                return b;
+            };
+            auto products = [&](int s, const BSet &b, f32x4 c) __attribute__((always_inline)) {
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, b.x[0]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, b.x[0]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, b.x[1]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, b.x[1]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][2]), __builtin_bit_cast(bf16x8, b.x[0]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, b.x[2]), c, 0, 0, 0);
+                return c;
+            };
+            static_assert(!SK_MFMA_PREFETCH_B || kGroups == 2, "the read-ahead below alternates between two row groups");
+            if constexpr (SK_MFMA_PREFETCH_B) {
+                // a row group's samples are on their way from LDS while the matrix instructions work on the other group's: the
+                // second group of window s during the first group's six products, the first group of window s + 1 during the
+                // second's (past the last window the read repeats it: no branch, never beyond the tile's span)
+                BSet b0 = read_b(0, 0);
 #pragma unroll
-                for (int rg = 0; rg < kGroups; ++rg) {
-                    const unsigned char *bp = planes + (rg * 16 + j) * kMfmaPitch + 2 * (off + 32 * s + 8 * q);
-                    const u32x4 x0 = *reinterpret_cast<const u32x4 *>(bp), x1 = *reinterpret_cast<const u32x4 *>(bp + kMfmaPlane),
-                                x2 = *reinterpret_cast<const u32x4 *>(bp + 2 * kMfmaPlane);
-                    f32x4 c = acc[rg];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x1), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, x1), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][2]), __builtin_bit_cast(bf16x8, x0), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, x2), c, 0, 0, 0);
-                    acc[rg] = c;
+                for (int s = 0; s < kMaxWindows; ++s) {
+                    if (s >= windows) continue;  // (wave-uniform; no break: the loop must unroll for h[s] to stay in registers)
+                    const BSet b1 = read_b(s, 1);
+                    acc[0] = products(s, b0, acc[0]);
+                    b0 = read_b(s + 1 < windows ? s + 1 : s, 0);
+                    acc[1] = products(s, b1, acc[1]);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < kMaxWindows; ++s) {
+                    if (s >= windows) continue;
+#pragma unroll
+                    for (int rg = 0; rg < kGroups; ++rg) acc[rg] = products(s, read_b(s, rg), acc[rg]);
                 }
             }
             // D[i][j]: lane (j, q) holds outputs i = 4 q .. 4 q + 3 of row j of each row group
 #pragma unroll
             for (int rg = 0; rg < kGroups; ++rg) {
-                const uint32_t row = rb * kMfmaRows + (uint32_t)(rg * 16 + j);
-                if (row >= a.rows) continue;
-                if (a.row_map && a.row_map[row] == 0xffffffffu) continue;  // a padding row of the host's grouping
-                float *dst = a.out + (size_t)row * a.out_stride + (a.out_off ? a.out_off[row] : 0);
+                float *dst = dst_of[rg];
+                if (!dst) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const uint32_t mo = 16u * t + 4u * (uint32_t)q + (uint32_t)r;
