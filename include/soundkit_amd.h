@@ -580,8 +580,11 @@ typedef struct sk_tick_output {
     uint16_t reserved;
 } sk_tick_output;
 
-/* upper bounds for the two output arrays of a tick */
+/* upper bounds for the two output arrays of a tick: from the table alone (a resampling stream is taken for the largest ratio there
+ * is, 8 -> 48 kHz: 48 KB per chunk and output channel at 32 bits), or -- _on -- from what the engine knows of the streams (their
+ * resamplers' own ratios): the scheduler sizes its pinned output buffers with the second (the first made them gigabytes) */
 size_t sk_tick_out_bound(const sk_tick_stream *streams, uint32_t n_streams, uint32_t *max_outputs);
+size_t sk_tick_out_bound_on(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, uint32_t *max_outputs);
 /* coeffs: host memory (pinned for full overlap), packed like sk_aac_synthesize_f32's.  Blocks until out_bytes holds
  * the results.  *out_bytes_used receives the bytes written. */
 int sk_tick_run(sk_engine *, const sk_tick_stream *streams, uint32_t n_streams, const sk_aac_frame_desc *descs,

@@ -293,6 +293,7 @@ _sig = {
     "sk_engine_debug_fail_after": (_i, [_vp, _i]),
     "sk_pipeline_debug_dump": (_sz, [_vp, _vp, _sz]),
     "sk_tick_out_bound": (_sz, [_vp, _u32, C.POINTER(_u32)]),
+    "sk_tick_out_bound_on": (_sz, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "sk_tick_run": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
     "sk_tick_run_mixed": (_i, [_vp, _vp, _u32, _vp, _vp, _sz, _vp, _u32, C.POINTER(_u32), C.POINTER(_sz)]),
 }

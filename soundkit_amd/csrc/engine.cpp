@@ -52,11 +52,16 @@ struct DevBuf {
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         size_t want = bytes + bytes / 4 + 4096;
+        static const bool trace = std::getenv("SK_TICK_TRACE") != nullptr;
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
+        if (trace)
+            std::fprintf(stderr, "sk_engine: device buffer regrown to %zu bytes in %.2f ms\n", want,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         return e;
     }
     void release() {
@@ -2736,29 +2741,57 @@ struct TickMp3 {  // the MP3 part of sk_tick_input
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n_streams, uint32_t *max_outputs) try {
-    sk::abi_enter();
+// What a tick can hand back at most.  A resampling stream emits one AudioData per completed 4096-frame chunk (+ one carried chunk + the
+// flush); everything else one per unit (1024 PCM frames at most).  With the engine at hand the frames of a chunk follow from the
+// stream's own ratio; without it they are taken for the largest ratio there is (8 kHz -> 48 kHz).  (The tick lays its output out before
+// it launches anything and refuses a buffer that is too small: the bound only has to be one.)
+size_t tick_out_bound(const sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, uint32_t *max_outputs) {
     size_t bytes = 0;
     uint64_t outs = 0;
     for (uint32_t i = 0; i < n_streams; ++i) {
-        // a resampling stream emits at most one AudioData per 4096 input frames (+ one carried chunk + the flush),
-        // each at most 4096 * 6 + 2 frames (8 kHz -> 48 kHz); everything else one per access unit
         const uint64_t n = ts[i].n_frames;
+        const uint64_t width = (ts[i].out_bits == 16 || ts[i].out_bits == 24 || ts[i].out_bits == 32) ? ts[i].out_bits / 8u : 4u;
+        const uint64_t frame_bytes = width * ((ts[i].out_channels == 1 || ts[i].out_channels == 2) ? ts[i].out_channels : 2u);
         if (ts[i].resample) {
+            uint64_t chunk_frames = 4096 * 6 + 2;
+            if (e && ts[i].stream < e->streams.size()) {
+                const StreamInfo &s = e->streams[ts[i].stream];
+                if (s.open && s.rs_open && s.rs_in_hz) chunk_frames = (uint64_t)(4096.0 * (double)s.rs_out_hz / (double)s.rs_in_hz) + 8;
+            }
             const uint64_t chunks = n / 4 + 2;
-            bytes += chunks * ((4096 * 6 + 2) * 2 * 4 + 16);
+            bytes += chunks * (chunk_frames * frame_bytes + 16) + 16;
             outs += chunks + 1;
         } else {
-            bytes += n * (1024 * 2 * 4 + 16);
+            bytes += n * (1024 * frame_bytes + 16) + 16;
             outs += n + 1;
         }
     }
     if (max_outputs) *max_outputs = (uint32_t)std::min<uint64_t>(outs, 0xffffffffu);
     return bytes;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n_streams, uint32_t *max_outputs) try {
+    sk::abi_enter();
+    if (!ts && n_streams) return 0;
+    return tick_out_bound(nullptr, ts, n_streams, max_outputs);
 } catch (...) {
     (void)sk::abi_caught("sk_tick_out_bound");
+    return 0;
+}
+
+size_t sk_tick_out_bound_on(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, uint32_t *max_outputs) try {
+    sk::abi_enter();
+    if (!e || (!ts && n_streams)) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return tick_out_bound(e, ts, n_streams, max_outputs);
+} catch (...) {
+    (void)sk::abi_caught("sk_tick_out_bound_on");
     return 0;
 }
 

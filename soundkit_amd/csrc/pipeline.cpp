@@ -163,6 +163,7 @@ struct sk_lane {
     std::condition_variable batch_cv;   // submission thread: work arrived / writers done
     std::condition_variable room_cv;    // workers: the filling batch has room again
     size_t au_pass_budget = 0;          // gpu_entropy: access-unit bytes one worker pass may stage (= what an empty batch holds)
+    std::atomic<size_t> out_cap_seen{0};  // the largest pinned output buffer a batch of this lane has asked for
     static constexpr int kBatches = 3;  // one filling, one on the GPU, one being delivered
     Batch batches[kBatches];
     int filling = 0;
@@ -780,15 +781,24 @@ void submit_body(sk_lane *p) {
         b->rc = SK_OK;
         b->n_out = 0;
         if (!ts.empty()) {
-            const size_t bound = sk_tick_out_bound(ts.data(), (uint32_t)ts.size(), &max_out);
+            const size_t bound = sk_tick_out_bound_on(p->engine, ts.data(), (uint32_t)ts.size(), &max_out);
             if (bound > b->out_pinned_cap) {
+                // Pinned memory is slow to get (10 ms per 64 MB on an idle device, many times that beside a running lane): the
+                // bound is the engine's own (the streams' real ratios and widths, not the 8 -> 48 kHz stereo 32-bit case), with room
+                // to grow into, and what one batch of the lane has needed the others ask for at once.
+                const Clock::time_point t_alloc = Clock::now();
+                const size_t want = std::max(bound + bound / 2, p->out_cap_seen.load());
                 if (b->out_pinned) (void)hipHostFree(b->out_pinned);
                 b->out_pinned = nullptr;
                 b->out_pinned_cap = 0;
-                if (hipHostMalloc((void **)&b->out_pinned, bound + bound / 4, hipHostMallocPortable) == hipSuccess)
-                    b->out_pinned_cap = bound + bound / 4;
-                else
+                if (hipHostMalloc((void **)&b->out_pinned, want, hipHostMallocPortable) == hipSuccess) {
+                    b->out_pinned_cap = want;
+                    p->out_cap_seen.store(want);
+                } else {
                     b->rc = SK_ERR_OOM;
+                }
+                static const bool trace = std::getenv("SK_TICK_TRACE") != nullptr;
+                if (trace) std::fprintf(stderr, "sk_pipeline: output buffer of batch %d regrown to %zu bytes in %.2f ms\n", index, b->out_pinned_cap, ns_since(t_alloc) * 1e-6);
             }
             if (b->recs.size() < max_out) b->recs.resize(max_out);
             if (b->rc == SK_OK && b->n_mp3) {  // streams of both codecs in this tick: the AAC units in the lane's form, the MP3 granules beside them

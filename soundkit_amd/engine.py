@@ -412,7 +412,7 @@ class Engine:
             ts[i].out_bits, ts[i].out_channels = int(s.get("out_bits", 16)), int(s["out_channels"])
             ts[i].resample, ts[i].flush = int(bool(s.get("resample", 0))), int(bool(s.get("flush", 0)))
         max_out = C.c_uint32()
-        cap = lib.sk_tick_out_bound(ts, len(streams), C.byref(max_out))
+        cap = lib.sk_tick_out_bound_on(self._h, ts, len(streams), C.byref(max_out))
         out = np.zeros(max(cap, 16), np.uint8)
         recs = (TickOutput * max(max_out.value, 1))()
         n_out, used = C.c_uint32(), C.c_size_t()
@@ -437,7 +437,7 @@ class Engine:
             ts[i].out_bits, ts[i].out_channels = int(s.get("out_bits", 16)), int(s["out_channels"])
             ts[i].resample, ts[i].flush = int(bool(s.get("resample", 0))), int(bool(s.get("flush", 0)))
         max_out = C.c_uint32()
-        cap = lib.sk_tick_out_bound(ts, len(streams), C.byref(max_out))
+        cap = lib.sk_tick_out_bound_on(self._h, ts, len(streams), C.byref(max_out))
         out = np.zeros(max(cap, 16), np.uint8)
         recs = (TickOutput * max(max_out.value, 1))()
         n_out, used = C.c_uint32(), C.c_size_t()
@@ -466,7 +466,7 @@ class Engine:
             blob += bytes(au) + b"\0" * (8 + (-len(au)) % 4)   # >= 8 zero bytes, next unit 4-byte aligned
         blob = np.frombuffer(bytes(blob) + b"\0" * 8, np.uint8)
         max_out = C.c_uint32()
-        cap = lib.sk_tick_out_bound(ts, len(streams), C.byref(max_out))
+        cap = lib.sk_tick_out_bound_on(self._h, ts, len(streams), C.byref(max_out))
         out = np.zeros(max(cap, 16), np.uint8)
         recs = (TickOutput * max(max_out.value, 1))()
         n_out, used = C.c_uint32(), C.c_size_t()

@@ -79,6 +79,7 @@ size_t sk_tick_out_bound(const sk_tick_stream *ts, uint32_t n, uint32_t *max_out
     *max_outputs = outs;
     return bytes;
 }
+size_t sk_tick_out_bound_on(sk_engine *, const sk_tick_stream *ts, uint32_t n, uint32_t *max_outputs) { return sk_tick_out_bound(ts, n, max_outputs); }
 // What every stand-in tick shares: one "AudioData" per access unit -- or, for a resampling stream, per chunk of four
 // units plus the flush tail, the boundaries of the real tick (lib.rs:1970-2003) -- carrying (stream, running unit
 // number, checksum, magic).
