@@ -3041,6 +3041,13 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     TClock::time_point t_mark = TClock::now();
     double t_sec[6] = {0, 0, 0, 0, 0, 0};
     double t_au[3] = {0, 0, 0};  // au mode, inside section 1: host work until the launches are queued | waiting for them | reading the statuses
+    double t_rs[4] = {0, 0, 0, 0};  // inside section 2: append jobs built | uploaded + launched | rs_process_ready | the rest
+    TClock::time_point t_sub = t_mark;
+    auto sub = [&](int k) {
+        const TClock::time_point now = TClock::now();
+        t_rs[k] += std::chrono::duration<double, std::milli>(now - t_sub).count();
+        t_sub = now;
+    };
     auto lap = [&](int k) {
         const TClock::time_point now = TClock::now();
         t_sec[k] += std::chrono::duration<double, std::milli>(now - t_mark).count();
@@ -3293,6 +3300,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     }
 
     lap(1);
+    t_sub = t_mark;
     // ---- streaming resamplers ----
     std::vector<RsCall> calls;
     std::vector<uint32_t> call_stream;  // RsCall -> index into ts
@@ -3323,6 +3331,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
         std::vector<sk::RowCopy> jobs;
         std::vector<size_t> ready;
         std::vector<uint32_t> before;
+        sub(3);
         for (;;) {
             jobs.clear();
             ready.clear();
@@ -3332,18 +3341,43 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                 StreamInfo &s = e->streams[c.id];
                 const uint32_t total_in = t.good * t.ulen;
                 uint32_t take = std::min(total_in - c.consumed, kRsMaxFill - s.rs_fill);  // a tick's units of a stream: one round
-                while (take) {  // pieces never straddle a unit of the packed synthesis output
+                // Pieces never straddle a unit of the packed synthesis output.  Whole units whose rows lie a constant distance apart
+                // (the usual case: a stream's units of a tick) go down as ONE job per channel.
+                size_t run_at = 0;        // index in `jobs` of the open run's first channel, valid while run_pieces > 0
+                uint32_t run_pieces = 0;
+                uint64_t run_row = 0, run_stride = 0;
+                while (take) {
                     const uint32_t frame = c.consumed / t.ulen, within = c.consumed % t.ulen;
                     const uint32_t n = std::min(take, t.ulen - within);
-                    for (uint32_t ch = 0; ch < c.channels; ++ch)  // MP3 rows hold q / 32768 already: a plain copy
-                        jobs.push_back(sk::RowCopy{(unit_row(call_stream[ci], frame) + ch) * 1024 + within,
-                                                   ((uint64_t)c.id * 2 + ch) * kRsRow + kRsBase + kRsHist + s.rs_fill, n, t.mp3 ? 0u : 1u});
+                    const uint64_t row = unit_row(call_stream[ci], frame);
+                    const bool whole = within == 0 && n == t.ulen;
+                    bool joined = false;
+                    if (whole && run_pieces) {
+                        const uint64_t stride = row - run_row;  // (of a row above the run's last one; anything else starts a new run)
+                        if (row > run_row && (run_pieces == 1 || stride == run_stride) && stride * 1024 <= 0xffffffffull) {
+                            for (uint32_t ch = 0; ch < c.channels; ++ch) {
+                                jobs[run_at + ch].pieces += 1;
+                                jobs[run_at + ch].src_stride = (uint32_t)(stride * 1024);
+                            }
+                            run_stride = stride, run_row = row, run_pieces += 1;
+                            joined = true;
+                        }
+                    }
+                    if (!joined) {
+                        run_at = jobs.size();
+                        for (uint32_t ch = 0; ch < c.channels; ++ch)  // MP3 rows hold q / 32768 already: a plain copy
+                            jobs.push_back(sk::RowCopy{(row + ch) * 1024 + within, ((uint64_t)c.id * 2 + ch) * kRsRow + kRsBase + kRsHist + s.rs_fill, n,
+                                                       t.mp3 ? 0u : 1u});
+                        run_pieces = whole ? 1 : 0;
+                        run_row = row;
+                    }
                     s.rs_fill += n;
                     c.consumed += n;
                     take -= n;
                 }
                 if (s.rs_fill >= kRsChunk) ready.push_back(ci);
             }
+            sub(0);
             if (jobs.empty() && ready.empty()) break;
             if (!jobs.empty()) {
                 const sk::RowCopy *d_jobs = nullptr;
@@ -3352,9 +3386,11 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
                     SK_HIP(sk::launch_row_copies(d_pcm, e->d_rs, d_jobs + j0, (uint32_t)std::min<size_t>(65535, jobs.size() - j0),
                                                  e->stream), "tick append chunk");
             }
+            sub(1);
             if (!ready.empty()) {
                 rc = rs_process_ready(e, calls, ready, d_res, res_stride, res_cap, aux);
                 if (rc != SK_OK) return rc;
+                sub(2);
                 for (size_t ci : ready) {  // one AudioData per chunk (lib.rs:1979-2003), empty ones are not sent
                     RsCall &c = calls[ci];
                     for (const auto &o : c.outs)
@@ -3402,6 +3438,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
         }
     }
 
+    sub(3);
     lap(2);
     // ---- output records and the pack jobs that fill them ----
     std::vector<sk::PackJob> packs;
@@ -3496,8 +3533,8 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     if (bounce) std::memcpy(out, bounce, cursor);
     lap(4);
     if (trace)
-        std::fprintf(stderr, "sk_tick_run: %u streams %u frames | plan %.2f  h2d+synth %.2f  resample %.2f  pack %.2f  sync %.2f ms | au: queue %.2f wait %.2f\n",
-                     n_streams, n_frames, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4], t_au[0], t_au[1]);
+        std::fprintf(stderr, "sk_tick_run: %u streams %u frames | plan %.2f  h2d+synth %.2f  resample %.2f  pack %.2f  sync %.2f ms | au: queue %.2f wait %.2f | resample: jobs %.2f copies %.2f process %.2f rest %.2f\n",
+                     n_streams, n_frames, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4], t_au[0], t_au[1], t_rs[0], t_rs[1], t_rs[2], t_rs[3]);
     *n_outs = n_rec;
     if (out_bytes) *out_bytes = cursor;
     return SK_OK;

@@ -623,15 +623,13 @@ __global__ __launch_bounds__(256) void k_row_copies(const float *src_base, float
     const RowCopy job = jobs[j];
     const float *src = src_base + job.src_off;
     float *dst = dst_base + job.dst_off;
-    if (job.via_s16) {
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < job.count; i += gridDim.x * blockDim.x) {
-            // float_sample_to_i16 (soundkit-decoder lib.rs:1815-1827), then audio_data_to_f32_channels' / 32768
-            const int r = dev_float_sample_to_i16_f32(src[i]);
-            dst[i] = (float)r / 32768.0f;
-        }
-        return;
+    const uint32_t total = job.count * job.pieces;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t piece = job.pieces > 1 ? i / job.count : 0u;  // (block-uniform branch; one job, one `pieces`)
+        const float x = src[(size_t)piece * job.src_stride + (i - piece * job.count)];
+        // via_s16: float_sample_to_i16 (soundkit-decoder lib.rs:1815-1827), then audio_data_to_f32_channels' / 32768
+        dst[i] = job.via_s16 ? (float)dev_float_sample_to_i16_f32(x) / 32768.0f : x;
     }
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < job.count; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 }  // namespace
