@@ -670,7 +670,7 @@ typedef struct sk_pipeline_config {
     uint32_t entropy_threads;            /* 0 = usable CPUs (affinity, cgroup quota) - 5, at most 64 */
     uint32_t max_streams;                /* handles open at once; 0 = 1024 (<= the engine's max_streams) */
     uint32_t max_frames_per_tick;        /* access units per GPU tick; 0 = 16384 (65536 with gpu_entropy) */
-    uint32_t max_stream_frames_per_tick; /* of one stream; 0 = 8 (16 with gpu_entropy) */
+    uint32_t max_stream_frames_per_tick; /* of one stream; 0 = 8 (32 with gpu_entropy: this quota decides how full the ticks are) */
     uint32_t input_buffer;               /* chunks per input queue; 0 = DEFAULT_INPUT_BUFFER 128 (lib.rs:77) */
     uint32_t output_buffer;              /* AudioData per output queue; 0 = DEFAULT_OUTPUT_BUFFER 16 (lib.rs:78) */
     uint32_t tick_wait_us;               /* how long a non-empty batch may wait for more frames; 0 = 200 (2000 with gpu_entropy) */
@@ -680,8 +680,8 @@ typedef struct sk_pipeline_config {
                                           * side records; dequantisation, PNS, stereo tools and TNS run on the GPU (sk_tick_run_q) */
     uint32_t lanes;                      /* engines the streams are spread over, each with its own batches and submission
                                           * thread, so that ticks overlap on the device; lane 0 is the caller's engine, the
-                                          * others are created on the same device.  0 = 2 with gpu_entropy and max_streams >= four ticks' worth of
-                                          * streams (16384 at the defaults), else 1; at most 8.
+                                          * others are created on the same device.  0 = 2 with gpu_entropy and max_streams >= two ticks' worth of
+                                          * streams (4096 at the defaults), else 1; at most 8.
                                           * entropy_threads and max_streams are totals, split over the lanes */
 } sk_pipeline_config;
 

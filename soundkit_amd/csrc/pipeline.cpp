@@ -1117,7 +1117,7 @@ int lane_create(sk_engine *e, const sk_pipeline_config *cfg, OutQueue *oq, uint3
     // size (the time of one unit), so ticks should be big; with the host front-end the tick is PCIe-bound and the host
     // threads want their results back soon.
     if (!p->cfg.max_frames_per_tick) p->cfg.max_frames_per_tick = p->cfg.gpu_entropy == 1 ? 65536 : 16384;
-    if (!p->cfg.max_stream_frames_per_tick) p->cfg.max_stream_frames_per_tick = p->cfg.gpu_entropy == 1 ? 16 : 8;
+    if (!p->cfg.max_stream_frames_per_tick) p->cfg.max_stream_frames_per_tick = p->cfg.gpu_entropy == 1 ? 32 : 8;
     if (p->cfg.max_stream_frames_per_tick > p->cfg.max_frames_per_tick) p->cfg.max_stream_frames_per_tick = p->cfg.max_frames_per_tick;
     if (!p->cfg.input_buffer) p->cfg.input_buffer = 128;   // DEFAULT_INPUT_BUFFER, lib.rs:77
     if (!p->cfg.output_buffer) p->cfg.output_buffer = 16;  // DEFAULT_OUTPUT_BUFFER, lib.rs:78
@@ -1469,16 +1469,19 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
     *out = nullptr;
     sk_pipeline_config c{};
     if (cfg) c = *cfg;
-    // Two lanes when the front-end runs on the GPU and there are streams enough to fill two ticks at a time: a tick is then
-    // ~7 ms of dependent launches whatever its size, and the second engine's tick fills the device while the first
-    // one's drains.  Measured with 16 384 streams: 6.2-8.3 M access units/s on two lanes against 5.5-6.9 M on one; with
-    // 8192 streams two lanes run half-empty ticks and lose (3.5-6.3 M against 5.5-6.8 M), so one lane stays the default
-    // there.  With the host front-end the host threads are the limit and a second lane only splits them.
+    // A stream hands a tick at most `max_stream_frames_per_tick` units and is not scheduled again until that tick has been delivered, so
+    // with N streams a tick carries well under N times that: the quota decides how full the ticks are, and a tick costs ~2 ms of waits
+    // and launches whatever its size.  With the GPU front-end (where the host threads only frame) the default is 32 units -- two
+    // resampler rounds of four chunks; the output queue of a resampling stream has room for 64 -- and TWO lanes (engines) when every
+    // lane can still fill a whole tick from its own streams: the second engine's tick fills the device while the first one's drains.
+    // Measured with 4096 streams, whole decode (gpurun_out/r4_ab_quota*.log): quota 16 / one lane 5.6-5.9 M access units/s; 32 / one
+    // lane 7.5-8.3 M; 32 / two lanes 9.6-10.2 M; 48 / two 10.0-10.5 M; 64 / two 9.6 M.  With the host front-end the host threads are
+    // the limit and a second lane only splits them.
     if (!c.max_streams) c.max_streams = 1024;
     const uint32_t tick_frames = c.max_frames_per_tick ? c.max_frames_per_tick : (c.gpu_entropy == 1 ? 65536u : 16384u);
-    const uint32_t stream_frames = c.max_stream_frames_per_tick ? c.max_stream_frames_per_tick : (c.gpu_entropy == 1 ? 16u : 8u);
+    const uint32_t stream_frames = c.max_stream_frames_per_tick ? c.max_stream_frames_per_tick : (c.gpu_entropy == 1 ? 32u : 8u);
     const uint32_t streams_per_tick = std::max(1u, tick_frames / std::max(1u, stream_frames));
-    uint32_t n_lanes = c.lanes ? c.lanes : ((c.gpu_entropy == 1 && c.max_streams >= 4 * streams_per_tick) ? 2u : 1u);
+    uint32_t n_lanes = c.lanes ? c.lanes : ((c.gpu_entropy == 1 && c.max_streams >= 2 * streams_per_tick) ? 2u : 1u);
     if (n_lanes > 8) return SK_ERR_INVALID_ARG;
     if (n_lanes > c.max_streams) n_lanes = c.max_streams;
     if (!c.entropy_threads) {
