@@ -186,3 +186,54 @@ def test_free_format_and_mixed_block_intensity_streams_behind_the_scheduler(engi
         assert all(a.sampling_rate == spec["rate"] and a.channel_count == spec["channels"] for a in outs)
         mine = np.concatenate([np.frombuffer(a.data.tobytes(), "<i2") for a in outs])
         assert np.array_equal(mine, samples)
+
+
+@pytest.mark.parametrize("front_end", [0, 1, 2], ids=["host_front_end", "gpu_front_end", "host_huffman_gpu_rest"])
+def test_two_lanes_and_the_default_quota_give_every_stream_its_single_decoder_output(engine, front_end):
+    """The configuration a GPU-front-end pipeline of 4096 streams gets by default since round 4: the streams dealt out over TWO
+    lanes (engines on the same device, each with its own batches, submission and delivery threads) behind one handle space, 32
+    units per stream and tick.  AAC and MP3 streams, resampled and not, in random chunkings: every stream delivers exactly what
+    its single decoder gives -- which lane it lands on, and what shares its ticks, must not show."""
+    names = [n for pair in zip(AAC * 2, (MP3 * 4)) for n in pair] + AAC  # 20 streams: handles alternate between the lanes
+    datas = [read(n) for n in names]
+    want = {n: single_decoder(engine, n, read(n)) for n in set(names)}
+    rng = np.random.default_rng(40 + front_end)
+    chunks = [int(c) for c in rng.integers(150, 9000, len(names))]
+    sched = pipeline.BatchScheduler(engine, entropy_threads=4, max_streams=32, max_frames_per_tick=256, max_stream_frames_per_tick=32,
+                                    gpu_entropy=front_end, lanes=2)
+    try:
+        handles = [sched.spawn() for _ in names]
+        assert len({h.id % 2 for h in handles}) == 2, "handles of both lanes"
+        feeder = threading.Thread(target=feed_all, args=(handles, datas, chunks))
+        feeder.start()
+        outs = drain(handles, 120)
+        feeder.join()
+        # a second generation on the same handles' slots: a lane's streams are closed and opened again while the other lane runs
+        for h in handles[:6]:
+            h.cancel()
+        again = [sched.spawn(pipeline.DecodeOptions(16, 8000, 1)) for _ in range(6)]
+        feeder = threading.Thread(target=feed_all, args=(again, datas[:6], chunks[:6]))
+        feeder.start()
+        outs2 = drain(again, 120)
+        feeder.join()
+        for h in handles[6:] + again:
+            h.cancel()
+    finally:
+        sched.close()
+    for name, got in zip(names, outs):
+        rate, channels, samples = want[name]
+        assert got and not any(isinstance(a, Exception) for a in got), (name, [a for a in got if isinstance(a, Exception)][:1])
+        assert all(a.sampling_rate == rate and a.channel_count == channels and a.bits_per_sample == 16 for a in got)
+        mine = np.concatenate([np.frombuffer(a.data.tobytes(), "<i2") for a in got])
+        assert mine.size == samples.size and np.array_equal(mine, samples), name
+    for name, got in zip(names[:6], outs2):
+        assert got and not any(isinstance(a, Exception) for a in got), name
+        assert all(a.sampling_rate == 8000 and a.channel_count == 1 and a.bits_per_sample == 16 for a in got)
+        rate, _, samples = want[name]
+        total = sum(a.data.size // 2 for a in got)
+        expect = samples.size // want[name][1] * 8000 / rate
+        assert abs(total - expect) < 2200, (name, total, expect)  # the resampler's delay line and the flush's trim
+    by_name = {}
+    for name, got in zip(names[:6], outs2):  # streams of one file, whichever lane: the same bytes
+        blob = b"".join(a.data.tobytes() for a in got)
+        assert by_name.setdefault(name, blob) == blob, name
