@@ -1069,7 +1069,7 @@ def main():
             import copy
             a2 = copy.copy(args)
             a2.workload, a2.front_end, a2.gpu_entropy = "end_to_end", "gpu", True
-            a2.steps, a2.warmup = 90, 4   # 4096 streams x 48 units x 90 = 17.7 M access units: 3-4 s at the measured rates
+            a2.steps, a2.warmup = 180, 4   # 4096 streams x 48 units x 180 = 35.4 M access units: 3-4 s at the measured rates (10 M/s)
             try:
                 e2e = end_to_end(a2, eng, torch, dist, world, rank, device, emit=False)
             except EndToEndStalled:
