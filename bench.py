@@ -428,6 +428,12 @@ def end_to_end(args, eng, torch, dist, world, rank, device, emit=True, cpu_basel
         cpu = pcm_stats_s16(lg, want)
         same_len = want.size == captured.size
         d = np.abs(want.astype(np.int32) - captured.astype(np.int32)) if same_len else None
+        if same_len and os.environ.get("SK_BENCH_DUMP_DIFF") and d.size and int(d.max()) > 1:  # where a run leaves the CPU chain by more than the FIR's LSB
+            bad = np.flatnonzero(d > 1)
+            sys.stderr.write("pcm diff > 1 LSB at %d samples, first %s .. last %s; per 4096-frame chunk (1365.33 outputs): %s\n"
+                             % (bad.size, bad[:12].tolist(), bad[-4:].tolist(), sorted(set((bad * 3 // 4096).tolist()))[:20]))
+            for i in bad[:24]:
+                sys.stderr.write("   [%d] want %d got %d\n" % (i, int(want[i]), int(captured[i])))
         out["pcm_stats"]["cpu_chain"] = dict(cpu, max_abs_diff_lsb=int(d.max()) if same_len and d.size else None,
                                              differing_fraction=float((d > 0).mean()) if same_len and d.size else None,
                                              same_sample_count=bool(same_len),

@@ -681,7 +681,9 @@ typedef struct sk_pipeline_config {
     uint32_t lanes;                      /* engines the streams are spread over, each with its own batches and submission
                                           * thread, so that ticks overlap on the device; lane 0 is the caller's engine, the
                                           * others are created on the same device.  0 = 2 with gpu_entropy and max_streams >= two ticks' worth of
-                                          * streams (4096 at the defaults), else 1; at most 8.
+                                          * streams (4096 at the defaults), else 1; at most 8.  The engines of a device take turns with
+                                          * their ticks' device work (ticks on the device at the same time were found to corrupt samples,
+                                          * round 4): a lane plans, uploads and delivers while another's tick has the device.
                                           * entropy_threads and max_streams are totals, split over the lanes */
 } sk_pipeline_config;
 

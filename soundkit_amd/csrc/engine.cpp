@@ -302,6 +302,15 @@ struct sk_aac_plan {
 
 namespace {
 
+// Engines of one process on one device never have a tick's device work in flight at the same time.  Found in round 4: with two
+// engines (the scheduler's lanes) running their ticks concurrently on separate hardware queues, a third of 4096 identical streams
+// came out with short bursts of slightly wrong samples (tools/debug/stream_hashes.py; none with GPU_MAX_HW_QUEUES=1, none with the
+// ticks serialised, none with one engine).  The cause is not known yet (profiles/r04_lanes_corruption.md), so the ticks take turns:
+// from the first upload of a tick to its last wait, per device.  The host's planning of a tick still overlaps the other engine's
+// device work.  A process with one engine per device never waits here.
+std::mutex g_device_turn[16];
+std::atomic<int> g_engines_on_device[16];
+
 struct DeviceGuard {
     explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); want = dev; }
     // the usual form at an entry point (engine lock held): the engine's device, and the state of the streams opened since
@@ -537,6 +546,7 @@ int sk_engine_create(int device, uint32_t max_streams, sk_engine **out) try {
     if (!e) return SK_ERR_OOM;
     e->device = device;
     e->max_streams = max_streams;
+    g_engines_on_device[device & 15].fetch_add(1);
     DeviceGuard guard(device);
     int rc = SK_OK;
     do {
@@ -572,6 +582,7 @@ int sk_engine_create(int device, uint32_t max_streams, sk_engine **out) try {
 void sk_engine_destroy(sk_engine *e) try {
     sk::abi_enter();
     if (!e) return;
+    g_engines_on_device[e->device & 15].fetch_sub(1);
     {
         DeviceGuard guard(e);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -3116,6 +3127,9 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
             }
     }
     lap(0);
+    // from here to the tick's last wait the device belongs to this engine (see g_device_turn)
+    std::unique_lock<std::mutex> turn;
+    if (g_engines_on_device[e->device & 15].load() > 1) turn = std::unique_lock<std::mutex>(g_device_turn[e->device & 15]);
     const size_t elems = (size_t)hp.off1024 * 1024;
     const size_t arena_bytes = ((size_t)16 << 20) + (size_t)n_frames * 512 + (size_t)n_streams * 1024 + (size_t)mp3.n * 512;
     SK_HIP(e->in_buf.reserve(elems * 4 + 16), "alloc tick coeffs");

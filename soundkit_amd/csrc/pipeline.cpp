@@ -1162,8 +1162,11 @@ int lane_create(sk_engine *e, const sk_pipeline_config *cfg, OutQueue *oq, uint3
     for (int i = 1; i < sk_lane::kBatches; ++i) p->free_batches.push_back(i);
     for (uint32_t i = 0; i < p->cfg.entropy_threads; ++i) p->workers.emplace_back(worker_main, p);
     p->submitter = std::thread(submit_main, p);
-    // with the front-end on the GPU the entropy threads have little to do and delivery is the busiest host stage
-    p->n_deliver = p->cfg.gpu_entropy == 1 ? std::max(1u, std::min(4u, p->cfg.entropy_threads / 2)) : 1;
+    // With the front-end on the GPU the entropy threads have little to do and delivery is the busiest host stage -- and on the streams'
+    // way back into the next tick: a stream is schedulable again when its outputs have been handed over.  As many delivery threads as
+    // the lane has entropy threads, four at most (whole decode, 4096 streams on two lanes of four entropy threads each: 6.4 / 10.2 /
+    // 10.7 / 11.3 / 11.7 M access units/s with 1 / 2 / 3 / 4 / 6 delivery threads per lane, gpurun_out/r4_ab_deliver.log).
+    p->n_deliver = p->cfg.gpu_entropy == 1 ? std::max(1u, std::min(4u, p->cfg.entropy_threads)) : 1;
     if (const char *env = std::getenv("SK_PIPELINE_DELIVER_THREADS")) {  // tuning / test override
         const int n = std::atoi(env);
         if (n >= 1 && n <= 16) p->n_deliver = (uint32_t)n;
@@ -1472,11 +1475,13 @@ int sk_pipeline_create(sk_engine *e, const sk_pipeline_config *cfg, sk_pipeline 
     // A stream hands a tick at most `max_stream_frames_per_tick` units and is not scheduled again until that tick has been delivered, so
     // with N streams a tick carries well under N times that: the quota decides how full the ticks are, and a tick costs ~2 ms of waits
     // and launches whatever its size.  With the GPU front-end (where the host threads only frame) the default is 32 units -- two
-    // resampler rounds of four chunks; the output queue of a resampling stream has room for 64 -- and TWO lanes (engines) when every
-    // lane can still fill a whole tick from its own streams: the second engine's tick fills the device while the first one's drains.
-    // Measured with 4096 streams, whole decode (gpurun_out/r4_ab_quota*.log): quota 16 / one lane 5.6-5.9 M access units/s; 32 / one
-    // lane 7.5-8.3 M; 32 / two lanes 9.6-10.2 M; 48 / two 10.0-10.5 M; 64 / two 9.6 M.  With the host front-end the host threads are
-    // the limit and a second lane only splits them.
+    // resampler rounds of four chunks; the output queue of a resampling stream has room for 64.  Whole decode, 4096 streams, one
+    // lane (gpurun_out/r4_ab_quota*.log): quota 16: 5.6-5.9 M access units/s; 24: 7.3-7.7 M; 32: 7.5-8.3 M; 48: 8.5-9.5 M.
+    // TWO lanes (engines) when every lane can still fill a whole tick from its own streams: one lane plans, uploads and delivers
+    // while the other's tick has the device (8.2 M on one lane, 11.3 M on two, quota 32).  The engines of a device take TURNS with
+    // their ticks' device work (engine.cpp, g_device_turn): two ticks on the device at the same time measured no faster (9.6-10.2 M)
+    // and delivered short bursts of slightly wrong samples in a third of the streams (profiles/r04_lanes_corruption.md).  With the
+    // host front-end the host threads are the limit and a second lane only splits them.
     if (!c.max_streams) c.max_streams = 1024;
     const uint32_t tick_frames = c.max_frames_per_tick ? c.max_frames_per_tick : (c.gpu_entropy == 1 ? 65536u : 16384u);
     const uint32_t stream_frames = c.max_stream_frames_per_tick ? c.max_stream_frames_per_tick : (c.gpu_entropy == 1 ? 32u : 8u);

@@ -96,3 +96,40 @@ def test_8192_streams_through_the_scheduler(engine, expected, gpu_entropy):
         mine = np.frombuffer(buf[k, :int(lens[k])].tobytes(), "<i2").astype(np.int32)
         d = np.abs(mine - exp)
         assert d.max() <= 1 and (d > 0).mean() < 0.01, (k, int(d.max()), float((d > 0).mean()))
+
+
+@pytest.mark.parametrize("lanes, quota", [(2, 32), (1, 32)])
+def test_every_stream_delivers_the_same_bytes_over_many_ticks(engine, lanes, quota):
+    """2048 streams x 2880 access units each, the GPU front-end, 48 kHz stereo -> 16 kHz mono s16: every stream is fed the same
+    bytes, so every stream's order-sensitive hash over its AudioData must be the same -- over thousands of chunks per stream, with
+    the ticks' contents changing from tick to tick.  With two lanes this is the regression test of round 4's finding: two engines
+    whose ticks ran on the device at the same time delivered short bursts of slightly wrong samples in a third of the streams
+    (tools/debug/stream_hashes.py, profiles/r04_lanes_corruption.md); the engines of a device take turns since."""
+    from soundkit_amd import aac_lc
+    streams, loops = 2048, 60
+    clip = open(CLIP, "rb").read()
+    frames = aac_lc.split_adts(clip)
+    clip = clip[:sum(len(au) + 7 for _, au in frames)]
+    lg = C.CDLL(os.path.join(ROOT, "soundkit_amd", "libsk_loadgen.so"))
+    lg.sk_loadgen_run_checked.restype = C.c_int
+    lg.sk_loadgen_run_checked.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                          C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    hashes, outputs = np.zeros(streams, np.uint64), np.zeros(streams, np.uint32)
+    nbytes, errors = np.zeros(streams, np.uint64), np.zeros(streams, np.uint32)
+    capture = np.array([0], np.uint32)
+    buf, lens = np.zeros((1, 1 << 22), np.uint8), np.zeros(1, np.uint64)
+    chk = Check(hashes.ctypes.data, outputs.ctypes.data, nbytes.ctypes.data, errors.ctypes.data, capture.ctypes.data, 1, buf.ctypes.data,
+                buf.shape[1], lens.ctypes.data)
+    sched = pipeline.BatchScheduler(engine, max_streams=streams, gpu_entropy=1, lanes=lanes, max_stream_frames_per_tick=quota)
+    try:
+        res = Result()
+        opt = DecodeOptionsC(16000, 16, 1, 0)
+        rc = lg.sk_loadgen_run_checked(sched._h, clip, len(clip), len(frames), streams, loops, C.byref(opt), 4, 0, C.byref(res), C.byref(chk))
+        assert rc == 0
+    finally:
+        sched.close()
+    assert res.errors == 0 and not errors.any()
+    assert res.access_units == streams * loops * len(frames)
+    assert np.unique(outputs).size == 1 and np.unique(nbytes).size == 1
+    odd = np.flatnonzero(hashes != hashes[0])
+    assert odd.size == 0, "%d of %d streams delivered other bytes than stream 0 (first: %s)" % (odd.size, streams, odd[:8].tolist())
