@@ -98,15 +98,16 @@ def test_8192_streams_through_the_scheduler(engine, expected, gpu_entropy):
         assert d.max() <= 1 and (d > 0).mean() < 0.01, (k, int(d.max()), float((d > 0).mean()))
 
 
-@pytest.mark.parametrize("lanes, quota", [(2, 32), (1, 32)])
-def test_every_stream_delivers_the_same_bytes_over_many_ticks(engine, lanes, quota):
-    """2048 streams x 2880 access units each, the GPU front-end, 48 kHz stereo -> 16 kHz mono s16: every stream is fed the same
+@pytest.mark.parametrize("lanes, quota, front_end, loops", [(2, 32, 1, 60), (1, 32, 1, 60), (2, 8, 0, 30), (2, 8, 2, 30)],
+                         ids=["two_lanes_gpu_front_end", "one_lane_gpu_front_end", "two_lanes_host_front_end", "two_lanes_split_front_end"])
+def test_every_stream_delivers_the_same_bytes_over_many_ticks(engine, lanes, quota, front_end, loops):
+    """2048 streams x 2880 (1440) access units each, 48 kHz stereo -> 16 kHz mono s16: every stream is fed the same
     bytes, so every stream's order-sensitive hash over its AudioData must be the same -- over thousands of chunks per stream, with
     the ticks' contents changing from tick to tick.  With two lanes this is the regression test of round 4's finding: two engines
     whose ticks ran on the device at the same time delivered short bursts of slightly wrong samples in a third of the streams
     (tools/debug/stream_hashes.py, profiles/r04_lanes_corruption.md); the engines of a device take turns since."""
     from soundkit_amd import aac_lc
-    streams, loops = 2048, 60
+    streams = 2048
     clip = open(CLIP, "rb").read()
     frames = aac_lc.split_adts(clip)
     clip = clip[:sum(len(au) + 7 for _, au in frames)]
@@ -120,7 +121,7 @@ def test_every_stream_delivers_the_same_bytes_over_many_ticks(engine, lanes, quo
     buf, lens = np.zeros((1, 1 << 22), np.uint8), np.zeros(1, np.uint64)
     chk = Check(hashes.ctypes.data, outputs.ctypes.data, nbytes.ctypes.data, errors.ctypes.data, capture.ctypes.data, 1, buf.ctypes.data,
                 buf.shape[1], lens.ctypes.data)
-    sched = pipeline.BatchScheduler(engine, max_streams=streams, gpu_entropy=1, lanes=lanes, max_stream_frames_per_tick=quota)
+    sched = pipeline.BatchScheduler(engine, max_streams=streams, gpu_entropy=front_end, lanes=lanes, max_stream_frames_per_tick=quota)
     try:
         res = Result()
         opt = DecodeOptionsC(16000, 16, 1, 0)
