@@ -47,8 +47,19 @@ def work(t):
             elif h != first[0]:
                 bad[t] += 1
                 if bad[t] <= 3:
-                    d = (pcm != first[1]).nonzero()
-                    print("thread", t, "iteration", it, "differs at", d.shape[0], "elements, first", d[0].tolist(), flush=True)
+                    a, b = pcm.to(torch.float64), first[1].to(torch.float64)
+                    diff = (a - b).abs()
+                    where = diff.nonzero()
+                    rel = diff / b.abs().clamp_min(1e-30)
+                    frames_hit = torch.unique(where[:, 0]).numel()
+                    print("thread", t, "iteration", it, "differs at", where.shape[0], "elements in", frames_hit, "frames; max abs", float(diff.max()),
+                          "max rel", float(rel[diff > 0].max()), "median rel", float(rel[diff > 0].median()), "| reference rms", float(b.pow(2).mean().sqrt()),
+                          "first", where[0].tolist(), flush=True)
+                    if bad[t] == 1 and len(sys.argv) > 6:  # keep the first hit frames and the frame behind each for a look at the error's shape
+                        rows = torch.unique(where[:, 0])[:24].tolist()
+                        keep = sorted(set(rows) | {r + 1 for r in rows if (r + 1) % frames})
+                        np.savez(sys.argv[6], rows=np.array(keep), hit=np.array(rows), frames=frames, got=pcm[keep].cpu().numpy(), ref=first[1][keep].cpu().numpy(),
+                                 coeffs=coeffs[keep].cpu().numpy(), all_hit=torch.unique(where[:, 0]).cpu().numpy())
     plan.destroy()
 
 
