@@ -617,7 +617,9 @@ def main():
                          "PCM (round 1's chain)")
     ap.add_argument("--tail", default="separate", choices=["separate", "fused"],
                     help="pipeline, s16 chain: the two launches (synthesis to planar s16, then the FIR) or sk_aac_plan_run_tail_s16_dev, "
-                         "the same work as one launch with the PCM kept in LDS")
+                         "the same work as one launch with the PCM kept in LDS -- WITHDRAWN: at this batch size the platform computes "
+                         "that kernel wrongly (profiles/r04_lanes_corruption.md); 'fused' sets SK_AAC_TAIL_ONE_LAUNCH=1 and its line "
+                         "says \"valid\": false")
     ap.add_argument("--no-extras", action="store_true",
                     help="pipeline: skip the two extra measurements the default line carries (the mixed-window synthesis launch and a "
                          "few seconds of the whole decode through the scheduler)")
@@ -638,6 +640,8 @@ def main():
     ap.add_argument("--out-rate", type=int, default=16000, help="end_to_end: DecodeOptions.output_sample_rate (0 = source rate)")
     ap.add_argument("--out-channels", type=int, default=1, help="end_to_end: DecodeOptions.output_channels (0 = source)")
     args = ap.parse_args()
+    if args.tail == "fused":
+        os.environ["SK_AAC_TAIL_ONE_LAUNCH"] = "1"  # the entry point is withdrawn; the line below is marked invalid
 
     # `python bench.py --gpus N` on its own: become the launcher of N ranks (before anything here touches the GPU)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -925,6 +929,10 @@ def main():
                        "sample_rate": 48000, "channels": ch, "seed": "0x12345678 + stream*0x9e3779b9 + frame*2 + ch", "spectrum": "dsp.rs:725-738 seeded_spectrum x %g" % SPECTRUM_GAIN,
                        "parallelism": "streams sharded, %d rank(s), no collective" % world},
         }
+        if args.tail == "fused" and args.workload == "pipeline":
+            out["valid"] = False
+            out["invalid_because"] = ("k_aac_tail runs synthesis waves and matrix-instruction waves on the same SIMDs; at this batch the "
+                                      "platform computes it wrongly (3 % of the samples, differently in every run): profiles/r04_lanes_corruption.md")
         rl = {}
         if "k_aac_synth" in per_kernel:
             # aac-wasm-bench lib.rs:526-549: 1/rtf summed over the batch -- of the decode TAIL this workload is (no entropy

@@ -528,10 +528,14 @@ int sk_downsample_48k_16k_frames_s16_to_f32_dev(sk_engine *, const int16_t *d_pc
                                                 uint32_t channels, uint32_t n_streams, uint32_t frames_per_stream,
                                                 float *d_out, size_t out_stride, uint32_t *out_frames);
 
-/* sk_aac_plan_run_s16_planar_dev + sk_downsample_48k_16k_frames_s16_to_s16_dev over all frames of a plan as ONE launch
+/* WITHDRAWN (round 4): returns SK_ERR_UNSUPPORTED for every plan -- use the two calls -- unless SK_AAC_TAIL_ONE_LAUNCH=1 is in
+ * the environment, which is for reproducing the defect only: a kernel whose waves run the synthesis while others of them run
+ * matrix instructions on the same SIMDs is what this platform computes wrongly (profiles/r04_lanes_corruption.md); at the
+ * headline batch 3 % of its samples are wrong, differently in every run.  What it was:
+ * sk_aac_plan_run_s16_planar_dev + sk_downsample_48k_16k_frames_s16_to_s16_dev over all frames of a plan as ONE launch
  * (decode_aac_access_unit + apply_output_options, lib.rs:1793-1813, 3324-3456): the s16 PCM between the two never crosses
  * HBM -- each channel's wave keeps its last 2048 samples as the FIR's two f16 planes in LDS and runs the FIR on them as
- * they complete.  Same results bit for bit (same arithmetic in the same order).  For plans whose channels are all free of
+ * they complete.  Same arithmetic in the same order as the two calls.  For plans whose channels are all free of
  * EightShort frames and pair up (two channels of equal length), every stream with `channels` channels and
  * `frames_per_stream` frames from its frame 0; anything else returns SK_ERR_UNSUPPORTED: use the two calls.
  * stream_stride: samples between the first frames of consecutive streams in the spectra's packing (as above);

@@ -1077,10 +1077,17 @@ int sk_aac_plan_run_s16_planar_dev(sk_engine *e, const sk_aac_plan *p, const flo
 }
 
 // The decode tail as one launch (k_aac_tail): sk_aac_plan_run_s16_planar_dev followed by the one-shot
-// sk_downsample_48k_16k_frames_s16_to_s16_dev over all frames of the plan, same results bit for bit, without the s16 PCM in
-// HBM.  For plans the fused kernel covers -- every channel free of EightShort frames and paired (two channels of equal
-// length: build_plan_host), every stream with the same channel count and the same number of frames, each stream's frames
-// `frames_per_stream` consecutive entries from its frame 0; anything else: SK_ERR_UNSUPPORTED, use the two calls.
+// sk_downsample_48k_16k_frames_s16_to_s16_dev over all frames of the plan, without the s16 PCM in HBM.  For plans the fused kernel
+// covers -- every channel free of EightShort frames and paired (two channels of equal length: build_plan_host), every stream with
+// the same channel count and the same number of frames, each stream's frames `frames_per_stream` consecutive entries from its
+// frame 0; anything else: SK_ERR_UNSUPPORTED, use the two calls.
+//
+// WITHDRAWN in round 4: SK_ERR_UNSUPPORTED for every plan unless SK_AAC_TAIL_ONE_LAUNCH=1 is in the environment (read at each
+// call).  The kernel has synthesis waves and matrix-instruction FIR work resident on the same SIMDs, which is exactly the
+// co-residency the platform gets wrong (profiles/r04_lanes_corruption.md): the same arithmetic in the same order as the two
+// launches, bit-identical as long as a launch is no more than a workgroup or so per CU (what the tests ran), and at the headline
+// batch 3 % of the samples wrong by up to 5000 LSB, differently in every run (tools/debug/fused_tail_repeats.py).  The switch
+// is for reproducing that, not for use.
 int sk_aac_plan_run_tail_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, size_t stream_stride, uint32_t channels,
                                  uint32_t frames_per_stream, int16_t *d_out, size_t out_stride, uint32_t *out_frames) try {
     sk::abi_enter();
@@ -1096,6 +1103,10 @@ int sk_aac_plan_run_tail_s16_dev(sk_engine *e, const sk_aac_plan *p, const float
     if (!d_coeffs || !d_out || out_stride < n_out || out_stride % 4 || stream_stride < (size_t)channels * SK_AAC_FRAME_LEN ||
         ((uintptr_t)d_out & 7))
         return SK_ERR_INVALID_ARG;
+    {
+        const char *v = std::getenv("SK_AAC_TAIL_ONE_LAUNCH");
+        if (!(v && v[0] == '1' && v[1] == 0)) return SK_ERR_UNSUPPORTED;  // withdrawn: see above
+    }
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e);
     sk::TailArgs ta{};

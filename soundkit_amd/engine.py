@@ -94,8 +94,9 @@ class Plan:
               "sk_aac_plan_run_s16_planar_dev", self.engine._h)
 
     def run_tail_s16(self, d_coeffs, stream_stride, channels, frames_per_stream, d_out, out_stride):
-        """sk_aac_plan_run_tail_s16_dev: run_s16_planar + the one-shot 48k->16k FIR to interleaved s16 as one launch (raises
-        SoundkitError -6 for plans the fused kernel does not cover)"""
+        """sk_aac_plan_run_tail_s16_dev: run_s16_planar + the one-shot 48k->16k FIR to interleaved s16 as one launch.  WITHDRAWN:
+        raises SoundkitError -6 (unsupported) unless SK_AAC_TAIL_ONE_LAUNCH=1 is set -- the kernel is computed wrongly by the platform
+        once several workgroups share a CU (include/soundkit_amd.h); also -6 for plans the fused kernel does not cover"""
         got = C.c_uint32()
         check(lib.sk_aac_plan_run_tail_s16_dev(self.engine._h, self._h, _ptr(d_coeffs), stream_stride, channels, frames_per_stream,
                                                _ptr(d_out), out_stride, C.byref(got)), "sk_aac_plan_run_tail_s16_dev", self.engine._h)

@@ -233,14 +233,17 @@ def test_full_size_s16_chain_spot_checked_against_oracle(oracle):
 
 @pytest.mark.parametrize("layout", ["frame", "stream"])
 @pytest.mark.parametrize("ch,n_frames", [(2, 7), (1, 7), (2, 3), (2, 12), (1, 1)])
-def test_fused_tail_equals_the_two_calls(engine, oracle, layout, ch, n_frames):
-    """sk_aac_plan_run_tail_s16_dev (k_aac_tail: synthesis, s16 narrowing, the FIR's f16 planes in an LDS ring, the MFMA FIR on
+def test_fused_tail_equals_the_two_calls(engine, oracle, layout, ch, n_frames, monkeypatch):
+    """(The entry point is withdrawn -- next test; this runs the kernel behind its diagnostic switch, at a size where a launch is
+    a few workgroups and the platform's co-residency defect does not show: include/soundkit_amd.h.)
+    sk_aac_plan_run_tail_s16_dev (k_aac_tail: synthesis, s16 narrowing, the FIR's f16 planes in an LDS ring, the MFMA FIR on
     the wave's own channel, interleaved s16 out -- one launch, no PCM in HBM) against sk_aac_plan_run_s16_planar_dev +
     sk_downsample_48k_16k_frames_s16_to_s16_dev: three calls back to back on the same streams (the overlap state carries;
     OnlyLong, LongStart and LongStop frames with both window shapes; frame counts that end in partial tiles), bit for bit,
     and the carried state afterwards."""
     import torch
     from soundkit_amd._lib import SoundkitError
+    monkeypatch.setenv("SK_AAC_TAIL_ONE_LAUNCH", "1")
     n_streams = 10
     coeffs = np.empty((n_streams, n_frames, ch, 1024), np.float32)
     for s in range(n_streams):
@@ -297,6 +300,32 @@ def test_fused_tail_equals_the_two_calls(engine, oracle, layout, ch, n_frames):
     for sid, (d, sh) in zip(sids, state_want):
         d2, sh2 = engine.get_state(int(sid), ch)
         assert np.array_equal(d, d2) and np.array_equal(sh, sh2)
+    plan.destroy()
+    for sid in sids:
+        engine.close_stream(int(sid))
+
+
+def test_fused_tail_is_withdrawn(engine, monkeypatch):
+    """Without SK_AAC_TAIL_ONE_LAUNCH=1 the one-launch tail refuses every plan (SK_ERR_UNSUPPORTED: use the two calls) and writes
+    nothing: synthesis waves and matrix-instruction waves sharing SIMDs inside one launch is what the platform computes wrongly
+    (profiles/r04_lanes_corruption.md; tools/debug/fused_tail_repeats.py shows it at the headline batch)."""
+    import torch
+    from soundkit_amd._lib import SoundkitError
+    monkeypatch.delenv("SK_AAC_TAIL_ONE_LAUNCH", raising=False)
+    n_streams, n_frames, ch = 4, 3, 2
+    sids = np.array([engine.open_stream(48000, ch) for _ in range(n_streams)], np.uint32)
+    ids = np.repeat(sids, n_frames)
+    descs, n = soundkit_amd.descs_from_arrays(ids, ch, np.zeros((n_streams * n_frames, 2), np.uint8), np.zeros((n_streams * n_frames, 2), np.uint8))
+    plan = engine.plan(descs, n)
+    x = torch.ones((n_streams * n_frames, ch, 1024), dtype=torch.float32, device="cuda")
+    n_out = engine.downsample_out_frames(n_frames * 1024)
+    stride = (n_out + 7) // 8 * 8
+    out = torch.zeros((n_streams, stride, ch), dtype=torch.int16, device="cuda")
+    with pytest.raises(SoundkitError) as err:
+        plan.run_tail_s16(x, n_frames * ch * 1024, ch, n_frames, out, stride)
+    assert err.value.status == -6
+    engine.synchronize()
+    assert not out.any()
     plan.destroy()
     for sid in sids:
         engine.close_stream(int(sid))

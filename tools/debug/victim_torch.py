@@ -1,6 +1,6 @@
 """Library-free victims for the co-residency experiments: stock PyTorch/rocFFT/rocBLAS kernels on fixed inputs, each compared bit for
 bit with its own first result.  Run it alone (every line must say 0) and beside tools/probe/mfma_aggressor.hip in another process.
-python tools/debug/victim_torch.py [runs]"""
+python tools/debug/victim_torch.py [runs] [only the victims whose name starts with this]"""
 import sys
 
 import torch
@@ -23,7 +23,10 @@ victims = {
     "matmul f32 4096^3": lambda: m @ m,
     "matmul bf16 4096^3": lambda: (mb @ mb).float(),
 }
+only = sys.argv[2] if len(sys.argv) > 2 else ""
 for name, fn in victims.items():
+    if not name.startswith(only):
+        continue
     first = fn().clone()
     torch.cuda.synchronize()
     bad, words, worst = 0, 0, 0.0
