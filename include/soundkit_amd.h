@@ -25,6 +25,15 @@
  * points enqueue on the engine's HIP stream (sk_engine_hip_stream) and return
  * without synchronising.  All other pointers are host memory and those entry
  * points return with results complete.
+ *
+ * One engine per GPU is the design.  A process MAY create several engines on one device (the scheduler's lanes are that), and
+ * then they take turns with the device: on this platform a wave executing the FIR's / resampler's matrix instructions
+ * (v_mfma_f32_16x16x32_*) corrupts synthesis kernels of other launches on its CU (profiles/r04_lanes_corruption.md), so kernels of
+ * two engines must never be resident together.  While a second engine exists on the device, a tick holds the device from its
+ * first upload to its last wait, and every other compute entry point (sk_aac_plan_run_*, sk_downsample_*, sk_resampler_*,
+ * sk_mp3_* synthesis) holds it for the call and WAITS for its own work before returning -- the *_dev entry points are synchronous
+ * then.  Nothing of the kind can be done across processes: do not let two processes decode on one GPU, nor a decoder share its
+ * CUs with any other matrix-instruction workload (HSA_CU_MASK with disjoint masks is safe).
  */
 #ifndef SOUNDKIT_AMD_H
 #define SOUNDKIT_AMD_H

@@ -311,14 +311,32 @@ namespace {
 // device work.  A process with one engine per device never waits here.
 std::mutex g_device_turn[16];
 std::atomic<int> g_engines_on_device[16];
+#ifdef SK_NO_DEVICE_TURNS  // experiment builds only: shows what the turns prevent (tests/test_scale_gpu.py fails with it)
+constexpr int kTurnFrom = 1 << 30;
+#else
+constexpr int kTurnFrom = 1;  // engines on a device beyond which they take turns
+#endif
 
+struct ComputeTurn {};  // tag: an entry point that launches transform or matrix-instruction kernels
 struct DeviceGuard {
     explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); want = dev; }
     // the usual form at an entry point (engine lock held): the engine's device, and the state of the streams opened since
     // the last call is cleared before anything else is queued
     explicit DeviceGuard(sk_engine *e);
-    ~DeviceGuard() { if (prev != want && prev >= 0) (void)hipSetDevice(prev); }
+    // the same for an entry point that queues compute kernels outside a tick: while the process has several engines on the device
+    // it also takes the device's turn (g_device_turn) and, before giving it back, waits for what it queued -- such a call is
+    // synchronous then.  With one engine per device (the design) nothing is taken and nothing is waited for.
+    DeviceGuard(sk_engine *e, ComputeTurn);
+    ~DeviceGuard() {
+        if (turn.owns_lock()) {
+            (void)hipStreamSynchronize(turn_stream);  // an error stays on the stream: the next call of the engine reports it
+            turn.unlock();
+        }
+        if (prev != want && prev >= 0) (void)hipSetDevice(prev);
+    }
     int prev = -1, want = -1;
+    std::unique_lock<std::mutex> turn;
+    hipStream_t turn_stream = nullptr;
 };
 
 void flush_stream_resets(sk_engine *e) {
@@ -345,6 +363,13 @@ void flush_stream_resets(sk_engine *e) {
 }
 
 DeviceGuard::DeviceGuard(sk_engine *e) : DeviceGuard(e->device) { flush_stream_resets(e); }
+DeviceGuard::DeviceGuard(sk_engine *e, ComputeTurn) : DeviceGuard(e->device) {
+    if (g_engines_on_device[e->device & 15].load() > kTurnFrom) {
+        turn = std::unique_lock<std::mutex>(g_device_turn[e->device & 15]);
+        turn_stream = e->stream;
+    }
+    flush_stream_resets(e);
+}
 
 template <typename T>
 hipError_t upload(T **dst, const std::vector<T> &src) {
@@ -1058,7 +1083,7 @@ int sk_aac_plan_run_f32_dev(sk_engine *e, const sk_aac_plan *p, const float *d_c
     if (p->n_tasks == 0) return SK_OK;
     if (!d_coeffs || !d_pcm) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     return run_plan(e, p, d_coeffs, d_pcm);
 } catch (...) {
     return sk::abi_caught("sk_aac_plan_run_f32_dev");
@@ -1070,7 +1095,7 @@ int sk_aac_plan_run_s16_planar_dev(sk_engine *e, const sk_aac_plan *p, const flo
     if (p->n_tasks == 0) return SK_OK;
     if (!d_coeffs || !d_pcm16 || ((uintptr_t)d_pcm16 & 7)) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     return run_plan(e, p, d_coeffs, nullptr, d_pcm16);
 } catch (...) {
     return sk::abi_caught("sk_aac_plan_run_s16_planar_dev");
@@ -1108,7 +1133,7 @@ int sk_aac_plan_run_tail_s16_dev(sk_engine *e, const sk_aac_plan *p, const float
         if (!(v && v[0] == '1' && v[1] == 0)) return SK_ERR_UNSUPPORTED;  // withdrawn: see above
     }
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     sk::TailArgs ta{};
     ta.s.coeffs = d_coeffs;
     ta.s.delay = e->d_delay;
@@ -1134,7 +1159,7 @@ int sk_aac_plan_run_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_c
     if (p->n_tasks == 0) return SK_OK;
     if (!d_coeffs || !d_pcm) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     SK_HIP(e->aux_buf.reserve(p->elements * sizeof(float)), "alloc planar scratch");
     int rc = run_plan(e, p, d_coeffs, (float *)e->aux_buf.p);
     if (rc != SK_OK) return rc;
@@ -1154,7 +1179,7 @@ static int synthesize_host(sk_engine *e, const sk_aac_frame_desc *descs, const f
     if (rc != SK_OK) return rc;
     {
         std::lock_guard<std::mutex> lock(e->mu);
-        DeviceGuard guard(e);
+        DeviceGuard guard(e, ComputeTurn{});
         const size_t elems = (size_t)p->elements;
         do {
             hipError_t he = e->in_buf.reserve(elems * sizeof(float));
@@ -1509,7 +1534,7 @@ int sk_downsample_48k_16k_f32_dev(sk_engine *e, const float *d_in, size_t in_str
     if (rows == 0 || n_out == 0) return SK_OK;
     if (!d_in || !d_out || in_stride < frames || out_stride < n_out) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     sk::FirArgs a = fir_base(e);
     a.in = d_in;
     a.out = d_out;
@@ -1539,7 +1564,7 @@ int sk_downsample_48k_16k_frames_dev(sk_engine *e, const float *d_pcm, size_t st
     if (!d_pcm || !d_out || out_stride < n_out || frame_stride < (size_t)channels * SK_AAC_FRAME_LEN)
         return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     sk::FirArgs a = fir_base(e);
     a.in = d_pcm;
     a.out = d_out;
@@ -1573,7 +1598,7 @@ int sk_downsample_48k_16k_frames_s16_dev(sk_engine *e, const float *d_pcm, size_
     if (!d_pcm || !d_out || out_stride < n_out || frame_stride < (size_t)channels * SK_AAC_FRAME_LEN)
         return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     sk::FirArgs a = fir_base(e);
     a.in = d_pcm;
     a.out = nullptr;
@@ -1634,7 +1659,7 @@ static int fir_from_s16(sk_engine *e, const int16_t *d_pcm16, size_t stream_stri
         stream_stride % 4 || frame_stride % 4 || ((uintptr_t)d_pcm16 & 7))
         return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     sk::FirArgs a = fir_base(e);
     a.in16 = d_pcm16;
     if (d_out) {
@@ -1787,7 +1812,7 @@ int sk_downsample_f32_dev(sk_engine *e, const float *d_in, size_t in_stride, uin
     if (rows == 0 || n_out == 0) return SK_OK;
     if (!d_in || !d_out || in_stride < frames || out_stride < n_out) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     int table = -1;
     int rc = ratio_table_for(e, in_hz, out_hz, &table);
     if (rc != SK_OK) return rc;
@@ -2003,7 +2028,7 @@ int mp3_synthesize(sk_engine *e, const sk_mp3_granule_desc *descs, const float *
     if (!e || (n && (!descs || !xr || !pcm_out))) return SK_ERR_INVALID_ARG;
     if (n == 0) return SK_OK;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     return mp3_synthesize_locked(e, descs, xr, pcm_out, n, status, s16, device_ptrs);
 }
 
@@ -2210,7 +2235,7 @@ int mp3_decode_granules(sk_engine *e, const sk_mp3_requant_granule *granules, co
         rows += granules[i].channels;
     }
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     const size_t pcm_bytes = rows * 576 * (s16 ? sizeof(int16_t) : sizeof(float));
     size_t lines = 0;
     std::vector<int32_t> requant_status(n, 0);
@@ -2236,7 +2261,7 @@ int sk_mp3_requantize(sk_engine *e, const sk_mp3_requant_granule *granules, cons
     for (uint32_t i = 0; i < n; ++i)
         if (granules[i].channels < 1 || granules[i].channels > 2) return SK_ERR_INVALID_ARG;  // the layout of is / xr depends on it
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     size_t lines = 0;
     const int rc = mp3_requantize_locked(e, granules, is, n, status, 0, &lines);
     if (rc != SK_OK) return rc;
@@ -2620,7 +2645,7 @@ int sk_resampler_process_f32(sk_engine *e, const uint32_t *streams, uint32_t n_s
     sk::abi_enter();
     if (!e || (n_streams && (!streams || !out_frames)) || (frames && n_streams && !in)) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     std::vector<RsCall> calls;
     size_t total_rows = 0;
     int rc = rs_collect(e, streams, n_streams, calls, &total_rows);
@@ -2685,7 +2710,7 @@ int sk_resampler_flush_f32(sk_engine *e, const uint32_t *streams, uint32_t n_str
     sk::abi_enter();
     if (!e || (n_streams && (!streams || !out_frames || !out))) return SK_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(e->mu);
-    DeviceGuard guard(e);
+    DeviceGuard guard(e, ComputeTurn{});
     std::vector<RsCall> calls;
     size_t total_rows = 0;
     int rc = rs_collect(e, streams, n_streams, calls, &total_rows);
@@ -3141,7 +3166,7 @@ int tick_body(sk_engine *e, const sk_tick_stream *ts, uint32_t n_streams, const 
     lap(0);
     // from here to the tick's last wait the device belongs to this engine (see g_device_turn)
     std::unique_lock<std::mutex> turn;
-    if (g_engines_on_device[e->device & 15].load() > 1) turn = std::unique_lock<std::mutex>(g_device_turn[e->device & 15]);
+    if (g_engines_on_device[e->device & 15].load() > kTurnFrom) turn = std::unique_lock<std::mutex>(g_device_turn[e->device & 15]);
     const size_t elems = (size_t)hp.off1024 * 1024;
     const size_t arena_bytes = ((size_t)16 << 20) + (size_t)n_frames * 512 + (size_t)n_streams * 1024 + (size_t)mp3.n * 512;
     SK_HIP(e->in_buf.reserve(elems * 4 + 16), "alloc tick coeffs");

@@ -134,3 +134,64 @@ def test_every_stream_delivers_the_same_bytes_over_many_ticks(engine, lanes, quo
     assert np.unique(outputs).size == 1 and np.unique(nbytes).size == 1
     odd = np.flatnonzero(hashes != hashes[0])
     assert odd.size == 0, "%d of %d streams delivered other bytes than stream 0 (first: %s)" % (odd.size, streams, odd[:8].tolist())
+
+
+def test_two_engines_called_directly_from_two_threads_take_turns():
+    """Two engines of one process on one device, driven through the plain entry points (no scheduler): one thread keeps the 48 -> 16 kHz
+    FIR on f32 rows in flight (matrix instructions), the other runs a synthesis plan on a fixed input again and again.  On this platform
+    a synthesis launch that shares CUs with those matrix instructions comes out wrong in 29 of 30 launches
+    (profiles/r04_lanes_corruption.md); while a process has several engines on a device, the compute entry points take the device's turn
+    and wait for their work before they give it back, so every synthesis result must be the first one's, bit for bit."""
+    import threading
+
+    import torch
+
+    import soundkit_amd
+    dev = torch.device("cuda:0")
+    streams, frames = 2048, 16
+    eng_a, eng_b = soundkit_amd.Engine(0, 64), soundkit_amd.Engine(0, streams + 8)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(21)
+        rows = 4096
+        x = (torch.rand((rows, 48000), generator=g) * 2 - 1).to(dev)
+        n16 = eng_a.downsample_out_frames(48000)
+        y = torch.empty((rows, n16), device=dev)
+        coeffs = ((torch.rand((streams * frames, 2, 1024), generator=g) * 24) - 12).to(dev)
+        sids = np.array([eng_b.open_stream(48000, 2) for _ in range(streams)], np.uint32)
+        shapes = np.tile((np.arange(frames) & 1).astype(np.uint8), streams)[:, None].repeat(2, 1)
+        descs, n = soundkit_amd.descs_from_arrays(np.repeat(sids, frames), 2, np.zeros((streams * frames, 2), np.uint8), shapes)
+        plan = eng_b.plan(descs, n)
+        torch.cuda.synchronize()
+        stop = threading.Event()
+        fir_calls = [0]
+
+        def aggressor():
+            while not stop.is_set():
+                eng_a.downsample_48k_16k_dev(x, 48000, rows, 48000, y, n16)
+                fir_calls[0] += 1
+            eng_a.synchronize()
+
+        th = threading.Thread(target=aggressor)
+        th.start()
+        try:
+            pcm = torch.empty_like(coeffs)
+            first, deviating = None, 0
+            for it in range(40):
+                for sid in sids:
+                    eng_b.reset_stream(int(sid))
+                plan.run_f32(coeffs, pcm)
+                eng_b.synchronize()
+                got = pcm.view(torch.int32).clone()
+                if first is None:
+                    first = got
+                elif not torch.equal(got, first):
+                    deviating += 1
+        finally:
+            stop.set()
+            th.join()
+        assert fir_calls[0] > 40  # the other engine was at work throughout
+        assert deviating == 0, deviating
+        plan.destroy()
+    finally:
+        eng_a.close()
+        eng_b.close()
