@@ -617,9 +617,9 @@ def main():
                          "PCM (round 1's chain)")
     ap.add_argument("--tail", default="separate", choices=["separate", "fused"],
                     help="pipeline, s16 chain: the two launches (synthesis to planar s16, then the FIR) or sk_aac_plan_run_tail_s16_dev, "
-                         "the same work as one launch with the PCM kept in LDS -- WITHDRAWN: at this batch size the platform computes "
-                         "that kernel wrongly (profiles/r04_lanes_corruption.md); 'fused' sets SK_AAC_TAIL_ONE_LAUNCH=1 and its line "
-                         "says \"valid\": false")
+                         "the same work as one launch with the PCM kept in LDS.  (In a library built with PACKED_F32=1 that kernel is "
+                         "withdrawn -- the platform computes it wrongly at this batch size, profiles/r04_lanes_corruption.md -- and "
+                         "'fused' runs it through SK_AAC_TAIL_ONE_LAUNCH=1 with \"valid\": false in its line)")
     ap.add_argument("--no-extras", action="store_true",
                     help="pipeline: skip the two extra measurements the default line carries (the mixed-window synthesis launch and a "
                          "few seconds of the whole decode through the scheduler)")
@@ -641,7 +641,7 @@ def main():
     ap.add_argument("--out-channels", type=int, default=1, help="end_to_end: DecodeOptions.output_channels (0 = source)")
     args = ap.parse_args()
     if args.tail == "fused":
-        os.environ["SK_AAC_TAIL_ONE_LAUNCH"] = "1"  # the entry point is withdrawn; the line below is marked invalid
+        os.environ["SK_AAC_TAIL_ONE_LAUNCH"] = "1"  # only read by a packed-f32 build, whose line is then marked invalid
 
     # `python bench.py --gpus N` on its own: become the launcher of N ranks (before anything here touches the GPU)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -929,7 +929,10 @@ def main():
                        "sample_rate": 48000, "channels": ch, "seed": "0x12345678 + stream*0x9e3779b9 + frame*2 + ch", "spectrum": "dsp.rs:725-738 seeded_spectrum x %g" % SPECTRUM_GAIN,
                        "parallelism": "streams sharded, %d rank(s), no collective" % world},
         }
-        if args.tail == "fused" and args.workload == "pipeline":
+        out["config"]["kernel_build"] = ("packed-f32 instructions (make PACKED_F32=1: needs the GPU to itself)" if soundkit_amd._lib.lib.sk_kernels_use_packed_f32()
+                                         else "no packed-f32 instructions (the default: immune to the platform's matrix-instruction co-residency defect, "
+                                              "profiles/r04_lanes_corruption.md; 2-3 % slower than PACKED_F32=1)")
+        if args.tail == "fused" and args.workload == "pipeline" and soundkit_amd._lib.lib.sk_kernels_use_packed_f32():
             out["valid"] = False
             out["invalid_because"] = ("k_aac_tail runs synthesis waves and matrix-instruction waves on the same SIMDs; at this batch the "
                                       "platform computes it wrongly (3 % of the samples, differently in every run): profiles/r04_lanes_corruption.md")

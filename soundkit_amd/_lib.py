@@ -181,6 +181,7 @@ _sig = {
     "sk_engine_hip_stream": (_vp, [_vp]),
     "sk_engine_synchronize": (_i, [_vp]),
     "sk_engine_last_hip_error": (C.c_char_p, [_vp]),
+    "sk_kernels_use_packed_f32": (C.c_int, []),
     "sk_strerror": (C.c_char_p, [_i]),
     "sk_version": (C.c_char_p, []),
     "sk_stream_open": (_i, [_vp, _u32, C.c_uint8, C.POINTER(_u32)]),

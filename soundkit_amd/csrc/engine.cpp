@@ -662,6 +662,12 @@ void *sk_engine_hip_stream(sk_engine *e) try {
     (void)sk::abi_caught("sk_engine_hip_stream");
     return nullptr;
 }
+int sk_kernels_use_packed_f32(void) try {
+    return SK_PACKED_F32;
+} catch (...) {
+    return sk::abi_caught("sk_kernels_use_packed_f32");
+}
+
 const char *sk_engine_last_hip_error(const sk_engine *e) try {
     sk::abi_enter();
     return e ? e->last_hip_error.c_str() : "";
@@ -1107,12 +1113,13 @@ int sk_aac_plan_run_s16_planar_dev(sk_engine *e, const sk_aac_plan *p, const flo
 // the same channel count and the same number of frames, each stream's frames `frames_per_stream` consecutive entries from its
 // frame 0; anything else: SK_ERR_UNSUPPORTED, use the two calls.
 //
-// WITHDRAWN in round 4: SK_ERR_UNSUPPORTED for every plan unless SK_AAC_TAIL_ONE_LAUNCH=1 is in the environment (read at each
-// call).  The kernel has synthesis waves and matrix-instruction FIR work resident on the same SIMDs, which is exactly the
-// co-residency the platform gets wrong (profiles/r04_lanes_corruption.md): the same arithmetic in the same order as the two
-// launches, bit-identical as long as a launch is no more than a workgroup or so per CU (what the tests ran), and at the headline
-// batch 3 % of the samples wrong by up to 5000 LSB, differently in every run (tools/debug/fused_tail_repeats.py).  The switch
-// is for reproducing that, not for use.
+// In a library built WITH packed-f32 instructions (make PACKED_F32=1) the entry point is withdrawn: SK_ERR_UNSUPPORTED for every plan
+// unless SK_AAC_TAIL_ONE_LAUNCH=1 is in the environment (read at each call).  The kernel has synthesis waves and matrix-instruction
+// FIR work resident on the same SIMDs, which is exactly the co-residency the platform gets wrong for packed-f32 instructions
+// (profiles/r04_lanes_corruption.md): bit-identical to the two launches as long as a launch is no more than a workgroup or so per
+// CU (what the tests of round 3 ran), and at the headline batch 3 % of the samples wrong by up to 5000 LSB, differently in every run
+// (tools/debug/fused_tail_repeats.py).  The switch is for reproducing that, not for use.  In the default build (no packed-f32
+// instructions) the kernel is exact at every size and the entry point works.
 int sk_aac_plan_run_tail_s16_dev(sk_engine *e, const sk_aac_plan *p, const float *d_coeffs, size_t stream_stride, uint32_t channels,
                                  uint32_t frames_per_stream, int16_t *d_out, size_t out_stride, uint32_t *out_frames) try {
     sk::abi_enter();
@@ -1128,10 +1135,12 @@ int sk_aac_plan_run_tail_s16_dev(sk_engine *e, const sk_aac_plan *p, const float
     if (!d_coeffs || !d_out || out_stride < n_out || out_stride % 4 || stream_stride < (size_t)channels * SK_AAC_FRAME_LEN ||
         ((uintptr_t)d_out & 7))
         return SK_ERR_INVALID_ARG;
+#if SK_PACKED_F32
     {
         const char *v = std::getenv("SK_AAC_TAIL_ONE_LAUNCH");
-        if (!(v && v[0] == '1' && v[1] == 0)) return SK_ERR_UNSUPPORTED;  // withdrawn: see above
+        if (!(v && v[0] == '1' && v[1] == 0)) return SK_ERR_UNSUPPORTED;  // withdrawn in this flavour: see above
     }
+#endif
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e, ComputeTurn{});
     sk::TailArgs ta{};

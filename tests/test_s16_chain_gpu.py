@@ -234,8 +234,8 @@ def test_full_size_s16_chain_spot_checked_against_oracle(oracle):
 @pytest.mark.parametrize("layout", ["frame", "stream"])
 @pytest.mark.parametrize("ch,n_frames", [(2, 7), (1, 7), (2, 3), (2, 12), (1, 1)])
 def test_fused_tail_equals_the_two_calls(engine, oracle, layout, ch, n_frames, monkeypatch):
-    """(The entry point is withdrawn -- next test; this runs the kernel behind its diagnostic switch, at a size where a launch is
-    a few workgroups and the platform's co-residency defect does not show: include/soundkit_amd.h.)
+    """(In a packed-f32 build the entry point is withdrawn and this runs the kernel behind its diagnostic switch, at a size where a
+    launch is a few workgroups and the platform's co-residency defect does not show: include/soundkit_amd.h.)
     sk_aac_plan_run_tail_s16_dev (k_aac_tail: synthesis, s16 narrowing, the FIR's f16 planes in an LDS ring, the MFMA FIR on
     the wave's own channel, interleaved s16 out -- one launch, no PCM in HBM) against sk_aac_plan_run_s16_planar_dev +
     sk_downsample_48k_16k_frames_s16_to_s16_dev: three calls back to back on the same streams (the overlap state carries;
@@ -305,12 +305,15 @@ def test_fused_tail_equals_the_two_calls(engine, oracle, layout, ch, n_frames, m
         engine.close_stream(int(sid))
 
 
-def test_fused_tail_is_withdrawn(engine, monkeypatch):
-    """Without SK_AAC_TAIL_ONE_LAUNCH=1 the one-launch tail refuses every plan (SK_ERR_UNSUPPORTED: use the two calls) and writes
-    nothing: synthesis waves and matrix-instruction waves sharing SIMDs inside one launch is what the platform computes wrongly
-    (profiles/r04_lanes_corruption.md; tools/debug/fused_tail_repeats.py shows it at the headline batch)."""
+def test_fused_tail_is_withdrawn_in_a_packed_f32_build(engine, monkeypatch):
+    """A library built with packed-f32 instructions (make PACKED_F32=1) refuses the one-launch tail for every plan unless
+    SK_AAC_TAIL_ONE_LAUNCH=1 (SK_ERR_UNSUPPORTED: use the two calls) and writes nothing: synthesis waves using those instructions and
+    matrix-instruction waves sharing SIMDs inside one launch is what the platform computes wrongly (profiles/r04_lanes_corruption.md).
+    The default build has no such instructions: the entry point works (the other tests here)."""
     import torch
-    from soundkit_amd._lib import SoundkitError
+    from soundkit_amd._lib import SoundkitError, lib
+    if lib.sk_kernels_use_packed_f32() == 0:
+        pytest.skip("default build: no packed-f32 instructions, the one-launch tail is exact")
     monkeypatch.delenv("SK_AAC_TAIL_ONE_LAUNCH", raising=False)
     n_streams, n_frames, ch = 4, 3, 2
     sids = np.array([engine.open_stream(48000, ch) for _ in range(n_streams)], np.uint32)
@@ -329,3 +332,45 @@ def test_fused_tail_is_withdrawn(engine, monkeypatch):
     plan.destroy()
     for sid in sids:
         engine.close_stream(int(sid))
+
+
+def test_fused_tail_at_a_full_device_equals_the_two_calls():
+    """The one-launch tail with every CU holding several workgroups (4096 stereo streams x 8 frames): synthesis waves and the FIR's
+    matrix instructions share SIMDs there.  Built with packed-f32 instructions the kernel came out wrong in half of the streams at this
+    size, differently in every run (round 4, profiles/r04_lanes_corruption.md) -- the tests of round 3 ran ten streams and never saw
+    it.  Three runs against the two-launch chain, bit for bit."""
+    import torch
+    from soundkit_amd._lib import lib
+    if lib.sk_kernels_use_packed_f32() != 0:
+        pytest.skip("packed-f32 build: the one-launch tail is withdrawn")
+    dev = torch.device("cuda")
+    streams, frames, ch = 4096, 8, 2
+    eng = soundkit_amd.Engine(0, streams + 8)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(5)
+        coeffs = ((torch.rand((streams * frames, ch, 1024), generator=g) * 2 - 1) * 2.5e5).to(dev)
+        sids = np.array([eng.open_stream(48000, ch) for _ in range(streams)], np.uint32)
+        shapes = np.tile((np.arange(frames) & 1).astype(np.uint8), streams)[:, None].repeat(2, 1)
+        descs, n = soundkit_amd.descs_from_arrays(np.repeat(sids, frames), ch, np.zeros((streams * frames, 2), np.uint8), shapes)
+        plan = eng.plan(descs, n)
+        stream_stride, frame_stride = frames * ch * 1024, ch * 1024
+        n_out = eng.downsample_out_frames(frames * 1024)
+        stride = (n_out + 7) // 8 * 8
+        torch.cuda.synchronize()
+        pcm16 = torch.zeros(coeffs.shape, dtype=torch.int16, device=dev)
+        want = torch.zeros((streams, stride, ch), dtype=torch.int16, device=dev)
+        plan.run_s16_planar(coeffs, pcm16)
+        assert eng.downsample_48k_16k_frames_s16_to_s16_dev(pcm16, stream_stride, frame_stride, ch, streams, frames, want, stride) == n_out
+        eng.synchronize()
+        assert float(want.float().pow(2).mean().sqrt()) > 500
+        for _ in range(3):
+            for sid in sids:
+                eng.reset_stream(int(sid))
+            got = torch.zeros_like(want)
+            torch.cuda.synchronize()
+            assert plan.run_tail_s16(coeffs, stream_stride, ch, frames, got, stride) == n_out
+            eng.synchronize()
+            assert torch.equal(got, want), int((got != want).sum())
+        plan.destroy()
+    finally:
+        eng.close()
