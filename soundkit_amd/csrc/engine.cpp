@@ -305,9 +305,10 @@ namespace {
 // Engines of one process on one device never have a tick's device work in flight at the same time.  Found in round 4: with two
 // engines (the scheduler's lanes) running their ticks concurrently on separate hardware queues, a third of 4096 identical streams
 // came out with short bursts of slightly wrong samples (tools/debug/stream_hashes.py; none with GPU_MAX_HW_QUEUES=1, none with the
-// ticks serialised, none with one engine).  Traced to the platform: a wave executing v_mfma_f32_16x16x32_* (the FIR's) disturbs
-// FFT-shaped kernels of other launches on its CU (the synthesis; stock rocFFT as well -- profiles/r04_lanes_corruption.md), so the
-// ticks take turns: from the first upload of a tick to its last wait, per device.  The host's planning of a tick still overlaps the other engine's
+// ticks serialised, none with one engine).  Traced to the platform: packed-f32 instructions (the synthesis; stock rocFFT's as well)
+// go wrong now and then while another wave of their CU executes v_mfma_f32_16x16x32_* (the FIR's) -- profiles/r04_lanes_corruption.md.
+// The default build has no packed-f32 instructions any more (Makefile, PACKED_F32); the turns stay for the build that has them, and
+// cost nothing measurable: from the first upload of a tick to its last wait, per device.  The host's planning of a tick still overlaps the other engine's
 // device work.  A process with one engine per device never waits here.
 std::mutex g_device_turn[16];
 std::atomic<int> g_engines_on_device[16];
