@@ -1166,7 +1166,11 @@ int lane_create(sk_engine *e, const sk_pipeline_config *cfg, OutQueue *oq, uint3
     // way back into the next tick: a stream is schedulable again when its outputs have been handed over.  As many delivery threads as
     // the lane has entropy threads, four at most (whole decode, 4096 streams on two lanes of four entropy threads each: 6.4 / 10.2 /
     // 10.7 / 11.3 / 11.7 M access units/s with 1 / 2 / 3 / 4 / 6 delivery threads per lane, gpurun_out/r4_ab_deliver.log).
-    p->n_deliver = p->cfg.gpu_entropy == 1 ? std::max(1u, std::min(4u, p->cfg.entropy_threads)) : 1;
+    // With the front-end on host threads one delivery thread per three of them, three at most: MP3 (576-sample granules: many small
+    // AudioData) is bound by a single delivery thread -- 2048 streams, nine entropy threads: 1.1-1.5 / 1.7-1.8 / 2.2-2.3 M granules/s
+    // with 1 / 2 / 3, the single thread 0.8-0.99 busy and the run anywhere between 0.8 and 2.3 M from box to box; AAC with the host
+    // front-end does not care (2.6-2.8 M access units/s with any of them; gpurun_ab/ab_mp3_deliver.sh, profiles/r04_tick_sections.md).
+    p->n_deliver = p->cfg.gpu_entropy == 1 ? std::max(1u, std::min(4u, p->cfg.entropy_threads)) : std::max(1u, std::min(3u, p->cfg.entropy_threads / 3));
     if (const char *env = std::getenv("SK_PIPELINE_DELIVER_THREADS")) {  // tuning / test override
         const int n = std::atoi(env);
         if (n >= 1 && n <= 16) p->n_deliver = (uint32_t)n;
