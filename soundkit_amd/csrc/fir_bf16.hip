@@ -241,7 +241,7 @@ struct BFrag {
 };
 
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 &av, const u32x4 &bv, const f32x4 &c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+    return dev_mfma_bf16(av, bv, c);
 }
 
 __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &av, const u32x4 &bv, const f32x4 &c) { return dev_mfma_f16(av, bv, c); }

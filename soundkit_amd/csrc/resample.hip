@@ -564,12 +564,12 @@ __global__ __launch_bounds__(kMfmaTiles * 64, SK_MFMA_BLOCKS) void k_sinc_mfma(S
                 return b;
             };
             auto products = [&](int s, const BSet &b, f32x4 c) __attribute__((always_inline)) {
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, b.x[0]), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, b.x[0]), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, b.x[1]), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][1]), __builtin_bit_cast(bf16x8, b.x[1]), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][2]), __builtin_bit_cast(bf16x8, b.x[0]), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, h[s][0]), __builtin_bit_cast(bf16x8, b.x[2]), c, 0, 0, 0);
+                c = dev_mfma_bf16(h[s][0], b.x[0], c);
+                c = dev_mfma_bf16(h[s][1], b.x[0], c);
+                c = dev_mfma_bf16(h[s][0], b.x[1], c);
+                c = dev_mfma_bf16(h[s][1], b.x[1], c);
+                c = dev_mfma_bf16(h[s][2], b.x[0], c);
+                c = dev_mfma_bf16(h[s][0], b.x[2], c);
                 return c;
             };
             static_assert(!SK_MFMA_PREFETCH_B || kGroups == 2, "the read-ahead below alternates between two row groups");

@@ -196,8 +196,28 @@ __device__ __forceinline__ void dev_split_pair16_f16(uint32_t u, uint32_t &p1, u
     p2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r.x, r.y));
 }
 __device__ __forceinline__ sk_f32x4 dev_mfma_f16(const sk_u32x4 &av, const sk_u32x4 &bv, const sk_f32x4 &c) {
+#if SK_MFMA_K16  // experiment (-DSK_MFMA_K16=1): the K = 16 form older parts have, twice -- a lane's eight k values as two groups of four,
+                 // the same products, summed in another order.  Half the matrix rate; not an aggressor for other kernels' packed-f32
+                 // instructions (profiles/r04_lanes_corruption.md).
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const sk_f32x4 t = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, (u32x2){av.x, av.y}), __builtin_bit_cast(f16x4, (u32x2){bv.x, bv.y}), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, (u32x2){av.z, av.w}), __builtin_bit_cast(f16x4, (u32x2){bv.z, bv.w}), t, 0, 0, 0);
+#else
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ sk_f32x4 dev_mfma_bf16(const sk_u32x4 &av, const sk_u32x4 &bv, const sk_f32x4 &c) {
+#if SK_MFMA_K16
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const sk_f32x4 t = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, (u32x2){av.x, av.y}), __builtin_bit_cast(s16x4, (u32x2){bv.x, bv.y}), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, (u32x2){av.z, av.w}), __builtin_bit_cast(s16x4, (u32x2){bv.z, bv.w}), t, 0, 0, 0);
+#else
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+#endif
 }
 // products kept per window of 32 samples, in the order x1h1 | x1h2, x2h1 (fir_bf16.hip explains the budget)
 __device__ constexpr int kFirProductsF16[10] = {1, 3, 3, 3, 3, 3, 3, 3, 1, 1};
