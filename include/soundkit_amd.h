@@ -29,9 +29,9 @@
  * One engine per GPU is the design.  A process MAY create several engines on one device (the scheduler's lanes are that), and
  * then they take turns with the device.  Why: on this platform a packed-f32 instruction delivers a wrong low half now and then while
  * another wave of its CU executes a 16x16x32 matrix instruction -- the FIR's and the resampler's (profiles/r04_lanes_corruption.md).
- * The default build contains no packed-f32 instructions and is immune (sk_kernels_use_packed_f32() == 0); the turns are kept as the
- * protection of a PACKED_F32=1 build inside a process.  While a second engine exists on the device, a tick holds the device from
- * its first upload to its last wait, and every other compute entry point (sk_aac_plan_run_*, sk_downsample_*, sk_resampler_*,
+ * The default build contains no packed-f32 instructions, is immune (sk_kernels_use_packed_f32() == 0) and takes no turns: its
+ * engines' work overlaps freely on the device.  The turns are the protection of a PACKED_F32=1 build inside a process: there, while
+ * a second engine exists on the device, a tick holds the device from its first upload to its last wait, and every other compute entry point (sk_aac_plan_run_*, sk_downsample_*, sk_resampler_*,
  * sk_mp3_* synthesis) holds it for the call and WAITS for its own work before returning -- the *_dev entry points are synchronous
  * then.  Across processes nothing protects a PACKED_F32=1 build: it needs its GPU (or disjoint CUs, HSA_CU_MASK) to itself.
  */

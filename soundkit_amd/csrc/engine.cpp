@@ -307,12 +307,16 @@ namespace {
 // came out with short bursts of slightly wrong samples (tools/debug/stream_hashes.py; none with GPU_MAX_HW_QUEUES=1, none with the
 // ticks serialised, none with one engine).  Traced to the platform: packed-f32 instructions (the synthesis; stock rocFFT's as well)
 // go wrong now and then while another wave of their CU executes v_mfma_f32_16x16x32_* (the FIR's) -- profiles/r04_lanes_corruption.md.
-// The default build has no packed-f32 instructions any more (Makefile, PACKED_F32); the turns stay for the build that has them, and
-// cost nothing measurable: from the first upload of a tick to its last wait, per device.  The host's planning of a tick still overlaps the other engine's
+// The default build has no packed-f32 instructions any more (Makefile, PACKED_F32) and takes no turns; they stay for the build that
+// has them: from the first upload of a tick to its last wait, per device.  The host's planning of a tick still overlaps the other engine's
 // device work.  A process with one engine per device never waits here.
 std::mutex g_device_turn[16];
 std::atomic<int> g_engines_on_device[16];
-#ifdef SK_NO_DEVICE_TURNS  // experiment builds only: shows what the turns prevent (tests/test_scale_gpu.py fails with it)
+// Only a library built WITH packed-f32 instructions (make PACKED_F32=1) needs the turns; the default build is immune, and there two
+// lanes whose ticks overlap on the device are worth 7 % of the whole decode (11.2 -> 12.1 M access units/s, three alternations, every
+// stream's hash and the bench's checksum unchanged: profiles/r04_lanes_corruption.md).  -DSK_NO_DEVICE_TURNS takes them out of a packed
+// build to show what they prevent (tests/test_scale_gpu.py fails then).
+#if defined(SK_NO_DEVICE_TURNS) || !SK_PACKED_F32
 constexpr int kTurnFrom = 1 << 30;
 #else
 constexpr int kTurnFrom = 1;  // engines on a device beyond which they take turns
