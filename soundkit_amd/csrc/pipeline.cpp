@@ -917,7 +917,8 @@ void deliver_body(sk_lane *p) {
             BatchEntry &be = b->entries[i];
             PStream &s = *p->streams[be.handle];
             const uint32_t row = b->entry_row[i];
-            bool release = false;
+            bool release = false, was_cancelled = false;  // was_cancelled: as seen under the lock that cleared `busy` -- a cancel that
+                                                          // arrives later finds the stream idle and frees the slot itself
             {
                 std::lock_guard<std::mutex> lk(s.mu);
                 for (uint32_t k = row == kNoStream ? 0 : b->rec_begin[row]; row != kNoStream && rc == SK_OK && k < b->rec_begin[row + 1]; ++k) {
@@ -950,7 +951,8 @@ void deliver_body(sk_lane *p) {
                     s.finished = true;
                 }
                 s.busy = false;
-                release = s.finished || s.cancelled;
+                was_cancelled = s.cancelled;
+                release = s.finished || was_cancelled;
                 if (s.cancelled) {
                     s.out.clear();
                     s.in.clear();
@@ -964,7 +966,7 @@ void deliver_body(sk_lane *p) {
             }
             if (release) {
                 release_device_side(p, s);
-                if (s.cancelled) {  // the handle was dropped while its frames were in flight: free the slot now
+                if (was_cancelled) {  // the handle was dropped while its frames were in flight: free the slot now
                     {
                         std::lock_guard<std::mutex> lk(s.mu);
                         s.open = false;
